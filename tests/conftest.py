@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FIXTURES = os.path.join(GOLDEN, "reference_fixtures")
+WEIGHTS = os.path.join(FIXTURES, "silero_v31_16k.testtensor")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def weights_path():
+    return WEIGHTS
+
+
+@pytest.fixture(scope="session")
+def weights_blob():
+    with open(WEIGHTS, "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def fixture_path():
+    return lambda name: os.path.join(FIXTURES, name + ".testtensor")
