@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Silero v3.1 hot path on MI355X (metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--chunks-per-step C]
+
+A "step" = one pass of the hot path (front end -> 4 encoder layers -> LSTM+decoder) over one batch of
+synthetic 16 kHz s16le audio: S independent streams x C consecutive 1536-sample chunks per stream, LSTM state
+carried on the device from step to step.  Inputs are resident in HBM before the timed region.
+value = streams x chunks x 0.096 s / wall_s  (audio-seconds per second == concurrent real-time streams),
+whole job over all ranks.  For N > 1 the driver launches one rank per GPU (torch.distributed, RCCL); streams
+are sharded across ranks with no data-path collective; the per-step speech probabilities are gathered to
+rank 0 with one RCCL gather (north star), inside the timed region.
+
+The JSON line also carries
+  roofline     -- dominant kernel: algorithmic FLOP per launch / HIP-event duration vs the fp32 peak
+  cpu_baseline -- the CPU oracle (kind "port") or oracle/_ref (kind "reference") timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHUNK_SECONDS = 1536 / 16000.0
+# algorithmic work per chunk, FLOP = 2 x MAC
+FLOP_PER_CHUNK = {
+    "k_frontend": 2 * 1_651_200,
+    "k_layer1": 2 * 181_053, "k_layer2": 2 * 112_208, "k_layer3": 2 * 61_600, "k_layer4": 2 * 236_768,
+    "k_lstm": 2 * (458_752 + 896),
+}
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
+
+
+def cpu_baseline(blob, weights_path, seconds_budget=12.0):
+    """Reported baseline, not the target: the oracle on ONE host core over a bounded sample."""
+    from oracle import oracle as O
+    from vadc_amd import synth
+    pcm = synth.speech_like(256 * 1536, seed=9)
+    kind, runner = "port", None
+    try:
+        ref = O.Reference(weights_path)
+        x = pcm.astype(np.float32) / np.float32(32768)
+        kind, runner = "reference", (lambda n: ref.run(x[: n * 1536], batch=96))
+    except (FileNotFoundError, OSError, ValueError):
+        orc = O.Oracle(blob)
+        runner = lambda n: orc.forward_stream(pcm[: n * 1536])
+    runner(8)
+    t0 = time.perf_counter(); runner(32); dt = time.perf_counter() - t0
+    n = int(min(256, max(32, 32 * seconds_budget / max(dt, 1e-6))))
+    t0 = time.perf_counter(); runner(n); dt = time.perf_counter() - t0
+    return {"value": round(n * CHUNK_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": 1, "kind": kind,
+            "sample": f"{n} consecutive chunks of one synthetic speech stream, single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
+    ap.add_argument("--chunks-per-step", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from vadc_amd import synth
+    from vadc_amd.engine import Engine
+
+    weights_path = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor")
+    blob = open(weights_path, "rb").read()
+    S, Cn = args.streams, args.chunks_per_step
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
+
+    # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
+    base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
+    pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(f"cuda:{local_rank}") for i in range(2)]
+    d_probs = torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}")
+    gather_list = [torch.empty_like(d_probs) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.gather(d_probs, gather_list, dst=0)          # the only collective: final probability gather
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.reset_kernel_times()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        chunks_per_step = S * Cn * world
+        value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
+        kt = eng.kernel_times()
+        dom = max(kt, key=lambda k: kt[k][1])
+        launches, total_ms = kt[dom]
+        avg_s = total_ms / max(launches, 1) / 1e3
+        achieved = FLOP_PER_CHUNK[dom] * S * Cn / avg_s / 1e12
+        out = {
+            "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k",
+            "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Silero v3.1 16k, batch={S} streams/GPU x {Cn} chunks/step, fp32, s16le input resident in HBM",
+                       "streams_per_gpu": S, "chunks_per_step": Cn, "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_s * 1e3, 4),
+                         "note": "fp32 peak (vector == matrix); the parity STFT is unfused mul+add => ceiling 0.5"},
+            "kernels_ms_per_step": {k: round(v[1] / max(v[0], 1), 4) for k, v in kt.items()},
+            "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(blob, weights_path)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * vadc_amd.h -- C-ABI of the MI355X-native Silero VAD backend (libvadc_amd.so).
+ *
+ * This is the drop-in boundary for the per-chunk forward pass of IntendedConsequence/vadc.  In the
+ * reference the boundary is the compile-time backend trio selected at vadc.c:15-19:
+ *
+ *     backend_init            silero.h:48  / onnx_helpers.h:62
+ *     backend_create_tensors  silero.h:76  / onnx_helpers.h:81
+ *     backend_run             silero.h:53  / onnx_helpers.h:75
+ *
+ * whose only arithmetic is silero_run_one_batch_with_context (silero_v3.c:72-215).  The entry points
+ * below are what an FFI binding for that path binds (plain pointers and sizes, no reference-internal
+ * types such as MemoryArena / String8).  include/vadc_backend_hip.h adapts them to the exact
+ * backend_* trio so that the header can be #included from a vadc-shaped host as a third backend.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VADC_AMD_E* code; vadc_amd_last_error() gives
+ *     the message of the calling thread's last failure.
+ *   - there is NO CPU fallback: without a usable gfx950 device vadc_amd_create fails with
+ *     VADC_AMD_ENODEVICE.
+ *   - audio layout: samples[stream][chunk][1536], probabilities[stream][chunk][2] (element 1 is the speech
+ *     probability, vadc.c:704-713 "output_dims == 3"), both stream-major.  Chunks of one stream are
+ *     consecutive in time; LSTM state (h,c [2][64] per stream) lives on the device and is carried
+ *     from call to call (the C-backend convention, silero.h:36-37, silero_v3.c:178-179).
+ *   - the reference's `batch` (consecutive chunks of ONE stream, lstm.c:275-277) is n_streams = 1,
+ *     n_chunks = batch.
+ */
+#ifndef VADC_AMD_H
+#define VADC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VADC_AMD_CHUNK_SAMPLES 1536
+#define VADC_AMD_HIDDEN        64
+#define VADC_AMD_LSTM_LAYERS   2
+
+enum {
+   VADC_AMD_OK        =  0,
+   VADC_AMD_EINVAL    = -1,   /* bad argument (NULL, out-of-range stream/chunk count, ...)        */
+   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 .testtensor container  */
+   VADC_AMD_ENODEVICE = -3,   /* no usable gfx950 device / HIP runtime failure at creation         */
+   VADC_AMD_EHIP      = -4,   /* HIP runtime error during a call                                    */
+   VADC_AMD_ENOMEM    = -5
+};
+
+/* precision selector for vadc_amd_create (room for the bf16x3 variant of BASELINE config 3) */
+enum {
+   VADC_AMD_PRECISION_FP32 = 0   /* fp32 everywhere, STFT with the reference's exact reduction tree */
+};
+
+typedef struct vadc_amd_engine vadc_amd_engine;
+
+/* What backend_init reports back through Silero_Config (vadc.h:10-43; values silero.h:39-43). */
+typedef struct vadc_amd_caps {
+   int32_t batch_size_restriction;        /* -1: any                                   */
+   int32_t is_silero_v5;                  /* 0                                         */
+   int32_t input_size_min;                /* 1536                                      */
+   int32_t input_size_max;                /* 1536                                      */
+   int32_t output_dims;                   /* 3  => output [B,2,1]                      */
+   int32_t output_stride;                 /* 2                                         */
+   int32_t silero_probability_out_index;  /* 1                                         */
+   int32_t lstm_hidden_size;              /* 64                                        */
+   int32_t max_streams;
+   int32_t max_chunks_per_call;
+   int32_t device;
+   int32_t precision;
+} vadc_amd_caps;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Replaces backend_init (silero.h:21-46): parses the weights container (tensor.h:201-253 format,
+ * positional order tensor.h:114-191), uploads/repacks the weights, allocates the device workspace for
+ * max_streams x max_chunks_per_call chunks and zeroes every stream's LSTM state.
+ * device < 0 selects the current HIP device. */
+int  vadc_amd_create(const void *weights_blob, size_t weights_len, int device,
+                     int max_streams, int max_chunks_per_call, int precision,
+                     vadc_amd_engine **out_engine);
+void vadc_amd_destroy(vadc_amd_engine *e);
+const char *vadc_amd_last_error(void);
+int  vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps);
+
+/* ---- the hot path: replaces backend_run (silero.h:53-74) ------------------------------------ */
+
+/* Host buffers, synchronous (copies in, runs, copies out).  samples: f32 in [-1,1) exactly as
+ * process_chunks hands them over (vadc.c:74-75); probs: [n_streams][n_chunks][2]. */
+int  vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, int n_chunks, float *probs);
+/* Same from s16le PCM; the /32768.0f of vadc.c:883,898 happens on the device (exact in fp32). */
+int  vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs);
+
+/* Device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the engine's stream).
+ * d_* are device pointers valid on the engine's device. */
+int  vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks,
+                             float *d_probs, void *hip_stream);
+int  vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks,
+                             float *d_probs, void *hip_stream);
+int  vadc_amd_synchronize(vadc_amd_engine *e);
+
+/* ---- per-stream state (the reference has one implicit stream; silero.h:36-37) ---------------- */
+/* Zero the state of the listed streams (stream_ids == NULL: all max_streams). */
+int  vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *stream_ids, int n);
+int  vadc_amd_get_state(vadc_amd_engine *e, int stream, float *h /*[2][64]*/, float *c /*[2][64]*/);
+int  vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h, const float *c);
+
+/* ---- stage taps: the counterpart of the reference's bottom-up known-answer tests (test.c) ----- */
+enum {
+   VADC_AMD_STAGE_MAGNITUDE  = 0,   /* [n,129,25]  reflect pad + STFT + magnitude   stft.c:15-224      */
+   VADC_AMD_STAGE_NORMALIZED = 1,   /* [n,129,25]  adaptive normalization           misc.c:1-124       */
+   VADC_AMD_STAGE_LAYER1     = 2,   /* [n,16,13]   transformer_layer 1              transformer.c:237  */
+   VADC_AMD_STAGE_LAYER2     = 3,   /* [n,32,7]                                                       */
+   VADC_AMD_STAGE_LAYER3     = 4,   /* [n,32,7]                                                       */
+   VADC_AMD_STAGE_LAYER4     = 5,   /* [n,64,7]    encoder output                   silero_v3.c:4-64   */
+   VADC_AMD_STAGE_COUNT      = 6
+};
+/* Run the front end + encoder on n chunks (host f32 samples [n][1536], no LSTM, state untouched) and
+ * copy out the requested stage. */
+int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples, int n, int stage, float *out);
+/* Feed `in` as the OUTPUT of stage `from_stage` (host, [n,...] in that stage's shape; MAGNITUDE or
+ * NORMALIZED or LAYER1..3) and copy out stage `to_stage` (> from_stage). */
+int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
+/* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
+int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
+/* Select an implementation variant of a kernel (A/B testing and bring-up): key "lstm" -> 0 mfma, 1 simple. */
+int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
+
+/* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
+enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,
+       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_COUNT };
+/* When enabled every kernel launch of run_* is bracketed by hipEventRecord on its stream. */
+int  vadc_amd_set_profiling(vadc_amd_engine *e, int enabled);
+/* Synchronizes, then returns launch count and summed duration (ms) since the last reset. */
+int  vadc_amd_get_kernel_time(vadc_amd_engine *e, int kernel, int *launches, double *total_ms);
+int  vadc_amd_reset_kernel_times(vadc_amd_engine *e);
+const char *vadc_amd_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VADC_AMD_H */

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C-ABI, libvadc_amd.so) with the CPU oracle, the committed goldens of
+the reference C backend and the reference's own known-answer fixtures.  Needs an MI355X: `-m gpu`.
+
+Bars (north star): STFT magnitudes BIT-EXACT; per-chunk speech probability within 1e-4 of the reference C
+backend; segment chunk indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from vadc_amd import synth, testtensor as tt
+from vadc_amd.engine import Engine, VadcAmdError
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4
+STREAMS = ["speech0", "speech1", "speech2", "zeros", "noise", "square"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng(weights_blob):
+    e = Engine(weights_blob, max_streams=64, max_chunks_per_call=64, device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(weights_blob):
+    return O.Oracle(weights_blob)
+
+
+@pytest.fixture(scope="module")
+def gold_c():
+    return np.load(os.path.join(GOLDEN, "c_reference_v31.npz"))
+
+
+@pytest.fixture(scope="module")
+def gold_py():
+    return np.load(os.path.join(GOLDEN, "python_reference_v31.npz"))
+
+
+def f32(pcm):
+    return pcm.astype(np.float32) / np.float32(32768)
+
+
+# ---------------------------------------------------------------------------------------------- caps
+def test_caps_match_backend_init(eng):
+    c = eng.caps()                                   # silero.h:39-43, vadc.c:704-713
+    assert (c["batch_size_restriction"], c["is_silero_v5"], c["input_size_min"], c["input_size_max"]) == (-1, 0, 1536, 1536)
+    assert (c["output_dims"], c["output_stride"], c["silero_probability_out_index"], c["lstm_hidden_size"]) == (3, 2, 1, 64)
+
+
+# ---------------------------------------------------------------------------------------------- STFT
+def test_stft_magnitude_bit_exact_vs_oracle(eng, orc, gold_py):
+    x = f32(gold_py["pcm_speech0"])[: 12 * 1536]
+    got = eng.stage_from_samples(x, "magnitude")
+    for i in range(12):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(bits(got[i]), bits(taps["magnitude"])), f"chunk {i}"
+
+
+def test_stft_magnitude_bit_exact_vs_c_reference_golden(eng, gold_c, gold_py):
+    x = f32(gold_py["pcm_speech0"])
+    sel = np.concatenate([x[0:1536], x[20 * 1536:21 * 1536]])
+    got = eng.stage_from_samples(sel, "magnitude")
+    assert np.array_equal(bits(got), bits(gold_c["stft_mag_speech0_chunks_0_20"]))
+
+
+@pytest.mark.parametrize("kind", ["zeros", "noise", "square"])
+def test_stft_edge_inputs_bit_exact(eng, orc, kind):
+    x = f32(synth.control_stream(kind, 3 * 1536, seed=3))
+    got = eng.stage_from_samples(x, "magnitude")
+    for i in range(3):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(bits(got[i]), bits(taps["magnitude"]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 61, 64, 123])
+def test_stft_ragged_counts(eng, orc, n):
+    """wave tiling (61 producing lanes, 28 blocks/chunk) must not depend on the chunk count"""
+    x = f32(synth.speech_like(n * 1536, seed=900 + n))
+    got = eng.stage_from_samples(x, "magnitude")
+    for i in sorted({0, n // 2, n - 1}):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(bits(got[i]), bits(taps["magnitude"])), (n, i)
+
+
+# ---------------------------------------------------------------------------------------------- stages
+@pytest.mark.parametrize("stage,tol", [("normalized", 2e-5), ("layer1", 1e-4), ("layer2", 1e-4), ("layer3", 1e-4), ("layer4", 1e-4)])
+def test_stage_vs_oracle(eng, orc, gold_py, stage, tol):
+    x = f32(gold_py["pcm_speech1"])[: 10 * 1536]
+    got = eng.stage_from_samples(x, stage)
+    key = {"layer1": "l1", "layer2": "l2", "layer3": "l3", "layer4": "l4"}.get(stage, stage)
+    worst = 0.0
+    for i in range(10):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        worst = max(worst, float(np.abs(got[i] - taps[key]).max()))
+    assert worst < tol, worst
+
+
+# ---------------------------------------------------------------------------------------------- reference fixtures on the GPU
+def _blob_with(weights_blob, replace):
+    ts = tt.loads(weights_blob)
+    for idx, arr in replace.items():
+        assert ts[idx][1].shape == arr.shape, (idx, ts[idx][1].shape, arr.shape)
+        ts[idx] = (ts[idx][0], arr)
+    return tt.dumps(ts)
+
+
+LAYER_START = {1: 1, 2: 25, 3: 49, 4: 71}   # index of each layer's first tensor in the 99-tensor file
+
+
+@pytest.mark.parametrize("name,first,last", [
+    ("transformer_first_layer", 1, 1),             # test.c:1196
+    ("transformer_layers_1_2", 1, 2),              # test.c:1239
+    ("transformer_layers_3", 3, 3),                # test.c:1918
+    ("transformer_layers_1_2_3", 1, 3),            # test.c:1320
+    ("transformer_layers_1_2_3_4", 1, 4),          # test.c:1392
+])
+def test_reference_fixture_transformer_layers(weights_blob, fixture_path, name, first, last):
+    ts = [a for _, a in tt.load(fixture_path(name))]
+    x, ref = ts[-2], ts[-1]
+    rep = {LAYER_START[first] + i: a for i, a in enumerate(ts[:-2])}
+    e = Engine(_blob_with(weights_blob, rep), max_streams=1, max_chunks_per_call=4, device=0)
+    src = "normalized" if first == 1 else f"layer{first - 1}"
+    got = e.stage_from_stage(x, src, f"layer{last}")
+    e.close()
+    assert float(np.abs(got - ref).max()) < 1e-4
+
+
+def test_reference_fixture_adaptive_normalization_encoder(weights_blob, fixture_path):   # test.c:1434
+    ts = [a for _, a in tt.load(fixture_path("adaptive_normalization_encoder"))]
+    x, ref = ts[-2], ts[-1]
+    rep = {1 + i: a for i, a in enumerate(ts[:-2])}
+    e = Engine(_blob_with(weights_blob, rep), max_streams=1, max_chunks_per_call=4, device=0)
+    got = e.stage_from_stage(x, "magnitude", "layer4")
+    e.close()
+    assert float(np.abs(got - ref).max()) < 1e-4
+
+
+def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):               # test.c:1071
+    x, ref = [a for _, a in tt.load(fixture_path("adaptive_audio_normalization_test"))]
+    got = eng.stage_from_stage(x, "magnitude", "normalized")
+    assert float(np.abs(got - ref).max()) < 1e-4
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_reference_fixture_lstm(weights_blob, fixture_path, variant):                     # test.c:243
+    x, h0, c0, w, b, ref = [a for _, a in tt.load(fixture_path("lstm_nito_reference_randn"))]
+    e = Engine(_blob_with(weights_blob, {95: w, 96: b}), max_streams=1, max_chunks_per_call=4, device=0)
+    e.set_option("lstm", variant)
+    e.set_state(0, h0, c0)
+    e.lstm_decoder(np.ascontiguousarray(x.T).reshape(1, 1, 64, 7))
+    h, c = e.get_state(0)
+    e.close()
+    assert float(np.abs(h - ref[7:9]).max()) < 1e-4 and float(np.abs(c - ref[9:11]).max()) < 1e-4
+    assert float(np.abs(h[1] - ref[6]).max()) < 1e-4     # last output row == top-layer h
+
+
+# ---------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("name", STREAMS)
+@pytest.mark.parametrize("dtype", ["s16", "f32"])
+def test_probabilities_vs_c_reference_golden(eng, gold_c, gold_py, name, dtype):
+    pcm = gold_py[f"pcm_{name}"]
+    eng.reset_streams()
+    x = pcm if dtype == "s16" else f32(pcm)
+    got = eng.run(x.reshape(1, -1))[0]
+    want = gold_c[f"probs_{name}"]
+    assert float(np.abs(got - want).max()) <= PROB_TOL
+    h, c = eng.get_state(0)
+    assert float(np.abs(h - gold_c[f"h_{name}"]).max()) < 1e-3 and float(np.abs(c - gold_c[f"c_{name}"]).max()) < 1e-3
+
+
+def test_s16_and_f32_inputs_agree_bitwise(eng, gold_py):
+    pcm = gold_py["pcm_speech2"][: 8 * 1536].reshape(1, -1)
+    eng.reset_streams()
+    a = eng.run(pcm)
+    eng.reset_streams()
+    b = eng.run(f32(pcm))
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_backend_run_shape_and_batch_invariance(eng, gold_c, gold_py):
+    """reference semantics: `batch` = consecutive chunks of one stream; any batch gives the same answer (Appendix D)"""
+    x = f32(gold_py["pcm_speech0"])
+    outs = []
+    for batch in (1, 4, 48):
+        eng.reset_streams()
+        o = np.concatenate([eng.backend_run(x[i * 1536:(i + batch) * 1536], batch) for i in range(0, 48, batch)])
+        assert o.shape == (48, 2)
+        outs.append(o)
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    assert float(np.abs(outs[0] - gold_c["probs_speech0"]).max()) <= PROB_TOL
+
+
+@pytest.mark.parametrize("S,Cn", [(1, 1), (5, 3), (17, 2), (33, 7), (64, 16)])
+def test_multi_stream_vs_oracle(eng, orc, S, Cn):
+    pcm = synth.make_streams(S, Cn, seed0=1000 + S)
+    eng.reset_streams()
+    got = eng.run(pcm)[:, :, 1]
+    want = orc.forward_streams(pcm)
+    assert float(np.abs(got - want).max()) <= PROB_TOL
+
+
+def test_streams_are_independent_and_order_free(eng):
+    pcm = synth.make_streams(20, 4, seed0=77)
+    eng.reset_streams()
+    a = eng.run(pcm)
+    perm = np.random.default_rng(0).permutation(20)
+    eng.reset_streams()
+    b = eng.run(pcm[perm])
+    assert np.array_equal(bits(a[perm]), bits(b))
+
+
+def test_state_is_carried_across_calls(eng):
+    pcm = synth.make_streams(9, 12, seed0=300)
+    eng.reset_streams()
+    whole = eng.run(pcm)
+    eng.reset_streams()
+    parts = np.concatenate([eng.run(pcm[:, i * 1536:(i + 3) * 1536]) for i in range(0, 12, 3)], axis=1)
+    assert np.array_equal(bits(whole), bits(parts))
+
+
+def test_reset_and_state_roundtrip(eng):
+    pcm = synth.make_streams(3, 5, seed0=11)
+    eng.reset_streams()
+    first = eng.run(pcm)
+    h1, c1 = eng.get_state(1)
+    assert np.abs(h1).max() > 0
+    eng.reset_streams(np.array([1], np.int32))
+    h, c = eng.get_state(1)
+    assert not h.any() and not c.any()
+    h0, _ = eng.get_state(0)
+    assert np.abs(h0).max() > 0                     # other streams untouched
+    eng.set_state(1, h1, c1)
+    h, c = eng.get_state(1)
+    assert np.array_equal(bits(h), bits(h1)) and np.array_equal(bits(c), bits(c1))
+    eng.reset_streams()
+    again = eng.run(pcm)
+    assert np.array_equal(bits(first), bits(again))
+
+
+def test_lstm_variants_agree(eng):
+    pcm = synth.make_streams(19, 6, seed0=5)
+    eng.set_option("lstm", 0); eng.reset_streams(); a = eng.run(pcm)
+    eng.set_option("lstm", 1); eng.reset_streams(); b = eng.run(pcm)
+    eng.set_option("lstm", 0)
+    assert float(np.abs(a - b).max()) < 2e-5
+
+
+def test_limits_are_enforced(eng):
+    with pytest.raises(VadcAmdError):
+        eng.run(np.zeros((65, 1536), np.int16))                 # > max_streams
+    with pytest.raises(VadcAmdError):
+        eng.run(np.zeros((64, 65 * 1536), np.int16))            # > workspace
+    with pytest.raises(ValueError):
+        eng.run(np.zeros((1, 1000), np.int16))                  # ragged chunk
+
+
+def test_segment_indices_bit_exact(eng, gold_c, gold_py):
+    """bit-exact segment chunk indices: same hysteresis decisions from HIP probabilities as from the C backend's"""
+    for name in ("speech0", "speech1", "speech2"):
+        eng.reset_streams()
+        got = eng.run(gold_py[f"pcm_{name}"].reshape(1, -1))[0, :, 1]
+        for kw in ({}, {"threshold": 0.35, "neg_threshold_relative": 0.1}, {"min_silence_ms": 100.0, "speech_pad_ms": 0.0}):
+            s_got, i_got = O.segments(got, **kw)
+            s_ref, i_ref = O.segments(gold_c[f"probs_{name}"][:, 1], **kw)
+            assert np.array_equal(i_got, i_ref) and np.array_equal(bits(s_got), bits(s_ref))
+
+
+def test_device_pointer_path_matches_host_path(eng):
+    import torch
+    pcm = synth.make_streams(8, 4, seed0=21)
+    eng.reset_streams()
+    want = eng.run(pcm)
+    eng.reset_streams()
+    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream()
+    eng.run_device(d_in.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
+
+
+def test_large_batch_properties(weights_blob, orc):
+    """BASELINE config 2 size (256 streams): spot-check streams against the oracle + determinism."""
+    S, Cn = 256, 8
+    pcm = synth.make_streams(S, Cn, seed0=5000)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    a = e.run(pcm)
+    e.reset_streams()
+    b = e.run(pcm)
+    assert np.array_equal(bits(a), bits(b))
+    assert np.isfinite(a).all() and (a >= 0).all() and (a <= 1).all()
+    idx = [0, 1, 15, 16, 17, 100, 255]
+    want = orc.forward_streams(pcm[idx])
+    assert float(np.abs(a[idx, :, 1] - want).max()) <= PROB_TOL
+    e.close()

@@ -1,0 +1,71 @@
+"""ctypes loader for libvadc_amd.so (the C-ABI of include/vadc_amd.h).
+
+The library is built in-tree by `make -C vadc_amd/csrc` (or __graft_entry__.build()).  There is no Python or
+CPU fallback: if the shared object is missing this module raises at import of the symbols.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvadc_amd.so")
+
+# every symbol include/vadc_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
+SYMBOLS = [
+    "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps",
+    "vadc_amd_run_f32", "vadc_amd_run_s16", "vadc_amd_run_device_f32", "vadc_amd_run_device_s16",
+    "vadc_amd_synchronize", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
+    "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder",
+    "vadc_amd_set_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
+    "vadc_amd_kernel_name",
+]
+
+
+class Caps(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch_size_restriction", "is_silero_v5", "input_size_min", "input_size_max", "output_dims",
+        "output_stride", "silero_probability_out_index", "lstm_hidden_size", "max_streams",
+        "max_chunks_per_call", "device", "precision")]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C vadc_amd/csrc). vadc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    L.vadc_amd_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, i32, C.POINTER(vp)]
+    L.vadc_amd_destroy.argtypes = [vp]
+    L.vadc_amd_destroy.restype = None
+    L.vadc_amd_last_error.restype = C.c_char_p
+    L.vadc_amd_get_caps.argtypes = [vp, C.POINTER(Caps)]
+    L.vadc_amd_run_f32.argtypes = [vp, vp, i32, i32, vp]
+    L.vadc_amd_run_s16.argtypes = [vp, vp, i32, i32, vp]
+    L.vadc_amd_run_device_f32.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.vadc_amd_run_device_s16.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.vadc_amd_synchronize.argtypes = [vp]
+    L.vadc_amd_reset_streams.argtypes = [vp, vp, i32]
+    L.vadc_amd_get_state.argtypes = [vp, i32, vp, vp]
+    L.vadc_amd_set_state.argtypes = [vp, i32, vp, vp]
+    L.vadc_amd_debug_stage_from_samples.argtypes = [vp, vp, i32, i32, vp]
+    L.vadc_amd_debug_stage_from_stage.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.vadc_amd_debug_lstm_decoder.argtypes = [vp, vp, i32, i32, vp]
+    L.vadc_amd_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.vadc_amd_set_profiling.argtypes = [vp, i32]
+    L.vadc_amd_get_kernel_time.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]
+    L.vadc_amd_reset_kernel_times.argtypes = [vp]
+    L.vadc_amd_kernel_name.argtypes = [i32]
+    L.vadc_amd_kernel_name.restype = C.c_char_p
+    for name in SYMBOLS:
+        if getattr(L, name).restype is C.c_int or name in ("vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_kernel_name"):
+            continue
+    _lib = L
+    return L

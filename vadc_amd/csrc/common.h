@@ -1,0 +1,49 @@
+// common.h -- shapes and device-side weight views shared by the kernels and the engine.
+// Silero v3.1 / 16 kHz / 1536-sample chunk (reference tensor.h:154-191).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vadc {
+
+constexpr int kChunk     = 1536;
+constexpr int kPad       = 128;
+constexpr int kPadded    = 1792;
+constexpr int kBlocks    = 28;      // 64-sample blocks in the reflect-padded chunk
+constexpr int kFilterLen = 256;
+constexpr int kBins      = 129;
+constexpr int kFilters   = 258;
+constexpr int kFrames    = 25;
+constexpr int kHidden    = 64;
+
+// One encoder layer's weights on the device.  Matrices keep the reference's [out][in] layout
+// (rows contiguous over `in`) except the conv-block pointwise/proj weights which are stored
+// transposed [in][out] because the conv block walks input channels in its outer loop.
+struct LayerWeights {
+   const float *dw_w;     // [cin][5]
+   const float *dw_b;     // [cin]
+   const float *pwT;      // [cin][d]
+   const float *pw_b;     // [d]
+   const float *pjT;      // [cin][d] or nullptr
+   const float *pj_b;     // [d]      or nullptr
+   const float *qkv_w;    // [3d][d]
+   const float *qkv_b;    // [3d]
+   const float *out_w;    // [d][d]
+   const float *out_b;    // [d]
+   const float *n1_w, *n1_b;
+   const float *l1_w, *l1_b;
+   const float *l2_w, *l2_b;
+   const float *n2_w, *n2_b;
+   const float *cv_w;     // [d][d]  strided 1x1 conv with BatchNorm folded in at load time
+   const float *cv_b;     // [d]
+};
+
+struct LstmWeights {
+   const float *w;        // [2][256][128]  reference layout: [layer][gate*64+unit][x(64) | h(64)]
+   const float *wT;       // [2][128][256]  k-major copy for the simple kernel
+   const float *b;        // [2][256]
+   const float *dec_w;    // [2][64]
+   const float *dec_b;    // [2]
+};
+
+}  // namespace vadc

@@ -1,0 +1,597 @@
+// engine.hip -- the C-ABI of include/vadc_amd.h: weights loading/repacking, device workspace, per-stream
+// LSTM state, kernel launches, stage taps and HIP-event timing.
+//
+// Host-side counterpart of the reference's backend glue (silero.h:21-81) and of the orchestration in
+// silero_run_one_batch_with_context (silero_v3.c:72-215).  No arithmetic of the path happens on the host
+// except the load-time weight repacking (transposes, basis permutation, BatchNorm folding).
+#include "../../include/vadc_amd.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace vadc {
+void launch_frontend_f32(const float *, const float *, float *, float *, int, int, hipStream_t);
+void launch_frontend_s16(const int16_t *, const float *, float *, float *, int, int, hipStream_t);
+void launch_normalize_tap(const float *, const float *, float *, int, hipStream_t);
+void launch_lognorm_from_magnitude(const float *, float *, float *, int, hipStream_t);
+void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, hipStream_t);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, hipStream_t);
+}  // namespace vadc
+
+using namespace vadc;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+   char buf[512];
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(buf, sizeof(buf), fmt, ap);
+   va_end(ap);
+   g_err = buf;
+   return code;
+}
+
+#define HIP_TRY(expr, code)                                                                       \
+   do {                                                                                           \
+      hipError_t e_ = (expr);                                                                     \
+      if (e_ != hipSuccess) return fail(code, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+   } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// weights container (tensor.h:97-102, 201-253) -> host tensors, positional wiring tensor.h:114-191
+// ---------------------------------------------------------------------------------------------------
+struct HostTensor { std::vector<int> dims; const float *data; int size; };
+
+static bool parse_testtensor(const unsigned char *p, size_t len, std::vector<HostTensor> &out)
+{
+   size_t off = 0;
+   auto rd = [&](int32_t &v) { if (off + 4 > len) return false; memcpy(&v, p + off, 4); off += 4; return true; };
+   int32_t version, count;
+   if (!rd(version) || !rd(count) || version != 1 || count <= 0 || count > 4096) return false;
+   for (int i = 0; i < count; ++i) {
+      int32_t n;
+      if (!rd(n) || n <= 0 || off + (size_t)n > len) return false;
+      off += (size_t)n;
+   }
+   out.resize(count);
+   for (int i = 0; i < count; ++i) {
+      int32_t ndim, size, nbytes;
+      if (!rd(ndim) || ndim < 0 || ndim > 8) return false;
+      out[i].dims.resize(ndim);
+      long prod = 1;
+      for (int d = 0; d < ndim; ++d) { int32_t v; if (!rd(v) || v <= 0) return false; out[i].dims[d] = v; prod *= v; }
+      if (!rd(size) || !rd(nbytes) || size <= 0 || nbytes != size * 4 || prod != size) return false;
+      if (off + (size_t)nbytes > len) return false;
+      out[i].data = reinterpret_cast<const float *>(p + off);   // may be unaligned: only memcpy'd below
+      out[i].size = size;
+      off += (size_t)nbytes;
+   }
+   return off == len;
+}
+
+struct LayerShape { int cin, d, t, stride, proj; };
+static const LayerShape kLayers[4] = {{129, 16, 25, 2, 1}, {16, 32, 13, 2, 1}, {32, 32, 7, 1, 0}, {32, 64, 7, 1, 1}};
+static const int kStageElems[VADC_AMD_STAGE_COUNT] = {129 * 25, 129 * 25, 16 * 13, 32 * 7, 32 * 7, 64 * 7};
+
+struct Packer {
+   std::vector<float> buf;
+   // every sub-array starts on a 64-byte boundary so scalar dwordx16 loads never straddle
+   size_t add(const float *src, size_t n)
+   {
+      size_t off = (buf.size() + 15) & ~size_t(15);
+      buf.resize(off + n);
+      if (src) memcpy(buf.data() + off, src, n * sizeof(float));
+      return off;
+   }
+};
+
+struct vadc_amd_engine {
+   int device = 0;
+   int max_streams = 0, max_chunks = 0, precision = 0;
+   size_t max_items = 0;
+   hipStream_t stream = nullptr;
+   float *d_weights = nullptr;
+   const float *d_basis = nullptr;
+   LayerWeights lw[4];
+   LstmWeights lstm;
+   // workspace
+   float *d_in_f32 = nullptr;
+   int16_t *d_in_s16 = nullptr;
+   float *d_Y = nullptr, *d_FM = nullptr, *d_tap = nullptr;
+   float *d_act[4] = {nullptr, nullptr, nullptr, nullptr};
+   float *d_probs = nullptr;
+   float *d_h = nullptr, *d_c = nullptr;
+   int lstm_variant = 0;
+   // profiling
+   bool profiling = false;
+   struct EvPair { hipEvent_t a, b; };
+   std::vector<EvPair> pending[VADC_AMD_KERNEL_COUNT];
+   std::vector<EvPair> pool;
+   int launches[VADC_AMD_KERNEL_COUNT] = {0};
+   double total_ms[VADC_AMD_KERNEL_COUNT] = {0};
+};
+
+static void copy_unaligned(std::vector<float> &dst, const HostTensor &t)
+{
+   dst.resize(t.size);
+   memcpy(dst.data(), t.data, (size_t)t.size * 4);
+}
+
+static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
+{
+   if (ts.size() != 99) return fail(VADC_AMD_EWEIGHTS, "weights: expected 99 tensors, found %zu", ts.size());
+   Packer pk;
+   std::vector<float> tmp, tmp2;
+   int idx = 0;
+   auto need = [&](int i, int n) { return ts[i].size == n; };
+
+   // [0] STFT basis [258,1,256] -> consumption order of k_frontend: [f][i = 3,2,1,0][l][j]
+   if (!need(idx, kFilters * kFilterLen)) return fail(VADC_AMD_EWEIGHTS, "weights: bad forward_basis_buffer");
+   copy_unaligned(tmp, ts[idx++]);
+   tmp2.resize(tmp.size());
+   for (int f = 0; f < kFilters; ++f)
+      for (int ii = 0; ii < 4; ++ii)
+         for (int l = 0; l < 8; ++l)
+            for (int j = 0; j < 8; ++j)
+               tmp2[(size_t)f * 256 + ii * 64 + l * 8 + j] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + l];
+   const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
+   pk.add(nullptr, 64);   // the pipeline's final prefetch reads 32 floats past filter 129's start: keep slack anyway
+
+   struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b; } lo[4];
+   for (int l = 0; l < 4; ++l) {
+      const LayerShape &s = kLayers[l];
+      const int D = s.d, C = s.cin;
+      auto take = [&](int n, std::vector<float> &v) -> bool { if (!need(idx, n)) return false; copy_unaligned(v, ts[idx++]); return true; };
+      auto transposed = [&](const std::vector<float> &src) { std::vector<float> r((size_t)C * D); for (int o = 0; o < D; ++o) for (int c = 0; c < C; ++c) r[(size_t)c * D + o] = src[(size_t)o * C + c]; return r; };
+      std::vector<float> v;
+      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
+      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
+      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); }
+      if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size());
+      lo[l].pjT = lo[l].pj_b = (size_t)-1;
+      if (s.proj) {
+         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); }
+         if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size());
+      }
+      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size());
+      if (!take(3 * D, v)) goto bad;     lo[l].qkv_b = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].out_b = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].n1_w = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].n1_b = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].l1_b = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].l2_b = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].n2_w = pk.add(v.data(), v.size());
+      if (!take(D, v)) goto bad;         lo[l].n2_b = pk.add(v.data(), v.size());
+      {
+         // strided 1x1 conv + BatchNorm1d (transformer.c:279-288, misc.c:221-258) folded:
+         //   ((W z + b) - mean) / sqrt(var + eps) * gamma + beta  =  (W * s) z + ((b - mean) * s + beta)
+         std::vector<float> cw, cb, g, be, mu, var;
+         if (!take(D * D, cw) || !take(D, cb) || !take(D, g) || !take(D, be) || !take(D, mu) || !take(D, var)) goto bad;
+         for (int o = 0; o < D; ++o) {
+            const float sc = g[o] / sqrtf(var[o] + 1e-5f);
+            for (int d = 0; d < D; ++d) cw[(size_t)o * D + d] *= sc;
+            cb[o] = (cb[o] - mu[o]) * sc + be[o];
+         }
+         lo[l].cv_w = pk.add(cw.data(), cw.size());
+         lo[l].cv_b = pk.add(cb.data(), cb.size());
+      }
+   }
+   {
+      if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 128) || !need(idx + 3, 2)) goto bad;
+      std::vector<float> W, B, dw, db;
+      copy_unaligned(W, ts[idx]); copy_unaligned(B, ts[idx + 1]); copy_unaligned(dw, ts[idx + 2]); copy_unaligned(db, ts[idx + 3]);
+      std::vector<float> WT(W.size());
+      for (int l = 0; l < 2; ++l)
+         for (int r = 0; r < 256; ++r)
+            for (int k = 0; k < 128; ++k) WT[((size_t)l * 128 + k) * 256 + r] = W[((size_t)l * 256 + r) * 128 + k];
+      const size_t o_w = pk.add(W.data(), W.size()), o_wT = pk.add(WT.data(), WT.size());
+      const size_t o_b = pk.add(B.data(), B.size()), o_dw = pk.add(dw.data(), dw.size()), o_db = pk.add(db.data(), db.size());
+
+      HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
+      HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      const float *base = e->d_weights;
+      e->d_basis = base + off_basis;
+      for (int l = 0; l < 4; ++l) {
+         LayerWeights &w = e->lw[l];
+         w.dw_w = base + lo[l].dw_w; w.dw_b = base + lo[l].dw_b; w.pwT = base + lo[l].pwT; w.pw_b = base + lo[l].pw_b;
+         w.pjT = kLayers[l].proj ? base + lo[l].pjT : nullptr; w.pj_b = kLayers[l].proj ? base + lo[l].pj_b : nullptr;
+         w.qkv_w = base + lo[l].qkv_w; w.qkv_b = base + lo[l].qkv_b; w.out_w = base + lo[l].out_w; w.out_b = base + lo[l].out_b;
+         w.n1_w = base + lo[l].n1_w; w.n1_b = base + lo[l].n1_b; w.l1_w = base + lo[l].l1_w; w.l1_b = base + lo[l].l1_b;
+         w.l2_w = base + lo[l].l2_w; w.l2_b = base + lo[l].l2_b; w.n2_w = base + lo[l].n2_w; w.n2_b = base + lo[l].n2_b;
+         w.cv_w = base + lo[l].cv_w; w.cv_b = base + lo[l].cv_b;
+      }
+      e->lstm.w = base + o_w; e->lstm.wT = base + o_wT; e->lstm.b = base + o_b; e->lstm.dec_w = base + o_dw; e->lstm.dec_b = base + o_db;
+   }
+   return VADC_AMD_OK;
+bad:
+   return fail(VADC_AMD_EWEIGHTS, "weights: tensor %d has an unexpected size", idx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------------
+extern "C" const char *vadc_amd_last_error(void) { return g_err.c_str(); }
+
+extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
+{
+   if (!e) return;
+   (void)hipSetDevice(e->device);
+   if (e->stream) (void)hipStreamSynchronize(e->stream);
+   for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
+      for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+   for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
+                   e->d_act[2], e->d_act[3], e->d_probs, e->d_h, e->d_c};
+   for (void *p : ptrs) if (p) (void)hipFree(p);
+   if (e->stream) (void)hipStreamDestroy(e->stream);
+   delete e;
+}
+
+extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max_streams, int max_chunks,
+                               int precision, vadc_amd_engine **out)
+{
+   if (!out) return fail(VADC_AMD_EINVAL, "create: out_engine is NULL");
+   *out = nullptr;
+   if (!blob || len < 8) return fail(VADC_AMD_EWEIGHTS, "create: empty weights blob");
+   if (max_streams <= 0 || max_chunks <= 0 || (long)max_streams * max_chunks > (1L << 24))
+      return fail(VADC_AMD_EINVAL, "create: max_streams=%d max_chunks_per_call=%d out of range", max_streams, max_chunks);
+   if (precision != VADC_AMD_PRECISION_FP32) return fail(VADC_AMD_EINVAL, "create: unsupported precision %d", precision);
+
+   std::vector<HostTensor> ts;
+   if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
+      return fail(VADC_AMD_EWEIGHTS, "create: weights blob is not a valid .testtensor container");
+   if (ts.size() != 99) return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors, found %zu", ts.size());
+
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(VADC_AMD_ENODEVICE, "create: no HIP device available (this backend has no CPU fallback)");
+   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+   if (device >= ndev) return fail(VADC_AMD_ENODEVICE, "create: device %d out of range (%d devices)", device, ndev);
+   HIP_TRY(hipSetDevice(device), VADC_AMD_ENODEVICE);
+   hipDeviceProp_t prop;
+   HIP_TRY(hipGetDeviceProperties(&prop, device), VADC_AMD_ENODEVICE);
+   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(VADC_AMD_ENODEVICE, "create: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+
+   vadc_amd_engine *e = new vadc_amd_engine();
+   e->device = device; e->max_streams = max_streams; e->max_chunks = max_chunks; e->precision = precision;
+   e->max_items = (size_t)max_streams * max_chunks;
+   int rc = build_weights(e, ts);
+   if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
+   const size_t N = e->max_items;
+   hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+   if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
+   if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_FM, N * kFrames * sizeof(float));
+   for (int l = 0; l < 4 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
+   if (he == hipSuccess) he = hipMemset(e->d_h, 0, (size_t)max_streams * 128 * sizeof(float));
+   if (he == hipSuccess) he = hipMemset(e->d_c, 0, (size_t)max_streams * 128 * sizeof(float));
+   if (he == hipSuccess) he = hipDeviceSynchronize();
+   if (he != hipSuccess) {
+      rc = fail(VADC_AMD_ENOMEM, "create: device allocation failed: %s", hipGetErrorString(he));
+      vadc_amd_destroy(e);
+      return rc;
+   }
+   *out = e;
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
+{
+   if (!e || !caps) return fail(VADC_AMD_EINVAL, "get_caps: NULL argument");
+   caps->batch_size_restriction = -1;          // silero.h:39
+   caps->is_silero_v5 = 0;                     // silero.h:40
+   caps->input_size_min = kChunk;              // silero.h:41
+   caps->input_size_max = kChunk;              // silero.h:42
+   caps->output_dims = 3;                      // silero.h:43
+   caps->output_stride = 2;                    // vadc.c:704-708
+   caps->silero_probability_out_index = 1;
+   caps->lstm_hidden_size = kHidden;
+   caps->max_streams = e->max_streams;
+   caps->max_chunks_per_call = e->max_chunks;
+   caps->device = e->device;
+   caps->precision = e->precision;
+   return VADC_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------------------------------
+static int drain_events(vadc_amd_engine *e)
+{
+   for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k) {
+      for (auto &p : e->pending[k]) {
+         HIP_TRY(hipEventSynchronize(p.b), VADC_AMD_EHIP);
+         float ms = 0.0f;
+         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b), VADC_AMD_EHIP);
+         e->total_ms[k] += ms;
+         e->launches[k] += 1;
+         e->pool.push_back(p);
+      }
+      e->pending[k].clear();
+   }
+   return VADC_AMD_OK;
+}
+
+struct KernelTimer {
+   vadc_amd_engine *e; int k; hipStream_t st; vadc_amd_engine::EvPair p; bool on;
+   KernelTimer(vadc_amd_engine *e_, int k_, hipStream_t st_) : e(e_), k(k_), st(st_), on(e_->profiling)
+   {
+      if (!on) return;
+      if (e->pool.empty()) { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+      else { p = e->pool.back(); e->pool.pop_back(); }
+      (void)hipEventRecord(p.a, st);
+   }
+   ~KernelTimer()
+   {
+      if (!on) return;
+      (void)hipEventRecord(p.b, st);
+      e->pending[k].push_back(p);
+   }
+};
+
+extern "C" int vadc_amd_set_profiling(vadc_amd_engine *e, int enabled)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "set_profiling: NULL engine");
+   e->profiling = enabled != 0;
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_get_kernel_time(vadc_amd_engine *e, int kernel, int *launches, double *total_ms)
+{
+   if (!e || kernel < 0 || kernel >= VADC_AMD_KERNEL_COUNT) return fail(VADC_AMD_EINVAL, "get_kernel_time: bad argument");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   int rc = drain_events(e);
+   if (rc) return rc;
+   if (launches) *launches = e->launches[kernel];
+   if (total_ms) *total_ms = e->total_ms[kernel];
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_reset_kernel_times(vadc_amd_engine *e)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "reset_kernel_times: NULL engine");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   int rc = drain_events(e);
+   if (rc) return rc;
+   for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k) { e->launches[k] = 0; e->total_ms[k] = 0.0; }
+   return VADC_AMD_OK;
+}
+
+extern "C" const char *vadc_amd_kernel_name(int kernel)
+{
+   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"};
+   return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
+}
+
+extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
+{
+   if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
+   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 1)) { e->lstm_variant = value; return VADC_AMD_OK; }
+   return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------------------------------
+static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const char *who)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "%s: NULL engine", who);
+   if (n_streams <= 0 || n_chunks <= 0) return fail(VADC_AMD_EINVAL, "%s: n_streams=%d n_chunks=%d must be positive", who, n_streams, n_chunks);
+   if (n_streams > e->max_streams) return fail(VADC_AMD_EINVAL, "%s: n_streams=%d exceeds max_streams=%d", who, n_streams, e->max_streams);
+   if ((size_t)n_streams * n_chunks > e->max_items)
+      return fail(VADC_AMD_EINVAL, "%s: %d x %d chunks exceed the workspace (%zu)", who, n_streams, n_chunks, e->max_items);
+   return VADC_AMD_OK;
+}
+
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, hipStream_t st)
+{
+   for (int l = first; l <= last; ++l) {
+      KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
+      const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
+      launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, st);
+   }
+}
+
+template <typename T>
+static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+{
+   const int n = n_streams * n_chunks;
+   {
+      KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
+      if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, 0, st);
+      else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, 0, st);
+   }
+   run_encoder_layers(e, 0, 3, n, st);
+   {
+      KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
+      launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
+   }
+   hipError_t he = hipGetLastError();
+   if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks, float *d_probs, void *hip_stream)
+{
+   int rc = check_shape(e, n_streams, n_chunks, "run_device_f32");
+   if (rc) return rc;
+   if (!d_samples || !d_probs) return fail(VADC_AMD_EINVAL, "run_device_f32: NULL buffer");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   return run_device<float>(e, d_samples, n_streams, n_chunks, d_probs, hip_stream ? (hipStream_t)hip_stream : e->stream);
+}
+
+extern "C" int vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks, float *d_probs, void *hip_stream)
+{
+   int rc = check_shape(e, n_streams, n_chunks, "run_device_s16");
+   if (rc) return rc;
+   if (!d_pcm || !d_probs) return fail(VADC_AMD_EINVAL, "run_device_s16: NULL buffer");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   return run_device<int16_t>(e, d_pcm, n_streams, n_chunks, d_probs, hip_stream ? (hipStream_t)hip_stream : e->stream);
+}
+
+extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "synchronize: NULL engine");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, int n_chunks, float *probs)
+{
+   int rc = check_shape(e, n_streams, n_chunks, "run_f32");
+   if (rc) return rc;
+   if (!samples || !probs) return fail(VADC_AMD_EINVAL, "run_f32: NULL buffer");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   const size_t n = (size_t)n_streams * n_chunks;
+   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, n * kChunk * sizeof(float), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   rc = run_device<float>(e, e->d_in_f32, n_streams, n_chunks, e->d_probs, e->stream);
+   if (rc) return rc;
+   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs)
+{
+   int rc = check_shape(e, n_streams, n_chunks, "run_s16");
+   if (rc) return rc;
+   if (!pcm || !probs) return fail(VADC_AMD_EINVAL, "run_s16: NULL buffer");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   const size_t n = (size_t)n_streams * n_chunks;
+   HIP_TRY(hipMemcpyAsync(e->d_in_s16, pcm, n * kChunk * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   rc = run_device<int16_t>(e, e->d_in_s16, n_streams, n_chunks, e->d_probs, e->stream);
+   if (rc) return rc;
+   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-stream state
+// ---------------------------------------------------------------------------------------------------
+extern "C" int vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *ids, int n)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "reset_streams: NULL engine");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   if (!ids) {
+      HIP_TRY(hipMemsetAsync(e->d_h, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
+      HIP_TRY(hipMemsetAsync(e->d_c, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
+   } else {
+      for (int i = 0; i < n; ++i) {
+         if (ids[i] < 0 || ids[i] >= e->max_streams) return fail(VADC_AMD_EINVAL, "reset_streams: stream %d out of range", ids[i]);
+         HIP_TRY(hipMemsetAsync(e->d_h + (size_t)ids[i] * 128, 0, 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
+         HIP_TRY(hipMemsetAsync(e->d_c + (size_t)ids[i] * 128, 0, 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
+      }
+   }
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_get_state(vadc_amd_engine *e, int stream, float *h, float *c)
+{
+   if (!e || !h || !c || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "get_state: bad argument");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpy(h, e->d_h + (size_t)stream * 128, 128 * sizeof(float), hipMemcpyDeviceToHost), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpy(c, e->d_c + (size_t)stream * 128, 128 * sizeof(float), hipMemcpyDeviceToHost), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h, const float *c)
+{
+   if (!e || !h || !c || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "set_state: bad argument");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpy(e->d_h + (size_t)stream * 128, h, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpy(e->d_c + (size_t)stream * 128, c, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage taps
+// ---------------------------------------------------------------------------------------------------
+static float *stage_buffer(vadc_amd_engine *e, int stage)
+{
+   switch (stage) {
+   case VADC_AMD_STAGE_MAGNITUDE:  return e->d_Y;
+   case VADC_AMD_STAGE_NORMALIZED: return e->d_tap;
+   default:                        return e->d_act[stage - VADC_AMD_STAGE_LAYER1];
+   }
+}
+
+extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples, int n, int stage, float *out)
+{
+   if (!e || !samples || !out || stage < 0 || stage >= VADC_AMD_STAGE_COUNT) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: bad argument");
+   if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: n=%d out of range", n);
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   hipStream_t st = e->stream;
+   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, n, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
+   if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, st);
+   HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * kStageElems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out)
+{
+   if (!e || !in || !out || from_stage < 0 || to_stage >= VADC_AMD_STAGE_COUNT || to_stage <= from_stage)
+      return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: bad argument");
+   if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: n=%d out of range", n);
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   hipStream_t st = e->stream;
+   const size_t in_bytes = (size_t)n * kStageElems[from_stage] * sizeof(float);
+   int first_layer = 0;
+   if (from_stage == VADC_AMD_STAGE_MAGNITUDE) {
+      HIP_TRY(hipMemcpyAsync(e->d_tap, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      launch_lognorm_from_magnitude(e->d_tap, e->d_Y, e->d_FM, n, st);
+   } else if (from_stage == VADC_AMD_STAGE_NORMALIZED) {
+      // already normalized: feed as Y with zero frame means (offset 0)
+      HIP_TRY(hipMemcpyAsync(e->d_Y, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(hipMemsetAsync(e->d_FM, 0, (size_t)n * kFrames * sizeof(float), st), VADC_AMD_EHIP);
+   } else {
+      first_layer = from_stage - VADC_AMD_STAGE_LAYER1 + 1;
+      HIP_TRY(hipMemcpyAsync(e->d_act[first_layer - 1], in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   }
+   if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
+   else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, st);
+   HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * kStageElems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs)
+{
+   int rc = check_shape(e, n_streams, n_chunks, "debug_lstm_decoder");
+   if (rc) return rc;
+   if (!x || !probs) return fail(VADC_AMD_EINVAL, "debug_lstm_decoder: NULL buffer");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   hipStream_t st = e->stream;
+   const size_t n = (size_t)n_streams * n_chunks;
+   HIP_TRY(hipMemcpyAsync(e->d_act[3], x, n * 448 * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, st);
+   HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}

@@ -1,0 +1,246 @@
+// kernels_frontend.hip -- reflect pad + STFT (strided conv with the [258,1,256] basis, hop 64) +
+// magnitude + log1p(2^20 x) + per-frame bin mean, for gfx950.
+//
+// Replaces, per chunk (reference file:line):
+//   tensor_reflect_pad_last_dim_lr  tensor.h:912-958
+//   my_stft_                        stft.c:15-224   (AVX2 loop :82-190, magnitude :194-213)
+//   first two loops of adaptive_audio_normalization_inplace  misc.c:40-63
+//
+// NUMERICS.  The parity of the whole engine is decided here: the reference's
+// 256-tap dot product is a fixed fp32 tree with separately rounded products and sums
+//     tap t = 64 i + 8 j + l ;  g_i[l] = ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))  over j
+//     v[l] = (g_0[l] + g_1[l]) + (g_2[l] + g_3[l]) ;  y = ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7))
+// and this kernel evaluates exactly that expression: this file is compiled with -ffp-contract=off and
+// carries `#pragma clang fp contract(off)`; no FMA, no MFMA, no reassociation.  The output magnitudes are
+// bit-identical to the reference's (tests/test_gpu_parity.py::test_stft_magnitude_bit_exact).
+//
+// MAPPING (MI355X-first, not the reference's loop nest).  hop == 64 == the tree's group size, so with the
+// padded chunk cut into 28 blocks of 64 samples, frame n group i multiplies block n+i with basis taps
+// [64i, 64i+64).  One LANE owns one block: its 64 samples stay in 64 VGPRs for the whole kernel, and for
+// every filter it evaluates G_i[l] for i = 0..3 (4 x (64 mul + 56 add)).  The basis value is the same for
+// every lane of the wave, so it is fetched with SCALAR loads (s_load_dwordx8 from the L2-resident, host-
+// permuted basis) and used as the SGPR operand of v_mul_f32: the inner loop has no vector memory and no
+// LDS traffic at all.  Frame n then needs G_0(n), G_1(n+1), G_2(n+2), G_3(n+3): three wave shifts.
+//     t01 = G_0 + shift1(G_1) ; t23 = G_2 + shift1(G_3) ; v = t01 + shift2(t23)
+// Waves overlap by 3 halo lanes (61 producing lanes per wave), blocks 25..27 of a chunk only feed their
+// neighbours: lane efficiency 61/64 * 25/28 = 85 %.  ~100 VGPRs => 4-5 waves/SIMD to cover scalar-load
+// latency.  Algorithmic work: 258*25*(256 mul + 255 add) = 3.30 M VALU lane-ops per chunk, which bounds this
+// kernel at 1/2 of the FMA peak by construction (2 instructions per MAC).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace vadc {
+
+constexpr int kLanesOut = 61;   // producing lanes per wave; lanes 61..63 are halo for the shifts
+
+__device__ __forceinline__ float sample_to_f32(float v) { return v; }
+__device__ __forceinline__ float sample_to_f32(int16_t v) { return (float)v * (1.0f / 32768.0f); }  // exact
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// Software-pipelined scalar loads of the basis.  hipcc serialises `s_load -> s_waitcnt -> use` through one
+// SGPR tuple when left alone, exposing the full L2 latency every 32 VALU instructions; here the next 32 taps
+// are requested (two s_load_dwordx16 into the OTHER buffer) before the current 32 are consumed, and the
+// wait sits behind the arithmetic.  SMEM returns out of order, so the wait is always lgkmcnt(0); tying the
+// buffers to the wait statement ("+s") keeps every consumer behind it (hipcc does not track asm loads).
+#define VADC_SLOAD32(A, B, BASE, BYTEOFF)                                               \
+   asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"              \
+                : "=&s"(A), "=&s"(B)                                                     \
+                : "s"(BASE), "n"(BYTEOFF), "n"((BYTEOFF) + 64));                          \
+   __builtin_amdgcn_sched_barrier(0)   /* keep the consumer arithmetic BEHIND the request */
+#define VADC_SWAIT(A, B)                                                                \
+   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B));                             \
+   __builtin_amdgcn_sched_barrier(0)
+
+// G[l] = ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)),  p_j = x[8j+l] * k[j]   (stft.c:141-160)
+// KV/O: the 8 basis taps of this (i,l) in j order inside a 16-float SGPR tuple.
+#define VADC_TREE8(dst, L, KV, O)                                                       \
+   {                                                                                    \
+      const float p0 = x[0 * 8 + (L)] * KV[(O) + 0], p1 = x[1 * 8 + (L)] * KV[(O) + 1]; \
+      const float p2 = x[2 * 8 + (L)] * KV[(O) + 2], p3 = x[3 * 8 + (L)] * KV[(O) + 3]; \
+      const float p4 = x[4 * 8 + (L)] * KV[(O) + 4], p5 = x[5 * 8 + (L)] * KV[(O) + 5]; \
+      const float p6 = x[6 * 8 + (L)] * KV[(O) + 6], p7 = x[7 * 8 + (L)] * KV[(O) + 7]; \
+      const float p01 = p0 + p1, p23 = p2 + p3, p45 = p4 + p5, p67 = p6 + p7;           \
+      const float p0123 = p01 + p23, p4567 = p45 + p67;                                 \
+      dst = p0123 + p4567;                                                              \
+   }
+
+// one pipeline stage = 32 taps = lanes-of-the-tree l in [LB, LB+4) of one 64-tap group
+#define VADC_STAGE(G, LB, CA, CB_)                                                      \
+   VADC_TREE8(G[(LB) + 0], (LB) + 0, CA, 0) VADC_TREE8(G[(LB) + 1], (LB) + 1, CA, 8)    \
+   VADC_TREE8(G[(LB) + 2], (LB) + 2, CB_, 0) VADC_TREE8(G[(LB) + 3], (LB) + 3, CB_, 8)
+
+// One filter for this lane's frame.  Taps at kf + BASEOFF bytes, 256 floats in order [i = 3,2,1,0][l][j].
+// On entry (pa,pb) hold the first 32 taps (already waited for); on exit they hold the first 32 taps found at
+// next_base + NEXTOFF (the following filter), so the pipeline never drains.
+template <int BASEOFF, int NEXTOFF>
+__device__ __forceinline__ float stft_filter(const float (&x)[64], const float *kf, const float *next_base,
+                                             f16v &pa, f16v &pb)
+{
+   f16v qa, qb;
+   float ga[8], gb[8], t23[8], v[8];
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_STAGE(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_3, l 0..3
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_STAGE(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);   // G_3, l 4..7
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_2
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+#pragma unroll
+   for (int l = 0; l < 8; ++l) t23[l] = gb[l] + __shfl_down(ga[l], 1);     // g_2 + g_3   (stft.c:166)
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_STAGE(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_1
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_STAGE(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_0
+   VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+#pragma unroll
+   for (int l = 0; l < 8; ++l) {
+      const float t01 = gb[l] + __shfl_down(ga[l], 1);                     // g_0 + g_1   (stft.c:165)
+      v[l] = t01 + __shfl_down(t23[l], 2);                                 // stft.c:167
+   }
+   const float s01 = v[0] + v[1], s23 = v[2] + v[3], s45 = v[4] + v[5], s67 = v[6] + v[7];   // stft.c:176-184
+   const float s0123 = s01 + s23, s4567 = s45 + s67;
+   return s0123 + s4567;
+}
+
+// MODE 0: Y = log1p(2^20 * magnitude), FM = mean over the 129 bins (the engine's normal path)
+// MODE 1: Y = magnitude (stage tap for the bit-exact STFT parity test), FM untouched
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 3) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
+                                                  const float *__restrict__ basis,    // [258][256] permuted
+                                                  float *__restrict__ Y,              // [n_chunks][129][25]
+                                                  float *__restrict__ FM,             // [n_chunks][25]
+                                                  int n_chunks)
+{
+   const int lane = threadIdx.x & 63;
+   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const long total_slots = (long)n_chunks * kBlocks;
+   const long slot0 = (long)wave * kLanesOut;
+   if (slot0 >= total_slots) return;                    // wave-uniform
+   const long slot = slot0 + lane;
+   const bool live = slot < total_slots;
+   const int chunk = live ? (int)(slot / kBlocks) : n_chunks - 1;
+   const int m = live ? (int)(slot - (long)chunk * kBlocks) : kBlocks - 1;
+
+   // this lane's block of the reflect-padded chunk (tensor.h:931-954): padded index 64m+k, source
+   // index s = 64m + k - 128, mirrored at both ends without repeating the edge sample.
+   float x[64];
+   const T *src = pcm + (size_t)chunk * kChunk;
+   if (m >= 2 && m <= 25) {
+      const T *p = src + (64 * m - kPad);
+#pragma unroll
+      for (int k = 0; k < 64; ++k) x[k] = sample_to_f32(p[k]);
+   } else {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+         int s = 64 * m + k - kPad;
+         s = s < 0 ? -s : s;
+         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
+         x[k] = sample_to_f32(src[s]);
+      }
+   }
+
+   const bool writer = live && lane < kLanesOut && m < kFrames;
+   float *yout = Y + (size_t)chunk * (kBins * kFrames) + m;
+   float bin_sum = 0.0f;
+   constexpr int kImOff = kBins * kFilterLen * 4;       // byte offset from filter f to filter f+129
+   f16v pa, pb;
+   VADC_SLOAD32(pa, pb, basis, 0);
+   VADC_SWAIT(pa, pb);
+   for (int f = 0; f < kBins; ++f) {
+      const float *kf = basis + (size_t)f * kFilterLen; // wave-uniform
+      const float re = stft_filter<0, kImOff>(x, kf, kf, pa, pb);
+      // the prefetch issued by the last stage of `im` reads filter f+1 (row 129 = im of bin 0 when f == 128)
+      const float im = stft_filter<kImOff, kFilterLen * 4>(x, kf, kf, pa, pb);
+      const float re2 = re * re, im2 = im * im;
+      const float mag = sqrtf(re2 + im2);                                  // stft.c:209
+      float val;
+      if (MODE == 0) {
+         val = log1pf(mag * 1048576.0f);                                   // misc.c:42-45
+         bin_sum += val;                                                   // misc.c:55-59 (channel order)
+      } else {
+         val = mag;
+      }
+      if (writer) yout[f * kFrames] = val;
+   }
+   if (MODE == 0 && writer) FM[(size_t)chunk * kFrames + m] = bin_sum / 129.0f;   // misc.c:60
+}
+
+template __global__ void k_frontend<float, 0>(const float *, const float *, float *, float *, int);
+template __global__ void k_frontend<float, 1>(const float *, const float *, float *, float *, int);
+template __global__ void k_frontend<int16_t, 0>(const int16_t *, const float *, float *, float *, int);
+template __global__ void k_frontend<int16_t, 1>(const int16_t *, const float *, float *, float *, int);
+
+// Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
+// The engine's normal path folds this subtraction into the first encoder layer.
+__device__ __forceinline__ float norm_offset(const float *__restrict__ fm)
+{
+   const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
+                          0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
+                          0.03663284704089164733887f};
+   float total = 0.0f;
+   for (int t = 0; t < kFrames; ++t) {
+      float r = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+         int q = t + i - 3;                              // reflect pad 3, no edge repeat
+         q = q < 0 ? -q : q;
+         q = q >= kFrames ? 2 * (kFrames - 1) - q : q;
+         const float pv = fm[q] * filt[i];
+         r += pv;
+      }
+      total += r;
+   }
+   return total / 25.0f;
+}
+
+__global__ void k_normalize_tap(const float *__restrict__ Y, const float *__restrict__ FM, float *__restrict__ out, int n_chunks)
+{
+   const int chunk = blockIdx.x;
+   if (chunk >= n_chunks) return;
+   const float mm = norm_offset(FM + (size_t)chunk * kFrames);
+   for (int i = threadIdx.x; i < kBins * kFrames; i += blockDim.x)
+      out[(size_t)chunk * kBins * kFrames + i] = Y[(size_t)chunk * kBins * kFrames + i] - mm;
+}
+
+// Stage tap only: inverse of the above for feeding a NORMALIZED or MAGNITUDE tensor into the encoder:
+// from magnitudes compute Y and FM with the reference's element order.
+__global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *__restrict__ Y, float *__restrict__ FM, int n_chunks)
+{
+   const int chunk = blockIdx.x;
+   const int t = threadIdx.x;
+   if (chunk >= n_chunks || t >= kFrames) return;
+   float s = 0.0f;
+   for (int f = 0; f < kBins; ++f) {
+      const size_t idx = (size_t)chunk * kBins * kFrames + f * kFrames + t;
+      const float v = log1pf(mag[idx] * 1048576.0f);
+      Y[idx] = v;
+      s += v;
+   }
+   FM[(size_t)chunk * kFrames + t] = s / 129.0f;
+}
+
+void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, int n, int mode, hipStream_t st)
+{
+   const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
+   const int blocks = (int)((waves + 3) / 4);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+   else           hipLaunchKernelGGL((k_frontend<float, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+}
+
+void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int mode, hipStream_t st)
+{
+   const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
+   const int blocks = (int)((waves + 3) / 4);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+}
+
+void launch_normalize_tap(const float *Y, const float *FM, float *out, int n, hipStream_t st)
+{
+   hipLaunchKernelGGL(k_normalize_tap, dim3(n), dim3(256), 0, st, Y, FM, out, n);
+}
+
+void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, int n, hipStream_t st)
+{
+   hipLaunchKernelGGL(k_lognorm_from_magnitude, dim3(n), dim3(64), 0, st, mag, Y, FM, n);
+}
+
+}  // namespace vadc
