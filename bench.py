@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
     ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=0, help="chunk groups pipelined per step (0 = engine default)")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +88,8 @@ def main():
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
+    if args.groups:
+        eng.set_option("groups", args.groups)
 
     # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
     base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
@@ -94,7 +97,8 @@ def main():
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(f"cuda:{local_rank}") for i in range(2)]
     d_probs = torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}")
     gather_list = [torch.empty_like(d_probs) for _ in range(world)] if (world > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # the HIP stream every launch of the hot path is issued on
+    torch.cuda.set_stream(stream)
 
     def step(i):
         eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs.data_ptr(), stream.cuda_stream)

@@ -92,8 +92,9 @@ int  vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, i
 /* Same from s16le PCM; the /32768.0f of vadc.c:883,898 happens on the device (exact in fp32). */
 int  vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs);
 
-/* Device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the engine's stream).
- * d_* are device pointers valid on the engine's device. */
+/* Device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's default stream, as in
+ * hipLaunchKernelGGL).  d_* are device pointers valid on the engine's device.  The call enqueues work only
+ * (no allocation, no host synchronisation), so it may be captured into a hipGraph for steady-state replay. */
 int  vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks,
                              float *d_probs, void *hip_stream);
 int  vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks,
@@ -124,7 +125,11 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* Select an implementation variant of a kernel (A/B testing and bring-up): key "lstm" -> 0 mfma, 1 simple. */
+/* Tuning / bring-up switches:  "lstm"   0 = MFMA kernel (default), 1 = simple reference kernel
+ *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
+ *                                      group g overlaps the front end + encoder of group g+1.
+ *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline
+ *                                      streams disjoint CU masks; 0: never mask. */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */

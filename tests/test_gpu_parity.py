@@ -258,6 +258,16 @@ def test_lstm_variants_agree(eng):
     assert float(np.abs(a - b).max()) < 2e-5
 
 
+@pytest.mark.parametrize("groups", [1, 2, 3, 4, 8])
+def test_chunk_group_pipeline_is_bit_identical(eng, groups):
+    """the fork/join over two HIP streams (front end + encoder || LSTM) must not change a bit"""
+    pcm = synth.make_streams(21, 13, seed0=64)
+    eng.set_option("groups", 1); eng.reset_streams(); want = eng.run(pcm)
+    eng.set_option("groups", groups); eng.reset_streams(); got = eng.run(pcm)
+    eng.set_option("groups", 0)
+    assert np.array_equal(bits(want), bits(got))
+
+
 def test_limits_are_enforced(eng):
     with pytest.raises(VadcAmdError):
         eng.run(np.zeros((65, 1536), np.int16))                 # > max_streams

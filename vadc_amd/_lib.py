@@ -32,6 +32,26 @@ class Caps(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  libvadc_amd.so needs `libamdhip64.so.7` (system ROCm by default).  A
+    PyTorch-ROCm wheel bundles its own copy and asks for it by the unversioned file name, so if OUR library
+    pulled in the system runtime first, torch would later load a second runtime and find no GPU.  When torch
+    is installed, load its bundled runtime first (by SONAME both resolve to it); C hosts never get here and
+    use the system runtime through DT_NEEDED.  Set VADC_AMD_HIP_RUNTIME=system to skip."""
+    if os.environ.get("VADC_AMD_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -40,6 +60,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C vadc_amd/csrc). vadc_amd has no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     L.vadc_amd_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, i32, C.POINTER(vp)]
@@ -65,7 +86,6 @@ def load() -> C.CDLL:
     L.vadc_amd_kernel_name.argtypes = [i32]
     L.vadc_amd_kernel_name.restype = C.c_char_p
     for name in SYMBOLS:
-        if getattr(L, name).restype is C.c_int or name in ("vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_kernel_name"):
-            continue
+        getattr(L, name)          # AttributeError here == header/library mismatch
     _lib = L
     return L

@@ -38,6 +38,33 @@ struct LayerWeights {
    const float *cv_b;     // [d]
 };
 
+// A launch may cover only chunks [c0, c0+cg) of every stream (the engine pipelines chunk groups so that the
+// latency-bound LSTM of group g overlaps the front end / encoder of group g+1).  Buffers keep the full
+// stream-major layout item n = stream * C + chunk; launch-local item i maps to n as below.
+struct ItemMap {
+   int C, c0, cg;
+   __host__ __device__ __forceinline__ int operator()(int i) const
+   {
+      const int s = i / cg;
+      return s * C + c0 + (i - s * cg);
+   }
+   __host__ __device__ __forceinline__ void split(int i, int &stream, int &chunk) const
+   {
+      stream = i / cg;
+      chunk = c0 + (i - stream * cg);
+   }
+};
+
+// Encoder -> LSTM hand-off layout ("LSTM-native"): streams are tiled by 16 (the MFMA N dimension) and one
+// (tile, chunk) block holds the chunk's 7 frames as [t][unit][stream-in-tile], i.e. exactly the LDS image
+// k_lstm_mfma uses as its B operand, so the LSTM stages a chunk with coalesced 16-byte loads.
+//   X[((tile * C + chunk) * 7 + t) * 64 + unit) * 16 + stream % 16]
+constexpr int kLstmTile = 16;
+__host__ __device__ __forceinline__ size_t lstm_x_index(int stream, int chunk, int C, int t, int unit)
+{
+   return ((((size_t)(stream / kLstmTile) * C + chunk) * 7 + t) * 64 + unit) * kLstmTile + (stream % kLstmTile);
+}
+
 struct LstmWeights {
    const float *w;        // [2][256][128]  reference layout: [layer][gate*64+unit][x(64) | h(64)]
    const float *wT;       // [2][128][256]  k-major copy for the simple kernel

@@ -15,12 +15,12 @@
 #include <vector>
 
 namespace vadc {
-void launch_frontend_f32(const float *, const float *, float *, float *, int, int, hipStream_t);
-void launch_frontend_s16(const int16_t *, const float *, float *, float *, int, int, hipStream_t);
+void launch_frontend_f32(const float *, const float *, float *, float *, int, ItemMap, int, hipStream_t);
+void launch_frontend_s16(const int16_t *, const float *, float *, float *, int, ItemMap, int, hipStream_t);
 void launch_normalize_tap(const float *, const float *, float *, int, hipStream_t);
 void launch_lognorm_from_magnitude(const float *, float *, float *, int, hipStream_t);
-void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, hipStream_t);
-void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, hipStream_t);
+void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, hipStream_t);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t);
 }  // namespace vadc
 
 using namespace vadc;
@@ -109,6 +109,14 @@ struct vadc_amd_engine {
    float *d_probs = nullptr;
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
+   // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
+   static constexpr int kMaxGroups = 16;
+   int groups = 0;                              // 0 = auto
+   hipStream_t sA = nullptr, sB = nullptr;
+   int n_cus = 0;
+   int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
+   int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
+   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr, ev_fe[kMaxGroups] = {nullptr};
    // profiling
    bool profiling = false;
    struct EvPair { hipEvent_t a, b; };
@@ -234,6 +242,10 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
                    e->d_act[2], e->d_act[3], e->d_probs, e->d_h, e->d_c};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
+   if (e->sA) (void)hipStreamDestroy(e->sA);
+   if (e->sB) (void)hipStreamDestroy(e->sB);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
 
@@ -270,12 +282,19 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+   e->n_cus = prop.multiProcessorCount;
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
    if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_FM, N * kFrames * sizeof(float));
-   for (int l = 0; l < 4 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
+   for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
+   // encoder output: LSTM-native layout, streams padded to whole tiles of 16
+   const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
+   if (he == hipSuccess) he = hipMalloc(&e->d_act[3], padded_streams * max_chunks * 448 * sizeof(float));
+   if (he == hipSuccess) he = hipMemset(e->d_act[3], 0, padded_streams * max_chunks * 448 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -383,6 +402,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 1)) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
+   if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
 }
 
@@ -399,28 +420,107 @@ static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const ch
    return VADC_AMD_OK;
 }
 
-static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, hipStream_t st)
+// lstm_layout: the last layer writes the LSTM-native tile layout (hot path) instead of [n][64][7] (stage taps)
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st)
 {
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, st);
+      launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, st);
    }
 }
 
 template <typename T>
-static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, hipStream_t st)
 {
-   const int n = n_streams * n_chunks;
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, 0, st);
-      else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, 0, st);
+      if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, map, 0, st);
+      else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, map, 0, st);
    }
-   run_encoder_layers(e, 0, 3, n, st);
-   {
+   run_encoder_layers(e, 0, 3, n, map, 1, st);
+}
+
+// Streams A (front end + encoder) and B (LSTM) of the chunk-group pipeline.  The LSTM of a small batch is
+// latency-bound on a handful of workgroups (16 streams each) while the front end wants every CU, and a
+// front-end grid that already fills the machine would keep the LSTM workgroups waiting for a free CU.  So
+// when the LSTM needs few CUs the two streams get DISJOINT CU masks (hipExtStreamCreateWithCUMask): the
+// LSTM chain owns `want` CUs outright and runs truly concurrently with the next group's front end.
+static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
+{
+   const int lstm_wgs = (n_streams + 15) / 16;
+   int want = 0;
+   if (e->cu_partition && lstm_wgs <= e->n_cus / 4) want = ((lstm_wgs + 7) / 8) * 8;   // multiples of 8: one per XCD
+   if (e->lstm_cus == want && e->sA && e->sB) return VADC_AMD_OK;
+   if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
+   if (e->sB) { HIP_TRY(hipStreamSynchronize(e->sB), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
+   bool masked = false;
+   if (want > 0) {
+      const int words = (e->n_cus + 31) / 32;
+      std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
+      for (int cu = 0; cu < e->n_cus; ++cu) (cu < want ? mb : ma)[cu / 32] |= 1u << (cu % 32);
+      hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
+      hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
+      masked = (ea == hipSuccess && eb == hipSuccess);
+      if (!masked) {
+         (void)hipGetLastError();
+         if (e->sA) { (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
+         if (e->sB) { (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
+      }
+   }
+   if (!masked) {
+      want = 0;
+      HIP_TRY(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking), VADC_AMD_EHIP);
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = highest priority
+      HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
+   }
+   e->lstm_cus = want;
+   return VADC_AMD_OK;
+}
+
+static int pick_groups(const vadc_amd_engine *e, int n_chunks)
+{
+   int g = e->groups;
+   if (g <= 0) g = n_chunks >= 16 ? 4 : (n_chunks >= 4 ? 2 : 1);
+   if (g > n_chunks) g = n_chunks;
+   return g < 1 ? 1 : g;
+}
+
+// The whole hot path for n_streams x n_chunks chunks; asynchronous on `st`.  No allocation, no host sync:
+// the sequence (including the fork/join over the two internal streams) can be captured into a hipGraph.
+template <typename T>
+static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+{
+   const int G = pick_groups(e, n_chunks);
+   if (G == 1) {
+      const ItemMap map{n_chunks, 0, n_chunks};
+      run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, st);
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-      launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
+      launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st);
+   } else {
+      int rc = ensure_pipeline_streams(e, n_streams);
+      if (rc) return rc;
+      // fork: stream A = front end + encoder of every chunk group in order, stream B = the LSTM chain
+      (void)hipEventRecord(e->ev_in, st);
+      (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
+      (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+      const int cg_max = (n_chunks + G - 1) / G;
+      int gi = 0;
+      for (int c0 = 0; c0 < n_chunks; c0 += cg_max, ++gi) {
+         const int cg = (c0 + cg_max <= n_chunks) ? cg_max : n_chunks - c0;
+         const ItemMap map{n_chunks, c0, cg};
+         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, e->sA);
+         (void)hipEventRecord(e->ev_fe[gi], e->sA);
+         (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
+         KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
+         launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB);
+      }
+      // join
+      (void)hipEventRecord(e->ev_a, e->sA);
+      (void)hipEventRecord(e->ev_b, e->sB);
+      (void)hipStreamWaitEvent(st, e->ev_a, 0);
+      (void)hipStreamWaitEvent(st, e->ev_b, 0);
    }
    hipError_t he = hipGetLastError();
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
@@ -433,7 +533,7 @@ extern "C" int vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_sample
    if (rc) return rc;
    if (!d_samples || !d_probs) return fail(VADC_AMD_EINVAL, "run_device_f32: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
-   return run_device<float>(e, d_samples, n_streams, n_chunks, d_probs, hip_stream ? (hipStream_t)hip_stream : e->stream);
+   return run_device<float>(e, d_samples, n_streams, n_chunks, d_probs, (hipStream_t)hip_stream);
 }
 
 extern "C" int vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks, float *d_probs, void *hip_stream)
@@ -442,7 +542,7 @@ extern "C" int vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm,
    if (rc) return rc;
    if (!d_pcm || !d_probs) return fail(VADC_AMD_EINVAL, "run_device_s16: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
-   return run_device<int16_t>(e, d_pcm, n_streams, n_chunks, d_probs, hip_stream ? (hipStream_t)hip_stream : e->stream);
+   return run_device<int16_t>(e, d_pcm, n_streams, n_chunks, d_probs, (hipStream_t)hip_stream);
 }
 
 extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
@@ -543,9 +643,10 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
-   launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, n, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   const ItemMap map{n, 0, n};
+   launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
-   if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, st);
+   if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * kStageElems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
@@ -573,7 +674,7 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
       HIP_TRY(hipMemcpyAsync(e->d_act[first_layer - 1], in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    }
    if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
-   else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, st);
+   else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, ItemMap{n, 0, n}, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * kStageElems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
@@ -588,8 +689,18 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    hipStream_t st = e->stream;
    const size_t n = (size_t)n_streams * n_chunks;
-   HIP_TRY(hipMemcpyAsync(e->d_act[3], x, n * 448 * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
-   launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, st);
+   {
+      // pure data movement: reference layout [S][C][64][7] -> LSTM-native tiles (common.h)
+      const size_t padded = (size_t)((n_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
+      std::vector<float> tiles(padded * n_chunks * 448, 0.0f);
+      for (int s = 0; s < n_streams; ++s)
+         for (int c = 0; c < n_chunks; ++c)
+            for (int u = 0; u < 64; ++u)
+               for (int t = 0; t < 7; ++t)
+                  tiles[lstm_x_index(s, c, n_chunks, t, u)] = x[(((size_t)s * n_chunks + c) * 64 + u) * 7 + t];
+      HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   }
+   launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);

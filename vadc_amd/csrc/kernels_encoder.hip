@@ -80,12 +80,12 @@ __device__ __forceinline__ void layer_norm(float (&x)[D], const float *__restric
    for (int i = 0; i < D; ++i) x[i] = fmaf(fmaf(x[i], rstd, -mr), w[i], b[i]);
 }
 
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, int CB, int NTHREADS>
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, int CB, int NTHREADS, bool LSTM_OUT>
 __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [n][25] (FIRST) or null
                                                     LayerWeights w,
                                                     float *__restrict__ out,        // [n][D][TOUT]
-                                                    int n_chunks)
+                                                    int n_chunks, ItemMap map)
 {
    constexpr int TOUT = 1 + (T - 1) / STRIDE;
    constexpr int HD = D / 2;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
    const int t = tid - cb * T;
    const int chunk_raw = blockIdx.x * CB + cb;
    const bool valid = (cb < CB) && (chunk_raw < n_chunks);
-   const int chunk = valid ? chunk_raw : (n_chunks - 1);   // clamped: loads stay in bounds, stores are skipped
+   const int chunk = map(valid ? chunk_raw : (n_chunks - 1));   // clamped: loads stay in bounds, stores are skipped
    const int cbs = cb < CB ? cb : CB - 1;
 
    const float *x_in = in + (size_t)chunk * CIN * T;
@@ -220,7 +220,16 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
 
    // ---- conv k=1 stride s (+ folded BatchNorm) -> ReLU; only the surviving time steps -------------------
    if (valid && (t % STRIDE) == 0) {
-      float *dst = out + (size_t)chunk * D * TOUT + t / STRIDE;
+      // reference layout [n][D][TOUT] (element stride TOUT), or the LSTM-native tile layout (last layer)
+      constexpr int ostride = LSTM_OUT ? kLstmTile : TOUT;
+      float *dst;
+      if (LSTM_OUT) {
+         int st_, ch_;
+         map.split(chunk_raw, st_, ch_);
+         dst = out + lstm_x_index(st_, ch_, map.C, t / STRIDE, 0);
+      } else {
+         dst = out + (size_t)chunk * D * TOUT + t / STRIDE;
+      }
 #pragma unroll
       for (int o = 0; o < D; o += 4) {
          float a0 = w.cv_b[o], a1 = w.cv_b[o + 1], a2 = w.cv_b[o + 2], a3 = w.cv_b[o + 3];
@@ -231,10 +240,10 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
             a2 = fmaf(w.cv_w[(o + 2) * D + d], y[d], a2);
             a3 = fmaf(w.cv_w[(o + 3) * D + d], y[d], a3);
          }
-         dst[(o + 0) * TOUT] = fmaxf(a0, 0.0f);
-         dst[(o + 1) * TOUT] = fmaxf(a1, 0.0f);
-         dst[(o + 2) * TOUT] = fmaxf(a2, 0.0f);
-         dst[(o + 3) * TOUT] = fmaxf(a3, 0.0f);
+         dst[(o + 0) * ostride] = fmaxf(a0, 0.0f);
+         dst[(o + 1) * ostride] = fmaxf(a1, 0.0f);
+         dst[(o + 2) * ostride] = fmaxf(a2, 0.0f);
+         dst[(o + 3) * ostride] = fmaxf(a3, 0.0f);
       }
    }
 }
@@ -242,13 +251,17 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
 // chunks per workgroup / threads per workgroup, chosen so that CB*T fills the waves
 //   L1: T=25 -> 10 chunks = 250 of 256 lanes     L2: T=13 -> 9 chunks = 117 of 128 lanes
 //   L3/L4: T=7 -> 9 chunks = 63 of 64 lanes
-void launch_layer(int layer, const float *in, const float *fm, const LayerWeights &w, float *out, int n, hipStream_t st)
+void launch_layer(int layer, const float *in, const float *fm, const LayerWeights &w, float *out, int n, ItemMap map,
+                  int lstm_layout, hipStream_t st)
 {
    switch (layer) {
-   case 0: hipLaunchKernelGGL((k_layer<129, 16, 25, 2, true, true, 10, 256>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n); break;
-   case 1: hipLaunchKernelGGL((k_layer<16, 32, 13, 2, true, false, 9, 128>), dim3((n + 8) / 9), dim3(128), 0, st, in, fm, w, out, n); break;
-   case 2: hipLaunchKernelGGL((k_layer<32, 32, 7, 1, false, false, 9, 64>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n); break;
-   case 3: hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n); break;
+   case 0: hipLaunchKernelGGL((k_layer<129, 16, 25, 2, true, true, 10, 256, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map); break;
+   case 1: hipLaunchKernelGGL((k_layer<16, 32, 13, 2, true, false, 9, 128, false>), dim3((n + 8) / 9), dim3(128), 0, st, in, fm, w, out, n, map); break;
+   case 2: hipLaunchKernelGGL((k_layer<32, 32, 7, 1, false, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map); break;
+   case 3:
+      if (lstm_layout) hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, true>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map);
+      else             hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map);
+      break;
    }
 }
 

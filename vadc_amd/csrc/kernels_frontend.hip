@@ -71,10 +71,25 @@ typedef float f16v __attribute__((ext_vector_type(16)));
    VADC_TREE8(G[(LB) + 0], (LB) + 0, CA, 0) VADC_TREE8(G[(LB) + 1], (LB) + 1, CA, 8)    \
    VADC_TREE8(G[(LB) + 2], (LB) + 2, CB_, 0) VADC_TREE8(G[(LB) + 3], (LB) + 3, CB_, 8)
 
+// lane i <- lane i+1 (0 shifted in at lane 63).  SHIFT = 0: ds_bpermute (__shfl_down); SHIFT = 1: DPP
+// wave_shl:1 folded into the consuming v_add_f32 (no LDS-queue traffic, no lgkmcnt wait).
+template <int SHIFT>
+__device__ __forceinline__ float lane_up1(float v)
+{
+   if (SHIFT == 0) return __shfl_down(v, 1);
+   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+template <int SHIFT>
+__device__ __forceinline__ float lane_up2(float v)
+{
+   if (SHIFT == 0) return __shfl_down(v, 2);
+   return lane_up1<1>(lane_up1<1>(v));
+}
+
 // One filter for this lane's frame.  Taps at kf + BASEOFF bytes, 256 floats in order [i = 3,2,1,0][l][j].
 // On entry (pa,pb) hold the first 32 taps (already waited for); on exit they hold the first 32 taps found at
 // next_base + NEXTOFF (the following filter), so the pipeline never drains.
-template <int BASEOFF, int NEXTOFF>
+template <int BASEOFF, int NEXTOFF, int SHIFT>
 __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *kf, const float *next_base,
                                              f16v &pa, f16v &pb)
 {
@@ -85,15 +100,68 @@ __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *
    VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_2
    VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
 #pragma unroll
-   for (int l = 0; l < 8; ++l) t23[l] = gb[l] + __shfl_down(ga[l], 1);     // g_2 + g_3   (stft.c:166)
+   for (int l = 0; l < 8; ++l) t23[l] = gb[l] + lane_up1<SHIFT>(ga[l]);     // g_2 + g_3   (stft.c:166)
    VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_STAGE(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_1
    VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_STAGE(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);
    VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_0
    VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
 #pragma unroll
    for (int l = 0; l < 8; ++l) {
-      const float t01 = gb[l] + __shfl_down(ga[l], 1);                     // g_0 + g_1   (stft.c:165)
-      v[l] = t01 + __shfl_down(t23[l], 2);                                 // stft.c:167
+      const float t01 = gb[l] + lane_up1<SHIFT>(ga[l]);                    // g_0 + g_1   (stft.c:165)
+      v[l] = t01 + lane_up2<SHIFT>(t23[l]);                                // stft.c:167
+   }
+   const float s01 = v[0] + v[1], s23 = v[2] + v[3], s45 = v[4] + v[5], s67 = v[6] + v[7];   // stft.c:176-184
+   const float s0123 = s01 + s23, s4567 = s45 + s67;
+   return s0123 + s4567;
+}
+
+// ---- PIPE = 1: mul/add interleaved software pipeline -------------------------------------------------
+// Measured on MI355X (tools/valu_rate.hip): v_mul_f32/v_add_f32 with VGPR operands issue at 2 cycles per
+// wave64 instruction, but any VALU op with an SGPR operand takes 4 -- unless SGPR-operand and VGPR-only
+// instructions ALTERNATE, in which case the pair costs ~4.8 (2.4 each).  The tree needs 256 SGPR-operand muls
+// and 255 VGPR-only adds per output, so the stream is arranged as (mul of tree t+1, add of tree t) pairs:
+// each "slot" multiplies the 8 products of a new tree while it reduces the 8 products of the previous one.
+// sched_barrier(0) after every pair pins the order (the expression, hence every rounding, is unchanged).
+#define VADC_SB __builtin_amdgcn_sched_barrier(0)
+#define VADC_SLOT(DST, LN, KV, O)                                                                     \
+   {                                                                                                  \
+      const float q0 = x[0 * 8 + (LN)] * KV[(O) + 0]; const float a01 = p[0] + p[1]; VADC_SB;         \
+      const float q1 = x[1 * 8 + (LN)] * KV[(O) + 1]; const float a23 = p[2] + p[3]; VADC_SB;         \
+      const float q2 = x[2 * 8 + (LN)] * KV[(O) + 2]; const float a45 = p[4] + p[5]; VADC_SB;         \
+      const float q3 = x[3 * 8 + (LN)] * KV[(O) + 3]; const float a67 = p[6] + p[7]; VADC_SB;         \
+      const float q4 = x[4 * 8 + (LN)] * KV[(O) + 4]; const float b03 = a01 + a23; VADC_SB;           \
+      const float q5 = x[5 * 8 + (LN)] * KV[(O) + 5]; const float b47 = a45 + a67; VADC_SB;           \
+      const float q6 = x[6 * 8 + (LN)] * KV[(O) + 6]; DST = b03 + b47; VADC_SB;                       \
+      const float q7 = x[7 * 8 + (LN)] * KV[(O) + 7]; VADC_SB;                                        \
+      p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3; p[4] = q4; p[5] = q5; p[6] = q6; p[7] = q7;         \
+   }
+// four trees: three from the current buffer (C*), then -- after the wait -- the first tree of the next one (N*)
+#define VADC_PSTAGE(G, LB, CA, CB_, NA, NB, GN, LNEXT)                                                \
+   VADC_SLOT(G[(LB) + 0], (LB) + 1, CA, 8) VADC_SLOT(G[(LB) + 1], (LB) + 2, CB_, 0)                   \
+   VADC_SLOT(G[(LB) + 2], (LB) + 3, CB_, 8) VADC_SWAIT(NA, NB); VADC_SLOT(G[(LB) + 3], LNEXT, NA, 0)
+
+// Same contract as stft_filter plus the carry p[8]: on entry the products of this filter's first tree, on
+// exit the products of the next filter's first tree.
+template <int BASEOFF, int NEXTOFF, int SHIFT>
+__device__ __forceinline__ float stft_filter_pipe(const float (&x)[64], const float *kf, const float *next_base,
+                                                  f16v &pa, f16v &pb, float (&p)[8])
+{
+   f16v qa, qb;
+   float ga[8], gb[8], t23[8], v[8];
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_PSTAGE(ga, 0, pa, pb, qa, qb, ga, 4)   // G_3
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_PSTAGE(ga, 4, qa, qb, pa, pb, gb, 0)
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_PSTAGE(gb, 0, pa, pb, qa, qb, gb, 4)   // G_2
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_PSTAGE(gb, 4, qa, qb, pa, pb, ga, 0)
+#pragma unroll
+   for (int l = 0; l < 8; ++l) t23[l] = gb[l] + lane_up1<SHIFT>(ga[l]);     // g_2 + g_3   (stft.c:166)
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_PSTAGE(ga, 0, pa, pb, qa, qb, ga, 4)   // G_1
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_PSTAGE(ga, 4, qa, qb, pa, pb, gb, 0)
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_PSTAGE(gb, 0, pa, pb, qa, qb, gb, 4)   // G_0
+   VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_PSTAGE(gb, 4, qa, qb, pa, pb, ga, 0)   // + next filter's tree 0
+#pragma unroll
+   for (int l = 0; l < 8; ++l) {
+      const float t01 = gb[l] + lane_up1<SHIFT>(ga[l]);                    // g_0 + g_1   (stft.c:165)
+      v[l] = t01 + lane_up2<SHIFT>(t23[l]);                                // stft.c:167
    }
    const float s01 = v[0] + v[1], s23 = v[2] + v[3], s45 = v[4] + v[5], s67 = v[6] + v[7];   // stft.c:176-184
    const float s0123 = s01 + s23, s4567 = s45 + s67;
@@ -102,22 +170,28 @@ __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *
 
 // MODE 0: Y = log1p(2^20 * magnitude), FM = mean over the 129 bins (the engine's normal path)
 // MODE 1: Y = magnitude (stage tap for the bit-exact STFT parity test), FM untouched
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, 3) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
+// Tuning knobs (tools/fe_bench.hip sweeps them on the device):
+//   NT       threads per workgroup              MINW   min waves per SIMD (register cap)
+//   SHIFT    0 ds_bpermute / 1 DPP wave shift   LOCK   1: one barrier per filter pair keeps the workgroup's waves
+//            on the same basis rows so that they share scalar-cache lines
+//   STAGGER  1: each workgroup starts at a different filter (rotated order) to spread the L2 channels
+template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int LOCK = 0, int STAGGER = 0, int PIPE = 0>
+__global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                   const float *__restrict__ basis,    // [258][256] permuted
                                                   float *__restrict__ Y,              // [n_chunks][129][25]
                                                   float *__restrict__ FM,             // [n_chunks][25]
-                                                  int n_chunks)
+                                                  int n_chunks, ItemMap map)
 {
    const int lane = threadIdx.x & 63;
    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
    const long total_slots = (long)n_chunks * kBlocks;
    const long slot0 = (long)wave * kLanesOut;
-   if (slot0 >= total_slots) return;                    // wave-uniform
+   if (!LOCK && slot0 >= total_slots) return;           // wave-uniform (with LOCK every wave must reach the barriers)
    const long slot = slot0 + lane;
    const bool live = slot < total_slots;
-   const int chunk = live ? (int)(slot / kBlocks) : n_chunks - 1;
-   const int m = live ? (int)(slot - (long)chunk * kBlocks) : kBlocks - 1;
+   const int item = live ? (int)(slot / kBlocks) : n_chunks - 1;
+   const int m = live ? (int)(slot - (long)item * kBlocks) : kBlocks - 1;
+   const int chunk = map(item);                         // position in the stream-major buffers
 
    // this lane's block of the reflect-padded chunk (tensor.h:931-954): padded index 64m+k, source
    // index s = 64m + k - 128, mirrored at both ends without repeating the edge sample.
@@ -141,14 +215,28 @@ __global__ __launch_bounds__(256, 3) void k_frontend(const T *__restrict__ pcm, 
    float *yout = Y + (size_t)chunk * (kBins * kFrames) + m;
    float bin_sum = 0.0f;
    constexpr int kImOff = kBins * kFilterLen * 4;       // byte offset from filter f to filter f+129
+   const int f_start = STAGGER ? (int)((blockIdx.x * 37u) % (unsigned)kBins) : 0;
    f16v pa, pb;
-   VADC_SLOAD32(pa, pb, basis, 0);
-   VADC_SWAIT(pa, pb);
-   for (int f = 0; f < kBins; ++f) {
+   {
+      const float *k0 = basis + (size_t)f_start * kFilterLen;
+      VADC_SLOAD32(pa, pb, k0, 0);
+      VADC_SWAIT(pa, pb);
+   }
+   float p[8];                                          // PIPE: products of the first tree of the first filter
+#pragma unroll
+   for (int j = 0; j < 8; ++j) p[j] = PIPE ? x[j * 8] * pa[j] : 0.0f;
+   for (int fi = 0; fi < kBins; ++fi) {
+      const int f = STAGGER ? (fi + f_start >= kBins ? fi + f_start - kBins : fi + f_start) : fi;
+      const int fn = STAGGER ? (f + 1 >= kBins ? 0 : f + 1) : f + 1;
       const float *kf = basis + (size_t)f * kFilterLen; // wave-uniform
-      const float re = stft_filter<0, kImOff>(x, kf, kf, pa, pb);
-      // the prefetch issued by the last stage of `im` reads filter f+1 (row 129 = im of bin 0 when f == 128)
-      const float im = stft_filter<kImOff, kFilterLen * 4>(x, kf, kf, pa, pb);
+      const float *kn = basis + (size_t)fn * kFilterLen;
+      if (LOCK) __syncthreads();
+      const float re = PIPE ? stft_filter_pipe<0, kImOff, SHIFT>(x, kf, kf, pa, pb, p)
+                            : stft_filter<0, kImOff, SHIFT>(x, kf, kf, pa, pb);
+      // the prefetch issued by the last stage of `im` reads the next filter's first taps (row 129 = im of
+      // bin 0 when f == 128 and there is no stagger: in bounds, unused)
+      const float im = PIPE ? stft_filter_pipe<kImOff, 0, SHIFT>(x, kf, kn, pa, pb, p)
+                            : stft_filter<kImOff, 0, SHIFT>(x, kf, kn, pa, pb);
       const float re2 = re * re, im2 = im * im;
       const float mag = sqrtf(re2 + im2);                                  // stft.c:209
       float val;
@@ -163,10 +251,6 @@ __global__ __launch_bounds__(256, 3) void k_frontend(const T *__restrict__ pcm, 
    if (MODE == 0 && writer) FM[(size_t)chunk * kFrames + m] = bin_sum / 129.0f;   // misc.c:60
 }
 
-template __global__ void k_frontend<float, 0>(const float *, const float *, float *, float *, int);
-template __global__ void k_frontend<float, 1>(const float *, const float *, float *, float *, int);
-template __global__ void k_frontend<int16_t, 0>(const int16_t *, const float *, float *, float *, int);
-template __global__ void k_frontend<int16_t, 1>(const int16_t *, const float *, float *, float *, int);
 
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
@@ -217,20 +301,21 @@ __global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *_
    FM[(size_t)chunk * kFrames + t] = s / 129.0f;
 }
 
-void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, int n, int mode, hipStream_t st)
+// n = number of items in this launch (= n_streams * map.cg)
+void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const int blocks = (int)((waves + 3) / 4);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
-   else           hipLaunchKernelGGL((k_frontend<float, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
+   else           hipLaunchKernelGGL((k_frontend<float, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
 }
 
-void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int mode, hipStream_t st)
+void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const int blocks = (int)((waves + 3) / 4);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
-   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
+   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
 }
 
 void launch_normalize_tap(const float *Y, const float *FM, float *out, int n, hipStream_t st)

@@ -16,7 +16,7 @@
 //   Wave w owns hidden units [16w,16w+16) for ALL four gates, so the i,f,g,o values of one (unit, stream) land in
 //   the same lane/register of its four accumulators and the cell update is register-local.  Both layers' weights
 //   live in registers as MFMA A-fragments (2 x 4 x 32 VGPRs) for the whole call; [x;h] is the B operand, read
-//   from a small LDS tile.  4 barriers per step.
+//   from a small LDS tile that double-buffers h: one barrier per (step, layer).
 // k_lstm_simple: bring-up/reference variant (one wave per stream, weights streamed from L2), selectable with
 //   vadc_amd_set_option(e, "lstm", 1); used by the tests to A/B the MFMA kernel on the device.
 #include "common.h"
@@ -25,15 +25,21 @@ namespace vadc {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// Hardware-transcendental forms for the recurrent inner loop (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute
+// error <= ~3e-7 on values in (0,1) / (-1,1), two decades below what the 1e-4 probability bar needs, and the
+// recurrence is contractive.  The bring-up kernel keeps the libm-grade forms for A/B tests.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+
 // ------------------------------------------------------------------------------------------------
 // simple variant
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lstm_simple(const float *__restrict__ enc,   // [S][C][64][7]
+__global__ __launch_bounds__(64) void k_lstm_simple(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
                                                     LstmWeights w,
                                                     float *__restrict__ hs,          // [S][2][64]
                                                     float *__restrict__ cs,          // [S][2][64]
                                                     float *__restrict__ probs,       // [S][C][2]
-                                                    int n_streams, int n_chunks)
+                                                    int n_streams, int n_chunks, int ch0, int chn)
 {
    __shared__ float xh[128];
    const int s = blockIdx.x;
@@ -43,13 +49,13 @@ __global__ __launch_bounds__(64) void k_lstm_simple(const float *__restrict__ en
    float c0 = cs[(size_t)s * 128 + j], c1 = cs[(size_t)s * 128 + 64 + j];
    const float dw0 = w.dec_w[j], dw1 = w.dec_w[64 + j];
 
-   for (int ch = 0; ch < n_chunks; ++ch) {
-      const float *x = enc + ((size_t)s * n_chunks + ch) * 64 * 7;
+   for (int ch = ch0; ch < ch0 + chn; ++ch) {
+      const float *x = enc + lstm_x_index(s, ch, n_chunks, 0, j);        // + t * 64 * 16
       float d0 = 0.0f, d1 = 0.0f;                          // sum over t of (w . relu(h1_t))
       for (int t = 0; t < 7; ++t) {
 #pragma unroll
          for (int l = 0; l < 2; ++l) {
-            const float xin = (l == 0) ? x[j * 7 + t] : h0;
+            const float xin = (l == 0) ? x[(size_t)t * 64 * kLstmTile] : h0;
             __syncthreads();
             xh[j] = xin;
             xh[64 + j] = (l == 0) ? h0 : h1;
@@ -88,29 +94,40 @@ __global__ __launch_bounds__(64) void k_lstm_simple(const float *__restrict__ en
 // ------------------------------------------------------------------------------------------------
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int kTileS = 16;          // streams per workgroup (= MFMA N)
+// LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS base) + lane*16 without touching VGPRs
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+__device__ __forceinline__ void dma16(const float4 *src_lane, float *lds_wave_base)
+{
+   __builtin_amdgcn_global_load_lds((gbl_void_t *)src_lane, (lds_void_t *)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int kTileS = kLstmTile;    // streams per workgroup (= MFMA N)
+constexpr int kXTile = 7 * 64 * kTileS;   // floats of one (tile, chunk) block of the encoder output
 
 // v_mfma_f32_16x16x4_f32 lane maps (cdna_hip_programming.md section 3):
 //   A: lane l holds A[row = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][col = l & 15]
 //   D: lane l, reg r holds D[row = 4 (l >> 4) + r][col = l & 15]
-__global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ enc,   // [S][C][64][7]
+__global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
                                                       LstmWeights w,
                                                       float *__restrict__ hs, float *__restrict__ cs,
                                                       float *__restrict__ probs,
-                                                      int n_streams, int n_chunks)
+                                                      int n_streams, int n_chunks, int c0, int cg)
 {
-   __shared__ float xs[7 * 64 * kTileS];     // [t][unit][stream]  the chunk's encoder frames
-   __shared__ float hb[2][64 * kTileS];      // [layer][unit][stream]  current hidden state
-   __shared__ float dacc[2 * kTileS];
+   __shared__ __attribute__((aligned(16))) float xs[2][kXTile];   // [parity][t][unit][stream]  double buffered
+   __shared__ float hb[2][2][64 * kTileS];      // [layer][parity][unit][stream]  hidden state, double buffered
+   __shared__ float pd[4][2][kTileS];           // decoder partial dots per wave
+   __shared__ __attribute__((aligned(16))) float bl[2][256];                 // fused gate biases (accumulator init values)
 
    const int tid = threadIdx.x;
    const int lane = tid & 63;
-   const int wv = tid >> 6;                  // wave: owns hidden units [16 wv, 16 wv + 16)
-   const int col = lane & 15;                // stream within the tile
+   const int wv = tid >> 6;                     // wave: owns hidden units [16 wv, 16 wv + 16)
+   const int col = lane & 15;                   // stream within the tile
    const int quad = lane >> 4;
    const int s0 = blockIdx.x * kTileS;
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = (s0 + col) < n_streams;
+   const float4 *tile_base = reinterpret_cast<const float4 *>(enc + (size_t)blockIdx.x * n_chunks * kXTile);
 
    // A fragments: a[l][g][kk] = W[l][g*64 + 16 wv + (lane & 15)][4 kk + (lane >> 4)]
    float a[2][4][32];
@@ -122,38 +139,52 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 #pragma unroll
          for (int kk = 0; kk < 32; ++kk) a[l][g][kk] = row[4 * kk];
       }
-   // biases / cell state in the D layout: unit = 16 wv + 4 quad + r, stream = col
-   float bias[2][4][4], c[2][4];
+   // biases / cell state / decoder weights in the D layout: unit = 16 wv + 4 quad + r, stream = col
+   float c[2][4], dw[2][4];
+   for (int i = tid; i < 512; i += 256) bl[i >> 8][i & 255] = w.b[i];
 #pragma unroll
-   for (int l = 0; l < 2; ++l)
+   for (int r = 0; r < 4; ++r) {
+      const int u = 16 * wv + 4 * quad + r;
+      dw[0][r] = w.dec_w[u];
+      dw[1][r] = w.dec_w[64 + u];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const int u = 16 * wv + 4 * quad + r;
-#pragma unroll
-         for (int g = 0; g < 4; ++g) bias[l][g][r] = w.b[l * 256 + g * 64 + u];
+      for (int l = 0; l < 2; ++l) {
          c[l][r] = cs[(size_t)s_col * 128 + l * 64 + u];
-         hb[l][u * kTileS + col] = hs[(size_t)s_col * 128 + l * 64 + u];
+         hb[l][0][u * kTileS + col] = hs[(size_t)s_col * 128 + l * 64 + u];
       }
+   }
+   // stage the first chunk: 7168 contiguous floats, 7 coalesced float4 per thread
+   {
+      const float4 *src = tile_base + (size_t)c0 * (kXTile / 4);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) reinterpret_cast<float4 *>(xs[0])[tid + 256 * i] = src[tid + 256 * i];
+   }
+   int par = 0;                                 // parity of the buffers holding the CURRENT h of both layers
+   __syncthreads();
 
-   for (int ch = 0; ch < n_chunks; ++ch) {
-      __syncthreads();                       // previous chunk's readers of xs/dacc are done
-      for (int i = tid; i < kTileS * 448; i += 256) {
-         const int sc = i / 448, rem = i - sc * 448;          // rem = unit*7 + t  (coalesced over rem)
-         const int u = rem / 7, t = rem - u * 7;
-         const int ss = min(s0 + sc, n_streams - 1);
-         xs[(t * 64 + u) * kTileS + sc] = enc[((size_t)ss * n_chunks + ch) * 448 + rem];
+   for (int ch = c0; ch < c0 + cg; ++ch) {
+      const int xb = (ch - c0) & 1;
+      // prefetch the next chunk's frames straight into the other xs buffer (LDS-DMA, no registers); its last
+      // readers finished before the previous chunk's closing barrier.
+      if ((ch + 1) < (c0 + cg)) {
+         const float4 *src = tile_base + (size_t)(ch + 1) * (kXTile / 4);
+#pragma unroll
+         for (int i = 0; i < 7; ++i) dma16(src + tid + 256 * i, xs[xb ^ 1] + (256 * i + 64 * wv) * 4);
       }
-      if (tid < 2 * kTileS) dacc[tid] = 0.0f;
-      __syncthreads();
+      float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
       for (int t = 0; t < 7; ++t) {
 #pragma unroll
          for (int l = 0; l < 2; ++l) {
-            const float *xin = (l == 0) ? (xs + t * 64 * kTileS) : hb[0];   // rows k < 64
-            const float *hin = hb[l];                                        // rows k >= 64
+            // layer 0 reads x_t and h0(par); layer 1 reads h0(par^1) (just written) and h1(par)
+            const float *xin = (l == 0) ? (xs[xb] + t * 64 * kTileS) : hb[0][par ^ 1];
+            const float *hin = hb[l][par];
             f4v acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { acc[g][0] = bias[l][g][0]; acc[g][1] = bias[l][g][1]; acc[g][2] = bias[l][g][2]; acc[g][3] = bias[l][g][3]; }
+            for (int g = 0; g < 4; ++g) {
+               const float4 b4 = *reinterpret_cast<const float4 *>(&bl[l][g * 64 + 16 * wv + 4 * quad]);
+               acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
+            }
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
                const int k = 4 * kk + quad;
@@ -161,30 +192,36 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 #pragma unroll
                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[l][g][kk], bv, acc[g], 0, 0, 0);
             }
-            float hn[4];
+            float *hout = hb[l][par ^ 1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-               const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
-               const float gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+               const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
+               const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
                c[l][r] = fg * c[l][r] + ig * gg;
-               hn[r] = og * tanhf(c[l][r]);
+               const float hn = og * fast_tanh(c[l][r]);
+               hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
+               if (l == 1) rsum[r] += fmaxf(hn, 0.0f);
             }
-            __syncthreads();                 // every wave has finished reading hb[l] (and hb[0] as input)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hb[l][(16 * wv + 4 * quad + r) * kTileS + col] = hn[r];
+            // one barrier per (step, layer): the buffer written here (par^1) was last READ two barriers ago
             __syncthreads();
          }
-         // decoder partial for this step: 32 threads, (stream, output)
-         if (tid < 2 * kTileS) {
-            const int sc = tid & 15, f = tid >> 4;
-            float d = w.dec_b[f];
-            for (int u = 0; u < 64; ++u) d = fmaf(w.dec_w[f * 64 + u], fmaxf(hb[1][u * kTileS + sc], 0.0f), d);
-            dacc[tid] += d;
-         }
+         par ^= 1;
       }
+      // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
+      // every lane owns 4 units of one stream: partial dot, reduce over the 4 quads of the wave, then over waves.
+      {
+         float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); }
+         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
+      }
+      __syncthreads();                          // publishes pd and the prefetched xs buffer
       if (tid < 2 * kTileS) {
          const int sc = tid & 15, f = tid >> 4;
-         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + ch) * 2 + f] = sigmoidf_(dacc[tid] / 7.0f);
+         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
+         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + ch) * 2 + f] = sigmoidf_(m);
       }
    }
    __syncthreads();
@@ -195,18 +232,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
          for (int r = 0; r < 4; ++r) {
             const int u = 16 * wv + 4 * quad + r;
             cs[(size_t)s_col * 128 + l * 64 + u] = c[l][r];
-            hs[(size_t)s_col * 128 + l * 64 + u] = hb[l][u * kTileS + col];
+            hs[(size_t)s_col * 128 + l * 64 + u] = hb[l][par][u * kTileS + col];
          }
    }
 }
 
+// processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
 void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
-                 int n_streams, int n_chunks, hipStream_t st)
+                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (variant == 1)
-      hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks);
+      hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else
-      hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks);
+      hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
 }
 
 }  // namespace vadc
