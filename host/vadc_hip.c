@@ -1,0 +1,205 @@
+/*
+ * vadc_hip.c -- POSIX command-line host for the MI355X backend: the `vadc < audio.s16le` contract of the
+ * reference (README.md:52-60, vadc.c:670-1035) on Linux, in C, on top of the C-ABI of include/vadc_amd.h.
+ *
+ *   stdin : 16 kHz mono s16le PCM        stdout: one "start,end" line per speech segment (seconds, %.2f),
+ *                                                 or centiseconds (--output_centi_seconds), or one "%f" line per
+ *                                                 1536-sample chunk (--raw_probabilities)
+ *   stderr: diagnostics and --stats
+ *
+ * What is restated from the reference (own code, reference lines for parity checks):
+ *   option table and defaults            vadc.c:1084-1124   (values <= 0 are ignored :1215-1218)
+ *   96-chunk read window, s16 -> f32      vadc.c:799-805, 873-909   (conversion happens on the device here)
+ *   tail: a partial last chunk yields no probability   vadc.c:964
+ *   ms -> chunk rounding                 vadc.c:756-768
+ *   hysteresis segmenter                 vadc.c:165-221 (feed_probability), :262-299 (combine_or_emit),
+ *                                        :223-260 (emit, float32 time arithmetic), :1005-1027 (final flush)
+ * The forward pass itself is vadc_amd_run_s16 (GPU); there is no CPU path in this program.
+ */
+#include <inttypes.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "vadc_amd.h"
+
+#define WINDOW_CHUNKS 96
+#define CHUNK VADC_AMD_CHUNK_SAMPLES
+#define SAMPLE_RATE 16000
+
+typedef struct { int start, end, valid; } Segment;
+typedef struct { int temp_end, current_start, triggered; } FeedState;
+
+typedef struct {
+   float min_silence_ms, min_speech_ms, threshold, neg_threshold_relative, speech_pad_ms;
+   int batch, raw_probabilities, centiseconds, stats;
+   const char *model;
+} Options;
+
+static double g_total_speech = 0.0;
+
+static void emit_segment(Segment s, const Options *o, float spc)
+{
+   const float pad_s = o->speech_pad_ms / 1000.0f;
+   float end_p = (s.end * spc) + pad_s;
+   float start_p = (s.start * spc) - pad_s;
+   if (start_p < 0.0f) start_p = 0.0f;
+   g_total_speech += (double)end_p - (double)start_p;
+   if (o->centiseconds) {
+      int64_t a = (int64_t)((double)start_p * 100.0 + 0.5), b = (int64_t)((double)end_p * 100.0 + 0.5);
+      fprintf(stdout, "%" PRId64 ",%" PRId64 "\n", a, b);
+   } else {
+      fprintf(stdout, "%.2f,%.2f\n", start_p, end_p);
+   }
+   fflush(stdout);
+}
+
+static Segment combine_or_emit(Segment buffered, Segment cur, const Options *o, float spc)
+{
+   const float pad_s = o->speech_pad_ms / 1000.0f;
+   float cur_start_p = (cur.start * spc) - pad_s;
+   if (cur_start_p < 0.0f) cur_start_p = 0.0f;
+   if (buffered.valid) {
+      float buf_end_p = (buffered.end * spc) + pad_s;
+      if (buf_end_p >= cur_start_p) { buffered.end = cur.end; return buffered; }
+      emit_segment(buffered, o, spc);
+   }
+   return cur;
+}
+
+static Segment feed_probability(FeedState *st, int min_silence, int min_speech, float p, float thr, float neg_thr, int idx)
+{
+   Segment r = {0, 0, 0};
+   if (p >= thr && st->temp_end > 0) st->temp_end = 0;
+   if (!st->triggered) {
+      if (p >= thr) { st->triggered = 1; st->current_start = idx; }
+   } else if (p < neg_thr) {
+      if (st->temp_end == 0) st->temp_end = idx;
+      if (idx - st->temp_end >= min_silence) {
+         if (st->temp_end - st->current_start >= min_speech) { r.start = st->current_start; r.end = st->temp_end; r.valid = 1; }
+         st->current_start = 0; st->temp_end = 0; st->triggered = 0;
+      }
+   }
+   return r;
+}
+
+static size_t read_full(int fd, void *buf, size_t want)
+{
+   size_t got = 0;
+   while (got < want) {
+      ssize_t n = read(fd, (char *)buf + got, want - got);
+      if (n <= 0) break;
+      got += (size_t)n;
+   }
+   return got;
+}
+
+static int parse_options(int argc, char **argv, Options *o)
+{
+   for (int i = 1; i < argc; ++i) {
+      const char *a = argv[i];
+      if (!strcmp(a, "--raw_probabilities")) { o->raw_probabilities = 1; continue; }
+      if (!strcmp(a, "--output_centi_seconds")) { o->centiseconds = 1; continue; }
+      if (!strcmp(a, "--stats")) { o->stats = 1; continue; }
+      if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a); return -1; }
+      const char *v = argv[++i];
+      if (!strcmp(a, "--model")) { o->model = v; continue; }
+      float f = (float)atof(v);
+      if (f <= 0.0f) continue;                                   /* vadc.c:1215-1218 */
+      if (!strcmp(a, "--min_silence")) o->min_silence_ms = f;
+      else if (!strcmp(a, "--min_speech")) o->min_speech_ms = f;
+      else if (!strcmp(a, "--threshold")) o->threshold = f;
+      else if (!strcmp(a, "--neg_threshold_relative")) o->neg_threshold_relative = f;
+      else if (!strcmp(a, "--speech_pad")) o->speech_pad_ms = f;
+      else if (!strcmp(a, "--batch")) o->batch = (int)f;
+      else { fprintf(stderr, "unknown option %s\n", a); return -1; }
+   }
+   return 0;
+}
+
+int main(int argc, char **argv)
+{
+   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, "silero_v31_16k.testtensor"};  /* vadc.c:1110-1124 */
+   if (parse_options(argc, argv, &o)) return 2;
+   if (o.batch > WINDOW_CHUNKS) o.batch = WINDOW_CHUNKS;
+
+   FILE *wf = fopen(o.model, "rb");
+   if (!wf) { fprintf(stderr, "cannot open weights %s\n", o.model); return -1; }
+   fseek(wf, 0, SEEK_END); long wlen = ftell(wf); fseek(wf, 0, SEEK_SET);
+   void *blob = malloc((size_t)wlen);
+   if (!blob || fread(blob, 1, (size_t)wlen, wf) != (size_t)wlen) { fprintf(stderr, "cannot read weights\n"); return -1; }
+   fclose(wf);
+
+   vadc_amd_engine *eng = 0;
+   if (vadc_amd_create(blob, (size_t)wlen, -1, 1, WINDOW_CHUNKS, VADC_AMD_PRECISION_FP32, &eng) != VADC_AMD_OK) {
+      fprintf(stderr, "backend_init failed: %s\n", vadc_amd_last_error());
+      return -1;                                                   /* vadc.c:692-695 */
+   }
+   free(blob);
+   fprintf(stderr, "Running with batch size %d\n", o.batch);       /* vadc.c:716 */
+   fprintf(stderr, "Running with sequence count %d\n", CHUNK);     /* vadc.c:753 */
+
+   const float chunk_ms = CHUNK / (float)SAMPLE_RATE * 1000.0f;    /* vadc.c:756 */
+   int min_speech = (int)(o.min_speech_ms / chunk_ms + 0.5f);   if (min_speech < 1) min_speech = 1;
+   int min_silence = (int)(o.min_silence_ms / chunk_ms + 0.5f); if (min_silence < 1) min_silence = 1;
+   const float spc = (float)CHUNK / SAMPLE_RATE;                   /* vadc.c:846 */
+   const float neg_thr = o.threshold - o.neg_threshold_relative;   /* vadc.c:1243 */
+
+   static int16_t pcm[WINDOW_CHUNKS * CHUNK];
+   static float probs[WINDOW_CHUNKS * 2];
+   FeedState st = {0, 0, 0};
+   Segment buffered = {0, 0, 0};
+   int global_idx = 0;
+   int64_t total_samples = 0;
+   struct timespec t0, t1;
+   clock_gettime(CLOCK_MONOTONIC, &t0);
+
+   for (;;) {
+      size_t bytes = read_full(0, pcm, sizeof(pcm));
+      size_t values = bytes / sizeof(int16_t);
+      if (values == 0) break;
+      total_samples += (int64_t)values;
+      int n_chunks = (int)(values / CHUNK);                        /* vadc.c:964: a partial tail chunk is dropped */
+      for (int c0 = 0; c0 < n_chunks; c0 += o.batch) {
+         int n = n_chunks - c0 < o.batch ? n_chunks - c0 : o.batch;
+         if (vadc_amd_run_s16(eng, pcm + (size_t)c0 * CHUNK, 1, n, probs + 2 * c0) != VADC_AMD_OK) {
+            fprintf(stderr, "backend_run failed: %s\n", vadc_amd_last_error());
+            return 1;
+         }
+      }
+      for (int i = 0; i < n_chunks; ++i) {
+         float p = probs[2 * i + 1];
+         if (o.raw_probabilities) {
+            printf("%f\n", p);                                     /* vadc.c:995 */
+         } else {
+            Segment r = feed_probability(&st, min_silence, min_speech, p, o.threshold, neg_thr, global_idx);
+            if (r.valid) buffered = combine_or_emit(buffered, r, &o, spc);
+         }
+         ++global_idx;
+      }
+      if (bytes < sizeof(pcm)) break;
+   }
+   if (!o.raw_probabilities) {                                     /* vadc.c:1005-1027 */
+      if (st.triggered) {
+         int audio_len = (global_idx - 1) * CHUNK;
+         if (audio_len - (st.current_start * CHUNK) > (min_speech * CHUNK)) {
+            Segment fin = {st.current_start, audio_len / CHUNK, 1};
+            buffered = combine_or_emit(buffered, fin, &o, spc);
+         }
+      }
+      if (buffered.valid) emit_segment(buffered, &o, spc);
+   }
+   fflush(stdout);
+   if (o.stats) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      double wall = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+      double dur = (double)total_samples / SAMPLE_RATE;
+      fprintf(stderr, "time=%.2fs speech=%.2fs (%.1f%%), duration=%.2fs (%.1fx)\n", wall, g_total_speech,
+              dur > 0 ? 100.0 * g_total_speech / dur : 0.0, dur, wall > 0 ? dur / wall : 0.0);
+   }
+   vadc_amd_destroy(eng);
+   return 0;
+}

@@ -316,3 +316,52 @@ def test_large_batch_properties(weights_blob, orc):
     want = orc.forward_streams(pcm[idx])
     assert float(np.abs(a[idx, :, 1] - want).max()) <= PROB_TOL
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------- C host CLI
+def _run_cli(pcm, *args):
+    import subprocess
+    from conftest import ROOT, WEIGHTS
+    exe = os.path.join(ROOT, "host", "vadc_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
+    r = subprocess.run([exe, "--model", WEIGHTS, *args], input=pcm.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout.decode().splitlines(), r.stderr.decode()
+
+
+def test_cli_raw_probabilities_contract(gold_c, gold_py):
+    """`vadc --raw_probabilities < audio.s16le`: one %f line per full chunk (vadc.c:990-998); a partial tail chunk
+    produces no line (vadc.c:964)."""
+    pcm = np.concatenate([gold_py["pcm_speech0"], np.zeros(700, np.int16)])     # ragged tail
+    lines, err = _run_cli(pcm, "--raw_probabilities")
+    want = gold_c["probs_speech0"][:, 1]
+    assert len(lines) == want.size
+    got = np.array([float(x) for x in lines], np.float32)
+    assert float(np.abs(got - want).max()) <= PROB_TOL + 5e-7                   # %f quantises to 5e-7
+    assert "Running with batch size 96" in err
+
+
+@pytest.mark.parametrize("args,kw", [
+    ((), {}),
+    (("--output_centi_seconds", "--min_silence", "100"), {"min_silence_ms": 100.0}),
+    (("--threshold", "0.35", "--speech_pad", "60", "--batch", "7"), {"threshold": 0.35, "speech_pad_ms": 60.0}),
+])
+def test_cli_segments_match_reference_segmenter(gold_c, gold_py, args, kw):
+    """stdout `start,end` lines == the reference segmenter (oracle restatement of vadc.c:165-299,1005-1027) applied to
+    the C backend's golden probabilities: same chunk indices, same %.2f / centisecond text."""
+    for name in ("speech0", "speech1"):
+        lines, _ = _run_cli(gold_py[f"pcm_{name}"], *args)
+        sec, _ = O.segments(gold_c[f"probs_{name}"][:, 1], **kw)
+        if "--output_centi_seconds" in args:
+            want = ["%d,%d" % (int(float(np.float64(a)) * 100.0 + 0.5), int(float(np.float64(b)) * 100.0 + 0.5)) for a, b in sec]
+        else:
+            want = ["%.2f,%.2f" % (a, b) for a, b in sec]
+        assert lines == want and len(want) > 0
+
+
+def test_cli_empty_and_short_input():
+    lines, _ = _run_cli(np.zeros(0, np.int16))
+    assert lines == []
+    lines, _ = _run_cli(np.zeros(1000, np.int16), "--raw_probabilities")
+    assert lines == []
