@@ -97,6 +97,9 @@ def main():
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(f"cuda:{local_rank}") for i in range(2)]
     d_probs = torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}")
     gather_list = [torch.empty_like(d_probs) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from vadc_amd import shard
+    lo, hi = shard.stream_block(rank, world, S * world)     # weak scaling: S streams per GPU, contiguous blocks
+    assert hi - lo == S
     stream = torch.cuda.Stream()          # the HIP stream every launch of the hot path is issued on
     torch.cuda.set_stream(stream)
 
