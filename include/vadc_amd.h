@@ -126,6 +126,7 @@ int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n,
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
 /* Tuning / bring-up switches:  "lstm"   0 = MFMA kernel (default), 1 = simple reference kernel
+ *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels
  *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
  *                                      group g overlaps the front end + encoder of group g+1.
  *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline

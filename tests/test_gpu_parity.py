@@ -154,7 +154,7 @@ def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):     
     assert float(np.abs(got - ref).max()) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_reference_fixture_lstm(weights_blob, fixture_path, variant):                     # test.c:243
     x, h0, c0, w, b, ref = [a for _, a in tt.load(fixture_path("lstm_nito_reference_randn"))]
     e = Engine(_blob_with(weights_blob, {95: w, 96: b}), max_streams=1, max_chunks_per_call=4, device=0)
@@ -250,12 +250,24 @@ def test_reset_and_state_roundtrip(eng):
     assert np.array_equal(bits(first), bits(again))
 
 
+@pytest.mark.parametrize("stage", ["layer1", "layer2", "layer3", "layer4"])
+def test_encoder_variants_agree(eng, gold_py, stage):
+    """MFMA layer kernels vs the VALU bring-up kernels on the device (different summation orders, same fp32 math)"""
+    x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
+    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 1); b = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 0)
+    assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
+
+
 def test_lstm_variants_agree(eng):
     pcm = synth.make_streams(19, 6, seed0=5)
-    eng.set_option("lstm", 0); eng.reset_streams(); a = eng.run(pcm)
-    eng.set_option("lstm", 1); eng.reset_streams(); b = eng.run(pcm)
+    eng.set_option("lstm", 0); eng.reset_streams(); a = eng.run(pcm)     # layer-wavefront MFMA
+    eng.set_option("lstm", 1); eng.reset_streams(); b = eng.run(pcm)     # libm-grade reference kernel
+    eng.set_option("lstm", 2); eng.reset_streams(); c = eng.run(pcm)     # step-sequential MFMA
     eng.set_option("lstm", 0)
     assert float(np.abs(a - b).max()) < 2e-5
+    assert float(np.abs(a - c).max()) < 1e-6                             # same arithmetic, different schedule
 
 
 @pytest.mark.parametrize("groups", [1, 2, 3, 4, 8])

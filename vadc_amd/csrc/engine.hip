@@ -15,12 +15,17 @@
 #include <vector>
 
 namespace vadc {
-void launch_frontend_f32(const float *, const float *, float *, float *, int, ItemMap, int, hipStream_t);
-void launch_frontend_s16(const int16_t *, const float *, float *, float *, int, ItemMap, int, hipStream_t);
-void launch_normalize_tap(const float *, const float *, float *, int, hipStream_t);
-void launch_lognorm_from_magnitude(const float *, float *, float *, int, hipStream_t);
-void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, hipStream_t);
+void launch_frontend_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t);
+void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
+void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t);
+struct LayerWeightsM {
+   const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
+      *n2_w, *n2_b, *cv_f, *cv_b;
+};
+void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
 }  // namespace vadc
 
 using namespace vadc;
@@ -100,6 +105,8 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    LayerWeights lw[4];
+   LayerWeightsM lwm[4];
+   int encoder_variant = 0;                     // 0 = MFMA layers, 1 = VALU bring-up layers
    LstmWeights lstm;
    // workspace
    float *d_in_f32 = nullptr;
@@ -152,7 +159,20 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    pk.add(nullptr, 64);   // the pipeline's final prefetch reads 32 floats past filter 129's start: keep slack anyway
 
-   struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b; } lo[4];
+   struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
+                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f; } lo[4];
+   // MFMA A-fragment order for v_mfma_f32_16x16x4_f32: [m-tile][k-step][lane], lane l holds W[16mt + (l&15)][4kk + (l>>4)]
+   auto frag = [](const std::vector<float> &W, int M, int K) {
+      const int KKW = (K + 3) / 4;
+      std::vector<float> f((size_t)(M / 16) * KKW * 64, 0.0f);
+      for (int mt = 0; mt < M / 16; ++mt)
+         for (int kk = 0; kk < KKW; ++kk)
+            for (int l = 0; l < 64; ++l) {
+               const int k = 4 * kk + (l >> 4);
+               if (k < K) f[((size_t)mt * KKW + kk) * 64 + l] = W[(size_t)(16 * mt + (l & 15)) * K + k];
+            }
+      return f;
+   };
    for (int l = 0; l < 4; ++l) {
       const LayerShape &s = kLayers[l];
       const int D = s.d, C = s.cin;
@@ -161,22 +181,25 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       std::vector<float> v;
       if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
       if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
-      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); }
-      if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size());
-      lo[l].pjT = lo[l].pj_b = (size_t)-1;
+      std::vector<float> cbb;
+      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); }
+      if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size()); cbb = v;
+      lo[l].pjT = lo[l].pj_b = lo[l].pj_f = (size_t)-1;
       if (s.proj) {
-         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); }
+         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
          if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size());
+         for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
-      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size());
+      lo[l].cb_b = pk.add(cbb.data(), cbb.size());
+      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size()); { auto f = frag(v, 3 * D, D); lo[l].qkv_f = pk.add(f.data(), f.size()); }
       if (!take(3 * D, v)) goto bad;     lo[l].qkv_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].out_f = pk.add(f.data(), f.size()); }
       if (!take(D, v)) goto bad;         lo[l].out_b = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n1_w = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l1_f = pk.add(f.data(), f.size()); }
       if (!take(D, v)) goto bad;         lo[l].l1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size());
+      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l2_f = pk.add(f.data(), f.size()); }
       if (!take(D, v)) goto bad;         lo[l].l2_b = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n2_w = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n2_b = pk.add(v.data(), v.size());
@@ -192,6 +215,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          }
          lo[l].cv_w = pk.add(cw.data(), cw.size());
          lo[l].cv_b = pk.add(cb.data(), cb.size());
+         { auto f = frag(cw, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); }
       }
    }
    {
@@ -217,6 +241,11 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          w.n1_w = base + lo[l].n1_w; w.n1_b = base + lo[l].n1_b; w.l1_w = base + lo[l].l1_w; w.l1_b = base + lo[l].l1_b;
          w.l2_w = base + lo[l].l2_w; w.l2_b = base + lo[l].l2_b; w.n2_w = base + lo[l].n2_w; w.n2_b = base + lo[l].n2_b;
          w.cv_w = base + lo[l].cv_w; w.cv_b = base + lo[l].cv_b;
+         LayerWeightsM &m = e->lwm[l];
+         m.dw_w = w.dw_w; m.dw_b = w.dw_b; m.pw_f = base + lo[l].pw_f; m.pj_f = kLayers[l].proj ? base + lo[l].pj_f : nullptr;
+         m.cb_b = base + lo[l].cb_b; m.qkv_f = base + lo[l].qkv_f; m.qkv_b = w.qkv_b; m.out_f = base + lo[l].out_f; m.out_b = w.out_b;
+         m.n1_w = w.n1_w; m.n1_b = w.n1_b; m.l1_f = base + lo[l].l1_f; m.l1_b = w.l1_b; m.l2_f = base + lo[l].l2_f; m.l2_b = w.l2_b;
+         m.n2_w = w.n2_w; m.n2_b = w.n2_b; m.cv_f = base + lo[l].cv_f; m.cv_b = w.cv_b;
       }
       e->lstm.w = base + o_w; e->lstm.wT = base + o_wT; e->lstm.b = base + o_b; e->lstm.dec_w = base + o_dw; e->lstm.dec_b = base + o_db;
    }
@@ -289,7 +318,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
    if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
-   if (he == hipSuccess) he = hipMalloc(&e->d_FM, N * kFrames * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_FM, kBinSplit * N * kFrames * sizeof(float));
    for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
@@ -401,7 +430,8 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 1)) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 2) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
@@ -426,7 +456,8 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, st);
+      if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
+      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
    }
 }
 
@@ -435,8 +466,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, map, 0, st);
-      else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, n, map, 0, st);
+      if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+      else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
    }
    run_encoder_layers(e, 0, 3, n, map, 1, st);
 }
@@ -505,16 +536,27 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
-      const int cg_max = (n_chunks + G - 1) / G;
-      int gi = 0;
-      for (int c0 = 0; c0 < n_chunks; c0 += cg_max, ++gi) {
-         const int cg = (c0 + cg_max <= n_chunks) ? cg_max : n_chunks - c0;
+      // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
+      int sizes[vadc_amd_engine::kMaxGroups];
+      {
+         int first = n_chunks / (4 * G);
+         if (first < 1) first = 1;
+         if (G == 1) first = n_chunks;
+         sizes[0] = first;
+         int rest = n_chunks - first;
+         for (int g = 1; g < G; ++g) { sizes[g] = (rest + (G - g) - 1) / (G - g); rest -= sizes[g]; }
+      }
+      int c0 = 0;
+      for (int gi = 0; gi < G; ++gi) {
+         const int cg = sizes[gi];
+         if (cg <= 0) continue;
          const ItemMap map{n_chunks, c0, cg};
          run_front_and_encoder<T>(e, d_in, n_streams * cg, map, e->sA);
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
          launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB);
+         c0 += cg;
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
@@ -644,8 +686,8 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
+   launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * kStageElems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
@@ -664,16 +706,16 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    int first_layer = 0;
    if (from_stage == VADC_AMD_STAGE_MAGNITUDE) {
       HIP_TRY(hipMemcpyAsync(e->d_tap, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
-      launch_lognorm_from_magnitude(e->d_tap, e->d_Y, e->d_FM, n, st);
+      launch_lognorm_from_magnitude(e->d_tap, e->d_Y, e->d_FM, e->max_items * kFrames, n, st);
    } else if (from_stage == VADC_AMD_STAGE_NORMALIZED) {
       // already normalized: feed as Y with zero frame means (offset 0)
       HIP_TRY(hipMemcpyAsync(e->d_Y, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
-      HIP_TRY(hipMemsetAsync(e->d_FM, 0, (size_t)n * kFrames * sizeof(float), st), VADC_AMD_EHIP);
+      HIP_TRY(hipMemsetAsync(e->d_FM, 0, kBinSplit * e->max_items * kFrames * sizeof(float), st), VADC_AMD_EHIP);
    } else {
       first_layer = from_stage - VADC_AMD_STAGE_LAYER1 + 1;
       HIP_TRY(hipMemcpyAsync(e->d_act[first_layer - 1], in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    }
-   if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->d_tap, n, st);
+   if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
    else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, ItemMap{n, 0, n}, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * kStageElems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);

@@ -24,8 +24,10 @@
 
 namespace vadc {
 
-__device__ __forceinline__ float norm_offset_fast(const float *__restrict__ fm)
+__device__ __forceinline__ float norm_offset_fast(const float *__restrict__ fmp, size_t fm_stride)
 {
+   float fm[kFrames];
+   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + fmp[2 * fm_stride + q]) / 129.0f;
    const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                           0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                           0.03663284704089164733887f};
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
                                                     const float *__restrict__ fm,   // [n][25] (FIRST) or null
                                                     LayerWeights w,
                                                     float *__restrict__ out,        // [n][D][TOUT]
-                                                    int n_chunks, ItemMap map)
+                                                    int n_chunks, ItemMap map, size_t fm_stride)
 {
    constexpr int TOUT = 1 + (T - 1) / STRIDE;
    constexpr int HD = D / 2;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
 
    const float *x_in = in + (size_t)chunk * CIN * T;
    float mm = 0.0f;
-   if (FIRST) mm = norm_offset_fast(fm + (size_t)chunk * kFrames);         // misc.c:65-82
+   if (FIRST) mm = norm_offset_fast(fm + (size_t)chunk * kFrames, fm_stride);         // misc.c:65-82
 
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x) -------------------------------------------
    float y[D];
@@ -252,15 +254,15 @@ __global__ __launch_bounds__(NTHREADS) void k_layer(const float *__restrict__ in
 //   L1: T=25 -> 10 chunks = 250 of 256 lanes     L2: T=13 -> 9 chunks = 117 of 128 lanes
 //   L3/L4: T=7 -> 9 chunks = 63 of 64 lanes
 void launch_layer(int layer, const float *in, const float *fm, const LayerWeights &w, float *out, int n, ItemMap map,
-                  int lstm_layout, hipStream_t st)
+                  int lstm_layout, size_t fm_stride, hipStream_t st)
 {
    switch (layer) {
-   case 0: hipLaunchKernelGGL((k_layer<129, 16, 25, 2, true, true, 10, 256, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map); break;
-   case 1: hipLaunchKernelGGL((k_layer<16, 32, 13, 2, true, false, 9, 128, false>), dim3((n + 8) / 9), dim3(128), 0, st, in, fm, w, out, n, map); break;
-   case 2: hipLaunchKernelGGL((k_layer<32, 32, 7, 1, false, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map); break;
+   case 0: hipLaunchKernelGGL((k_layer<129, 16, 25, 2, true, true, 10, 256, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 1: hipLaunchKernelGGL((k_layer<16, 32, 13, 2, true, false, 9, 128, false>), dim3((n + 8) / 9), dim3(128), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 2: hipLaunchKernelGGL((k_layer<32, 32, 7, 1, false, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 3:
-      if (lstm_layout) hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, true>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map);
-      else             hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map);
+      if (lstm_layout) hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, true>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map, fm_stride);
+      else             hipLaunchKernelGGL((k_layer<32, 64, 7, 1, true, false, 9, 64, false>), dim3((n + 8) / 9), dim3(64), 0, st, in, fm, w, out, n, map, fm_stride);
       break;
    }
 }

@@ -1,0 +1,372 @@
+// kernels_encoder_mfma.hip -- one encoder ("transformer") layer per launch on the gfx950 matrix cores.
+//
+// Same arithmetic as kernels_encoder.hip (the VALU bring-up variant kept for A/B tests), re-mapped so that every
+// dense contraction of the layer -- pointwise + projection conv, QKV, attention out-projection, both FFN linears
+// and the strided 1x1 conv -- runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains):
+//
+//   Y[Cout x cols] = W[Cout x K] . X[K x cols]        cols = (chunk, time-step) of the workgroup's NCH chunks
+//
+// Replaces (reference file:line): conv_block conv.c:761-814 (dw :17-113, pw/proj :532-589); transformer_block
+// transformer.c:13-234 (tensor_linear tensor.h:675-723, softmax :751-784, layer_norm misc.c:143-210); conv k=1 stride s
+// + BatchNorm + ReLU transformer.c:279-290 (conv.c:597-709, misc.c:221-258); layer 1 also finishes
+// adaptive_audio_normalization_inplace misc.c:65-96.
+//
+// MAPPING.  A workgroup (4 waves) owns 64 columns; WAVE w owns the 16-column MFMA N-tile [16w,16w+16) for the whole
+// layer.  Activations live in LDS as [channel][column] (pitch 80 floats: the four k-rows an MFMA B-fragment reads
+// fall into different banks).  For a GEMM the wave reads its B fragments once (K/4 ds_read_b32), streams the weight
+// A-fragments from L2 in a host-prepacked fragment-major layout (one coalesced 256-B load per MFMA) and loops over the
+// Cout/16 M-tiles; accumulators start at the bias; epilogues (ReLU, residual) are applied in the accumulator layout
+// and written back to LDS.  LayerNorm reduces over channels = over the accumulator registers and the 4 lane-quads of
+// the wave (two DPP/permute shuffles), never across waves.  Only the depthwise conv (time neighbours) and attention
+// (all 7..25 steps of a chunk) look across columns, so those are the only phases that need workgroup barriers for
+// correctness; the VALU work there is spread over all 256 threads.
+// The input channels of the conv block are consumed in slabs of 32 (layer 1 has 129 -> 5 slabs), so LDS holds
+// 32 rows of x and of relu(dw(x)) at a time, aliased with the later Q/K/V + attention buffers.
+#include "common.h"
+
+namespace vadc {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int kCol = 64;      // columns per workgroup (4 MFMA N-tiles)
+constexpr int kPitch = 80;    // LDS row pitch in floats (80 % 32 == 16: rows k..k+3 of a B fragment hit disjoint banks)
+constexpr int kSlab = 32;     // input channels per conv-block slab
+
+struct LayerWeightsM {
+   const float *dw_w, *dw_b;          // [cin][5], [cin]
+   const float *pw_f, *pj_f;          // fragment-major [D/16][cinp/4][64]
+   const float *cb_b;                 // [D]   pw bias + proj bias
+   const float *qkv_f, *qkv_b;        // [3D/16][D/4][64], [3D]
+   const float *out_f, *out_b;
+   const float *n1_w, *n1_b;
+   const float *l1_f, *l1_b;
+   const float *l2_f, *l2_b;
+   const float *n2_w, *n2_b;
+   const float *cv_f, *cv_b;          // strided conv with BatchNorm folded
+};
+
+__device__ __forceinline__ float norm_offset_m(const float *__restrict__ fmp, size_t fm_stride)
+{
+   float fm[kFrames];
+   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + fmp[2 * fm_stride + q]) / 129.0f;
+   const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
+                          0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
+                          0.03663284704089164733887f};
+   float total = 0.0f;
+   for (int t = 0; t < kFrames; ++t) {
+      float r = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+         int q = t + i - 3;
+         q = q < 0 ? -q : q;
+         q = q >= kFrames ? 2 * (kFrames - 1) - q : q;
+         r += fm[q] * filt[i];
+      }
+      total += r;
+   }
+   return total / 25.0f;
+}
+
+// acc[mt] (+)= W[16mt.., :] . X[:, wave's 16 columns]   for mt < MT, K = 4*KK rows of X starting at xrow0.
+// wf: fragment-major weights [MT][KKW][64] (KKW = k-steps per M-tile in memory), kk0 = first k-step to use.
+template <int MT, int KK>
+__device__ __forceinline__ void gemm_acc(f4v (&acc)[MT], const float *__restrict__ wf, int KKW, int kk0,
+                                         const float *X, int lane, int wave)
+{
+   const int quad = lane >> 4, lc = lane & 15;
+   float b[KK];
+#pragma unroll
+   for (int kk = 0; kk < KK; ++kk) b[kk] = X[(4 * kk + quad) * kPitch + 16 * wave + lc];
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      const float *wp = wf + ((size_t)mt * KKW + kk0) * 64 + lane;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[kk * 64], b[kk], acc[mt], 0, 0, 0);
+   }
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_init(f4v (&acc)[MT], const float *__restrict__ bias, int lane)
+{
+   const int quad = lane >> 4;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      const float4 b4 = *reinterpret_cast<const float4 *>(bias + 16 * mt + 4 * quad);
+      acc[mt][0] = b4.x; acc[mt][1] = b4.y; acc[mt][2] = b4.z; acc[mt][3] = b4.w;
+   }
+}
+
+// accumulator layout <-> LDS [row][col]: lane (quad, lc), reg r  <->  row 16 mt + 4 quad + r, col 16 wave + lc
+template <int MT>
+__device__ __forceinline__ void acc_store(const f4v (&acc)[MT], float *Y, int lane, int wave)
+{
+   const int quad = lane >> 4, lc = lane & 15;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[(16 * mt + 4 * quad + r) * kPitch + 16 * wave + lc] = acc[mt][r];
+}
+
+// LayerNorm over the D = 16*MT channels of each column, in the accumulator layout (misc.c:143-210)
+template <int MT>
+__device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__restrict__ w, const float *__restrict__ b, int lane)
+{
+   constexpr int D = 16 * MT;
+   const int quad = lane >> 4;
+   float s = 0.0f;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) s += (x[mt][0] + x[mt][1]) + (x[mt][2] + x[mt][3]);
+   s += __shfl_xor(s, 16);
+   s += __shfl_xor(s, 32);
+   const float mean = s * (1.0f / D);
+   float vs = 0.0f;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = x[mt][r] - mean; vs = fmaf(d, d, vs); }
+   vs += __shfl_xor(vs, 16);
+   vs += __shfl_xor(vs, 32);
+   const float rstd = 1.0f / sqrtf(vs * (1.0f / D) + 1e-5f);
+   const float mr = mean * rstd;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      const float4 w4 = *reinterpret_cast<const float4 *>(w + 16 * mt + 4 * quad);
+      const float4 b4 = *reinterpret_cast<const float4 *>(b + 16 * mt + 4 * quad);
+      x[mt][0] = fmaf(fmaf(x[mt][0], rstd, -mr), w4.x, b4.x);
+      x[mt][1] = fmaf(fmaf(x[mt][1], rstd, -mr), w4.y, b4.y);
+      x[mt][2] = fmaf(fmaf(x[mt][2], rstd, -mr), w4.z, b4.z);
+      x[mt][3] = fmaf(fmaf(x[mt][3], rstd, -mr), w4.w, b4.w);
+   }
+}
+
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, bool LSTM_OUT, int NCH>
+__global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
+                                                    const float *__restrict__ fm,   // [n][25] (FIRST) or null
+                                                    LayerWeightsM w,
+                                                    float *__restrict__ out,
+                                                    int n_chunks, ItemMap map, size_t fm_stride)
+{
+   constexpr int NCOLV = NCH * T;                       // valid columns
+   static_assert(NCOLV <= kCol, "too many chunks per workgroup");
+   constexpr int TOUT = 1 + (T - 1) / STRIDE;
+   constexpr int HD = D / 2;
+   constexpr int MT = D / 16;
+   constexpr int CINP = (CIN + 3) / 4 * 4;
+   constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
+   constexpr int NSLAB = (CINP + kSlab - 1) / kSlab;
+   constexpr int ROWS_B = (4 * D > 2 * kSlab) ? 4 * D : 2 * kSlab;
+   __shared__ __attribute__((aligned(16))) float Yb[D * kPitch];          // conv-block output / residual stream
+   __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // {x slab, relu(dw) slab} then {Q,K,V, att}
+   __shared__ float mm_s[NCH];
+   float *XS = Bb, *DWR = Bb + kSlab * kPitch;
+   float *QKV = Bb, *ATT = Bb + 3 * D * kPitch;
+
+   const int tid = threadIdx.x;
+   const int lane = tid & 63, wave = tid >> 6;
+   const int quad = lane >> 4, lc = lane & 15;
+
+   // column owned by this thread in the element-wise phases: col = lane (64 columns), row group = wave
+   const int col = lane;
+   const int cb = col / T, t = col - cb * T;
+   const int item_raw = blockIdx.x * NCH + cb;
+   const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
+   const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
+
+   if (FIRST) {
+      if (tid < NCH) {
+         const int it = blockIdx.x * NCH + tid;
+         mm_s[tid] = norm_offset_m(fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * kFrames, fm_stride);   // misc.c:65-82
+      }
+      __syncthreads();
+   }
+   const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
+
+   // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
+   f4v acc[MT];
+   acc_init<MT>(acc, w.cb_b, lane);
+   const float *x_in = in + (size_t)chunk * CIN * T + t;
+#pragma unroll 1
+   for (int s = 0; s < NSLAB; ++s) {
+      const int c0 = s * kSlab;
+      if (s > 0) __syncthreads();                        // previous slab fully consumed
+      // x slab: 8 rows per wave; rows >= CIN and invalid columns are zero
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+         const int r = wave * 8 + i, ch = c0 + r;
+         float v = 0.0f;
+         if (cvalid && ch < CIN) v = x_in[(size_t)ch * T] - mm;            // misc.c:84-96
+         XS[r * kPitch + col] = v;
+      }
+      __syncthreads();
+      // depthwise k5 pad2 + ReLU (conv.c:17-53): neighbours are adjacent columns of the same chunk
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+         const int r = wave * 8 + i, ch = c0 + r;
+         float dv = 0.0f;
+         if (ch < CIN) {
+            const float *k = w.dw_w + ch * 5;
+            const float *xr = XS + r * kPitch + col;
+            dv = w.dw_b[ch];
+            dv = fmaf(t >= 2 ? xr[-2] : 0.0f, k[0], dv);
+            dv = fmaf(t >= 1 ? xr[-1] : 0.0f, k[1], dv);
+            dv = fmaf(xr[0], k[2], dv);
+            dv = fmaf(t + 1 < T ? xr[1] : 0.0f, k[3], dv);
+            dv = fmaf(t + 2 < T ? xr[2] : 0.0f, k[4], dv);
+            dv = fmaxf(dv, 0.0f);
+         }
+         DWR[r * kPitch + col] = cvalid ? dv : 0.0f;
+      }
+      __syncthreads();
+      constexpr int KK_FULL = kSlab / 4;
+      if (c0 + kSlab <= CINP) {
+         gemm_acc<MT, KK_FULL>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
+         if (HAS_PROJ) gemm_acc<MT, KK_FULL>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
+      } else {
+         constexpr int KK_TAIL = (CINP % kSlab) / 4 > 0 ? (CINP % kSlab) / 4 : 1;
+         gemm_acc<MT, KK_TAIL>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
+         if (HAS_PROJ) gemm_acc<MT, KK_TAIL>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
+      }
+   }
+   if (!HAS_PROJ) {                                       // identity residual (CIN == D, single slab): + x
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) acc[mt][r] += XS[(16 * mt + 4 * quad + r) * kPitch + 16 * wave + lc];
+   }
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   __syncthreads();                                       // slab buffers free, Yb visible
+
+   // ---- QKV = W y + b  -> LDS rows [0,D) Q, [D,2D) K, [2D,3D) V      transformer.c:69-99 -----------------
+   {
+      f4v q[3 * MT];
+      acc_init<3 * MT>(q, w.qkv_b, lane);
+      gemm_acc<3 * MT, D / 4>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
+      acc_store<3 * MT>(q, QKV, lane, wave);
+   }
+   __syncthreads();
+
+   // ---- attention per (column i, head h): a = softmax_j(k_i . q_j / sqrt(hd)), att_i = sum_j a_j v_j ----------
+   //      (K Q^T, not Q K^T: transformer.c:104-105)
+   for (int it = tid; it < 2 * kCol; it += 256) {
+      const int h = it >> 6, i = it & 63;
+      const int icb = i / T;
+      float *dst = ATT + (h * HD) * kPitch + i;
+      if (i < NCOLV) {
+         const int j0 = icb * T;
+         const float *Q = QKV + (h * HD) * kPitch, *K = QKV + (D + h * HD) * kPitch, *V = QKV + (2 * D + h * HD) * kPitch;
+         float kreg[HD];
+#pragma unroll
+         for (int e = 0; e < HD; ++e) kreg[e] = K[e * kPitch + i];
+         float sc[T];
+         float mx = -3.0e38f;
+         const float scale = 1.0f / sqrtf((float)HD);      // transformer.c:114
+#pragma unroll
+         for (int j = 0; j < T; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) a = fmaf(kreg[e], Q[e * kPitch + j0 + j], a);
+            sc[j] = a * scale;
+            mx = fmaxf(mx, sc[j]);
+         }
+         float sum = 0.0f;                                 // tensor.h:751-784
+#pragma unroll
+         for (int j = 0; j < T; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+         const float inv = 1.0f / sum;
+#pragma unroll
+         for (int e = 0; e < HD; ++e) {
+            float o = 0.0f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) o = fmaf(sc[j], V[e * kPitch + j0 + j], o);
+            dst[e * kPitch] = o * inv;
+         }
+      } else {
+#pragma unroll
+         for (int e = 0; e < HD; ++e) dst[e * kPitch] = 0.0f;
+      }
+   }
+   __syncthreads();
+
+   // ---- out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220 -------------------
+   {
+      f4v p[MT];
+      acc_init<MT>(p, w.out_b, lane);
+      gemm_acc<MT, D / 4>(p, w.out_f, D / 4, 0, ATT, lane, wave);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] += p[mt];
+   }
+   layer_norm_acc<MT>(acc, w.n1_w, w.n1_b, lane);
+   // the wave's own 16 columns only from here on: a wave-level LDS round trip turns the accumulator layout
+   // into the next GEMM's B fragments (workgroup barriers are kept for simplicity; they cost little here)
+   __syncthreads();                                       // everyone is done reading ATT / Yb
+   acc_store<MT>(acc, Yb, lane, wave);
+   __syncthreads();
+   {
+      f4v f[MT];
+      acc_init<MT>(f, w.l1_b, lane);
+      gemm_acc<MT, D / 4>(f, w.l1_f, D / 4, 0, Yb, lane, wave);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) f[mt][r] = fmaxf(f[mt][r], 0.0f);
+      acc_store<MT>(f, ATT, lane, wave);                  // reuse the attention rows for relu(lin1)
+   }
+   __syncthreads();
+   {
+      f4v g[MT];
+      acc_init<MT>(g, w.l2_b, lane);
+      gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, ATT, lane, wave);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
+   }
+   layer_norm_acc<MT>(acc, w.n2_w, w.n2_b, lane);
+   __syncthreads();
+   acc_store<MT>(acc, Yb, lane, wave);
+   __syncthreads();
+
+   // ---- conv k=1 stride s (+ folded BatchNorm) -> ReLU; only surviving time steps are stored -----------------
+   {
+      f4v z[MT];
+      acc_init<MT>(z, w.cv_b, lane);
+      gemm_acc<MT, D / 4>(z, w.cv_f, D / 4, 0, Yb, lane, wave);
+      // this lane's column in the accumulator layout
+      const int ocol = 16 * wave + lc;
+      const int ocb = ocol / T, ot = ocol - ocb * T;
+      const int oitem = blockIdx.x * NCH + ocb;
+      if (ocol < NCOLV && oitem < n_chunks && (ot % STRIDE) == 0) {
+         constexpr int ostride = LSTM_OUT ? kLstmTile : TOUT;
+         float *dst;
+         if (LSTM_OUT) {
+            int st_, ch_;
+            map.split(oitem, st_, ch_);
+            dst = out + lstm_x_index(st_, ch_, map.C, ot / STRIDE, 0);
+         } else {
+            dst = out + (size_t)map(oitem) * D * TOUT + ot / STRIDE;
+         }
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(16 * mt + 4 * quad + r) * ostride] = fmaxf(z[mt][r], 0.0f);
+      }
+   }
+}
+
+// chunks per workgroup: L1 T=25 -> 2 (50 of 64 columns), L2 T=13 -> 4 (52), L3/L4 T=7 -> 9 (63)
+void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                       int lstm_layout, size_t fm_stride, hipStream_t st)
+{
+   switch (layer) {
+   case 0: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 3:
+      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, true, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, false, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      break;
+   }
+}
+
+}  // namespace vadc

@@ -179,8 +179,8 @@ template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int L
 __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                   const float *__restrict__ basis,    // [258][256] permuted
                                                   float *__restrict__ Y,              // [n_chunks][129][25]
-                                                  float *__restrict__ FM,             // [n_chunks][25]
-                                                  int n_chunks, ItemMap map)
+                                                  float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
+                                                  int n_chunks, ItemMap map, size_t fm_stride)
 {
    const int lane = threadIdx.x & 63;
    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -215,7 +215,10 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
    float *yout = Y + (size_t)chunk * (kBins * kFrames) + m;
    float bin_sum = 0.0f;
    constexpr int kImOff = kBins * kFilterLen * 4;       // byte offset from filter f to filter f+129
-   const int f_start = STAGGER ? (int)((blockIdx.x * 37u) % (unsigned)kBins) : 0;
+   // blockIdx.y selects a third of the 129 bins: 3x more, 3x shorter waves (small launches fill the chip, short
+   // tails); each split writes its own partial bin sums, added in fixed order by the consumer (deterministic).
+   const int f_start = blockIdx.y * kBinsPerSplit;
+   const int f_end = min(f_start + kBinsPerSplit, kBins);
    f16v pa, pb;
    {
       const float *k0 = basis + (size_t)f_start * kFilterLen;
@@ -225,9 +228,8 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
    float p[8];                                          // PIPE: products of the first tree of the first filter
 #pragma unroll
    for (int j = 0; j < 8; ++j) p[j] = PIPE ? x[j * 8] * pa[j] : 0.0f;
-   for (int fi = 0; fi < kBins; ++fi) {
-      const int f = STAGGER ? (fi + f_start >= kBins ? fi + f_start - kBins : fi + f_start) : fi;
-      const int fn = STAGGER ? (f + 1 >= kBins ? 0 : f + 1) : f + 1;
+   for (int f = f_start; f < f_end; ++f) {
+      const int fn = f + 1;
       const float *kf = basis + (size_t)f * kFilterLen; // wave-uniform
       const float *kn = basis + (size_t)fn * kFilterLen;
       if (LOCK) __syncthreads();
@@ -248,14 +250,16 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
       }
       if (writer) yout[f * kFrames] = val;
    }
-   if (MODE == 0 && writer) FM[(size_t)chunk * kFrames + m] = bin_sum / 129.0f;   // misc.c:60
+   if (MODE == 0 && writer) FM[blockIdx.y * fm_stride + (size_t)chunk * kFrames + m] = bin_sum;   // /129 by the reader (misc.c:60)
 }
 
 
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
-__device__ __forceinline__ float norm_offset(const float *__restrict__ fm)
+__device__ __forceinline__ float norm_offset(const float *__restrict__ fmp, size_t fm_stride)
 {
+   float fm[kFrames];
+   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + fmp[2 * fm_stride + q]) / 129.0f;
    const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                           0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                           0.03663284704089164733887f};
@@ -275,18 +279,18 @@ __device__ __forceinline__ float norm_offset(const float *__restrict__ fm)
    return total / 25.0f;
 }
 
-__global__ void k_normalize_tap(const float *__restrict__ Y, const float *__restrict__ FM, float *__restrict__ out, int n_chunks)
+__global__ void k_normalize_tap(const float *__restrict__ Y, const float *__restrict__ FM, float *__restrict__ out, int n_chunks, size_t fm_stride)
 {
    const int chunk = blockIdx.x;
    if (chunk >= n_chunks) return;
-   const float mm = norm_offset(FM + (size_t)chunk * kFrames);
+   const float mm = norm_offset(FM + (size_t)chunk * kFrames, fm_stride);
    for (int i = threadIdx.x; i < kBins * kFrames; i += blockDim.x)
       out[(size_t)chunk * kBins * kFrames + i] = Y[(size_t)chunk * kBins * kFrames + i] - mm;
 }
 
 // Stage tap only: inverse of the above for feeding a NORMALIZED or MAGNITUDE tensor into the encoder:
 // from magnitudes compute Y and FM with the reference's element order.
-__global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *__restrict__ Y, float *__restrict__ FM, int n_chunks)
+__global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *__restrict__ Y, float *__restrict__ FM, int n_chunks, size_t fm_stride)
 {
    const int chunk = blockIdx.x;
    const int t = threadIdx.x;
@@ -298,34 +302,36 @@ __global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *_
       Y[idx] = v;
       s += v;
    }
-   FM[(size_t)chunk * kFrames + t] = s / 129.0f;
+   FM[(size_t)chunk * kFrames + t] = s;
+   FM[fm_stride + (size_t)chunk * kFrames + t] = 0.0f;
+   FM[2 * fm_stride + (size_t)chunk * kFrames + t] = 0.0f;
 }
 
 // n = number of items in this launch (= n_streams * map.cg)
-void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, int n, ItemMap map, int mode, hipStream_t st)
+void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
-   const int blocks = (int)((waves + 3) / 4);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
-   else           hipLaunchKernelGGL((k_frontend<float, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
+   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<float, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, int n, ItemMap map, int mode, hipStream_t st)
+void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
-   const int blocks = (int)((waves + 3) / 4);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
-   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), dim3(blocks), dim3(256), 0, st, pcm, basis, Y, FM, n, map);
+   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_normalize_tap(const float *Y, const float *FM, float *out, int n, hipStream_t st)
+void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, float *out, int n, hipStream_t st)
 {
-   hipLaunchKernelGGL(k_normalize_tap, dim3(n), dim3(256), 0, st, Y, FM, out, n);
+   hipLaunchKernelGGL(k_normalize_tap, dim3(n), dim3(256), 0, st, Y, FM, out, n, fm_stride);
 }
 
-void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, int n, hipStream_t st)
+void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, size_t fm_stride, int n, hipStream_t st)
 {
-   hipLaunchKernelGGL(k_lognorm_from_magnitude, dim3(n), dim3(64), 0, st, mag, Y, FM, n);
+   hipLaunchKernelGGL(k_lognorm_from_magnitude, dim3(n), dim3(64), 0, st, mag, Y, FM, n, fm_stride);
 }
 
 }  // namespace vadc

@@ -17,6 +17,8 @@
 //   the same lane/register of its four accumulators and the cell update is register-local.  Both layers' weights
 //   live in registers as MFMA A-fragments (2 x 4 x 32 VGPRs) for the whole call; [x;h] is the B operand, read
 //   from a small LDS tile that double-buffers h: one barrier per (step, layer).
+// k_lstm_wavefront (default, variant 0): the two layers run concurrently one step apart (see below); k_lstm_mfma
+//   (variant 2) is the step-sequential version of the same MFMA mapping.
 // k_lstm_simple: bring-up/reference variant (one wave per stream, weights streamed from L2), selectable with
 //   vadc_amd_set_option(e, "lstm", 1); used by the tests to A/B the MFMA kernel on the device.
 #include "common.h"
@@ -237,12 +239,139 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
    }
 }
 
+// ------------------------------------------------------------------------------------------------
+// layer-wavefront variant (default)
+// ------------------------------------------------------------------------------------------------
+// Layer 1 at step s and layer 0 at step s+1 both depend only on h0_s, so the two layers run CONCURRENTLY, one
+// step apart: a workgroup is 16 streams x 8 waves, waves 0-3 = layer 0, waves 4-7 = layer 1 (one of each per
+// SIMD).  In slot k layer 0 computes step k while layer 1 computes step k-1; both read h0_{k-1} from LDS.  A slot
+// costs one barrier instead of two, each wave keeps only ITS layer's weights in registers (128 VGPRs -> two waves
+// per SIMD fit), and on every SIMD the gate activations (VALU) of one layer overlap the MFMAs of the other.
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
+                                                           LstmWeights w,
+                                                           float *__restrict__ hs, float *__restrict__ cs,
+                                                           float *__restrict__ probs,
+                                                           int n_streams, int n_chunks, int c0, int cg)
+{
+   __shared__ __attribute__((aligned(16))) float xs[2][kXTile];   // [parity][t][unit][stream]
+   __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
+   __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
+   __shared__ float pd[4][2][kTileS];           // decoder partial dots per layer-1 wave
+   __shared__ __attribute__((aligned(16))) float bl[2][256];
+
+   const int tid = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = tid >> 6;
+   const int L = wave >> 2;                     // layer of this wave
+   const int wv = wave & 3;                     // owns hidden units [16 wv, 16 wv + 16) of its layer
+   const int col = lane & 15;
+   const int quad = lane >> 4;
+   const int s0 = blockIdx.x * kTileS;
+   const int s_col = min(s0 + col, n_streams - 1);
+   const bool col_ok = (s0 + col) < n_streams;
+   const float4 *tile_base = reinterpret_cast<const float4 *>(enc + (size_t)blockIdx.x * n_chunks * kXTile);
+
+   float a[4][32];                              // A fragments of this wave's layer
+#pragma unroll
+   for (int g = 0; g < 4; ++g) {
+      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + quad;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) a[g][kk] = row[4 * kk];
+   }
+   float c[4], dw[2][4];
+   for (int i = tid; i < 512; i += 512) bl[i >> 8][i & 255] = w.b[i];
+   float *hmine = L == 0 ? hb0[0] : hb1[0];
+#pragma unroll
+   for (int r = 0; r < 4; ++r) {
+      const int u = 16 * wv + 4 * quad + r;
+      dw[0][r] = w.dec_w[u];
+      dw[1][r] = w.dec_w[64 + u];
+      c[r] = cs[(size_t)s_col * 128 + L * 64 + u];
+      hmine[u * kTileS + col] = hs[(size_t)s_col * 128 + L * 64 + u];
+   }
+   for (int i = tid; i < kXTile / 4; i += 512)
+      reinterpret_cast<float4 *>(xs[0])[i] = (tile_base + (size_t)c0 * (kXTile / 4))[i];
+   int par0 = 0, par1 = 0;                      // buffers holding the CURRENT h0 / h1
+   float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+   __syncthreads();
+
+   const int total = 7 * cg;
+   for (int k = 0; k <= total; ++k) {
+      const bool active = (L == 0) ? (k < total) : (k >= 1);
+      const int step = (L == 0) ? k : k - 1;    // the step this wave computes in this slot
+      const int chi = step / 7, t = step - chi * 7;
+      if (L == 0 && active && t == 0 && (chi + 1) < cg) {
+         // prefetch the next chunk's frames straight into the other xs buffer (LDS-DMA); its last readers
+         // finished before the previous slot's barrier
+         const float4 *src = tile_base + (size_t)(c0 + chi + 1) * (kXTile / 4);
+#pragma unroll
+         for (int i = 0; i < 7; ++i) dma16(src + (tid & 255) + 256 * i, xs[(chi + 1) & 1] + (256 * i + 64 * wv) * 4);
+      }
+      if (active) {
+         const float *xin = (L == 0) ? (xs[chi & 1] + t * 64 * kTileS) : hb0[par0];
+         const float *hin = (L == 0) ? hb0[par0] : hb1[par1];
+         f4v acc[4];
+#pragma unroll
+         for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(&bl[L][g * 64 + 16 * wv + 4 * quad]);
+            acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
+         }
+#pragma unroll
+         for (int kk = 0; kk < 32; ++kk) {
+            const int kr = 4 * kk + quad;
+            const float bv = (kk < 16) ? xin[kr * kTileS + col] : hin[(kr - 64) * kTileS + col];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
+         }
+         float *hout = (L == 0) ? hb0[par0 ^ 1] : hb1[par1 ^ 1];
+#pragma unroll
+         for (int r = 0; r < 4; ++r) {
+            const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
+            const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            const float hn = og * fast_tanh(c[r]);
+            hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
+            if (L == 1) rsum[r] += fmaxf(hn, 0.0f);
+         }
+      }
+      const bool chunk_done = (L == 1) && active && (t == 6);
+      if (chunk_done) {
+         // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
+         float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
+         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
+      }
+      __syncthreads();                          // one barrier per slot
+      if (k < total) par0 ^= 1;                 // layer 0 wrote a new h0 in this slot
+      if (k >= 1) par1 ^= 1;                    // layer 1 wrote a new h1 in this slot
+      if (chunk_done && wv == 0 && lane < 2 * kTileS) {
+         const int sc = lane & 15, f = lane >> 4;
+         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
+         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
+      }
+   }
+   if (col_ok) {
+      const float *hfin = (L == 0) ? hb0[par0] : hb1[par1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wv + 4 * quad + r;
+         cs[(size_t)s_col * 128 + L * 64 + u] = c[r];
+         hs[(size_t)s_col * 128 + L * 64 + u] = hfin[u * kTileS + col];
+      }
+   }
+}
+
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
 void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
                  int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (variant == 1)
       hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 0)
+      hipLaunchKernelGGL(k_lstm_wavefront, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else
       hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
 }
