@@ -31,7 +31,8 @@ CHUNK_SECONDS = 1536 / 16000.0
 FLOP_PER_CHUNK = {
     "k_frontend": 2 * 1_651_200,
     "k_layer1": 2 * 181_053, "k_layer2": 2 * 112_208, "k_layer3": 2 * 61_600, "k_layer4": 2 * 236_768,
-    "k_lstm": 2 * (458_752 + 896),
+    "k_lstm": 2 * (458_752 - 114_688 + 896),      # recurrent part + decoder
+    "k_lstm_xproj": 2 * 114_688,                   # layer-0 input projection (256 x 64 x 7), hoisted GEMM
 }
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
 
@@ -65,6 +66,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
     ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
     ap.add_argument("--groups", type=int, default=0, help="chunk groups pipelined per step (0 = engine default)")
     args = ap.parse_args()
 
@@ -95,18 +97,21 @@ def main():
     base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
     pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(f"cuda:{local_rank}") for i in range(2)]
-    d_probs = torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}")
-    gather_list = [torch.empty_like(d_probs) for _ in range(world)] if (world > 1 and rank == 0) else None
+    d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
+    gather_list = [torch.empty_like(d_probs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
     from vadc_amd import shard
     lo, hi = shard.stream_block(rank, world, S * world)     # weak scaling: S streams per GPU, contiguous blocks
     assert hi - lo == S
-    stream = torch.cuda.Stream()          # the HIP stream every launch of the hot path is issued on
-    torch.cuda.set_stream(stream)
+    # Two caller streams used alternately: each step is strictly ordered on its own stream, and the engine's
+    # internal in-order streams overlap step k+1's front end + encoder with step k's LSTM.
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
     def step(i):
-        eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.gather(d_probs, gather_list, dst=0)          # the only collective: final probability gather
+        st = streams[i & 1]
+        with torch.cuda.stream(st):
+            eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs[i & 1].data_ptr(), st.cuda_stream)
+            if world > 1:
+                dist.gather(d_probs[i & 1], gather_list, dst=0)   # the only collective: final probability gather
 
     for i in range(args.warmup):
         step(i)
@@ -115,7 +120,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.reset_kernel_times()
-    eng.set_profiling(True)
+    eng.set_profiling(not args.graph)     # per-kernel HIP events need eager launches
+    if args.graph:
+        eng.set_option("graph", 1)
+        step(0); step(1)                  # capture both input buffers outside the timed region
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -125,6 +134,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
+    if args.graph:                        # kernel durations from an eager pass outside the timed region
+        eng.set_option("graph", 0)
+        eng.set_profiling(True)
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        eng.set_profiling(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
     if world > 1:
@@ -138,17 +154,27 @@ def main():
         dom = max(kt, key=lambda k: kt[k][1])
         launches, total_ms = kt[dom]
         avg_s = total_ms / max(launches, 1) / 1e3
-        achieved = FLOP_PER_CHUNK[dom] * S * Cn / avg_s / 1e12
+        # chunks one launch of the dominant kernel processes (a step may be split into chunk groups)
+        chunks_per_launch = S * Cn * (4 if args.graph else args.steps) / max(launches, 1)
+        achieved = FLOP_PER_CHUNK[dom] * chunks_per_launch / avg_s / 1e12
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
+            prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
+            if prof.get("streams") == S and prof.get("chunks_per_step") == Cn and dom in prof.get("kernels", {}):
+                traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Silero v3.1 16k, batch={S} streams/GPU x {Cn} chunks/step, fp32, s16le input resident in HBM",
-                       "streams_per_gpu": S, "chunks_per_step": Cn, "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
+                       "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "avg_launch_ms": round(avg_s * 1e3, 4),
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(avg_s * 1e3, 4), "chunks_per_launch": int(chunks_per_launch),
+                         "algorithmic_flop_per_chunk": FLOP_PER_CHUNK[dom],
                          "note": "fp32 peak (vector == matrix); the parity STFT is unfused mul+add => ceiling 0.5"},
             "kernels_ms_per_step": {k: round(v[1] / max(v[0], 1), 4) for k, v in kt.items()},
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),

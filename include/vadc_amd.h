@@ -125,17 +125,22 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* Tuning / bring-up switches:  "lstm"   0 = MFMA kernel (default), 1 = simple reference kernel
+/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront MFMA kernel, input projection hoisted
+ *                                      into a GEMM while the recurrence is latency-bound (few stream tiles);
+ *                                      1 = simple reference kernel, 2 = step-sequential MFMA, 3 = wavefront with
+ *                                      fused input projection, 4 = wavefront with hoisted input projection
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels
  *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
  *                                      group g overlaps the front end + encoder of group g+1.
+ *                             "graph"   1: capture the call's launch sequence into a hipGraph on first use and
+ *                                      replay it afterwards (steady-state serving); 0 (default): eager launches
  *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline
  *                                      streams disjoint CU masks; 0: never mask. */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
 enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,
-       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_COUNT };
+       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_LSTM_XPROJ, VADC_AMD_KERNEL_COUNT };
 /* When enabled every kernel launch of run_* is bracketed by hipEventRecord on its stream. */
 int  vadc_amd_set_profiling(vadc_amd_engine *e, int enabled);
 /* Synchronizes, then returns launch count and summed duration (ms) since the last reset. */

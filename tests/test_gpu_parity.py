@@ -280,6 +280,29 @@ def test_chunk_group_pipeline_is_bit_identical(eng, groups):
     assert np.array_equal(bits(want), bits(got))
 
 
+def test_hipgraph_replay_matches_eager(weights_blob):
+    """option "graph": the captured steady-state step replays bit-identically, state carried across replays"""
+    import torch
+    S, Cn = 40, 6
+    pcm = synth.make_streams(S, 3 * Cn, seed0=808)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    want = np.concatenate([e.run(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(3)], axis=1)
+    e.reset_streams()
+    e.set_option("graph", 1)
+    st = torch.cuda.Stream()
+    d_in = torch.empty((S, Cn * 1536), dtype=torch.int16, device="cuda:0")
+    d_out = torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0")
+    outs = []
+    with torch.cuda.stream(st):
+        for i in range(3):      # same buffers every step => one capture, two replays
+            d_in.copy_(torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])), non_blocking=False)
+            e.run_device(d_in.data_ptr(), np.int16, S, Cn, d_out.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            outs.append(d_out.cpu().numpy().copy())
+    e.close()
+    assert np.array_equal(bits(want), bits(np.concatenate(outs, axis=1)))
+
+
 def test_limits_are_enforced(eng):
     with pytest.raises(VadcAmdError):
         eng.run(np.zeros((65, 1536), np.int16))                 # > max_streams

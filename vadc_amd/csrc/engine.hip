@@ -20,7 +20,8 @@ void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
-void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t);
+void launch_lstm(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t);
+void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, hipStream_t);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b;
@@ -114,6 +115,7 @@ struct vadc_amd_engine {
    float *d_Y = nullptr, *d_FM = nullptr, *d_tap = nullptr;
    float *d_act[4] = {nullptr, nullptr, nullptr, nullptr};
    float *d_probs = nullptr;
+   float *d_gx = nullptr;                       // hoisted LSTM input projection (k_lstm_xproj)
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
    // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
@@ -122,7 +124,12 @@ struct vadc_amd_engine {
    hipStream_t sA = nullptr, sB = nullptr;
    int n_cus = 0;
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
+   bool ev_b_valid = false;                     // ev_b has been recorded by a previous forked call
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
+   // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
+   int use_graph = 0;
+   struct GraphEntry { const void *in; float *out; int S, C, elem, groups; hipStream_t st; hipGraph_t g; hipGraphExec_t x; };
+   std::vector<GraphEntry> graphs;
    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr, ev_fe[kMaxGroups] = {nullptr};
    // profiling
    bool profiling = false;
@@ -268,9 +275,10 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_act[3], e->d_probs, e->d_h, e->d_c};
+                   e->d_act[2], e->d_act[3], e->d_probs, e->d_h, e->d_c, e->d_gx};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
+   for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
    for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b}) if (ev) (void)hipEventDestroy(ev);
@@ -324,6 +332,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
    if (he == hipSuccess) he = hipMalloc(&e->d_act[3], padded_streams * max_chunks * 448 * sizeof(float));
    if (he == hipSuccess) he = hipMemset(e->d_act[3], 0, padded_streams * max_chunks * 448 * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_gx, padded_streams * max_chunks * 7 * 256 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -423,16 +432,17 @@ extern "C" int vadc_amd_reset_kernel_times(vadc_amd_engine *e)
 
 extern "C" const char *vadc_amd_kernel_name(int kernel)
 {
-   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"};
+   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_xproj"};
    return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 2) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
+   if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
 }
@@ -461,15 +471,24 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    }
 }
 
+// hold_last: event the stream must wait for before the LAST layer + input projection overwrite the encoder-output /
+// GX buffers (the previous call's LSTM may still be reading them on the other stream); nullptr = no wait
 template <typename T>
-static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, hipStream_t st)
+static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, int lstm_kernel, hipStream_t st,
+                                  hipEvent_t hold_last = nullptr)
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
       if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
    }
-   run_encoder_layers(e, 0, 3, n, map, 1, st);
+   run_encoder_layers(e, 0, 2, n, map, 0, st);
+   if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
+   run_encoder_layers(e, 3, 3, n, map, 1, st);
+   if (lstm_kernel == 0) {
+      KernelTimer t(e, VADC_AMD_KERNEL_LSTM_XPROJ, st);
+      launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st);
+   }
 }
 
 // Streams A (front end + encoder) and B (LSTM) of the chunk-group pipeline.  The LSTM of a small batch is
@@ -507,7 +526,17 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
    }
    e->lstm_cus = want;
+   e->ev_b_valid = false;                       // the old stream B was drained above
    return VADC_AMD_OK;
+}
+
+// LSTM kernel for this call: option "lstm" 0 = auto (hoisted input projection while the recurrence is latency-bound,
+// i.e. few stream tiles; fused otherwise), 1 = simple, 2 = step-sequential MFMA, 3 = fused wavefront, 4 = hoisted wavefront
+static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
+{
+   if (e->lstm_variant == 0) return ((n_streams + 15) / 16 <= e->n_cus / 2) ? 0 : 3;
+   if (e->lstm_variant == 4) return 0;
+   return e->lstm_variant;
 }
 
 static int pick_groups(const vadc_amd_engine *e, int n_chunks)
@@ -521,14 +550,19 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 // The whole hot path for n_streams x n_chunks chunks; asynchronous on `st`.  No allocation, no host sync:
 // the sequence (including the fork/join over the two internal streams) can be captured into a hipGraph.
 template <typename T>
-static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
 {
    const int G = pick_groups(e, n_chunks);
-   if (G == 1) {
+   const int lk = resolve_lstm(e, n_streams);
+   // Small calls run straight on the caller's stream.  Larger ones always fork onto the two internal streams, even
+   // with one group: the internal streams are in-order across calls, so a caller that alternates between two
+   // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
+   // while every call keeps strict stream semantics (its results are complete when its own stream reaches the join).
+   if (G == 1 && (long)n_streams * n_chunks < 2048) {
       const ItemMap map{n_chunks, 0, n_chunks};
-      run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, st);
+      run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-      launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st);
+      launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st);
    } else {
       int rc = ensure_pipeline_streams(e, n_streams);
       if (rc) return rc;
@@ -536,6 +570,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+      hipEvent_t hold = e->ev_b_valid ? e->ev_b : nullptr;     // previous call's LSTM still owns X / GX
       // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
       int sizes[vadc_amd_engine::kMaxGroups];
       {
@@ -551,21 +586,55 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          const int cg = sizes[gi];
          if (cg <= 0) continue;
          const ItemMap map{n_chunks, c0, cg};
-         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, e->sA);
+         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA, hold);
+         hold = nullptr;
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-         launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB);
+         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB);
          c0 += cg;
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
       (void)hipEventRecord(e->ev_b, e->sB);
+      e->ev_b_valid = true;
       (void)hipStreamWaitEvent(st, e->ev_a, 0);
       (void)hipStreamWaitEvent(st, e->ev_b, 0);
    }
    hipError_t he = hipGetLastError();
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
+   return VADC_AMD_OK;
+}
+
+// Steady-state replay: the first call with a given (buffers, shape, stream) signature captures the launch sequence
+// (including the fork/join over the internal streams) into a hipGraph; later calls are one hipGraphLaunch.
+// Profiling (per-kernel events) needs eager launches, so it bypasses the graph.  Kernel nodes do not inherit a
+// stream's CU mask, so the graph path always uses unmasked internal streams.
+template <typename T>
+static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+{
+   if (!e->use_graph || e->profiling) return run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
+   for (auto &ge : e->graphs)
+      if (ge.in == d_in && ge.out == d_probs && ge.S == n_streams && ge.C == n_chunks && ge.elem == (int)sizeof(T) &&
+          ge.groups == e->groups && ge.st == st) {
+         HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
+         return VADC_AMD_OK;
+      }
+   const int saved_partition = e->cu_partition;
+   if (saved_partition) { e->cu_partition = 0; e->lstm_cus = -1; }
+   int rc = ensure_pipeline_streams(e, n_streams);              // create the (unmasked) streams BEFORE capturing
+   if (rc) { e->cu_partition = saved_partition; return rc; }
+   vadc_amd_engine::GraphEntry ge{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), e->groups, st, nullptr, nullptr};
+   HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed), VADC_AMD_EHIP);
+   rc = run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
+   hipError_t he = hipStreamEndCapture(st, &ge.g);
+   e->cu_partition = saved_partition;
+   if (rc) return rc;
+   if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
+   HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
+   if (e->graphs.size() >= 8) { (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin()); }
+   e->graphs.push_back(ge);
+   HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
 
@@ -742,7 +811,9 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
                   tiles[lstm_x_index(s, c, n_chunks, t, u)] = x[(((size_t)s * n_chunks + c) * 64 + u) * 7 + t];
       HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    }
-   launch_lstm(e->lstm_variant, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
+   const int lk = resolve_lstm(e, n_streams);
+   if (lk == 0) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st);
+   launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);

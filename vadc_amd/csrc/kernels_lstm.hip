@@ -240,6 +240,45 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// input projection of layer 0, hoisted off the recurrent critical path
+// ------------------------------------------------------------------------------------------------
+// The x-part of layer 0's gates, W[0][:, 0:64] . x_t + b[0], does not depend on the recurrence: it is computed
+// for all 7 steps of every (stream tile, chunk) by the otherwise idle CUs in this small GEMM kernel and handed to
+// the recurrent kernel as the INITIAL VALUE of layer 0's accumulators (k-order x then h is unchanged, so the result
+// is bit-identical to doing both halves inside the recurrence).  Layout GX[tile][chunk][t][256 gate rows][16 streams].
+constexpr int kGxTile = 7 * 256 * kLstmTile;      // floats per (tile, chunk)
+
+__global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ enc,   // LSTM-native tiles
+                                                    LstmWeights w, float *__restrict__ gx,
+                                                    int n_chunks, int c0, int cg)
+{
+   const int tile = blockIdx.x / cg, ch = c0 + blockIdx.x % cg;
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int quad = lane >> 4, lc = lane & 15;
+   const float *X = enc + ((size_t)tile * n_chunks + ch) * (7 * 64 * kLstmTile);
+   float *G = gx + ((size_t)tile * n_chunks + ch) * kGxTile;
+#pragma unroll 1
+   for (int mi = 0; mi < 4; ++mi) {
+      const int mt = wave + 4 * mi;               // 16 gate rows [16 mt, 16 mt + 16)
+      float a[16];
+      const float *row = w.w + ((size_t)16 * mt + lc) * 128 + quad;      // layer 0, x half: k < 64
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a[kk] = row[4 * kk];
+      const float4 b4 = *reinterpret_cast<const float4 *>(w.b + 16 * mt + 4 * quad);
+#pragma unroll 1
+      for (int t = 0; t < 7; ++t) {
+         f4v acc;
+         acc[0] = b4.x; acc[1] = b4.y; acc[2] = b4.z; acc[3] = b4.w;
+#pragma unroll
+         for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], X[(t * 64 + 4 * kk + quad) * kLstmTile + lc], acc, 0, 0, 0);
+#pragma unroll
+         for (int r = 0; r < 4; ++r) G[((size_t)t * 256 + 16 * mt + 4 * quad + r) * kLstmTile + lc] = acc[r];
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
 // layer-wavefront variant (default)
 // ------------------------------------------------------------------------------------------------
 // Layer 1 at step s and layer 0 at step s+1 both depend only on h0_s, so the two layers run CONCURRENTLY, one
@@ -247,7 +286,146 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 // SIMD).  In slot k layer 0 computes step k while layer 1 computes step k-1; both read h0_{k-1} from LDS.  A slot
 // costs one barrier instead of two, each wave keeps only ITS layer's weights in registers (128 VGPRs -> two waves
 // per SIMD fit), and on every SIMD the gate activations (VALU) of one layer overlap the MFMAs of the other.
-__global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restrict__ gx,    // GX tiles from k_lstm_xproj
+                                                           LstmWeights w,
+                                                           float *__restrict__ hs, float *__restrict__ cs,
+                                                           float *__restrict__ probs,
+                                                           int n_streams, int n_chunks, int c0, int cg)
+{
+   __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
+   __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
+   __shared__ float pd[4][2][kTileS];           // decoder partial dots per layer-1 wave
+   __shared__ __attribute__((aligned(16))) float bl1[256];   // layer-1 fused biases (accumulator init)
+
+   const int tid = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = tid >> 6;
+   const int L = wave >> 2;                     // layer of this wave
+   const int wv = wave & 3;                     // owns hidden units [16 wv, 16 wv + 16) of its layer
+   const int col = lane & 15;
+   const int quad = lane >> 4;
+   const int s0 = blockIdx.x * kTileS;
+   const int s_col = min(s0 + col, n_streams - 1);
+   const bool col_ok = (s0 + col) < n_streams;
+   // this lane's 16 accumulator-init values of step (chunk, t): gx_lane[((chunk*7 + t)*256 + g*64) * 16 + r*16]
+   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + (size_t)(16 * wv + 4 * quad) * kTileS + col;
+
+   // A fragments: layer 0 keeps only the h half (k >= 64) -- its x half was applied by k_lstm_xproj
+   float a[4][32];
+#pragma unroll
+   for (int g = 0; g < 4; ++g) {
+      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + quad;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) a[g][kk] = (L == 0 && kk < 16) ? 0.0f : row[4 * kk];
+   }
+   float c[4], dw[2][4];
+   if (tid < 256) bl1[tid] = w.b[256 + tid];
+   float *hmine = L == 0 ? hb0[0] : hb1[0];
+#pragma unroll
+   for (int r = 0; r < 4; ++r) {
+      const int u = 16 * wv + 4 * quad + r;
+      dw[0][r] = w.dec_w[u];
+      dw[1][r] = w.dec_w[64 + u];
+      c[r] = cs[(size_t)s_col * 128 + L * 64 + u];
+      hmine[u * kTileS + col] = hs[(size_t)s_col * 128 + L * 64 + u];
+   }
+   int par0 = 0, par1 = 0;                      // buffers holding the CURRENT h0 / h1
+   float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+   // layer 0: accumulator init of the NEXT step, fetched one slot ahead
+   float gnext[4][4];
+   if (L == 0) {
+      const float *p = gx_lane + (size_t)c0 * kGxTile;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) gnext[g][r] = p[(size_t)(g * 64 + r) * kTileS];
+   }
+   __syncthreads();
+
+   const int total = 7 * cg;
+   for (int k = 0; k <= total; ++k) {
+      const bool active = (L == 0) ? (k < total) : (k >= 1);
+      const int step = (L == 0) ? k : k - 1;    // the step this wave computes in this slot
+      const int chi = step / 7, t = step - chi * 7;
+      if (active) {
+         f4v acc[4];
+         if (L == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
+            if (k + 1 < total) {                // prefetch the next step's init values (latency hidden by this slot)
+               const float *p = gx_lane + ((size_t)c0 * 7 + (k + 1)) * (256 * kTileS);
+#pragma unroll
+               for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) gnext[g][r] = p[(size_t)(g * 64 + r) * kTileS];
+            }
+            const float *hin = hb0[par0];
+#pragma unroll
+            for (int kk = 16; kk < 32; ++kk) {
+               const float bv = hin[(4 * kk + quad - 64) * kTileS + col];
+#pragma unroll
+               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
+            }
+         } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+               const float4 b4 = *reinterpret_cast<const float4 *>(&bl1[g * 64 + 16 * wv + 4 * quad]);
+               acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
+            }
+            const float *xin = hb0[par0], *hin = hb1[par1];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+               const int kr = 4 * kk + quad;
+               const float bv = (kk < 16) ? xin[kr * kTileS + col] : hin[(kr - 64) * kTileS + col];
+#pragma unroll
+               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
+            }
+         }
+         float *hout = (L == 0) ? hb0[par0 ^ 1] : hb1[par1 ^ 1];
+#pragma unroll
+         for (int r = 0; r < 4; ++r) {
+            const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
+            const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            const float hn = og * fast_tanh(c[r]);
+            hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
+            if (L == 1) rsum[r] += fmaxf(hn, 0.0f);
+         }
+      }
+      const bool chunk_done = (L == 1) && active && (t == 6);
+      if (chunk_done) {
+         // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
+         float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
+         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
+      }
+      __syncthreads();                          // one barrier per slot
+      if (k < total) par0 ^= 1;                 // layer 0 wrote a new h0 in this slot
+      if (k >= 1) par1 ^= 1;                    // layer 1 wrote a new h1 in this slot
+      if (chunk_done && wv == 0 && lane < 2 * kTileS) {
+         const int sc = lane & 15, f = lane >> 4;
+         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
+         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
+      }
+   }
+   if (col_ok) {
+      const float *hfin = (L == 0) ? hb0[par0] : hb1[par1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wv + 4 * quad + r;
+         cs[(size_t)s_col * 128 + L * 64 + u] = c[r];
+         hs[(size_t)s_col * 128 + L * 64 + u] = hfin[u * kTileS + col];
+      }
+   }
+}
+
+// Same layer-wavefront schedule with layer 0's input projection done INSIDE the recurrence (x frames staged by
+// LDS-DMA).  Used when there are many stream tiles (the LSTM is throughput- not latency-bound and the extra GX round
+// trip of the hoisted form does not pay).
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
                                                            LstmWeights w,
                                                            float *__restrict__ hs, float *__restrict__ cs,
                                                            float *__restrict__ probs,
@@ -365,15 +543,26 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
 }
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
-void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
+// gx: scratch for the hoisted input projection, [ceil(S/16)][n_chunks][7][256][16] floats (variant 0 only)
+void launch_lstm(int variant, const float *enc, float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
                  int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (variant == 1)
       hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 0)
-      hipLaunchKernelGGL(k_lstm_wavefront, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 3)
+      hipLaunchKernelGGL(k_lstm_wavefront_fused, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 0)   // consumes GX written by launch_lstm_xproj for the same chunk range
+      hipLaunchKernelGGL(k_lstm_wavefront, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else
       hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+}
+
+// layer-0 input projection for chunks [c0, c0 + cg): a wide GEMM, launched with the encoder (all CUs), not with the
+// recurrent kernel
+void launch_lstm_xproj(const float *enc, float *gx, const LstmWeights &w, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+{
+   const int tiles = (n_streams + kTileS - 1) / kTileS;
+   hipLaunchKernelGGL(k_lstm_xproj, dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
 }
 
 }  // namespace vadc

@@ -22,7 +22,7 @@ from . import _lib
 CHUNK = 1536
 STAGES = {"magnitude": 0, "normalized": 1, "layer1": 2, "layer2": 3, "layer3": 4, "layer4": 5}
 STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}
-KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"]
+KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_xproj"]
 
 
 class VadcAmdError(RuntimeError):
