@@ -20,8 +20,8 @@
 // the wave (two DPP/permute shuffles), never across waves.  Only the depthwise conv (time neighbours) and attention
 // (all 7..25 steps of a chunk) look across columns, so those are the only phases that need workgroup barriers for
 // correctness; the VALU work there is spread over all 256 threads.
-// The input channels of the conv block are consumed in slabs of 32 (layer 1 has 129 -> 5 slabs), so LDS holds
-// 32 rows of x and of relu(dw(x)) at a time, aliased with the later Q/K/V + attention buffers.
+// The conv block needs no LDS at all: a lane's B-fragment element for k-step kk is channel 4kk+quad at its own
+// column, so x and its time neighbours are loaded from global/L1 straight into fragment registers.
 #include "common.h"
 
 namespace vadc {
@@ -30,7 +30,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kCol = 64;      // columns per workgroup (4 MFMA N-tiles)
 constexpr int kPitch = 80;    // LDS row pitch in floats (80 % 32 == 16: rows k..k+3 of a B fragment hit disjoint banks)
-constexpr int kSlab = 32;     // input channels per conv-block slab
+
 
 struct LayerWeightsM {
    const float *dw_w, *dw_b;          // [cin][5], [cin]
@@ -139,7 +139,7 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
    }
 }
 
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, bool LSTM_OUT, int NCH>
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, bool LSTM_OUT, int NCH, bool DIRECT>
 __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [n][25] (FIRST) or null
                                                     LayerWeightsM w,
@@ -153,24 +153,18 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    constexpr int MT = D / 16;
    constexpr int CINP = (CIN + 3) / 4 * 4;
    constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
+   constexpr int kSlab = 32;                            // input channels per slab (slab path)
    constexpr int NSLAB = (CINP + kSlab - 1) / kSlab;
-   constexpr int ROWS_B = (4 * D > 2 * kSlab) ? 4 * D : 2 * kSlab;
+   constexpr int ROWS_B = (DIRECT || 4 * D > 2 * kSlab) ? 4 * D : 2 * kSlab;
    __shared__ __attribute__((aligned(16))) float Yb[D * kPitch];          // conv-block output / residual stream
-   __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // {x slab, relu(dw) slab} then {Q,K,V, att}
+   __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // Q, K, V rows then the attention / FFN rows
    __shared__ float mm_s[NCH];
-   float *XS = Bb, *DWR = Bb + kSlab * kPitch;
    float *QKV = Bb, *ATT = Bb + 3 * D * kPitch;
+   float *XS = Bb, *DWR = Bb + kSlab * kPitch;          // slab path only (aliases Q/K/V)
 
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = tid >> 6;
    const int quad = lane >> 4, lc = lane & 15;
-
-   // column owned by this thread in the element-wise phases: col = lane (64 columns), row group = wave
-   const int col = lane;
-   const int cb = col / T, t = col - cb * T;
-   const int item_raw = blockIdx.x * NCH + cb;
-   const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
-   const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
 
    if (FIRST) {
       if (tid < NCH) {
@@ -179,11 +173,63 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       }
       __syncthreads();
    }
-   const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
-
-   // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
    f4v acc[MT];
    acc_init<MT>(acc, w.cb_b, lane);
+   if constexpr (DIRECT) {
+   // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
+   // Direct-to-fragment: for k-step kk this lane's B-fragment element is channel 4kk+quad at ITS OWN column, so x
+   // (and its 4 time neighbours for the depthwise conv) is loaded straight from global/L1 into the fragment
+   // registers -- no LDS staging, no barriers, the 4 waves run independently.  x feeds the projection MFMA,
+   // relu(dw(x)) the pointwise MFMA.
+   const int mcol = 16 * wave + lc;                       // this lane's column in every MFMA phase
+   const int mcb = mcol / T, mt_ = mcol - mcb * T;
+   const int mitem = blockIdx.x * NCH + mcb;
+   const bool mvalid = (mcol < NCOLV) && (mitem < n_chunks);
+   const float *mx = in + (size_t)map(mvalid ? mitem : min(blockIdx.x * NCH, n_chunks - 1)) * CIN * T + mt_;
+   const float mmm = FIRST ? mm_s[mcb < NCH ? mcb : 0] : 0.0f;
+   const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < T, tr2 = mvalid && mt_ + 2 < T;
+#pragma unroll 4
+   for (int kk = 0; kk < KKW; ++kk) {
+      const int ch = 4 * kk + quad;
+      const bool chv = ch < CIN;
+      const float *xr = mx + (size_t)(chv ? ch : 0) * T;
+      const float x0 = (mvalid && chv) ? xr[0] - mmm : 0.0f;             // misc.c:84-96
+      const float xm2 = (tl2 && chv) ? xr[-2] - mmm : 0.0f, xm1 = (tl1 && chv) ? xr[-1] - mmm : 0.0f;
+      const float xp1 = (tr1 && chv) ? xr[1] - mmm : 0.0f, xp2 = (tr2 && chv) ? xr[2] - mmm : 0.0f;
+      const float *k5 = w.dw_w + (chv ? ch : 0) * 5;
+      float dv = w.dw_b[chv ? ch : 0];                                   // conv.c:17-53
+      dv = fmaf(xm2, k5[0], dv); dv = fmaf(xm1, k5[1], dv); dv = fmaf(x0, k5[2], dv);
+      dv = fmaf(xp1, k5[3], dv); dv = fmaf(xp2, k5[4], dv);
+      dv = (mvalid && chv) ? fmaxf(dv, 0.0f) : 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pw_f[((size_t)mt * KKW + kk) * 64 + lane], dv, acc[mt], 0, 0, 0);
+         if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
+      }
+   }
+   if (!HAS_PROJ) {                                       // identity residual (CIN == D): + x
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) acc[mt][r] += mvalid ? mx[(size_t)(16 * mt + 4 * quad + r) * T] : 0.0f;
+   }
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   __syncthreads();
+
+   } else {
+      // slab path (layer 1: 129 input channels): x and relu(dw(x)) staged through LDS 32 channels at a time
+   // column owned by this thread in the element-wise phases of the slab path: col = lane, row group = wave
+   const int col = lane;
+   const int cb = col / T, t = col - cb * T;
+   const int item_raw = blockIdx.x * NCH + cb;
+   const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
+   const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
+   const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
+   // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
    const float *x_in = in + (size_t)chunk * CIN * T + t;
 #pragma unroll 1
    for (int s = 0; s < NSLAB; ++s) {
@@ -240,6 +286,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
    __syncthreads();                                       // slab buffers free, Yb visible
 
+   }
    // ---- QKV = W y + b  -> LDS rows [0,D) Q, [D,2D) K, [2D,3D) V      transformer.c:69-99 -----------------
    {
       f4v q[3 * MT];
@@ -359,12 +406,12 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
                        int lstm_layout, size_t fm_stride, hipStream_t st)
 {
    switch (layer) {
-   case 0: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
-   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
-   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 0: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 3:
-      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, true, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, false, 9>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, true, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
       break;
    }
 }
