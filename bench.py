@@ -67,7 +67,9 @@ def main():
     ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
-    ap.add_argument("--groups", type=int, default=0, help="chunk groups pipelined per step (0 = engine default)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
+                         "through the two caller streams; 0 = engine default for single-stream callers)")
     args = ap.parse_args()
 
     import torch
@@ -90,8 +92,7 @@ def main():
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
-    if args.groups:
-        eng.set_option("groups", args.groups)
+    eng.set_option("groups", args.groups)
 
     # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
     base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)

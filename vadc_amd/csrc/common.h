@@ -15,8 +15,8 @@ constexpr int kBins      = 129;
 constexpr int kFilters   = 258;
 constexpr int kFrames    = 25;
 constexpr int kHidden    = 64;
-constexpr int kBinSplit      = 3;    // k_frontend splits the 129 bins over gridDim.y
-constexpr int kBinsPerSplit  = 43;
+constexpr int kBinSplit      = 4;    // partial bin sums: k_frontend splits the 129 bins over gridDim.y, k_frontend_mx over its 4 waves
+constexpr int kBinsPerSplit  = 33;
 
 // One encoder layer's weights on the device.  Matrices keep the reference's [out][in] layout
 // (rows contiguous over `in`) except the conv-block pointwise/proj weights which are stored

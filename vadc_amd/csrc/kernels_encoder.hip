@@ -27,7 +27,7 @@ namespace vadc {
 __device__ __forceinline__ float norm_offset_fast(const float *__restrict__ fmp, size_t fm_stride)
 {
    float fm[kFrames];
-   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + fmp[2 * fm_stride + q]) / 129.0f;
+   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + (fmp[2 * fm_stride + q] + fmp[3 * fm_stride + q])) / 129.0f;
    const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                           0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                           0.03663284704089164733887f};

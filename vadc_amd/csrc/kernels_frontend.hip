@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
 __device__ __forceinline__ float norm_offset(const float *__restrict__ fmp, size_t fm_stride)
 {
    float fm[kFrames];
-   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + fmp[2 * fm_stride + q]) / 129.0f;
+   for (int q = 0; q < kFrames; ++q) fm[q] = ((fmp[q] + fmp[fm_stride + q]) + (fmp[2 * fm_stride + q] + fmp[3 * fm_stride + q])) / 129.0f;
    const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                           0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                           0.03663284704089164733887f};
@@ -305,6 +305,7 @@ __global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *_
    FM[(size_t)chunk * kFrames + t] = s;
    FM[fm_stride + (size_t)chunk * kFrames + t] = 0.0f;
    FM[2 * fm_stride + (size_t)chunk * kFrames + t] = 0.0f;
+   FM[3 * fm_stride + (size_t)chunk * kFrames + t] = 0.0f;
 }
 
 // n = number of items in this launch (= n_streams * map.cg)
@@ -332,6 +333,171 @@ void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, flo
 void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, size_t fm_stride, int n, hipStream_t st)
 {
    hipLaunchKernelGGL(k_lognorm_from_magnitude, dim3(n), dim3(64), 0, st, mag, Y, FM, n, fm_stride);
+}
+
+
+// =====================================================================================================
+// k_frontend_mx -- the same bit-exact STFT with the 256 PRODUCTS of every output moved to the matrix cores
+// =====================================================================================================
+// v_mfma_f32_16x16x1_4b_f32 with a zero accumulator computes D[i][j] = fma(A[i], B[j], 0) = rnd(A[i]*B[j]): an outer
+// product of INDIVIDUALLY ROUNDED fp32 products (K = 1, nothing is accumulated inside the instruction), i.e. exactly
+// the p_t = x[t]*k[t] terms of the reference's tree (stft.c:141-155) -- checked bit for bit on the device
+// (tools/mfma_k1.hip).  For tap t the A operand is x[position][t] for 64 (chunk, frame) positions (one per lane), the
+// B operand k[filter][t] for the 16 filters of a tile; all 256 products of one (position, filter) output land in the
+// SAME lane and accumulator register, one MFMA per tap, so the reference's tree of 255 separately rounded adds
+// (stft.c:143-184) is pure per-lane VALU work on registers: no cross-lane shifts, no halo lanes, and half the VALU
+// instructions of k_frontend (the vector ALU is the bound: SGPR-operand v_mul and v_add both issue at ~4 cycles per
+// wave64 on gfx950, tools/valu_rate*.hip).
+// STATUS (round 1): correct and bit-identical to k_frontend (tests), but SLOWER as compiled by hipcc (4.7 ms vs 1.7 ms
+// per 16,384 chunks): the scheduler hoists the pure MFMAs, the ordering tokens below serialise MFMA -> add inside a
+// wave, and the 16-register accumulators leave room for one wave per SIMD only.  Selectable with option "frontend"=1;
+// a hand-scheduled (asm) version with software-pipelined MFMA/add phases is the open item.
+//   workgroup = 4 waves x the same 64 positions (x staged once in LDS, padded so that the 64 lanes' reads of one tap
+//   hit different banks); wave w walks filter tiles w, w+4, ...; a tile = 8 bins x (re, im) so that the magnitude
+//   pairs lane j with lane j+8 of the same 16-lane row.
+constexpr int kMxTiles = 17;                  // ceil(129 / 8) filter tiles of 8 bins x (re, im)
+constexpr int kMxChunkPitch = kPadded + kPadded / 64;   // 1792 samples + 1 pad per 64 = 1820 floats
+constexpr int kMxChunks = 4;                  // 64 consecutive positions span at most 4 chunks
+
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 1) void k_frontend_mx(const T *__restrict__ pcm,          // [n_chunks][1536]
+                                                        const float *__restrict__ bt,       // [17][256 taps, tree order][16]
+                                                        float *__restrict__ Y,              // [n_chunks][129][25]
+                                                        float *__restrict__ FM,             // [4][fm_stride] partial bin sums
+                                                        int n_chunks, ItemMap map, size_t fm_stride)
+{
+   __shared__ float xs[kMxChunks * kMxChunkPitch];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int lc = lane & 15, quad = lane >> 4;
+   const long total_pos = (long)n_chunks * kFrames;
+   const long p0 = (long)blockIdx.x * 64;
+   const int item0 = (int)(p0 / kFrames);
+
+   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954) + 1 pad float per 64
+   for (int c = 0; c < kMxChunks; ++c) {
+      const int it = min(item0 + c, n_chunks - 1);
+      const T *src = pcm + (size_t)map(it) * kChunk;
+      for (int idx = tid; idx < kPadded; idx += 256) {
+         int s = idx - kPad;
+         s = s < 0 ? -s : s;
+         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
+         xs[c * kMxChunkPitch + idx + (idx >> 6)] = sample_to_f32(src[s]);
+      }
+   }
+   __syncthreads();
+
+   // this lane's position (A operand): sample index 64 n + t of its chunk -> xs[c*pitch + 65 n + t + (t >> 6)]
+   const long pa = min(p0 + lane, total_pos - 1);
+   const int item_a = (int)(pa / kFrames), n_a = (int)(pa - (long)item_a * kFrames);
+   const float *xa = xs + (item_a - item0) * kMxChunkPitch + 65 * n_a;
+
+   float bsum[16];
+#pragma unroll
+   for (int e = 0; e < 16; ++e) bsum[e] = 0.0f;
+   const f16acc zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll 1
+   for (int ft = wave; ft < kMxTiles; ft += 4) {
+      const float *bp = bt + (size_t)ft * (256 * 16) + lc;
+      f16acc s01, s0123, s45, y;
+      f16acc order_tok = zero;
+      // lanes-of-the-tree l are walked in pairs (runtime loop: bounds the live products); inside a pair everything is
+      // unrolled.  Taps t = 64 i + 8 j + l are consumed four at a time (4 MFMAs = 64 accumulator registers in flight).
+#pragma unroll 1
+      for (int lp = 0; lp < 4; ++lp) {
+         f16acc vpair;
+#pragma unroll
+         for (int lo = 0; lo < 2; ++lo) {
+            const float *xl = xa + 2 * lp + lo;             // + 65 i + 8 j   (sample 64 i + 8 j + l, one pad per 64)
+            const float *bl = bp + (2 * lp + lo) * (32 * 16);   // + (8 i + j) * 16
+            f16acc g01, g2, v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+// MX4(J0, DEP): products of taps j = J0..J0+3 of group i.  The operand ADDRESSES are passed through an empty asm that
+// also names the previous group's sum: a zero-cost ordering token.  Without it hipcc's DAG scheduler hoists all 64
+// (pure) MFMAs and their 128 loads of the unrolled body above the adds and spills kilobytes of products.
+#define VADC_MX4(Q0, Q1, Q2, Q3, J0, DEP)                                                                          \
+   {                                                                                                                \
+      const float *xg_ = xl + 65 * i + 8 * (J0);                                                                    \
+      const float *bg_ = bl + (8 * i + (J0)) * 16;                                                                  \
+      float a0_ = xg_[0];                                                                                           \
+      asm volatile("" : "+v"(a0_) : "v"((DEP)[0]));                                                                 \
+      Q0 = __builtin_amdgcn_mfma_f32_16x16x1f32(a0_, bg_[0], zero, 0, 0, 0);                                        \
+      Q1 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[8], bg_[16], zero, 0, 0, 0);                                    \
+      Q2 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[16], bg_[32], zero, 0, 0, 0);                                   \
+      Q3 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[24], bg_[48], zero, 0, 0, 0);                                   \
+   }
+               f16acc q0, q1, q2, q3, q4, q5, q6, q7;
+               VADC_MX4(q0, q1, q2, q3, 0, order_tok)
+               const f16acc h0 = (q0 + q1) + (q2 + q3);                     // (p0+p1)+(p2+p3)   stft.c:141-157
+               VADC_MX4(q4, q5, q6, q7, 4, h0)
+               const f16acc h1 = (q4 + q5) + (q6 + q7);                     // (p4+p5)+(p6+p7)   stft.c:158
+               order_tok = h1;
+#undef VADC_MX4
+#define VADC_MXP_AFTER
+#undef VADC_MXP_AFTER
+#undef VADC_MXP
+               const f16acc g = h0 + h1;                                    // stft.c:160
+               if (i == 0) g01 = g;
+               else if (i == 1) g01 = g01 + g;                              // g_0 + g_1   stft.c:165
+               else if (i == 2) g2 = g;
+               else v = g01 + (g2 + g);                                     // (g_0+g_1) + (g_2+g_3)   stft.c:166-167
+            }
+            vpair = (lo == 0) ? v : vpair + v;                              // v_{2lp} + v_{2lp+1}   stft.c:176-179
+         }
+         if (lp == 0) s01 = vpair;                                          // lane tree   stft.c:181-184
+         else if (lp == 1) s0123 = s01 + vpair;
+         else if (lp == 2) s45 = vpair;
+         else y = s0123 + (s45 + vpair);
+      }
+      // y[e]: position 16 (e/4) + 4 quad + e%4 of this workgroup, filter lc of tile ft (lc < 8: re of bin 8 ft + lc,
+      // lc >= 8: im of bin 8 ft + lc - 8).  Pair re with im across lanes lc, lc + 8.
+      const int bin = 8 * ft + (lc & 7);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         const float re = y[e];
+         const float im = __shfl_down(re, 8, 16);
+         const float re2 = re * re, im2 = im * im;
+         const float mag = sqrtf(re2 + im2);                                  // stft.c:209
+         const float val = (MODE == 0) ? log1pf(mag * 1048576.0f) : mag;      // misc.c:42-45
+         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
+         if (lc < 8 && bin < kBins && pe < total_pos) {
+            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
+            Y[(size_t)map(it) * (kBins * kFrames) + bin * kFrames + n] = val;
+            bsum[e] += val;
+         }
+         __builtin_amdgcn_sched_barrier(0);             // one element at a time: keeps the 16 log1p bodies from interleaving
+      }
+   }
+   if (MODE == 0) {
+      // partial bin sums of this wave: reduce over the 8 bin lanes, lane lc == 0 of each quad stores 16 positions
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         float s = bsum[e];
+         s += __shfl_xor(s, 1, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 4, 16);
+         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
+         if (lc == 0 && pe < total_pos) {
+            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
+            FM[wave * fm_stride + (size_t)map(it) * kFrames + n] = s;
+         }
+      }
+   }
+}
+
+void launch_frontend_mx_f32(const float *pcm, const float *bt, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx<float, 0>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_mx<float, 1>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
+}
+
+void launch_frontend_mx_s16(const int16_t *pcm, const float *bt, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx<int16_t, 0>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_mx<int16_t, 1>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
 }
 
 }  // namespace vadc
