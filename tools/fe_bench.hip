@@ -14,20 +14,21 @@ using namespace vadc;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-template <int MODE, int NT, int MINW, int SHIFT, int LOCK, int STAGGER, int PIPE = 0>
+template <int MODE, int NT, int MINW, int SHIFT, int LOCK, int ABL, int PIPE = 0, int PK = 0>
 static float run(const char *name, const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int reps)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const int wpb = NT / 64;
-   const int blocks = (int)((waves + wpb - 1) / wpb);
+   const dim3 blocks((unsigned)((waves + wpb - 1) / wpb), kBinSplit);
+   const size_t fm_stride = (size_t)n * kFrames;
    const ItemMap map{n, 0, n};
    hipEvent_t a, b;
    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-   hipLaunchKernelGGL((k_frontend<int16_t, MODE, NT, MINW, SHIFT, LOCK, STAGGER, PIPE>), dim3(blocks), dim3(NT), 0, 0, pcm, basis, Y, FM, n, map);
+   hipLaunchKernelGGL((k_frontend<int16_t, MODE, NT, MINW, SHIFT, LOCK, ABL, PIPE, PK>), blocks, dim3(NT), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
    CK(hipDeviceSynchronize());
    CK(hipEventRecord(a, 0));
    for (int r = 0; r < reps; ++r)
-      hipLaunchKernelGGL((k_frontend<int16_t, MODE, NT, MINW, SHIFT, LOCK, STAGGER, PIPE>), dim3(blocks), dim3(NT), 0, 0, pcm, basis, Y, FM, n, map);
+      hipLaunchKernelGGL((k_frontend<int16_t, MODE, NT, MINW, SHIFT, LOCK, ABL, PIPE, PK>), blocks, dim3(NT), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
    CK(hipEventRecord(b, 0));
    CK(hipEventSynchronize(b));
    float ms = 0;
@@ -49,7 +50,7 @@ int main(int argc, char **argv)
    int16_t *pcm; float *basis, *Y0, *Y1, *FM;
    CK(hipMalloc(&pcm, h_pcm.size() * 2)); CK(hipMalloc(&basis, h_basis.size() * 4));
    CK(hipMalloc(&Y0, (size_t)n * kBins * kFrames * 4)); CK(hipMalloc(&Y1, (size_t)n * kBins * kFrames * 4));
-   CK(hipMalloc(&FM, (size_t)n * kFrames * 4));
+   CK(hipMalloc(&FM, (size_t)kBinSplit * n * kFrames * 4));
    CK(hipMemcpy(pcm, h_pcm.data(), h_pcm.size() * 2, hipMemcpyHostToDevice));
    CK(hipMemcpy(basis, h_basis.data(), h_basis.size() * 4, hipMemcpyHostToDevice));
    std::vector<float> ref((size_t)n * kBins * kFrames), got(ref.size());
@@ -64,14 +65,20 @@ int main(int argc, char **argv)
    run<1, 256, 3, 0, 0, 0>("baseline nt256 w3 bperm", pcm, basis, Y0, FM, n, reps);
    CK(hipMemcpy(ref.data(), Y0, ref.size() * 4, hipMemcpyDeviceToHost));
    run<1, 256, 3, 1, 0, 0>("dpp", pcm, basis, Y1, FM, n, reps);                     check("dpp", Y1);
-   run<1, 256, 3, 0, 0, 0, 1>("pipe bperm w3", pcm, basis, Y1, FM, n, reps);        check("pipe bperm w3", Y1);
-   run<1, 256, 3, 1, 0, 0, 1>("pipe dpp w3", pcm, basis, Y1, FM, n, reps);          check("pipe dpp w3", Y1);
-   run<1, 256, 4, 1, 0, 0, 1>("pipe dpp w4", pcm, basis, Y1, FM, n, reps);          check("pipe dpp w4", Y1);
-   run<1, 256, 2, 1, 0, 0, 1>("pipe dpp w2", pcm, basis, Y1, FM, n, reps);          check("pipe dpp w2", Y1);
-   run<1, 256, 5, 1, 0, 0, 1>("pipe dpp w5", pcm, basis, Y1, FM, n, reps);          check("pipe dpp w5", Y1);
-   run<1, 512, 4, 1, 0, 0, 1>("pipe dpp w4 nt512", pcm, basis, Y1, FM, n, reps);    check("pipe dpp w4 nt512", Y1);
-   run<0, 256, 3, 0, 0, 0>("baseline (log mode)", pcm, basis, Y0, FM, n, reps);
-   run<0, 256, 3, 1, 0, 0, 1>("pipe dpp w3 (log mode)", pcm, basis, Y1, FM, n, reps);
-   run<0, 256, 4, 1, 0, 0, 1>("pipe dpp w4 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 3, 0, 0, 1>("ABL1: v_mul by a VGPR (no SGPR operand)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 3, 0, 0, 2>("ABL2: products only (no tree adds)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 3, 0, 0, 3>("ABL3: tree adds only (no products)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 3, 0, 0, 0, 0, 1>("PK w3 (v_pk_mul products)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 0, 0, 0, 0, 1>("PK w4", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 2, 0, 0, 0, 0, 1>("PK w2", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 3, 1, 0, 0, 0, 1>("PK w3 dpp", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 3, 0, 0, 0, 0, 1>("PK w3 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 4, 0, 0, 0, 0, 1>("PK w4 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 3, 0, 0, 0, 0, 0>("baseline w3 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 4, 0, 0, 0, 0, 0>("baseline w4 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 5, 0, 0, 0, 0, 1>("PK w5 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 0, 0, 0>("baseline w4", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 0, 0, 1>("ABL1 w4", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 0, 0, 3>("ABL3 w4", pcm, basis, Y1, FM, n, reps);
    return 0;
 }

@@ -158,15 +158,17 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    int idx = 0;
    auto need = [&](int i, int n) { return ts[i].size == n; };
 
-   // [0] STFT basis [258,1,256] -> consumption order of k_frontend: [f][i = 3,2,1,0][l][j]
+   // [0] STFT basis [258,1,256] -> consumption order of k_frontend (PK form): [f][i = 3,2,1,0][l / 2][j][l % 2], so that
+   // the taps of tree lanes (l, l+1) for one j are an even-aligned SGPR pair = second operand of one v_pk_mul_f32
    if (!need(idx, kFilters * kFilterLen)) return fail(VADC_AMD_EWEIGHTS, "weights: bad forward_basis_buffer");
    copy_unaligned(tmp, ts[idx++]);
    tmp2.resize(tmp.size());
    for (int f = 0; f < kFilters; ++f)
       for (int ii = 0; ii < 4; ++ii)
-         for (int l = 0; l < 8; ++l)
+         for (int lp = 0; lp < 4; ++lp)
             for (int j = 0; j < 8; ++j)
-               tmp2[(size_t)f * 256 + ii * 64 + l * 8 + j] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + l];
+               for (int b = 0; b < 2; ++b)
+                  tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    // k_frontend_mx B operand: tile ft = 8 bins x (re, im); column jj < 8 -> filter 8 ft + jj, jj >= 8 -> 129 + 8 ft + jj - 8;
    // tap order = the order the tree consumes them: position (l*4 + i)*8 + j holds tap 64 i + 8 j + l

@@ -26,6 +26,8 @@
 // neighbours: lane efficiency 61/64 * 25/28 = 85 %.  ~100 VGPRs => 4-5 waves/SIMD to cover scalar-load
 // latency.  Algorithmic work: 258*25*(256 mul + 255 add) = 3.30 M VALU lane-ops per chunk, which bounds this
 // kernel at 1/2 of the FMA peak by construction (2 instructions per MAC).
+// The shipped instantiation is PK = 1 (products two at a time with v_pk_mul_f32 and an SGPR pair, see below): an
+// SGPR-operand v_mul_f32 issues at ~4.3 cycles per wave64 on gfx950, a v_pk_mul_f32 at ~4.7 for two products.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -55,16 +57,50 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 // G[l] = ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)),  p_j = x[8j+l] * k[j]   (stft.c:141-160)
 // KV/O: the 8 basis taps of this (i,l) in j order inside a 16-float SGPR tuple.
+// ABL (tools/fe_bench.hip only; 0 in the product): 1 = multiply by a VGPR instead of the SGPR tap, 2 = products only
+// (no tree adds), 3 = tree adds only (no products) -- timing ablations, results are garbage for ABL != 0
+#define VADC_PROD(J, L, KV, O) (ABL == 1 ? x[(J) * 8 + (L)] * vk : (ABL == 3 ? x[(J) * 8 + (L)] : x[(J) * 8 + (L)] * KV[(O) + (J)]))
 #define VADC_TREE8(dst, L, KV, O)                                                       \
    {                                                                                    \
-      const float p0 = x[0 * 8 + (L)] * KV[(O) + 0], p1 = x[1 * 8 + (L)] * KV[(O) + 1]; \
-      const float p2 = x[2 * 8 + (L)] * KV[(O) + 2], p3 = x[3 * 8 + (L)] * KV[(O) + 3]; \
-      const float p4 = x[4 * 8 + (L)] * KV[(O) + 4], p5 = x[5 * 8 + (L)] * KV[(O) + 5]; \
-      const float p6 = x[6 * 8 + (L)] * KV[(O) + 6], p7 = x[7 * 8 + (L)] * KV[(O) + 7]; \
-      const float p01 = p0 + p1, p23 = p2 + p3, p45 = p4 + p5, p67 = p6 + p7;           \
-      const float p0123 = p01 + p23, p4567 = p45 + p67;                                 \
-      dst = p0123 + p4567;                                                              \
+      const float p0 = VADC_PROD(0, L, KV, O), p1 = VADC_PROD(1, L, KV, O);             \
+      const float p2 = VADC_PROD(2, L, KV, O), p3 = VADC_PROD(3, L, KV, O);             \
+      const float p4 = VADC_PROD(4, L, KV, O), p5 = VADC_PROD(5, L, KV, O);             \
+      const float p6 = VADC_PROD(6, L, KV, O), p7 = VADC_PROD(7, L, KV, O);             \
+      if (ABL == 2) {                                                                   \
+         asm volatile("" ::"v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)); \
+         dst = p0;                                                                      \
+      } else {                                                                          \
+         const float p01 = p0 + p1, p23 = p2 + p3, p45 = p4 + p5, p67 = p6 + p7;        \
+         const float p0123 = p01 + p23, p4567 = p45 + p67;                              \
+         dst = p0123 + p4567;                                                           \
+      }                                                                                 \
    }
+
+// PK = 1: the two products of tree lanes (l, l+1) for the same j come from ONE v_pk_mul_f32 whose second operand is
+// an even-aligned SGPR pair.  Measured on gfx950 (tools/valu_rate.hip, tools/fe_bench.hip): v_mul_f32 with an SGPR
+// operand issues at ~4.3 cycles, v_pk_mul_f32 with an SGPR pair at ~4.7 for TWO products, VGPR-only v_add at ~2; the
+// 256 products per output therefore cost 128 x 4.7 instead of 256 x 4.3 cycles.  Each product is still one IEEE
+// fp32 multiply and the tree is unchanged, so the result is bit-identical.  Basis layout for PK: [i][l/2][j][l%2].
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define VADC_TREE8_PK(dstA, dstB, LP, KV)                                                        \
+   {                                                                                             \
+      const f2v q0 = x2[0 * 4 + (LP)] * (f2v){KV[0], KV[1]},   q1 = x2[1 * 4 + (LP)] * (f2v){KV[2], KV[3]};   \
+      const f2v q2 = x2[2 * 4 + (LP)] * (f2v){KV[4], KV[5]},   q3 = x2[3 * 4 + (LP)] * (f2v){KV[6], KV[7]};   \
+      const f2v q4 = x2[4 * 4 + (LP)] * (f2v){KV[8], KV[9]},   q5 = x2[5 * 4 + (LP)] * (f2v){KV[10], KV[11]}; \
+      const f2v q6 = x2[6 * 4 + (LP)] * (f2v){KV[12], KV[13]}, q7 = x2[7 * 4 + (LP)] * (f2v){KV[14], KV[15]}; \
+      {                                                                                          \
+         const float a01 = q0.x + q1.x, a23 = q2.x + q3.x, a45 = q4.x + q5.x, a67 = q6.x + q7.x; \
+         const float a0123 = a01 + a23, a4567 = a45 + a67;                                       \
+         dstA = a0123 + a4567;                                                                   \
+      }                                                                                          \
+      {                                                                                          \
+         const float b01 = q0.y + q1.y, b23 = q2.y + q3.y, b45 = q4.y + q5.y, b67 = q6.y + q7.y; \
+         const float b0123 = b01 + b23, b4567 = b45 + b67;                                       \
+         dstB = b0123 + b4567;                                                                   \
+      }                                                                                          \
+   }
+#define VADC_STAGE_PK(G, LB, CA, CB_)                                                            \
+   VADC_TREE8_PK(G[(LB) + 0], G[(LB) + 1], (LB) / 2, CA) VADC_TREE8_PK(G[(LB) + 2], G[(LB) + 3], (LB) / 2 + 1, CB_)
 
 // one pipeline stage = 32 taps = lanes-of-the-tree l in [LB, LB+4) of one 64-tap group
 #define VADC_STAGE(G, LB, CA, CB_)                                                      \
@@ -89,22 +125,25 @@ __device__ __forceinline__ float lane_up2(float v)
 // One filter for this lane's frame.  Taps at kf + BASEOFF bytes, 256 floats in order [i = 3,2,1,0][l][j].
 // On entry (pa,pb) hold the first 32 taps (already waited for); on exit they hold the first 32 taps found at
 // next_base + NEXTOFF (the following filter), so the pipeline never drains.
-template <int BASEOFF, int NEXTOFF, int SHIFT>
+template <int BASEOFF, int NEXTOFF, int SHIFT, int ABL = 0, int PK = 0>
 __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *kf, const float *next_base,
-                                             f16v &pa, f16v &pb)
+                                             f16v &pa, f16v &pb, float vk = 1.0f)
 {
    f16v qa, qb;
    float ga[8], gb[8], t23[8], v[8];
-   VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_STAGE(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_3, l 0..3
-   VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_STAGE(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);   // G_3, l 4..7
-   VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_2
-   VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+   const f2v *x2 = reinterpret_cast<const f2v *>(&x[0]);   // x[8 j + l], x[8 j + l + 1]  ->  x2[4 j + l / 2]
+   (void)x2;
+#define VADC_STG(G, LB, CA, CB_) if (PK) { VADC_STAGE_PK(G, LB, CA, CB_) } else { VADC_STAGE(G, LB, CA, CB_) }
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_STG(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_3, l 0..3
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_STG(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);   // G_3, l 4..7
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_STG(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_2
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_STG(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
 #pragma unroll
    for (int l = 0; l < 8; ++l) t23[l] = gb[l] + lane_up1<SHIFT>(ga[l]);     // g_2 + g_3   (stft.c:166)
-   VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_STAGE(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_1
-   VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_STAGE(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);
-   VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_STAGE(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_0
-   VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_STAGE(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_STG(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_1
+   VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_STG(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);
+   VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_STG(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_0
+   VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_STG(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
 #pragma unroll
    for (int l = 0; l < 8; ++l) {
       const float t01 = gb[l] + lane_up1<SHIFT>(ga[l]);                    // g_0 + g_1   (stft.c:165)
@@ -112,6 +151,7 @@ __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *
    }
    const float s01 = v[0] + v[1], s23 = v[2] + v[3], s45 = v[4] + v[5], s67 = v[6] + v[7];   // stft.c:176-184
    const float s0123 = s01 + s23, s4567 = s45 + s67;
+#undef VADC_STG
    return s0123 + s4567;
 }
 
@@ -174,8 +214,8 @@ __device__ __forceinline__ float stft_filter_pipe(const float (&x)[64], const fl
 //   NT       threads per workgroup              MINW   min waves per SIMD (register cap)
 //   SHIFT    0 ds_bpermute / 1 DPP wave shift   LOCK   1: one barrier per filter pair keeps the workgroup's waves
 //            on the same basis rows so that they share scalar-cache lines
-//   STAGGER  1: each workgroup starts at a different filter (rotated order) to spread the L2 channels
-template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int LOCK = 0, int STAGGER = 0, int PIPE = 0>
+//   ABL      timing ablations for tools/fe_bench.hip (0 in the product)
+template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int LOCK = 0, int ABL = 0, int PIPE = 0, int PK = 0>
 __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                   const float *__restrict__ basis,    // [258][256] permuted
                                                   float *__restrict__ Y,              // [n_chunks][129][25]
@@ -195,7 +235,7 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
 
    // this lane's block of the reflect-padded chunk (tensor.h:931-954): padded index 64m+k, source
    // index s = 64m + k - 128, mirrored at both ends without repeating the edge sample.
-   float x[64];
+   __attribute__((aligned(8))) float x[64];
    const T *src = pcm + (size_t)chunk * kChunk;
    if (m >= 2 && m <= 25) {
       const T *p = src + (64 * m - kPad);
@@ -234,11 +274,11 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
       const float *kn = basis + (size_t)fn * kFilterLen;
       if (LOCK) __syncthreads();
       const float re = PIPE ? stft_filter_pipe<0, kImOff, SHIFT>(x, kf, kf, pa, pb, p)
-                            : stft_filter<0, kImOff, SHIFT>(x, kf, kf, pa, pb);
+                            : stft_filter<0, kImOff, SHIFT, ABL, PK>(x, kf, kf, pa, pb, x[63]);
       // the prefetch issued by the last stage of `im` reads the next filter's first taps (row 129 = im of
       // bin 0 when f == 128 and there is no stagger: in bounds, unused)
       const float im = PIPE ? stft_filter_pipe<kImOff, 0, SHIFT>(x, kf, kn, pa, pb, p)
-                            : stft_filter<kImOff, 0, SHIFT>(x, kf, kn, pa, pb);
+                            : stft_filter<kImOff, 0, SHIFT, ABL, PK>(x, kf, kn, pa, pb, x[63]);
       const float re2 = re * re, im2 = im * im;
       const float mag = sqrtf(re2 + im2);                                  // stft.c:209
       float val;
@@ -313,16 +353,16 @@ void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<float, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<float, 1, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<int16_t, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, float *out, int n, hipStream_t st)
