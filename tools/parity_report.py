@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Parity statistics of the HIP engine against the CPU oracle on long synthetic speech streams (GPU box).
+Writes profiles/<round>/parity_report.json.   python tools/parity_report.py [out.json]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O            # noqa: E402  (checker)
+from vadc_amd import synth                # noqa: E402
+from vadc_amd.engine import Engine        # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_report.json")
+    blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
+    orc = O.Oracle(blob)
+    S, n = 8, 1000
+    pcm = synth.make_streams(S, n, seed0=9000)
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=100, device=0)
+    got = np.concatenate([eng.run(pcm[:, i * 1536:(i + 100) * 1536]) for i in range(0, n, 100)], axis=1)[:, :, 1]
+    want = orc.forward_streams(pcm)
+    d = np.abs(got.astype(np.float64) - want).ravel()
+    seg_equal = all(np.array_equal(O.segments(got[s])[1], O.segments(want[s])[1]) for s in range(S))
+    rep = {"streams": S, "chunks_per_stream": n, "max_abs_dp": float(d.max()), "p999_abs_dp": float(np.quantile(d, 0.999)),
+           "mean_abs_dp": float(d.mean()), "prob_range": [float(want.min()), float(want.max())],
+           "chunks_within_1e-3_of_threshold_0.5": int((np.abs(want - 0.5) < 1e-3).sum()),
+           "segment_chunk_indices_identical": bool(seg_equal), "tolerance": 1e-4}
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    json.dump(rep, open(out_path, "w"), indent=1)
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()
