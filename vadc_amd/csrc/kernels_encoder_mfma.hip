@@ -231,19 +231,31 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
    const float *x_in = in + (size_t)chunk * CIN * T + t;
+   // x slab: 8 rows per wave; rows >= CIN and invalid columns are zero.  The NEXT slab's rows are requested from
+   // HBM as soon as the current ones are in LDS, so their latency hides behind the depthwise conv and the MFMAs.
+   float xv[8];
+#pragma unroll
+   for (int i = 0; i < 8; ++i) {
+      const int ch = wave * 8 + i;
+      xv[i] = (cvalid && ch < CIN) ? x_in[(size_t)ch * T] : 0.0f;
+   }
 #pragma unroll 1
    for (int s = 0; s < NSLAB; ++s) {
       const int c0 = s * kSlab;
       if (s > 0) __syncthreads();                        // previous slab fully consumed
-      // x slab: 8 rows per wave; rows >= CIN and invalid columns are zero
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
          const int r = wave * 8 + i, ch = c0 + r;
-         float v = 0.0f;
-         if (cvalid && ch < CIN) v = x_in[(size_t)ch * T] - mm;            // misc.c:84-96
-         XS[r * kPitch + col] = v;
+         XS[r * kPitch + col] = (cvalid && ch < CIN) ? xv[i] - mm : 0.0f;  // misc.c:84-96
       }
       __syncthreads();
+      if (s + 1 < NSLAB) {
+#pragma unroll
+         for (int i = 0; i < 8; ++i) {
+            const int ch = c0 + kSlab + wave * 8 + i;
+            xv[i] = (cvalid && ch < CIN) ? x_in[(size_t)ch * T] : 0.0f;
+         }
+      }
       // depthwise k5 pad2 + ReLU (conv.c:17-53): neighbours are adjacent columns of the same chunk
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
