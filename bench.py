@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
     ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
     ap.add_argument("--groups", type=int, default=1,
                     help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
@@ -93,6 +95,9 @@ def main():
     S, Cn = args.streams, args.chunks_per_step
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
     eng.set_option("groups", args.groups)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 
     # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
     base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
