@@ -19,6 +19,8 @@ void launch_frontend_f32(const float *, const float *, float *, float *, size_t,
 void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
@@ -108,6 +110,7 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    const float *d_basis_mx = nullptr;           // k_frontend_mx: [17 tiles][256 taps in tree order][16 filters]
+   const float *d_basis_mx2 = nullptr;          // k_frontend_mx2: [17 tiles][l][i][j/4][16 filters][j%4]
    int frontend_variant = 0;                    // 0 = k_frontend (all VALU, default), 1 = k_frontend_mx (products on MFMA, experimental)
    LayerWeights lw[4];
    LayerWeightsM lwm[4];
@@ -187,6 +190,22 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                   }
       off_basis_mx = pk.add(bt.data(), bt.size());
    }
+   // k_frontend_mx2 B operand: same tiles, tap-quads contiguous per filter so that one global_load_dwordx4 fetches j..j+3
+   size_t off_basis_mx2;
+   {
+      std::vector<float> bt((size_t)17 * 256 * 16, 0.0f);
+      for (int ft = 0; ft < 17; ++ft)
+         for (int l = 0; l < 8; ++l)
+            for (int i = 0; i < 4; ++i)
+               for (int j = 0; j < 8; ++j)
+                  for (int jj = 0; jj < 16; ++jj) {
+                     const int bin = 8 * ft + (jj & 7);
+                     if (bin >= kBins) continue;
+                     const int filt = (jj < 8) ? bin : kBins + bin;
+                     bt[(size_t)ft * 4096 + (((l * 4 + i) * 2 + (j >> 2)) * 16 + jj) * 4 + (j & 3)] = tmp[(size_t)filt * 256 + 64 * i + 8 * j + l];
+                  }
+      off_basis_mx2 = pk.add(bt.data(), bt.size());
+   }
    pk.add(nullptr, 64);   // the pipeline's final prefetch reads 32 floats past filter 129's start: keep slack anyway
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
@@ -264,6 +283,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
       e->d_basis_mx = base + off_basis_mx;
+      e->d_basis_mx2 = base + off_basis_mx2;
       for (int l = 0; l < 4; ++l) {
          LayerWeights &w = e->lw[l];
          w.dw_w = base + lo[l].dw_w; w.dw_b = base + lo[l].dw_b; w.pwT = base + lo[l].pwT; w.pw_b = base + lo[l].pw_b;
@@ -464,7 +484,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 2) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
@@ -504,7 +524,10 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (e->frontend_variant == 1) {
+      if (e->frontend_variant == 2) {
+         if (sizeof(T) == 2) launch_frontend_mx2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+         else                launch_frontend_mx2_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+      } else if (e->frontend_variant == 1) {
          if (sizeof(T) == 2) launch_frontend_mx_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_mx_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       } else {
@@ -785,7 +808,8 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   if (e->frontend_variant == 1) launch_frontend_mx_f32(e->d_in_f32, e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   if (e->frontend_variant == 2) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   else if (e->frontend_variant == 1) launch_frontend_mx_f32(e->d_in_f32, e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);

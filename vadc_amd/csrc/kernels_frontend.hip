@@ -540,4 +540,115 @@ void launch_frontend_mx_s16(const int16_t *pcm, const float *bt, float *Y, float
    else           hipLaunchKernelGGL((k_frontend_mx<int16_t, 1>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
 }
 
+
+// =====================================================================================================
+// k_frontend_mx2 -- k_frontend_mx with the 256-tap tile hand-scheduled (generated asm, tools/gen_mx_asm.py)
+// =====================================================================================================
+// Same arithmetic as k_frontend_mx (products = v_mfma_f32_16x16x1_4b_f32 with C = 0, the reference's tree of 255
+// separately rounded adds on the vector ALU), but the tile's 256 MFMAs and 255 x 16 v_add_f32 are emitted by a generator
+// that schedules and register-allocates them: MFMA k is followed by the add row whose operands completed one slot
+// earlier, operands are prefetched two 8-tap groups ahead (x: ds_read_b128 from the tile in LDS, basis: global_load_dwordx4
+// from the L2-resident repacked basis), 9 x 16 tree registers are live at most => 192 VGPRs for the block, 2 waves/SIMD, so
+// one wave's MFMA overlaps the other wave's adds.
+//   x tile in LDS: per chunk 28 blocks of 64 samples, block pitch 68 floats, inside a block sample k = 8 j + l is stored at
+//   8 l + j so that the 8 taps j = 0..7 of one tree group (l, i) are two aligned 16-byte reads.
+//   basis tile ft: [l][i][j / 4][16 filters][j % 4]  (16 KB per tile; filter column jj < 8: re of bin 8 ft + jj, else im)
+#include "frontend_mx_tile.inc"
+constexpr int kMx2BlockPitch = 68;
+constexpr int kMx2ChunkPitch = kBlocks * kMx2BlockPitch;      // 1904 floats per chunk
+typedef __attribute__((address_space(3))) float lds_float_t;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ pcm,          // [n_chunks][1536]
+                                                         const float *__restrict__ bt2,      // [17][l 8][i 4][jq 2][16][4]
+                                                         float *__restrict__ Y,              // [n_chunks][129][25]
+                                                         float *__restrict__ FM,             // [4][fm_stride] partial bin sums
+                                                         int n_chunks, ItemMap map, size_t fm_stride)
+{
+   __shared__ __attribute__((aligned(16))) float xs[kMxChunks * kMx2ChunkPitch];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int lc = lane & 15, quad = lane >> 4;
+   const long total_pos = (long)n_chunks * kFrames;
+   const long p0 = (long)blockIdx.x * 64;
+   const int item0 = (int)(p0 / kFrames);
+
+   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954), j-contiguous inside a block
+   for (int c = 0; c < kMxChunks; ++c) {
+      const int it = min(item0 + c, n_chunks - 1);
+      const T *src = pcm + (size_t)map(it) * kChunk;
+      for (int idx = tid; idx < kPadded; idx += 256) {
+         int s = idx - kPad;
+         s = s < 0 ? -s : s;
+         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
+         const int k = idx & 63;
+         xs[c * kMx2ChunkPitch + (idx >> 6) * kMx2BlockPitch + (k & 7) * 8 + (k >> 3)] = sample_to_f32(src[s]);
+      }
+   }
+   __syncthreads();
+
+   // this lane's position (A operand): frame n of its chunk starts at block n
+   const long pa = min(p0 + lane, total_pos - 1);
+   const int item_a = (int)(pa / kFrames), n_a = (int)(pa - (long)item_a * kFrames);
+   const unsigned xaddr = (unsigned)(uintptr_t)(lds_float_t *)(xs + (item_a - item0) * kMx2ChunkPitch + kMx2BlockPitch * n_a);
+   const unsigned boff = lc * 16;
+
+   float bsum[16];
+#pragma unroll
+   for (int e = 0; e < 16; ++e) bsum[e] = 0.0f;
+
+#pragma unroll 1
+   for (int ft = wave; ft < kMxTiles; ft += 4) {
+      const float *bbase = bt2 + (size_t)__builtin_amdgcn_readfirstlane(ft) * (256 * 16);
+      f16acc y;
+      asm volatile(VADC_MX_TILE_ASM
+                   : VADC_MX_TILE_Y_CONSTRAINT(y)
+                   : [xaddr] "v"(xaddr), [boff] "v"(boff), [bbase] "s"(bbase)
+                   : VADC_MX_TILE_CLOBBERS);
+      // y[e]: position 16 (e/4) + 4 quad + e%4 of this workgroup, filter lc of tile ft (lc < 8: re of bin 8 ft + lc,
+      // lc >= 8: im of bin 8 ft + lc - 8).  Pair re with im across lanes lc, lc + 8.
+      const int bin = 8 * ft + (lc & 7);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         const float re = y[e];
+         const float im = __shfl_down(re, 8, 16);
+         const float re2 = re * re, im2 = im * im;
+         const float mag = sqrtf(re2 + im2);                                  // stft.c:209
+         const float val = (MODE == 0) ? log1pf(mag * 1048576.0f) : mag;      // misc.c:42-45
+         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
+         if (lc < 8 && bin < kBins && pe < total_pos) {
+            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
+            Y[(size_t)map(it) * (kBins * kFrames) + bin * kFrames + n] = val;
+            bsum[e] += val;
+         }
+         __builtin_amdgcn_sched_barrier(0);             // one element at a time: keeps the 16 log1p bodies from interleaving
+      }
+   }
+   if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         float s = bsum[e];
+         s += __shfl_xor(s, 1, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 4, 16);
+         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
+         if (lc == 0 && pe < total_pos) {
+            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
+            FM[wave * fm_stride + (size_t)map(it) * kFrames + n] = s;
+         }
+      }
+   }
+}
+
+void launch_frontend_mx2_f32(const float *pcm, const float *bt2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx2<float, 0>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_mx2<float, 1>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
+}
+
+void launch_frontend_mx2_s16(const int16_t *pcm, const float *bt2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx2<int16_t, 0>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_mx2<int16_t, 1>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
+}
+
 }  // namespace vadc
