@@ -129,8 +129,8 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                                      into a GEMM while the recurrence is latency-bound (few stream tiles);
  *                                      1 = simple reference kernel, 2 = step-sequential MFMA, 3 = wavefront with
  *                                      fused input projection, 4 = wavefront with hoisted input projection
- *                             "frontend" 0 = k_frontend (VALU tree, default), 1 = k_frontend_mx (products on MFMA K=1; experimental,
- *                                      bit-identical, currently slower)
+ *                             "frontend" 0 = k_frontend (VALU tree, default), 1 = k_frontend_mx2 (products issued as MFMA K=1;
+ *                                      experimental, bit-identical, not faster: fp32 MFMA shares the vector ALU lanes)
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels
  *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
  *                                      group g overlaps the front end + encoder of group g+1.

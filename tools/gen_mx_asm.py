@@ -101,7 +101,7 @@ VB      = 48                # first VGPR the block owns; the compiler keeps v0..
 GJ      = 4                 # taps per operand fetch (one ds_read_b128 / global_load_dwordx4)
 DA, DB  = 2, 3              # prefetch distance in fetch groups: x from LDS, basis from L2
 LDS_BLOCK_PITCH = 68        # floats per 64-sample block in the x tile (bank spread + 16-byte alignment)
-SKEW, ABLATE = True, set()
+SKEW, ABLATE, PKADD = True, set(), False
 SBASE   = 40                # s[40:41]: running base of the B tile (advanced by 4 KB every 16 fetch groups)
 
 def emit(path):
@@ -145,6 +145,11 @@ def emit(path):
         while need > 0:
             k = min(need, 16); ins(f"s_nop {k - 1}"); need -= k
         if "noadds" in ABLATE and r is not y: return
+        if PKADD:
+            for e in range(0, 16, 2):
+                d, a, b = reg0(r) + e, reg0(r.a) + e, reg0(r.b) + e
+                ins(f"v_pk_add_f32 v[{d}:{d + 1}], v[{a}:{a + 1}], v[{b}:{b + 1}]")
+            return
         for e in range(16):
             ins(f"v_add_f32 {buf(r, e)}, {buf(r.a, e)}, {buf(r.b, e)}")
     ins(f"s_mov_b64 s[{SBASE}:{SBASE + 1}], %[bbase]")
@@ -160,7 +165,9 @@ def emit(path):
             else: ins(f"s_waitcnt vmcnt({w * min(DB, n_groups - 1 - q)}) lgkmcnt({w * min(DA, n_groups - 1 - q)})")
         d0 = reg0(p)
         mfma_at[k] = n_instr
-        if "nomfma" not in ABLATE or k < 16:
+        if "k4" in ABLATE:       # experiment: a 4-register-result MFMA of the same 8 passes (garbage values)
+            ins(f"v_mfma_f32_16x16x4_f32 v[{d0}:{d0 + 3}], v{va + GJ * (q % (DA + 1)) + j}, v{vbb + GJ * (q % (DB + 1)) + j}, 0")
+        elif "nomfma" not in ABLATE or k < 16:
             ins(f"v_mfma_f32_16x16x1_4b_f32 v[{d0}:{d0 + 15}], v{va + GJ * (q % (DA + 1)) + j}, v{vbb + GJ * (q % (DB + 1)) + j}, 0")
         for r in slots[k]: row(r)
     for r in drain: row(r)
@@ -185,11 +192,13 @@ if __name__ == "__main__":
     ap.add_argument("path", nargs="?")
     ap.add_argument("--vb", type=int, default=VB); ap.add_argument("--gj", type=int, default=GJ)
     ap.add_argument("--da", type=int, default=DA); ap.add_argument("--db", type=int, default=DB)
+    ap.add_argument("--pkadd", action="store_true", help="add rows as 8 v_pk_add_f32 instead of 16 v_add_f32")
     ap.add_argument("--no-skew", action="store_true", help="experiment: one buffer pool, no bank skew")
-    ap.add_argument("--ablate", default="", help="experiments (tools/mx_tile_bench.hip): comma list of nomfma,noadds,noloads")
+    ap.add_argument("--ablate", default="", help="experiments (tools/mx_tile_bench.hip): comma list of nomfma,noadds,noloads,k4")
     args = ap.parse_args()
     VB, GJ, DA, DB, SKEW, ABLATE = args.vb, args.gj, args.da, args.db, not args.no_skew, set(filter(None, args.ablate.split(",")))
     path = args.path
+    PKADD = args.pkadd
     prods, slots, drain, y = schedule(1)
     nbuf, maxlive = allocate(prods, slots, drain)
     print(f"buffers {nbuf} (max live {maxlive}), drain rows {len(drain)}, empty slots {sum(1 for s in slots if not s)}")

@@ -17,8 +17,6 @@
 namespace vadc {
 void launch_frontend_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_mx_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_mx_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t);
@@ -109,9 +107,8 @@ struct vadc_amd_engine {
    hipStream_t stream = nullptr;
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
-   const float *d_basis_mx = nullptr;           // k_frontend_mx: [17 tiles][256 taps in tree order][16 filters]
    const float *d_basis_mx2 = nullptr;          // k_frontend_mx2: [17 tiles][l][i][j/4][16 filters][j%4]
-   int frontend_variant = 0;                    // 0 = k_frontend (all VALU, default), 1 = k_frontend_mx (products on MFMA, experimental)
+   int frontend_variant = 0;                    // 0 = k_frontend (all VALU, default), 1 = k_frontend_mx2 (products issued as MFMA, experimental)
    LayerWeights lw[4];
    LayerWeightsM lwm[4];
    int encoder_variant = 0;                     // 0 = MFMA layers, 1 = VALU bring-up layers
@@ -123,6 +120,11 @@ struct vadc_amd_engine {
    float *d_act[4] = {nullptr, nullptr, nullptr, nullptr};
    float *d_probs = nullptr;
    float *d_gx = nullptr;                       // hoisted LSTM input projection (k_lstm_xproj)
+   // Encoder -> LSTM hand-off buffers are double buffered over forked calls: d_act[3] / d_gx alias pair [xpar], so that
+   // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
+   float *d_xpair[2] = {nullptr, nullptr}, *d_gxpair[2] = {nullptr, nullptr};
+   int xpar = 0;
+   bool capturing = false;                      // inside hipStreamBeginCapture: no waits on events from outside the capture
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
    // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
@@ -131,13 +133,14 @@ struct vadc_amd_engine {
    hipStream_t sA = nullptr, sB = nullptr;
    int n_cus = 0;
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
-   bool ev_b_valid = false;                     // ev_b has been recorded by a previous forked call
+   bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
    struct GraphEntry { const void *in; float *out; int S, C, elem, groups; hipStream_t st; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
-   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr, ev_fe[kMaxGroups] = {nullptr};
+   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr};
+   bool ev_graph_valid = false;
    // profiling
    bool profiling = false;
    struct EvPair { hipEvent_t a, b; };
@@ -173,24 +176,9 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                for (int b = 0; b < 2; ++b)
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
-   // k_frontend_mx B operand: tile ft = 8 bins x (re, im); column jj < 8 -> filter 8 ft + jj, jj >= 8 -> 129 + 8 ft + jj - 8;
-   // tap order = the order the tree consumes them: position (l*4 + i)*8 + j holds tap 64 i + 8 j + l
-   size_t off_basis_mx;
-   {
-      std::vector<float> bt((size_t)17 * 256 * 16, 0.0f);
-      for (int ft = 0; ft < 17; ++ft)
-         for (int l = 0; l < 8; ++l)
-            for (int i = 0; i < 4; ++i)
-               for (int j = 0; j < 8; ++j)
-                  for (int jj = 0; jj < 16; ++jj) {
-                     const int bin = 8 * ft + (jj & 7);
-                     if (bin >= kBins) continue;
-                     const int filt = (jj < 8) ? bin : kBins + bin;
-                     bt[((size_t)ft * 256 + (l * 4 + i) * 8 + j) * 16 + jj] = tmp[(size_t)filt * 256 + 64 * i + 8 * j + l];
-                  }
-      off_basis_mx = pk.add(bt.data(), bt.size());
-   }
-   // k_frontend_mx2 B operand: same tiles, tap-quads contiguous per filter so that one global_load_dwordx4 fetches j..j+3
+   // k_frontend_mx2 B operand: tile ft = 8 bins x (re, im); column jj < 8 -> filter 8 ft + jj, jj >= 8 -> 129 + 8 ft + jj - 8;
+   // taps in the order the tree consumes them (l, i, j), tap-quads contiguous per filter so that one global_load_dwordx4
+   // fetches j..j+3
    size_t off_basis_mx2;
    {
       std::vector<float> bt((size_t)17 * 256 * 16, 0.0f);
@@ -282,7 +270,6 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
-      e->d_basis_mx = base + off_basis_mx;
       e->d_basis_mx2 = base + off_basis_mx2;
       for (int l = 0; l < 4; ++l) {
          LayerWeights &w = e->lw[l];
@@ -319,13 +306,13 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_act[3], e->d_probs, e->d_h, e->d_c, e->d_gx};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1]};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_graph}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
@@ -364,7 +351,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_graph}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
@@ -374,9 +361,13 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
-   if (he == hipSuccess) he = hipMalloc(&e->d_act[3], padded_streams * max_chunks * 448 * sizeof(float));
-   if (he == hipSuccess) he = hipMemset(e->d_act[3], 0, padded_streams * max_chunks * 448 * sizeof(float));
-   if (he == hipSuccess) he = hipMalloc(&e->d_gx, padded_streams * max_chunks * 7 * 256 * sizeof(float));
+   for (int p = 0; p < 2; ++p) {
+      if (he == hipSuccess) he = hipMalloc(&e->d_xpair[p], padded_streams * max_chunks * 448 * sizeof(float));
+      if (he == hipSuccess) he = hipMemset(e->d_xpair[p], 0, padded_streams * max_chunks * 448 * sizeof(float));
+      if (he == hipSuccess) he = hipMalloc(&e->d_gxpair[p], padded_streams * max_chunks * 7 * 256 * sizeof(float));
+   }
+   e->d_act[3] = e->d_xpair[0];
+   e->d_gx = e->d_gxpair[0];
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -484,7 +475,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 2) { e->frontend_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
@@ -516,20 +507,17 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    }
 }
 
-// hold_last: event the stream must wait for before the LAST layer + input projection overwrite the encoder-output /
-// GX buffers (the previous call's LSTM may still be reading them on the other stream); nullptr = no wait
+// hold_last: event the stream must wait for before the LAST layer + input projection overwrite this call's encoder-output /
+// GX pair (the LSTM of an earlier call that used the same pair may still be reading it on the other stream); nullptr = no wait
 template <typename T>
 static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, int lstm_kernel, hipStream_t st,
                                   hipEvent_t hold_last = nullptr)
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (e->frontend_variant == 2) {
+      if (e->frontend_variant == 1) {
          if (sizeof(T) == 2) launch_frontend_mx2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_mx2_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-      } else if (e->frontend_variant == 1) {
-         if (sizeof(T) == 2) launch_frontend_mx_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-         else                launch_frontend_mx_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       } else {
          if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
@@ -579,7 +567,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
    }
    e->lstm_cus = want;
-   e->ev_b_valid = false;                       // the old stream B was drained above
+   e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old stream B was drained above
    return VADC_AMD_OK;
 }
 
@@ -623,7 +611,12 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
-      hipEvent_t hold = e->ev_b_valid ? e->ev_b : nullptr;     // previous call's LSTM still owns X / GX
+      // this call's hand-off pair; its last reader was the LSTM of the forked call before the previous one
+      e->xpar ^= 1;
+      const int xp = e->xpar;
+      e->d_act[3] = e->d_xpair[xp];
+      e->d_gx = e->d_gxpair[xp];
+      hipEvent_t hold = (e->ev_b_valid[xp] && !e->capturing) ? e->ev_b[xp] : nullptr;
       // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
       int sizes[vadc_amd_engine::kMaxGroups];
       {
@@ -649,10 +642,10 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
-      (void)hipEventRecord(e->ev_b, e->sB);
-      e->ev_b_valid = true;
+      (void)hipEventRecord(e->ev_b[xp], e->sB);
+      e->ev_b_valid[xp] = !e->capturing;
       (void)hipStreamWaitEvent(st, e->ev_a, 0);
-      (void)hipStreamWaitEvent(st, e->ev_b, 0);
+      (void)hipStreamWaitEvent(st, e->ev_b[xp], 0);
    }
    hipError_t he = hipGetLastError();
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
@@ -663,6 +656,18 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
 // (including the fork/join over the internal streams) into a hipGraph; later calls are one hipGraphLaunch.
 // Profiling (per-kernel events) needs eager launches, so it bypasses the graph.  Kernel nodes do not inherit a
 // stream's CU mask, so the graph path always uses unmasked internal streams.
+// A captured step has no edges to the step before it (the eager path gets them from the in-order internal streams), and
+// all steps share the per-stream LSTM state and the intermediates: graph launches are chained through one event so that
+// they serialise even when the caller alternates streams.
+static int launch_graph_serialized(vadc_amd_engine *e, hipGraphExec_t x, hipStream_t st)
+{
+   if (e->ev_graph_valid) HIP_TRY(hipStreamWaitEvent(st, e->ev_graph, 0), VADC_AMD_EHIP);
+   HIP_TRY(hipGraphLaunch(x, st), VADC_AMD_EHIP);
+   HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
+   e->ev_graph_valid = true;
+   return VADC_AMD_OK;
+}
+
 template <typename T>
 static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
 {
@@ -670,8 +675,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    for (auto &ge : e->graphs)
       if (ge.in == d_in && ge.out == d_probs && ge.S == n_streams && ge.C == n_chunks && ge.elem == (int)sizeof(T) &&
           ge.groups == e->groups && ge.st == st) {
-         HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
-         return VADC_AMD_OK;
+         return launch_graph_serialized(e, ge.x, st);
       }
    const int saved_partition = e->cu_partition;
    if (saved_partition) { e->cu_partition = 0; e->lstm_cus = -1; }
@@ -679,7 +683,9 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (rc) { e->cu_partition = saved_partition; return rc; }
    vadc_amd_engine::GraphEntry ge{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), e->groups, st, nullptr, nullptr};
    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed), VADC_AMD_EHIP);
+   e->capturing = true;
    rc = run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
+   e->capturing = false;
    hipError_t he = hipStreamEndCapture(st, &ge.g);
    e->cu_partition = saved_partition;
    if (rc) return rc;
@@ -687,8 +693,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
    if (e->graphs.size() >= 8) { (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin()); }
    e->graphs.push_back(ge);
-   HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
-   return VADC_AMD_OK;
+   return launch_graph_serialized(e, ge.x, st);
 }
 
 extern "C" int vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks, float *d_probs, void *hip_stream)
@@ -808,8 +813,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   if (e->frontend_variant == 2) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   else if (e->frontend_variant == 1) launch_frontend_mx_f32(e->d_in_f32, e->d_basis_mx, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);

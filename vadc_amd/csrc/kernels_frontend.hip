@@ -377,186 +377,41 @@ void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, size_t
 
 
 // =====================================================================================================
-// k_frontend_mx -- the same bit-exact STFT with the 256 PRODUCTS of every output moved to the matrix cores
+// k_frontend_mx2 -- the same bit-exact STFT with the 256 PRODUCTS of every output issued as MFMA (experimental)
 // =====================================================================================================
 // v_mfma_f32_16x16x1_4b_f32 with a zero accumulator computes D[i][j] = fma(A[i], B[j], 0) = rnd(A[i]*B[j]): an outer
 // product of INDIVIDUALLY ROUNDED fp32 products (K = 1, nothing is accumulated inside the instruction), i.e. exactly
 // the p_t = x[t]*k[t] terms of the reference's tree (stft.c:141-155) -- checked bit for bit on the device
 // (tools/mfma_k1.hip).  For tap t the A operand is x[position][t] for 64 (chunk, frame) positions (one per lane), the
-// B operand k[filter][t] for the 16 filters of a tile; all 256 products of one (position, filter) output land in the
-// SAME lane and accumulator register, one MFMA per tap, so the reference's tree of 255 separately rounded adds
-// (stft.c:143-184) is pure per-lane VALU work on registers: no cross-lane shifts, no halo lanes, and half the VALU
-// instructions of k_frontend (the vector ALU is the bound: SGPR-operand v_mul and v_add both issue at ~4 cycles per
-// wave64 on gfx950, tools/valu_rate*.hip).
-// STATUS (round 1): correct and bit-identical to k_frontend (tests), but SLOWER as compiled by hipcc (4.7 ms vs 1.7 ms
-// per 16,384 chunks): the scheduler hoists the pure MFMAs, the ordering tokens below serialise MFMA -> add inside a
-// wave, and the 16-register accumulators leave room for one wave per SIMD only.  Selectable with option "frontend"=1;
-// a hand-scheduled (asm) version with software-pipelined MFMA/add phases is the open item.
-//   workgroup = 4 waves x the same 64 positions (x staged once in LDS, padded so that the 64 lanes' reads of one tap
-//   hit different banks); wave w walks filter tiles w, w+4, ...; a tile = 8 bins x (re, im) so that the magnitude
-//   pairs lane j with lane j+8 of the same 16-lane row.
-constexpr int kMxTiles = 17;                  // ceil(129 / 8) filter tiles of 8 bins x (re, im)
-constexpr int kMxChunkPitch = kPadded + kPadded / 64;   // 1792 samples + 1 pad per 64 = 1820 floats
-constexpr int kMxChunks = 4;                  // 64 consecutive positions span at most 4 chunks
-
-typedef float f16acc __attribute__((ext_vector_type(16)));
-
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, 1) void k_frontend_mx(const T *__restrict__ pcm,          // [n_chunks][1536]
-                                                        const float *__restrict__ bt,       // [17][256 taps, tree order][16]
-                                                        float *__restrict__ Y,              // [n_chunks][129][25]
-                                                        float *__restrict__ FM,             // [4][fm_stride] partial bin sums
-                                                        int n_chunks, ItemMap map, size_t fm_stride)
-{
-   __shared__ float xs[kMxChunks * kMxChunkPitch];
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int lc = lane & 15, quad = lane >> 4;
-   const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * 64;
-   const int item0 = (int)(p0 / kFrames);
-
-   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954) + 1 pad float per 64
-   for (int c = 0; c < kMxChunks; ++c) {
-      const int it = min(item0 + c, n_chunks - 1);
-      const T *src = pcm + (size_t)map(it) * kChunk;
-      for (int idx = tid; idx < kPadded; idx += 256) {
-         int s = idx - kPad;
-         s = s < 0 ? -s : s;
-         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
-         xs[c * kMxChunkPitch + idx + (idx >> 6)] = sample_to_f32(src[s]);
-      }
-   }
-   __syncthreads();
-
-   // this lane's position (A operand): sample index 64 n + t of its chunk -> xs[c*pitch + 65 n + t + (t >> 6)]
-   const long pa = min(p0 + lane, total_pos - 1);
-   const int item_a = (int)(pa / kFrames), n_a = (int)(pa - (long)item_a * kFrames);
-   const float *xa = xs + (item_a - item0) * kMxChunkPitch + 65 * n_a;
-
-   float bsum[16];
-#pragma unroll
-   for (int e = 0; e < 16; ++e) bsum[e] = 0.0f;
-   const f16acc zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-
-#pragma unroll 1
-   for (int ft = wave; ft < kMxTiles; ft += 4) {
-      const float *bp = bt + (size_t)ft * (256 * 16) + lc;
-      f16acc s01, s0123, s45, y;
-      f16acc order_tok = zero;
-      // lanes-of-the-tree l are walked in pairs (runtime loop: bounds the live products); inside a pair everything is
-      // unrolled.  Taps t = 64 i + 8 j + l are consumed four at a time (4 MFMAs = 64 accumulator registers in flight).
-#pragma unroll 1
-      for (int lp = 0; lp < 4; ++lp) {
-         f16acc vpair;
-#pragma unroll
-         for (int lo = 0; lo < 2; ++lo) {
-            const float *xl = xa + 2 * lp + lo;             // + 65 i + 8 j   (sample 64 i + 8 j + l, one pad per 64)
-            const float *bl = bp + (2 * lp + lo) * (32 * 16);   // + (8 i + j) * 16
-            f16acc g01, g2, v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-// MX4(J0, DEP): products of taps j = J0..J0+3 of group i.  The operand ADDRESSES are passed through an empty asm that
-// also names the previous group's sum: a zero-cost ordering token.  Without it hipcc's DAG scheduler hoists all 64
-// (pure) MFMAs and their 128 loads of the unrolled body above the adds and spills kilobytes of products.
-#define VADC_MX4(Q0, Q1, Q2, Q3, J0, DEP)                                                                          \
-   {                                                                                                                \
-      const float *xg_ = xl + 65 * i + 8 * (J0);                                                                    \
-      const float *bg_ = bl + (8 * i + (J0)) * 16;                                                                  \
-      float a0_ = xg_[0];                                                                                           \
-      asm volatile("" : "+v"(a0_) : "v"((DEP)[0]));                                                                 \
-      Q0 = __builtin_amdgcn_mfma_f32_16x16x1f32(a0_, bg_[0], zero, 0, 0, 0);                                        \
-      Q1 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[8], bg_[16], zero, 0, 0, 0);                                    \
-      Q2 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[16], bg_[32], zero, 0, 0, 0);                                   \
-      Q3 = __builtin_amdgcn_mfma_f32_16x16x1f32(xg_[24], bg_[48], zero, 0, 0, 0);                                   \
-   }
-               f16acc q0, q1, q2, q3, q4, q5, q6, q7;
-               VADC_MX4(q0, q1, q2, q3, 0, order_tok)
-               const f16acc h0 = (q0 + q1) + (q2 + q3);                     // (p0+p1)+(p2+p3)   stft.c:141-157
-               VADC_MX4(q4, q5, q6, q7, 4, h0)
-               const f16acc h1 = (q4 + q5) + (q6 + q7);                     // (p4+p5)+(p6+p7)   stft.c:158
-               order_tok = h1;
-#undef VADC_MX4
-#define VADC_MXP_AFTER
-#undef VADC_MXP_AFTER
-#undef VADC_MXP
-               const f16acc g = h0 + h1;                                    // stft.c:160
-               if (i == 0) g01 = g;
-               else if (i == 1) g01 = g01 + g;                              // g_0 + g_1   stft.c:165
-               else if (i == 2) g2 = g;
-               else v = g01 + (g2 + g);                                     // (g_0+g_1) + (g_2+g_3)   stft.c:166-167
-            }
-            vpair = (lo == 0) ? v : vpair + v;                              // v_{2lp} + v_{2lp+1}   stft.c:176-179
-         }
-         if (lp == 0) s01 = vpair;                                          // lane tree   stft.c:181-184
-         else if (lp == 1) s0123 = s01 + vpair;
-         else if (lp == 2) s45 = vpair;
-         else y = s0123 + (s45 + vpair);
-      }
-      // y[e]: position 16 (e/4) + 4 quad + e%4 of this workgroup, filter lc of tile ft (lc < 8: re of bin 8 ft + lc,
-      // lc >= 8: im of bin 8 ft + lc - 8).  Pair re with im across lanes lc, lc + 8.
-      const int bin = 8 * ft + (lc & 7);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         const float re = y[e];
-         const float im = __shfl_down(re, 8, 16);
-         const float re2 = re * re, im2 = im * im;
-         const float mag = sqrtf(re2 + im2);                                  // stft.c:209
-         const float val = (MODE == 0) ? log1pf(mag * 1048576.0f) : mag;      // misc.c:42-45
-         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
-         if (lc < 8 && bin < kBins && pe < total_pos) {
-            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
-            Y[(size_t)map(it) * (kBins * kFrames) + bin * kFrames + n] = val;
-            bsum[e] += val;
-         }
-         __builtin_amdgcn_sched_barrier(0);             // one element at a time: keeps the 16 log1p bodies from interleaving
-      }
-   }
-   if (MODE == 0) {
-      // partial bin sums of this wave: reduce over the 8 bin lanes, lane lc == 0 of each quad stores 16 positions
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         float s = bsum[e];
-         s += __shfl_xor(s, 1, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 4, 16);
-         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
-         if (lc == 0 && pe < total_pos) {
-            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
-            FM[wave * fm_stride + (size_t)map(it) * kFrames + n] = s;
-         }
-      }
-   }
-}
-
-void launch_frontend_mx_f32(const float *pcm, const float *bt, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
-{
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx<float, 0>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_mx<float, 1>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
-}
-
-void launch_frontend_mx_s16(const int16_t *pcm, const float *bt, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
-{
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx<int16_t, 0>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_mx<int16_t, 1>), grid, dim3(256), 0, st, pcm, bt, Y, FM, n, map, fm_stride);
-}
-
-
-// =====================================================================================================
-// k_frontend_mx2 -- k_frontend_mx with the 256-tap tile hand-scheduled (generated asm, tools/gen_mx_asm.py)
-// =====================================================================================================
-// Same arithmetic as k_frontend_mx (products = v_mfma_f32_16x16x1_4b_f32 with C = 0, the reference's tree of 255
-// separately rounded adds on the vector ALU), but the tile's 256 MFMAs and 255 x 16 v_add_f32 are emitted by a generator
-// that schedules and register-allocates them: MFMA k is followed by the add row whose operands completed one slot
+// B operand k[filter][t] for the 16 filters of a tile (8 bins x (re, im)); all 256 products of one (position, filter)
+// output land in the SAME lane and register, one MFMA per tap, so the reference's tree of 255 separately rounded adds
+// (stft.c:143-184) is per-lane VALU work: no cross-lane shifts, no halo lanes, half the instructions of k_frontend.
+// hipcc cannot schedule this (it hoists the pure MFMAs and spills kilobytes), so the tile's 256 MFMAs and 255 x 16
+// v_add_f32 are emitted by a generator (tools/gen_mx_asm.py) that schedules and register-allocates them: MFMA k is followed by the add row whose operands completed one slot
 // earlier, operands are prefetched two 8-tap groups ahead (x: ds_read_b128 from the tile in LDS, basis: global_load_dwordx4
 // from the L2-resident repacked basis), 9 x 16 tree registers are live at most => 192 VGPRs for the block, 2 waves/SIMD, so
-// one wave's MFMA overlaps the other wave's adds.
+// one wave's MFMA could overlap the other wave's adds.
+// STATUS / FINDING (tools/mx_tile_bench.hip, measured on MI355X): bit-identical to k_frontend, but NOT faster.  fp32 MFMA
+// executes on the same fp32 lanes as the vector ALU (which is why the fp32 matrix and vector peaks are both 157 TFLOP/s):
+// MFMA-only tile 48 cycles/tap, add-only 83, both 131 -- strictly additive, also with a 4-register-result MFMA, with one
+// or two waves per SIMD.  Products therefore cost the same ALU time wherever they are issued, and the exact tree is bound
+// by 511 fp32 lane-ops per output on either path.  In situ (16,384 chunks): 1.44 ms vs 1.41 ms for k_frontend, of which the
+// tiles are 1.19 ms and staging + sqrt/log1p + stores 0.26 ms.  Kept as option "frontend"=1 and as the record of that
+// measurement.
 //   x tile in LDS: per chunk 28 blocks of 64 samples, block pitch 68 floats, inside a block sample k = 8 j + l is stored at
 //   8 l + j so that the 8 taps j = 0..7 of one tree group (l, i) are two aligned 16-byte reads.
 //   basis tile ft: [l][i][j / 4][16 filters][j % 4]  (16 KB per tile; filter column jj < 8: re of bin 8 ft + jj, else im)
 #include "frontend_mx_tile.inc"
 constexpr int kMx2BlockPitch = 68;
 constexpr int kMx2ChunkPitch = kBlocks * kMx2BlockPitch;      // 1904 floats per chunk
+constexpr int kMxChunks = 4;                  // 64 consecutive positions span at most 4 chunks
+typedef float f16acc __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) float lds_float_t;
+
+__device__ __forceinline__ float dpp_row_ror8(float v)      // lane l of every 16-lane row reads lane (l + 8) % 16 of its row
+{
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ pcm,          // [n_chunks][1536]
@@ -566,6 +421,8 @@ __global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ p
                                                          int n_chunks, ItemMap map, size_t fm_stride)
 {
    __shared__ __attribute__((aligned(16))) float xs[kMxChunks * kMx2ChunkPitch];
+   __shared__ int posoff[64];                 // element offset of (chunk, frame) in Y, -1 = past the end
+   __shared__ float sy[4][8][65];             // per wave: one tile's 8 bins x 64 positions, transposed for coalesced stores
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int lc = lane & 15, quad = lane >> 4;
    const long total_pos = (long)n_chunks * kFrames;
@@ -584,6 +441,18 @@ __global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ p
          xs[c * kMx2ChunkPitch + (idx >> 6) * kMx2BlockPitch + (k & 7) * 8 + (k >> 3)] = sample_to_f32(src[s]);
       }
    }
+   int fo = -1;                               // this lane's position as OUTPUT lane: offset in the frame-major FM buffer
+   {
+      const long pe = p0 + lane;
+      int yo = -1;
+      if (pe < total_pos) {
+         const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
+         const int ch = map(it);
+         yo = ch * (kBins * kFrames) + n;       // < 2^31 (vadc_amd_create bounds max_streams * max_chunks)
+         fo = ch * kFrames + n;
+      }
+      if (wave == 0) posoff[lane] = yo;
+   }
    __syncthreads();
 
    // this lane's position (A operand): frame n of its chunk starts at block n
@@ -591,50 +460,48 @@ __global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ p
    const int item_a = (int)(pa / kFrames), n_a = (int)(pa - (long)item_a * kFrames);
    const unsigned xaddr = (unsigned)(uintptr_t)(lds_float_t *)(xs + (item_a - item0) * kMx2ChunkPitch + kMx2BlockPitch * n_a);
    const unsigned boff = lc * 16;
+   const int hi = lc >> 3;                    // epilogue: lanes 8..15 of a row take the second half of the accumulator
+   float bsum = 0.0f;                         // partial bin sum of position `lane` over this wave's tiles
 
-   float bsum[16];
-#pragma unroll
-   for (int e = 0; e < 16; ++e) bsum[e] = 0.0f;
-
+   // wave w owns tiles w, w+4, w+8, w+12; the 17th tile (bin 128 only) rotates over the waves with the workgroup index
+   const int extra = blockIdx.x & 3;
 #pragma unroll 1
-   for (int ft = wave; ft < kMxTiles; ft += 4) {
-      const float *bbase = bt2 + (size_t)__builtin_amdgcn_readfirstlane(ft) * (256 * 16);
+   for (int ti = 0; ti < 5; ++ti) {
+      if (ti == 4 && wave != extra) break;
+      const int ft = __builtin_amdgcn_readfirstlane(ti == 4 ? 16 : wave + 4 * ti);
+      const float *bbase = bt2 + (size_t)ft * (256 * 16);
       f16acc y;
       asm volatile(VADC_MX_TILE_ASM
                    : VADC_MX_TILE_Y_CONSTRAINT(y)
                    : [xaddr] "v"(xaddr), [boff] "v"(boff), [bbase] "s"(bbase)
                    : VADC_MX_TILE_CLOBBERS);
       // y[e]: position 16 (e/4) + 4 quad + e%4 of this workgroup, filter lc of tile ft (lc < 8: re of bin 8 ft + lc,
-      // lc >= 8: im of bin 8 ft + lc - 8).  Pair re with im across lanes lc, lc + 8.
-      const int bin = 8 * ft + (lc & 7);
+      // lc >= 8: im of bin 8 ft + lc - 8).  re and im of one output sit 8 lanes apart in the same register; lanes 0..7 of a
+      // row finish outputs e = 0..7, lanes 8..15 outputs e = 8..15, so all 64 lanes do useful epilogue work.  The values
+      // go through a per-wave LDS tile [bin][position] so that the global stores run along the frames of a chunk.
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         const float re = y[e];
-         const float im = __shfl_down(re, 8, 16);
+      for (int e = 0; e < 8; ++e) {
+         const float a = y[e], b = y[e + 8];
+         const float ra = dpp_row_ror8(a), rb = dpp_row_ror8(b);
+         const float re = hi ? rb : a, im = hi ? b : ra;
          const float re2 = re * re, im2 = im * im;
          const float mag = sqrtf(re2 + im2);                                  // stft.c:209
          const float val = (MODE == 0) ? log1pf(mag * 1048576.0f) : mag;      // misc.c:42-45
-         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
-         if (lc < 8 && bin < kBins && pe < total_pos) {
-            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
-            Y[(size_t)map(it) * (kBins * kFrames) + bin * kFrames + n] = val;
-            bsum[e] += val;
-         }
-         __builtin_amdgcn_sched_barrier(0);             // one element at a time: keeps the 16 log1p bodies from interleaving
+         sy[wave][lc & 7][16 * ((e >> 2) + 2 * hi) + 4 * quad + (e & 3)] = val;
+         if (e & 1) __builtin_amdgcn_sched_barrier(0);   // two elements at a time: bounds the live log1p temporaries
       }
-   }
-   if (MODE == 0) {
+      const int yo = posoff[lane];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         float s = bsum[e];
-         s += __shfl_xor(s, 1, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 4, 16);
-         const long pe = p0 + 16 * (e >> 2) + 4 * quad + (e & 3);
-         if (lc == 0 && pe < total_pos) {
-            const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
-            FM[wave * fm_stride + (size_t)map(it) * kFrames + n] = s;
+      for (int b = 0; b < 8; ++b) {
+         const float v = sy[wave][b][lane];                                    // same wave wrote it (LDS is in order per wave)
+         const int bin = 8 * ft + b;
+         if (yo >= 0 && bin < kBins) {
+            Y[(size_t)yo + bin * kFrames] = v;
+            bsum += v;
          }
       }
    }
+   if (MODE == 0 && fo >= 0) FM[wave * fm_stride + fo] = bsum;
 }
 
 void launch_frontend_mx2_f32(const float *pcm, const float *bt2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)

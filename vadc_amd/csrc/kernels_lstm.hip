@@ -30,8 +30,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // Hardware-transcendental forms for the recurrent inner loop (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute
 // error <= ~3e-7 on values in (0,1) / (-1,1), two decades below what the 1e-4 probability bar needs, and the
 // recurrence is contractive.  The bring-up kernel keeps the libm-grade forms for A/B tests.
-__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+// (__frcp_rn is the correctly rounded reciprocal: a 10-instruction v_div_scale/fmas/fixup sequence; v_rcp_f32 is 1 ulp.)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
 // ------------------------------------------------------------------------------------------------
 // simple variant
