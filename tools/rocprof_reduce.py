@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 output directories into the small summaries kept under profiles/.
+
+  python tools/rocprof_reduce.py --kernel-trace gpurun_out/prof_kt --fetch gpurun_out/prof_fetch --write gpurun_out/prof_write \
+         --out profiles/r01 --tag bench_256x64 --streams 256 --chunks-per-step 64
+
+* kernel trace:  <dir>/**/*_kernel_stats.csv  -> <out>/<tag>_kernel_stats.csv (copied, vadc kernels + totals only)
+* PMC passes  :  FETCH_SIZE and WRITE_SIZE were collected in SEPARATE runs (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE);
+                 per-kernel averages -> <out>/<tag>_pmc_traffic.json and profiles/latest_pmc_traffic.json, with the gfx950
+                 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request): hbm = (2*FETCH + WRITE) KB.
+"""
+import argparse, csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+SHORT = [("k_frontend_mx2", "k_frontend"), ("k_frontend", "k_frontend"), ("k_lstm_xproj", "k_lstm_xproj"), ("k_lstm", "k_lstm")]
+
+
+def short_name(full):
+    m = re.search(r"k_layer_mfma<(\d+), (\d+), (\d+)", full) or re.search(r"k_layer<(\d+), (\d+), (\d+)", full)
+    if m:
+        return {("129", "16"): "k_layer1", ("16", "32"): "k_layer2", ("32", "32"): "k_layer3", ("32", "64"): "k_layer4"}[(m.group(1), m.group(2))]
+    for key, name in SHORT:
+        if key in full:
+            return name
+    return None
+
+
+def find(d, pat):
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    if not hits:
+        sys.exit(f"no {pat} under {d}")
+    return hits[-1]
+
+
+def pmc_avg(d, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(find(d, "*_counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short_name(row["Kernel_Name"])
+            if k:
+                acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel-trace"); ap.add_argument("--fetch"); ap.add_argument("--write")
+    ap.add_argument("--out", required=True); ap.add_argument("--tag", required=True)
+    ap.add_argument("--streams", type=int, default=256); ap.add_argument("--chunks-per-step", type=int, default=64)
+    ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    if a.kernel_trace:
+        src = find(a.kernel_trace, "*_kernel_stats.csv")
+        with open(src) as f, open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w") as g:
+            for i, line in enumerate(f):
+                if i == 0 or "vadc::" in line:
+                    g.write(line)
+        print("wrote", os.path.join(a.out, a.tag + "_kernel_stats.csv"))
+    if a.fetch and a.write:
+        fe, wr = pmc_avg(a.fetch, "FETCH_SIZE"), pmc_avg(a.write, "WRITE_SIZE")
+        out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {a.command}",
+               "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 64 B per 128-B request; MI355X_MICROARCH.md section HBM)",
+               "streams": a.streams, "chunks_per_step": a.chunks_per_step, "kernels": {}}
+        for k in sorted(set(fe) | set(wr)):
+            out["kernels"][k] = {"FETCH_SIZE_KB": round(fe.get(k, 0.0), 1), "WRITE_SIZE_KB": round(wr.get(k, 0.0), 1),
+                                 "hbm_bytes_per_launch": int((2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024)}
+        p = os.path.join(a.out, a.tag + "_pmc_traffic.json")
+        json.dump(out, open(p, "w"), indent=1)
+        shutil.copy(p, os.path.join(os.path.dirname(os.path.abspath(a.out)), "latest_pmc_traffic.json"))
+        print("wrote", p)
+
+
+if __name__ == "__main__":
+    main()

@@ -475,7 +475,12 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) { e->frontend_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
+      if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
+         return fail(VADC_AMD_EINVAL, "set_option: frontend=1 indexes Y with 32-bit offsets; workspace too large");
+      e->frontend_variant = value;
+      return VADC_AMD_OK;
+   }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
