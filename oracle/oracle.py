@@ -23,7 +23,8 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> None:
     if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "silero_oracle.c")):
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f)) for f in
+                                             ("silero_oracle.c", "silero_v4_oracle.c", "silero_oracle.h", "silero_v4_oracle.h")):
         subprocess.check_call(["make", "-C", HERE, "libsilero_oracle.so"], stdout=subprocess.DEVNULL)
 
 
@@ -38,6 +39,14 @@ class _Layer(C.Structure):
 class _Taps(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_float)) for n in
                 ("padded", "stft_conv", "magnitude", "normalized", "l1", "l2", "l3", "l4", "lstm_out")]
+
+
+class _TapsV4(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("magnitude", "normalized", "l1", "l2", "l3", "l4", "lstm_out")]
+
+
+TAP_SHAPES_V4 = {"magnitude": (129, 24), "normalized": (129, 24), "l1": (16, 12), "l2": (32, 6), "l3": (32, 3),
+                 "l4": (64, 3), "lstm_out": (3, 64)}
 
 
 class _SegParams(C.Structure):
@@ -68,6 +77,13 @@ def lib():
         L.so_dot.argtypes = [_f32p, _f32p, C.c_int]
         L.so_segments.restype = C.c_int
         L.so_segments.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(_SegParams), _f32p, _i32p, C.c_int]
+        L.so4_model_from_bytes.restype = C.c_void_p
+        L.so4_model_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
+        L.so4_model_free.argtypes = [C.c_void_p]
+        L.so4_forward_chunk.restype = C.c_float
+        L.so4_forward_chunk.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.POINTER(_TapsV4)]
+        L.so4_forward_stream_f32.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        L.so4_forward_stream_s16.argtypes = [C.c_void_p, _i16p, C.c_int, _f32p, _f32p, _f32p]
         _lib = L
     return _lib
 
@@ -138,6 +154,53 @@ class Oracle:
         for s in range(S):
             out[s] = self.forward_stream(pcm[s], h[s], c[s])[:, 1]
         return out
+
+
+class OracleV4:
+    """Whole-path oracle for Silero v4 / 16 kHz (oracle/silero_v4_oracle.c; weights: 36-tensor container written by
+    vadc_amd/onnx_weights.py).  Returns ONE speech probability per chunk."""
+
+    def __init__(self, weights_blob: bytes):
+        self._L = lib()
+        self._blob = weights_blob
+        self._m = self._L.so4_model_from_bytes(weights_blob, len(weights_blob))
+        if not self._m:
+            raise ValueError("oracle: malformed v4 weights blob")
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            self._L.so4_model_free(self._m)
+            self._m = None
+
+    new_state = staticmethod(Oracle.new_state)
+
+    def forward_chunk(self, samples, h, c, taps=False):
+        samples = _c(samples)
+        assert samples.shape == (1536,) and h.shape == (2, 64) and c.shape == (2, 64)
+        tp, tapd = None, {}
+        if taps:
+            tp = _TapsV4()
+            for k, shp in TAP_SHAPES_V4.items():
+                tapd[k] = np.zeros(shp, np.float32)
+                setattr(tp, k, _fp(tapd[k]))
+        p = self._L.so4_forward_chunk(self._m, samples, h, c, C.byref(tp) if tp is not None else None)
+        return (p, tapd) if taps else p
+
+    def forward_stream(self, pcm_or_f32, h=None, c=None):
+        x = np.ascontiguousarray(pcm_or_f32).reshape(-1)
+        n = x.size // 1536
+        if h is None:
+            h, c = self.new_state()
+        probs = np.zeros(n, np.float32)
+        if x.dtype == np.int16:
+            self._L.so4_forward_stream_s16(self._m, x, n, h, c, probs)
+        else:
+            self._L.so4_forward_stream_f32(self._m, _c(x), n, h, c, probs)
+        return probs
+
+    def forward_streams(self, pcm):
+        pcm = np.ascontiguousarray(pcm)
+        return np.stack([self.forward_stream(pcm[s]) for s in range(pcm.shape[0])])
 
 
 def segments(probs, threshold=0.5, neg_threshold_relative=0.15, min_silence_ms=200.0, min_speech_ms=250.0,
