@@ -34,21 +34,29 @@ FLOP_PER_CHUNK = {
     "k_lstm": 2 * (458_752 - 114_688 + 896),      # recurrent part + decoder
     "k_lstm_xproj": 2 * 114_688,                   # layer-0 input projection (256 x 64 x 7), hoisted GEMM
 }
+# Silero v4 (BASELINE config 4, `--model v4`): parity-test configuration, not the headline
+FLOP_PER_CHUNK_V4 = {
+    "k_frontend": 2 * 1_585_152,
+    "k_layer1": 2 * 232_176, "k_layer2": 2 * 19_392, "k_layer3": 2 * 10_176, "k_layer4": 2 * 25_056,
+    "k_lstm": 2 * (196_608 - 49_152 + 192), "k_lstm_xproj": 2 * 49_152,
+}
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
 
 
-def cpu_baseline(blob, weights_path, seconds_budget=12.0):
+def cpu_baseline(blob, weights_path, seconds_budget=12.0, model="v31"):
     """Reported baseline, not the target: the oracle on ONE host core over a bounded sample."""
     from oracle import oracle as O
     from vadc_amd import synth
     pcm = synth.speech_like(256 * 1536, seed=9)
     kind, runner = "port", None
     try:
+        if model == "v4":                       # the reference has no C implementation of v4: only the restatement exists
+            raise FileNotFoundError
         ref = O.Reference(weights_path)
         x = pcm.astype(np.float32) / np.float32(32768)
         kind, runner = "reference", (lambda n: ref.run(x[: n * 1536], batch=96))
     except (FileNotFoundError, OSError, ValueError):
-        orc = O.Oracle(blob)
+        orc = O.OracleV4(blob) if model == "v4" else O.Oracle(blob)
         runner = lambda n: orc.forward_stream(pcm[: n * 1536])
     runner(8)
     t0 = time.perf_counter(); runner(32); dt = time.perf_counter() - t0
@@ -66,6 +74,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
     ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["v31", "v4"], default="v31",
+                    help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
@@ -91,6 +101,9 @@ def main():
     from vadc_amd.engine import Engine
 
     weights_path = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor")
+    if args.model == "v4":
+        weights_path = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor")
+        FLOP_PER_CHUNK.clear(); FLOP_PER_CHUNK.update(FLOP_PER_CHUNK_V4)
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
@@ -182,11 +195,12 @@ def main():
                 per_kernel[k] = {"ms_per_launch": round(ms / n_l, 4), "cu_share": round(cu_share[k], 4),
                                  "tflops": round(FLOP_PER_CHUNK[k] * (S * Cn * (4 if args.graph else args.steps) / n_l) / (ms / n_l / 1e3) / 1e12, 3)}
         out = {
-            "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k",
+            "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k" if args.model == "v31" else
+                      "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Silero v3.1 16k, batch={S} streams/GPU x {Cn} chunks/step, fp32, s16le input resident in HBM",
+            "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, fp32, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
@@ -198,7 +212,7 @@ def main():
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(blob, weights_path)
+            out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

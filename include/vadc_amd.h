@@ -42,10 +42,19 @@ extern "C" {
 enum {
    VADC_AMD_OK        =  0,
    VADC_AMD_EINVAL    = -1,   /* bad argument (NULL, out-of-range stream/chunk count, ...)        */
-   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 .testtensor container  */
+   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 / 36-tensor v4 container */
    VADC_AMD_ENODEVICE = -3,   /* no usable gfx950 device / HIP runtime failure at creation         */
    VADC_AMD_EHIP      = -4,   /* HIP runtime error during a call                                    */
    VADC_AMD_ENOMEM    = -5
+};
+
+/* model kind, decided by the weights container handed to vadc_amd_create and reported by vadc_amd_get_caps */
+enum {
+   VADC_AMD_MODEL_V31 = 0,   /* Silero v3.1 / 16 kHz: the 99-tensor .testtensor the reference's C backend loads (tensor.h:114-191) */
+   VADC_AMD_MODEL_V4  = 1    /* Silero v4 / 16 kHz: 36-tensor container written from the reference's silero_vad_v4.onnx by
+                                vadc_amd/onnx_weights.py.  The reference runs v4 only through onnxruntime (silero.h:59,
+                                onnx_helpers.c:83-115); arithmetic per silero_vad.py:191-236.  One probability per chunk, written
+                                to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */
 };
 
 /* precision selector for vadc_amd_create (room for the bf16x3 variant of BASELINE config 3) */
@@ -69,13 +78,16 @@ typedef struct vadc_amd_caps {
    int32_t max_chunks_per_call;
    int32_t device;
    int32_t precision;
+   int32_t model_kind;                    /* VADC_AMD_MODEL_*                          */
+   int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3 (v4)                         */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 
 /* Replaces backend_init (silero.h:21-46): parses the weights container (tensor.h:201-253 format,
  * positional order tensor.h:114-191), uploads/repacks the weights, allocates the device workspace for
- * max_streams x max_chunks_per_call chunks and zeroes every stream's LSTM state.
+ * max_streams x max_chunks_per_call chunks and zeroes every stream's LSTM state.  A 36-tensor container selects the
+ * Silero v4 path (VADC_AMD_MODEL_V4).
  * device < 0 selects the current HIP device. */
 int  vadc_amd_create(const void *weights_blob, size_t weights_len, int device,
                      int max_streams, int max_chunks_per_call, int precision,

@@ -1,0 +1,131 @@
+"""Silero v4 / 16 kHz on the HIP path (through the C-ABI) against the v4 CPU oracle and the goldens generated from the
+reference's PyTorch class silero_vad.py::Silero_V4 (tests/golden/gen_golden_v4_from_python_reference.py).
+Needs an MI355X: `-m gpu`.  Bar: per-chunk probability within 1e-4 (north star); stage taps within 2e-4 of float64 torch
+(relative to the stage's magnitude)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from vadc_amd import synth
+from vadc_amd.engine import Engine, VadcAmdError, MODEL_V4
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4
+TAP_TOL = 2e-4
+V4_WEIGHTS = os.path.join(GOLDEN, "silero_v4_16k.testtensor")
+STREAMS = ["speech0", "speech1", "speech2", "zeros", "noise", "square"]
+
+
+@pytest.fixture(scope="module")
+def blob():
+    return open(V4_WEIGHTS, "rb").read()
+
+
+@pytest.fixture(scope="module")
+def eng(blob):
+    e = Engine(blob, max_streams=64, max_chunks_per_call=64, device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(blob):
+    return O.OracleV4(blob)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "python_reference_v4.npz"))
+
+
+def f32(pcm):
+    return pcm.astype(np.float32) / np.float32(32768)
+
+
+def test_model_kind_comes_from_the_container(eng):
+    c = eng.caps()
+    assert c["model_kind"] == MODEL_V4 and c["lstm_steps_per_chunk"] == 3
+    assert (c["input_size_min"], c["input_size_max"], c["output_stride"], c["silero_probability_out_index"]) == (1536, 1536, 2, 1)
+    with pytest.raises(VadcAmdError):
+        eng.set_option("lstm", 2)                    # v3.1 bring-up variants do not exist for v4
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_probabilities_match_python_reference(eng, gold, name):
+    pcm = gold[f"pcm_{name}"]
+    eng.reset_streams()
+    p = eng.run(pcm.reshape(1, -1))[0]
+    assert np.array_equal(p[:, 0], p[:, 1])          # v4 has one output; both slots carry it
+    assert float(np.abs(p[:, 1] - gold[f"probs64_{name}"]).max()) < PROB_TOL
+
+
+def test_probabilities_match_oracle_many_streams(eng, orc):
+    S, n = 24, 40                                    # ragged vs the 16-stream LSTM tile
+    pcm = synth.make_streams(S, n, seed0=4242)
+    eng.reset_streams()
+    got = eng.run(pcm)[:, :, 1]
+    ref = orc.forward_streams(pcm)
+    assert float(np.abs(got - ref).max()) < PROB_TOL
+
+
+@pytest.mark.parametrize("ci", [0, 20])
+def test_stage_taps(eng, gold, ci):
+    x = f32(gold["pcm_speech0"])[ci * 1536:(ci + 1) * 1536]
+    for stage, key in (("magnitude", "magnitude"), ("normalized", "normalized"), ("layer1", "l1"), ("layer2", "l2"),
+                       ("layer3", "l3"), ("layer4", "l4")):
+        got = eng.stage_from_samples(x, stage)[0]
+        ref = gold[f"tap{ci}_{key}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert got.shape == ref.shape
+        assert float(np.abs(got - ref).max()) < TAP_TOL * scale, stage
+
+
+def test_stft_magnitude_is_the_exact_tree(eng, orc, gold):
+    """the v4 front end reuses the bit-exact STFT tree kernel with the v4 geometry (pad 96, 24 frames)"""
+    x = f32(gold["pcm_speech1"])[:3 * 1536]
+    got = eng.stage_from_samples(x, "magnitude")
+    for i in range(3):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(got[i].view(np.uint32), taps["magnitude"].view(np.uint32))
+
+
+def test_state_is_carried_and_split_invariant(eng, gold):
+    pcm = gold["pcm_speech2"].reshape(1, -1)
+    eng.reset_streams()
+    whole = eng.run(pcm)
+    eng.reset_streams()
+    parts = np.concatenate([eng.run(pcm[:, :17 * 1536]), eng.run(pcm[:, 17 * 1536:])], axis=1)
+    assert float(np.abs(whole - parts).max()) < 1e-6
+    h, c = eng.get_state(0)
+    assert float(np.abs(h - gold["h64_speech2"]).max()) < 2e-4 and float(np.abs(c - gold["c64_speech2"]).max()) < 2e-4
+
+
+def test_lstm_decoder_tap(eng, orc, gold):
+    """LSTM + v4 decoder (mean_t sigmoid(w . relu(h_t) + b)) fed with the golden encoder output"""
+    enc = gold["tap20_l4"].astype(np.float32).reshape(1, 1, 64, 3)
+    eng.reset_streams()
+    eng.set_state(0, gold["tap20_h_in"].astype(np.float32), gold["tap20_c_in"].astype(np.float32))
+    p = eng.lstm_decoder(enc)[0, 0]
+    assert abs(float(p[1]) - float(gold["tap20_prob"])) < PROB_TOL
+
+
+def test_device_pointer_and_graph_paths(eng, gold):
+    import torch
+    pcm = np.ascontiguousarray(np.tile(gold["pcm_speech0"][:32 * 1536], (8, 1)))
+    eng.reset_streams()
+    ref = eng.run(pcm)
+    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_out = torch.empty((8, 32, 2), dtype=torch.float32, device="cuda:0")
+    for graph in (0, 1):
+        eng.set_option("graph", graph)
+        eng.reset_streams()
+        st = torch.cuda.Stream(device="cuda:0")
+        eng.run_device(d_in.data_ptr(), np.int16, 8, 32, d_out.data_ptr(), hip_stream=st.cuda_stream)
+        st.synchronize()
+        assert float(np.abs(d_out.cpu().numpy() - ref).max()) < 1e-6
+    eng.set_option("graph", 0)

@@ -60,11 +60,12 @@ struct ItemMap {
 // Encoder -> LSTM hand-off layout ("LSTM-native"): streams are tiled by 16 (the MFMA N dimension) and one
 // (tile, chunk) block holds the chunk's 7 frames as [t][unit][stream-in-tile], i.e. exactly the LDS image
 // k_lstm_mfma uses as its B operand, so the LSTM stages a chunk with coalesced 16-byte loads.
-//   X[((tile * C + chunk) * 7 + t) * 64 + unit) * 16 + stream % 16]
+//   X[((tile * C + chunk) * steps + t) * 64 + unit) * 16 + stream % 16]
 constexpr int kLstmTile = 16;
-__host__ __device__ __forceinline__ size_t lstm_x_index(int stream, int chunk, int C, int t, int unit)
+// steps = LSTM steps per chunk: 7 (Silero v3.1) or 3 (Silero v4)
+__host__ __device__ __forceinline__ size_t lstm_x_index(int stream, int chunk, int C, int t, int unit, int steps = 7)
 {
-   return ((((size_t)(stream / kLstmTile) * C + chunk) * 7 + t) * 64 + unit) * kLstmTile + (stream % kLstmTile);
+   return ((((size_t)(stream / kLstmTile) * C + chunk) * steps + t) * 64 + unit) * kLstmTile + (stream % kLstmTile);
 }
 
 struct LstmWeights {

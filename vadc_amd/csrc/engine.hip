@@ -19,16 +19,19 @@ void launch_frontend_f32(const float *, const float *, float *, float *, size_t,
 void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t);
+void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
+void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
+void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
-void launch_lstm(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t);
-void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, hipStream_t);
+void launch_lstm(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
+void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, hipStream_t, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
+void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
 }  // namespace vadc
 
 using namespace vadc;
@@ -86,7 +89,10 @@ static bool parse_testtensor(const unsigned char *p, size_t len, std::vector<Hos
 
 struct LayerShape { int cin, d, t, stride, proj; };
 static const LayerShape kLayers[4] = {{129, 16, 25, 2, 1}, {16, 32, 13, 2, 1}, {32, 32, 7, 1, 0}, {32, 64, 7, 1, 1}};
-static const int kStageElems[VADC_AMD_STAGE_COUNT] = {129 * 25, 129 * 25, 16 * 13, 32 * 7, 32 * 7, 64 * 7};
+static const int kStageElemsV31[VADC_AMD_STAGE_COUNT] = {129 * 25, 129 * 25, 16 * 13, 32 * 7, 32 * 7, 64 * 7};
+// Silero v4 (silero_vad.py:157-236): 24 frames, encoder [16,12] [32,6] [32,3] [64,3]
+static const LayerShape kLayersV4[4] = {{258, 16, 24, 2, 1}, {16, 32, 12, 2, 1}, {32, 32, 6, 2, 0}, {32, 64, 3, 1, 1}};
+static const int kStageElemsV4[VADC_AMD_STAGE_COUNT] = {129 * 24, 129 * 24, 16 * 12, 32 * 6, 32 * 3, 64 * 3};
 
 struct Packer {
    std::vector<float> buf;
@@ -102,6 +108,11 @@ struct Packer {
 
 struct vadc_amd_engine {
    int device = 0;
+   int model = VADC_AMD_MODEL_V31;              // decided by the weights container: 99 tensors = v3.1, 36 = v4
+   int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
+   int lstm_steps = 7;                          // LSTM steps per chunk: 7 / 3
+   const int *stage_elems = nullptr;
+   float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
    int max_streams = 0, max_chunks = 0, precision = 0;
    size_t max_items = 0;
    hipStream_t stream = nullptr;
@@ -292,6 +303,84 @@ bad:
    return fail(VADC_AMD_EWEIGHTS, "weights: tensor %d has an unexpected size", idx);
 }
 
+// Silero v4 / 16 kHz: 36-tensor container written by vadc_amd/onnx_weights.py (order documented there)
+static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
+{
+   Packer pk;
+   std::vector<float> tmp, tmp2;
+   int idx = 0;
+   auto need = [&](int i, int n) { return ts[i].size == n; };
+   if (!need(idx, kFilters * kFilterLen)) return fail(VADC_AMD_EWEIGHTS, "weights: bad forward_basis_buffer");
+   copy_unaligned(tmp, ts[idx++]);
+   tmp2.resize(tmp.size());
+   for (int f = 0; f < kFilters; ++f)                     // same consumption order as v3.1 (k_frontend, PK form)
+      for (int ii = 0; ii < 4; ++ii)
+         for (int lp = 0; lp < 4; ++lp)
+            for (int j = 0; j < 8; ++j)
+               for (int b = 0; b < 2; ++b)
+                  tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
+   const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
+   pk.add(nullptr, 64);
+   auto frag = [](const std::vector<float> &W, int M, int K) {
+      const int KKW = (K + 3) / 4;
+      std::vector<float> f((size_t)(M / 16) * KKW * 64, 0.0f);
+      for (int mt = 0; mt < M / 16; ++mt)
+         for (int kk = 0; kk < KKW; ++kk)
+            for (int l = 0; l < 64; ++l) {
+               const int k = 4 * kk + (l >> 4);
+               if (k < K) f[((size_t)mt * KKW + kk) * 64 + l] = W[(size_t)(16 * mt + (l & 15)) * K + k];
+            }
+      return f;
+   };
+   struct LOff { size_t dw_w, dw_b, pw_f, pj_f, cb_b, cv_f, cv_b; } lo[4];
+   for (int l = 0; l < 4; ++l) {
+      const LayerShape &s = kLayersV4[l];
+      const int D = s.d, C = s.cin;
+      auto take = [&](int n, std::vector<float> &v) -> bool { if (!need(idx, n)) return false; copy_unaligned(v, ts[idx++]); return true; };
+      std::vector<float> v, cbb;
+      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
+      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
+      if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); }
+      if (!take(D, v)) goto bad;     cbb = v;
+      lo[l].pj_f = (size_t)-1;
+      if (s.proj) {
+         if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
+         if (!take(D, v)) goto bad;
+         for (int o = 0; o < D; ++o) cbb[o] += v[o];
+      }
+      lo[l].cb_b = pk.add(cbb.data(), cbb.size());
+      if (!take(D * D, v)) goto bad; { auto f = frag(v, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); }   // BatchNorm folded by the exporter
+      if (!take(D, v)) goto bad;     lo[l].cv_b = pk.add(v.data(), v.size());
+   }
+   {
+      if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 64) || !need(idx + 3, 1) || !need(idx + 4, 7)) goto bad;
+      std::vector<float> W, B, dw, db;
+      copy_unaligned(W, ts[idx]); copy_unaligned(B, ts[idx + 1]); copy_unaligned(dw, ts[idx + 2]); copy_unaligned(db, ts[idx + 3]);
+      dw.resize(128, 0.0f); db.resize(2, 0.0f);            // LstmWeights carries room for the v3.1 two-output decoder
+      std::vector<float> WT(W.size());
+      for (int l = 0; l < 2; ++l)
+         for (int r = 0; r < 256; ++r)
+            for (int k = 0; k < 128; ++k) WT[((size_t)l * 128 + k) * 256 + r] = W[((size_t)l * 256 + r) * 128 + k];
+      const size_t o_w = pk.add(W.data(), W.size()), o_wT = pk.add(WT.data(), WT.size());
+      const size_t o_b = pk.add(B.data(), B.size()), o_dw = pk.add(dw.data(), dw.size()), o_db = pk.add(db.data(), db.size());
+      HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
+      HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      const float *base = e->d_weights;
+      e->d_basis = base + off_basis;
+      for (int l = 0; l < 4; ++l) {
+         LayerWeightsM &m = e->lwm[l];
+         m = LayerWeightsM{};
+         m.dw_w = base + lo[l].dw_w; m.dw_b = base + lo[l].dw_b; m.pw_f = base + lo[l].pw_f;
+         m.pj_f = kLayersV4[l].proj ? base + lo[l].pj_f : nullptr;
+         m.cb_b = base + lo[l].cb_b; m.cv_f = base + lo[l].cv_f; m.cv_b = base + lo[l].cv_b;
+      }
+      e->lstm.w = base + o_w; e->lstm.wT = base + o_wT; e->lstm.b = base + o_b; e->lstm.dec_w = base + o_dw; e->lstm.dec_b = base + o_db;
+   }
+   return VADC_AMD_OK;
+bad:
+   return fail(VADC_AMD_EWEIGHTS, "weights (v4): tensor %d has an unexpected size", idx);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // lifetime
 // ---------------------------------------------------------------------------------------------------
@@ -305,7 +394,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
+   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1]};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -330,7 +419,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    std::vector<HostTensor> ts;
    if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
       return fail(VADC_AMD_EWEIGHTS, "create: weights blob is not a valid .testtensor container");
-   if (ts.size() != 99) return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors, found %zu", ts.size());
+   if (ts.size() != 99 && ts.size() != 36)
+      return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors (Silero v3.1) or 36 (Silero v4), found %zu", ts.size());
 
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -346,7 +436,11 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    vadc_amd_engine *e = new vadc_amd_engine();
    e->device = device; e->max_streams = max_streams; e->max_chunks = max_chunks; e->precision = precision;
    e->max_items = (size_t)max_streams * max_chunks;
-   int rc = build_weights(e, ts);
+   e->model = ts.size() == 36 ? VADC_AMD_MODEL_V4 : VADC_AMD_MODEL_V31;
+   e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
+   e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
+   e->stage_elems = e->model == VADC_AMD_MODEL_V4 ? kStageElemsV4 : kStageElemsV31;
+   int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -358,7 +452,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_FM, kBinSplit * N * kFrames * sizeof(float));
-   for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElems[2 + l] * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_MAG, N * kBins * kFrames * sizeof(float));
+   for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElemsV31[2 + l] * sizeof(float));   // >= the v4 shapes
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
    for (int p = 0; p < 2; ++p) {
@@ -398,6 +493,8 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    caps->max_chunks_per_call = e->max_chunks;
    caps->device = e->device;
    caps->precision = e->precision;
+   caps->model_kind = e->model;
+   caps->lstm_steps_per_chunk = e->lstm_steps;
    return VADC_AMD_OK;
 }
 
@@ -474,6 +571,8 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
+   if (e->model == VADC_AMD_MODEL_V4 && (strcmp(key, "lstm") == 0 || strcmp(key, "frontend") == 0 || strcmp(key, "encoder") == 0) && value != 0)
+      return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
@@ -507,7 +606,8 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
+      else if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
    }
 }
@@ -520,7 +620,10 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (e->frontend_variant == 1) {
+      if (e->model == VADC_AMD_MODEL_V4) {
+         if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
+         else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
+      } else if (e->frontend_variant == 1) {
          if (sizeof(T) == 2) launch_frontend_mx2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_mx2_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       } else {
@@ -533,7 +636,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    run_encoder_layers(e, 3, 3, n, map, 1, st);
    if (lstm_kernel == 0) {
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM_XPROJ, st);
-      launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st);
+      launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st, e->model);
    }
 }
 
@@ -580,6 +683,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 // i.e. few stream tiles; fused otherwise), 1 = simple, 2 = step-sequential MFMA, 3 = fused wavefront, 4 = hoisted wavefront
 static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
 {
+   if (e->model == VADC_AMD_MODEL_V4) return 0;            // v4: hoisted wavefront only
    if (e->lstm_variant == 0) return ((n_streams + 15) / 16 <= e->n_cus / 2) ? 0 : 3;
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
@@ -608,7 +712,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       const ItemMap map{n_chunks, 0, n_chunks};
       run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-      launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st);
+      launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
    } else {
       int rc = ensure_pipeline_streams(e, n_streams);
       if (rc) return rc;
@@ -642,7 +746,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB);
+         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
          c0 += cg;
       }
       // join
@@ -804,7 +908,7 @@ extern "C" int vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h
 static float *stage_buffer(vadc_amd_engine *e, int stage)
 {
    switch (stage) {
-   case VADC_AMD_STAGE_MAGNITUDE:  return e->d_Y;
+   case VADC_AMD_STAGE_MAGNITUDE:  return e->model == VADC_AMD_MODEL_V4 ? e->d_MAG : e->d_Y;
    case VADC_AMD_STAGE_NORMALIZED: return e->d_tap;
    default:                        return e->d_act[stage - VADC_AMD_STAGE_LAYER1];
    }
@@ -818,12 +922,13 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
+   else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
+   if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * kStageElems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * e->stage_elems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -833,9 +938,11 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    if (!e || !in || !out || from_stage < 0 || to_stage >= VADC_AMD_STAGE_COUNT || to_stage <= from_stage)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: bad argument");
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: n=%d out of range", n);
+   if (e->model == VADC_AMD_MODEL_V4 && from_stage < VADC_AMD_STAGE_LAYER1)
+      return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: the v4 first block takes magnitude AND normalized; feed LAYER1..3 or use from_samples");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    hipStream_t st = e->stream;
-   const size_t in_bytes = (size_t)n * kStageElems[from_stage] * sizeof(float);
+   const size_t in_bytes = (size_t)n * e->stage_elems[from_stage] * sizeof(float);
    int first_layer = 0;
    if (from_stage == VADC_AMD_STAGE_MAGNITUDE) {
       HIP_TRY(hipMemcpyAsync(e->d_tap, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
@@ -848,10 +955,10 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
       first_layer = from_stage - VADC_AMD_STAGE_LAYER1 + 1;
       HIP_TRY(hipMemcpyAsync(e->d_act[first_layer - 1], in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    }
-   if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st);
+   if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, ItemMap{n, 0, n}, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * kStageElems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * e->stage_elems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -867,17 +974,18 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
    {
       // pure data movement: reference layout [S][C][64][7] -> LSTM-native tiles (common.h)
       const size_t padded = (size_t)((n_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
-      std::vector<float> tiles(padded * n_chunks * 448, 0.0f);
+      const int TS = e->lstm_steps;
+      std::vector<float> tiles(padded * n_chunks * 64 * TS, 0.0f);
       for (int s = 0; s < n_streams; ++s)
          for (int c = 0; c < n_chunks; ++c)
             for (int u = 0; u < 64; ++u)
-               for (int t = 0; t < 7; ++t)
-                  tiles[lstm_x_index(s, c, n_chunks, t, u)] = x[(((size_t)s * n_chunks + c) * 64 + u) * 7 + t];
+               for (int t = 0; t < TS; ++t)
+                  tiles[lstm_x_index(s, c, n_chunks, t, u, TS)] = x[(((size_t)s * n_chunks + c) * 64 + u) * TS + t];
       HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    }
    const int lk = resolve_lstm(e, n_streams);
-   if (lk == 0) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st);
-   launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
+   if (lk == 0) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st, e->model);
+   launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);

@@ -45,6 +45,7 @@ struct LayerWeightsM {
    const float *cv_f, *cv_b;          // strided conv with BatchNorm folded
 };
 
+template <int kFrames>
 __device__ __forceinline__ float norm_offset_m(const float *__restrict__ fmp, size_t fm_stride)
 {
    float fm[kFrames];
@@ -64,7 +65,7 @@ __device__ __forceinline__ float norm_offset_m(const float *__restrict__ fmp, si
       }
       total += r;
    }
-   return total / 25.0f;
+   return total / (float)kFrames;
 }
 
 // acc[mt] (+)= W[16mt.., :] . X[:, wave's 16 columns]   for mt < MT, K = 4*KK rows of X starting at xrow0.
@@ -139,12 +140,17 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
    }
 }
 
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, bool FIRST, bool LSTM_OUT, int NCH, bool DIRECT>
+// FIRST: 0 = plain input [n][CIN][T]; 1 = Silero v3.1 first layer (input = Y - mm, finishing the adaptive normalization);
+//        2 = Silero v4 first block: input = concat(magnitude `in2` [n][129][T], Y - mm) = 258 channels (silero_vad.py:212).
+// HAS_TF: false = Silero v4 encoder stage (ConvBlock -> strided 1x1 conv with folded BatchNorm -> ReLU, no transformer
+//        block; silero_vad.py:157-189 with is_v4).
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, bool LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true>
 __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
-                                                    const float *__restrict__ fm,   // [n][25] (FIRST) or null
+                                                    const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
-                                                    int n_chunks, ItemMap map, size_t fm_stride)
+                                                    int n_chunks, ItemMap map, size_t fm_stride,
+                                                    const float *__restrict__ in2 = nullptr)
 {
    constexpr int NCOLV = NCH * T;                       // valid columns
    static_assert(NCOLV <= kCol, "too many chunks per workgroup");
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    if (FIRST) {
       if (tid < NCH) {
          const int it = blockIdx.x * NCH + tid;
-         mm_s[tid] = norm_offset_m(fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * kFrames, fm_stride);   // misc.c:65-82
+         mm_s[tid] = norm_offset_m<T>(fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * T, fm_stride);   // misc.c:65-82
       }
       __syncthreads();
    }
@@ -230,15 +236,18 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
-   const float *x_in = in + (size_t)chunk * CIN * T + t;
+   const float *x_in = in + (size_t)chunk * (FIRST == 2 ? kBins : CIN) * T + t;
+   const float *x_in2 = FIRST == 2 ? in2 + (size_t)chunk * kBins * T + t : nullptr;
+   auto load_x = [&](int ch) -> float {
+      if (!(cvalid && ch < CIN)) return 0.0f;
+      if (FIRST == 2) return ch < kBins ? x_in2[(size_t)ch * T] : x_in[(size_t)(ch - kBins) * T];
+      return x_in[(size_t)ch * T];
+   };
    // x slab: 8 rows per wave; rows >= CIN and invalid columns are zero.  The NEXT slab's rows are requested from
    // HBM as soon as the current ones are in LDS, so their latency hides behind the depthwise conv and the MFMAs.
    float xv[8];
 #pragma unroll
-   for (int i = 0; i < 8; ++i) {
-      const int ch = wave * 8 + i;
-      xv[i] = (cvalid && ch < CIN) ? x_in[(size_t)ch * T] : 0.0f;
-   }
+   for (int i = 0; i < 8; ++i) xv[i] = load_x(wave * 8 + i);
 #pragma unroll 1
    for (int s = 0; s < NSLAB; ++s) {
       const int c0 = s * kSlab;
@@ -246,15 +255,12 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
          const int r = wave * 8 + i, ch = c0 + r;
-         XS[r * kPitch + col] = (cvalid && ch < CIN) ? xv[i] - mm : 0.0f;  // misc.c:84-96
+         XS[r * kPitch + col] = (cvalid && ch < CIN) ? xv[i] - ((FIRST == 2 && ch < kBins) ? 0.0f : mm) : 0.0f;  // misc.c:84-96
       }
       __syncthreads();
       if (s + 1 < NSLAB) {
 #pragma unroll
-         for (int i = 0; i < 8; ++i) {
-            const int ch = c0 + kSlab + wave * 8 + i;
-            xv[i] = (cvalid && ch < CIN) ? x_in[(size_t)ch * T] : 0.0f;
-         }
+         for (int i = 0; i < 8; ++i) xv[i] = load_x(c0 + kSlab + wave * 8 + i);
       }
       // depthwise k5 pad2 + ReLU (conv.c:17-53): neighbours are adjacent columns of the same chunk
 #pragma unroll
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    __syncthreads();                                       // slab buffers free, Yb visible
 
    }
+   if constexpr (HAS_TF) {
    // ---- QKV = W y + b  -> LDS rows [0,D) Q, [D,2D) K, [2D,3D) V      transformer.c:69-99 -----------------
    {
       f4v q[3 * MT];
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    __syncthreads();
    acc_store<MT>(acc, Yb, lane, wave);
    __syncthreads();
+   }  // HAS_TF
 
    // ---- conv k=1 stride s (+ folded BatchNorm) -> ReLU; only surviving time steps are stored -----------------
    {
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
          if (LSTM_OUT) {
             int st_, ch_;
             map.split(oitem, st_, ch_);
-            dst = out + lstm_x_index(st_, ch_, map.C, ot / STRIDE, 0);
+            dst = out + lstm_x_index(st_, ch_, map.C, ot / STRIDE, 0, TOUT);
          } else {
             dst = out + (size_t)map(oitem) * D * TOUT + ot / STRIDE;
          }
@@ -424,6 +432,22 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
    case 3:
       if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, true, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
       else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      break;
+   }
+}
+
+// Silero v4 encoder stages (silero_vad.py:157-189, is_v4): T = 24 -> 12 -> 6 -> 3 -> 3
+// chunks per workgroup: 2 (48 of 64 columns), 5 (60), 10 (60), 21 (63)
+void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                     int lstm_layout, size_t fm_stride, hipStream_t st)
+{
+   switch (layer) {
+   case 0: hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 12, 2, true, 0, false, 5, true, false>), dim3((n + 4) / 5), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 6, 2, false, 0, false, 10, true, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 3:
+      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, true, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, false, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
       break;
    }
 }

@@ -215,13 +215,20 @@ __device__ __forceinline__ float stft_filter_pipe(const float (&x)[64], const fl
 //   SHIFT    0 ds_bpermute / 1 DPP wave shift   LOCK   1: one barrier per filter pair keeps the workgroup's waves
 //            on the same basis rows so that they share scalar-cache lines
 //   ABL      timing ablations for tools/fe_bench.hip (0 in the product)
-template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int LOCK = 0, int ABL = 0, int PIPE = 0, int PK = 0>
+// GEO: 0 = Silero v3.1 (reflect pad 128 -> 28 blocks, 25 frames), 1 = Silero v4 (reflect pad 96 -> 27 blocks, 24 frames;
+//      silero_vad.py:26 to_pad = (n_fft - stride) / 2).  MODE 2 (v4): Y = log1p(2^20 m) AND MAG = m (the v4 encoder takes both).
+template <typename T, int MODE, int NT = 256, int MINW = 3, int SHIFT = 0, int LOCK = 0, int ABL = 0, int PIPE = 0, int PK = 0, int GEO = 0>
 __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                   const float *__restrict__ basis,    // [258][256] permuted
-                                                  float *__restrict__ Y,              // [n_chunks][129][25]
+                                                  float *__restrict__ Y,              // [n_chunks][129][frames]
                                                   float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
-                                                  int n_chunks, ItemMap map, size_t fm_stride)
+                                                  int n_chunks, ItemMap map, size_t fm_stride, float *__restrict__ MAG = nullptr)
 {
+   constexpr int kPad = GEO == 0 ? vadc::kPad : 96;
+   constexpr int kBlocks = GEO == 0 ? vadc::kBlocks : 27;
+   constexpr int kFrames = GEO == 0 ? vadc::kFrames : 24;
+   constexpr int kFirstFull = (kPad + 63) / 64;                        // first block without mirrored samples
+   constexpr int kLastFull = (kChunk + kPad - 64) / 64;                // last block without mirrored samples
    const int lane = threadIdx.x & 63;
    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
    const long total_slots = (long)n_chunks * kBlocks;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
    // index s = 64m + k - 128, mirrored at both ends without repeating the edge sample.
    __attribute__((aligned(8))) float x[64];
    const T *src = pcm + (size_t)chunk * kChunk;
-   if (m >= 2 && m <= 25) {
+   if (m >= kFirstFull && m <= kLastFull) {
       const T *p = src + (64 * m - kPad);
 #pragma unroll
       for (int k = 0; k < 64; ++k) x[k] = sample_to_f32(p[k]);
@@ -282,20 +289,22 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
       const float re2 = re * re, im2 = im * im;
       const float mag = sqrtf(re2 + im2);                                  // stft.c:209
       float val;
-      if (MODE == 0) {
+      if (MODE == 0 || MODE == 2) {
          val = log1pf(mag * 1048576.0f);                                   // misc.c:42-45
          bin_sum += val;                                                   // misc.c:55-59 (channel order)
       } else {
          val = mag;
       }
       if (writer) yout[f * kFrames] = val;
+      if (MODE == 2 && writer) MAG[(size_t)chunk * (kBins * kFrames) + m + f * kFrames] = mag;
    }
-   if (MODE == 0 && writer) FM[blockIdx.y * fm_stride + (size_t)chunk * kFrames + m] = bin_sum;   // /129 by the reader (misc.c:60)
+   if ((MODE == 0 || MODE == 2) && writer) FM[blockIdx.y * fm_stride + (size_t)chunk * kFrames + m] = bin_sum;   // /129 by the reader (misc.c:60)
 }
 
 
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
+template <int kFrames>
 __device__ __forceinline__ float norm_offset(const float *__restrict__ fmp, size_t fm_stride)
 {
    float fm[kFrames];
@@ -316,14 +325,15 @@ __device__ __forceinline__ float norm_offset(const float *__restrict__ fmp, size
       }
       total += r;
    }
-   return total / 25.0f;
+   return total / (float)kFrames;
 }
 
+template <int kFrames>
 __global__ void k_normalize_tap(const float *__restrict__ Y, const float *__restrict__ FM, float *__restrict__ out, int n_chunks, size_t fm_stride)
 {
    const int chunk = blockIdx.x;
    if (chunk >= n_chunks) return;
-   const float mm = norm_offset(FM + (size_t)chunk * kFrames, fm_stride);
+   const float mm = norm_offset<kFrames>(FM + (size_t)chunk * kFrames, fm_stride);
    for (int i = threadIdx.x; i < kBins * kFrames; i += blockDim.x)
       out[(size_t)chunk * kBins * kFrames + i] = Y[(size_t)chunk * kBins * kFrames + i] - mm;
 }
@@ -365,9 +375,25 @@ void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float
    else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, float *out, int n, hipStream_t st)
+// Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
+void launch_frontend_v4_f32(const float *pcm, const float *basis, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map, hipStream_t st)
 {
-   hipLaunchKernelGGL(k_normalize_tap, dim3(n), dim3(256), 0, st, Y, FM, out, n, fm_stride);
+   const long waves = ((long)n * 27 + kLanesOut - 1) / kLanesOut;
+   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
+   hipLaunchKernelGGL((k_frontend<float, 2, 256, 4, 0, 0, 0, 0, 1, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
+}
+
+void launch_frontend_v4_s16(const int16_t *pcm, const float *basis, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map, hipStream_t st)
+{
+   const long waves = ((long)n * 27 + kLanesOut - 1) / kLanesOut;
+   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
+   hipLaunchKernelGGL((k_frontend<int16_t, 2, 256, 4, 0, 0, 0, 0, 1, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
+}
+
+void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, float *out, int n, hipStream_t st, int frames)
+{
+   if (frames == 24) hipLaunchKernelGGL(k_normalize_tap<24>, dim3(n), dim3(256), 0, st, Y, FM, out, n, fm_stride);
+   else              hipLaunchKernelGGL(k_normalize_tap<kFrames>, dim3(n), dim3(256), 0, st, Y, FM, out, n, fm_stride);
 }
 
 void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, size_t fm_stride, int n, hipStream_t st)

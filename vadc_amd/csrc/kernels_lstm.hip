@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 // for all 7 steps of every (stream tile, chunk) by the otherwise idle CUs in this small GEMM kernel and handed to
 // the recurrent kernel as the INITIAL VALUE of layer 0's accumulators (k-order x then h is unchanged, so the result
 // is bit-identical to doing both halves inside the recurrence).  Layout GX[tile][chunk][t][256 gate rows][16 streams].
-constexpr int kGxTile = 7 * 256 * kLstmTile;      // floats per (tile, chunk)
-
+// TS = LSTM steps per chunk: 7 (Silero v3.1) or 3 (Silero v4)
+template <int TS>
 __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ enc,   // LSTM-native tiles
                                                     LstmWeights w, float *__restrict__ gx,
                                                     int n_chunks, int c0, int cg)
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ en
    const int tile = blockIdx.x / cg, ch = c0 + blockIdx.x % cg;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int quad = lane >> 4, lc = lane & 15;
-   const float *X = enc + ((size_t)tile * n_chunks + ch) * (7 * 64 * kLstmTile);
+   constexpr int kGxTile = TS * 256 * kLstmTile;      // floats per (tile, chunk)
+   const float *X = enc + ((size_t)tile * n_chunks + ch) * (TS * 64 * kLstmTile);
    float *G = gx + ((size_t)tile * n_chunks + ch) * kGxTile;
 #pragma unroll 1
    for (int mi = 0; mi < 4; ++mi) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ en
       for (int kk = 0; kk < 16; ++kk) a[kk] = row[4 * kk];
       const float4 b4 = *reinterpret_cast<const float4 *>(w.b + 16 * mt + 4 * quad);
 #pragma unroll 1
-      for (int t = 0; t < 7; ++t) {
+      for (int t = 0; t < TS; ++t) {
          f4v acc;
          acc[0] = b4.x; acc[1] = b4.y; acc[2] = b4.z; acc[3] = b4.w;
 #pragma unroll
@@ -287,6 +288,9 @@ __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ en
 // SIMD).  In slot k layer 0 computes step k while layer 1 computes step k-1; both read h0_{k-1} from LDS.  A slot
 // costs one barrier instead of two, each wave keeps only ITS layer's weights in registers (128 VGPRs -> two waves
 // per SIMD fit), and on every SIMD the gate activations (VALU) of one layer overlap the MFMAs of the other.
+// TS = steps per chunk (7 / 3); DEC = decoder: 0 Silero v3.1 sigmoid(mean_t(W relu(h_t) + b)), two outputs (silero_v3.c:231-303);
+// 1 Silero v4 mean_t(sigmoid(w . relu(h_t) + b)), one output written to both probability slots (silero_vad.py:200-204,222)
+template <int TS, int DEC>
 __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restrict__ gx,    // GX tiles from k_lstm_xproj
                                                            LstmWeights w,
                                                            float *__restrict__ hs, float *__restrict__ cs,
@@ -295,7 +299,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
 {
    __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
    __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
-   __shared__ float pd[4][2][kTileS];           // decoder partial dots per layer-1 wave
+   __shared__ float pd[2][4][2][kTileS];        // decoder partial dots per layer-1 wave, double buffered over slots (DEC 1)
+   constexpr int kGxTile = TS * 256 * kLstmTile;
    __shared__ __attribute__((aligned(16))) float bl1[256];   // layer-1 fused biases (accumulator init)
 
    const int tid = threadIdx.x;
@@ -343,18 +348,19 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
    }
    __syncthreads();
 
-   const int total = 7 * cg;
+   const int total = TS * cg;
+   float psum = 0.0f;                           // DEC 1: sum over the chunk's steps of sigmoid(decoder dot), lanes 0..15 of wave 4
    for (int k = 0; k <= total; ++k) {
       const bool active = (L == 0) ? (k < total) : (k >= 1);
       const int step = (L == 0) ? k : k - 1;    // the step this wave computes in this slot
-      const int chi = step / 7, t = step - chi * 7;
+      const int chi = step / TS, t = step - chi * TS;
       if (active) {
          f4v acc[4];
          if (L == 0) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
             if (k + 1 < total) {                // prefetch the next step's init values (latency hidden by this slot)
-               const float *p = gx_lane + ((size_t)c0 * 7 + (k + 1)) * (256 * kTileS);
+               const float *p = gx_lane + ((size_t)c0 * TS + (k + 1)) * (256 * kTileS);
 #pragma unroll
                for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -390,26 +396,47 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
             c[r] = fg * c[r] + ig * gg;
             const float hn = og * fast_tanh(c[r]);
             hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
-            if (L == 1) rsum[r] += fmaxf(hn, 0.0f);
+            if (L == 1) rsum[r] = (DEC == 0 ? rsum[r] : 0.0f) + fmaxf(hn, 0.0f);
          }
       }
-      const bool chunk_done = (L == 1) && active && (t == 6);
-      if (chunk_done) {
+      const bool chunk_done = (L == 1) && active && (t == TS - 1);
+      if (DEC == 1 && L == 1 && active) {
+         // per step: partial dot of this wave's 16 units, finished after the barrier by wave 4
+         float d0 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) d0 = fmaf(dw[0][r], rsum[r], d0);
+         d0 += __shfl_xor(d0, 16);
+         d0 += __shfl_xor(d0, 32);
+         if (quad == 0) pd[k & 1][wv][0][col] = d0;
+      }
+      if (DEC == 0 && chunk_done) {
          // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
          float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
          for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
          d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
          d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
-         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
+         if (quad == 0) { pd[0][wv][0][col] = d0; pd[0][wv][1][col] = d1; }
       }
       __syncthreads();                          // one barrier per slot
       if (k < total) par0 ^= 1;                 // layer 0 wrote a new h0 in this slot
       if (k >= 1) par1 ^= 1;                    // layer 1 wrote a new h1 in this slot
-      if (chunk_done && wv == 0 && lane < 2 * kTileS) {
+      if (DEC == 0 && chunk_done && wv == 0 && lane < 2 * kTileS) {
          const int sc = lane & 15, f = lane >> 4;
-         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
+         const float m = ((pd[0][0][f][sc] + pd[0][1][f][sc]) + (pd[0][2][f][sc] + pd[0][3][f][sc])) / (float)TS + w.dec_b[f];
          if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
+      }
+      if (DEC == 1 && L == 1 && active && wv == 0 && lane < kTileS) {
+         const int q = k & 1;
+         psum += sigmoidf_(((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + w.dec_b[0]);
+         if (t == TS - 1) {
+            const float pr = psum / (float)TS;
+            if (s0 + lane < n_streams) {
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 0] = pr;
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 1] = pr;
+            }
+            psum = 0.0f;
+         }
       }
    }
    if (col_ok) {
@@ -426,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
 // Same layer-wavefront schedule with layer 0's input projection done INSIDE the recurrence (x frames staged by
 // LDS-DMA).  Used when there are many stream tiles (the LSTM is throughput- not latency-bound and the extra GX round
 // trip of the hoisted form does not pay).
+template <int TS, int DEC>
 __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
                                                            LstmWeights w,
                                                            float *__restrict__ hs, float *__restrict__ cs,
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
    __shared__ __attribute__((aligned(16))) float xs[2][kXTile];   // [parity][t][unit][stream]
    __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
    __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
-   __shared__ float pd[4][2][kTileS];           // decoder partial dots per layer-1 wave
+   __shared__ float pd[2][4][2][kTileS];        // decoder partial dots per layer-1 wave, double buffered over slots (DEC 1)
    __shared__ __attribute__((aligned(16))) float bl[2][256];
 
    const int tid = threadIdx.x;
@@ -474,11 +502,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
    float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
    __syncthreads();
 
-   const int total = 7 * cg;
+   const int total = TS * cg;
+   float psum = 0.0f;                           // DEC 1: sum over the chunk's steps of sigmoid(decoder dot), lanes 0..15 of wave 4
    for (int k = 0; k <= total; ++k) {
       const bool active = (L == 0) ? (k < total) : (k >= 1);
       const int step = (L == 0) ? k : k - 1;    // the step this wave computes in this slot
-      const int chi = step / 7, t = step - chi * 7;
+      const int chi = step / TS, t = step - chi * TS;
       if (L == 0 && active && t == 0 && (chi + 1) < cg) {
          // prefetch the next chunk's frames straight into the other xs buffer (LDS-DMA); its last readers
          // finished before the previous slot's barrier
@@ -510,26 +539,47 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
             c[r] = fg * c[r] + ig * gg;
             const float hn = og * fast_tanh(c[r]);
             hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
-            if (L == 1) rsum[r] += fmaxf(hn, 0.0f);
+            if (L == 1) rsum[r] = (DEC == 0 ? rsum[r] : 0.0f) + fmaxf(hn, 0.0f);
          }
       }
-      const bool chunk_done = (L == 1) && active && (t == 6);
-      if (chunk_done) {
+      const bool chunk_done = (L == 1) && active && (t == TS - 1);
+      if (DEC == 1 && L == 1 && active) {
+         // per step: partial dot of this wave's 16 units, finished after the barrier by wave 4
+         float d0 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) d0 = fmaf(dw[0][r], rsum[r], d0);
+         d0 += __shfl_xor(d0, 16);
+         d0 += __shfl_xor(d0, 32);
+         if (quad == 0) pd[k & 1][wv][0][col] = d0;
+      }
+      if (DEC == 0 && chunk_done) {
          // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
          float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
          for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
          d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
          d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
-         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
+         if (quad == 0) { pd[0][wv][0][col] = d0; pd[0][wv][1][col] = d1; }
       }
       __syncthreads();                          // one barrier per slot
       if (k < total) par0 ^= 1;                 // layer 0 wrote a new h0 in this slot
       if (k >= 1) par1 ^= 1;                    // layer 1 wrote a new h1 in this slot
-      if (chunk_done && wv == 0 && lane < 2 * kTileS) {
+      if (DEC == 0 && chunk_done && wv == 0 && lane < 2 * kTileS) {
          const int sc = lane & 15, f = lane >> 4;
-         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
+         const float m = ((pd[0][0][f][sc] + pd[0][1][f][sc]) + (pd[0][2][f][sc] + pd[0][3][f][sc])) / (float)TS + w.dec_b[f];
          if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
+      }
+      if (DEC == 1 && L == 1 && active && wv == 0 && lane < kTileS) {
+         const int q = k & 1;
+         psum += sigmoidf_(((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + w.dec_b[0]);
+         if (t == TS - 1) {
+            const float pr = psum / (float)TS;
+            if (s0 + lane < n_streams) {
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 0] = pr;
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 1] = pr;
+            }
+            psum = 0.0f;
+         }
       }
    }
    if (col_ok) {
@@ -545,25 +595,29 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
 // gx: scratch for the hoisted input projection, [ceil(S/16)][n_chunks][7][256][16] floats (variant 0 only)
+// model: 0 = Silero v3.1 (7 steps per chunk, all variants), 1 = Silero v4 (3 steps, hoisted wavefront only)
 void launch_lstm(int variant, const float *enc, float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
-                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
-   if (variant == 1)
+   if (model == 1)
+      hipLaunchKernelGGL((k_lstm_wavefront<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 1)
       hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 3)
-      hipLaunchKernelGGL(k_lstm_wavefront_fused, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      hipLaunchKernelGGL((k_lstm_wavefront_fused<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 0)   // consumes GX written by launch_lstm_xproj for the same chunk range
-      hipLaunchKernelGGL(k_lstm_wavefront, dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      hipLaunchKernelGGL((k_lstm_wavefront<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else
       hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
 }
 
 // layer-0 input projection for chunks [c0, c0 + cg): a wide GEMM, launched with the encoder (all CUs), not with the
 // recurrent kernel
-void launch_lstm_xproj(const float *enc, float *gx, const LstmWeights &w, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+void launch_lstm_xproj(const float *enc, float *gx, const LstmWeights &w, int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
    const int tiles = (n_streams + kTileS - 1) / kTileS;
-   hipLaunchKernelGGL(k_lstm_xproj, dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
+   if (model == 1) hipLaunchKernelGGL((k_lstm_xproj<3>), dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
+   else            hipLaunchKernelGGL((k_lstm_xproj<7>), dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
 }
 
 }  // namespace vadc

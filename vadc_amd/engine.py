@@ -21,7 +21,9 @@ from . import _lib
 
 CHUNK = 1536
 STAGES = {"magnitude": 0, "normalized": 1, "layer1": 2, "layer2": 3, "layer3": 4, "layer4": 5}
-STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}
+STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}          # Silero v3.1
+STAGE_SHAPES_V4 = {0: (129, 24), 1: (129, 24), 2: (16, 12), 3: (32, 6), 4: (32, 3), 5: (64, 3)}       # Silero v4
+MODEL_V31, MODEL_V4 = 0, 1
 KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_xproj"]
 
 
@@ -47,6 +49,8 @@ class Engine:
             raise VadcAmdError(rc, self._L.vadc_amd_last_error().decode())
         self.max_streams = max_streams
         self.max_chunks_per_call = max_chunks_per_call
+        self.model = self.caps()["model_kind"]          # decided by the weights container (99 tensors v3.1 / 36 v4)
+        self.stage_shapes = STAGE_SHAPES_V4 if self.model == MODEL_V4 else STAGE_SHAPES
 
     @classmethod
     def from_file(cls, path: str, **kw) -> "Engine":
@@ -129,19 +133,19 @@ class Engine:
     def stage_from_samples(self, samples_f32: np.ndarray, stage: str) -> np.ndarray:
         x = np.ascontiguousarray(samples_f32, dtype=np.float32).reshape(-1, CHUNK)
         s = STAGES[stage]
-        out = np.empty((x.shape[0],) + STAGE_SHAPES[s], np.float32)
+        out = np.empty((x.shape[0],) + self.stage_shapes[s], np.float32)
         self._check(self._L.vadc_amd_debug_stage_from_samples(self._h, _ptr(x), x.shape[0], s, _ptr(out)))
         return out
 
     def stage_from_stage(self, x: np.ndarray, from_stage: str, to_stage: str) -> np.ndarray:
         f, t = STAGES[from_stage], STAGES[to_stage]
-        x = np.ascontiguousarray(x, dtype=np.float32).reshape((-1,) + STAGE_SHAPES[f])
-        out = np.empty((x.shape[0],) + STAGE_SHAPES[t], np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape((-1,) + self.stage_shapes[f])
+        out = np.empty((x.shape[0],) + self.stage_shapes[t], np.float32)
         self._check(self._L.vadc_amd_debug_stage_from_stage(self._h, _ptr(x), x.shape[0], f, t, _ptr(out)))
         return out
 
     def lstm_decoder(self, enc: np.ndarray) -> np.ndarray:
-        """enc: [S, C, 64, 7] -> probs [S, C, 2] (uses and updates the engine's per-stream state)."""
+        """enc: [S, C, 64, steps] (steps = 7 for v3.1, 3 for v4) -> probs [S, C, 2] (uses and updates the per-stream state)."""
         enc = np.ascontiguousarray(enc, dtype=np.float32)
         S, Cn = enc.shape[0], enc.shape[1]
         out = np.empty((S, Cn, 2), np.float32)

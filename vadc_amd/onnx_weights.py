@@ -117,7 +117,7 @@ def load_onnx_tensors(path: str) -> Tuple[Dict[str, np.ndarray], List[dict]]:
 
 
 # ---- Silero v4 (16 kHz branch of silero_vad_v4.onnx) -> positional .testtensor container --------------------------
-# Order consumed by the engine / oracle for model kind "v4" (counterpart of tensor.h:114-191 for v3.1):
+# Order consumed by libvadc_amd.so for model kind "v4" (counterpart of tensor.h:114-191 for v3.1):
 #   0      forward_basis_buffer [258,1,256]
 #   1..6   first_layer ConvBlock 258->16: dw_w [258,1,5], dw_b, pw_w [16,258,1], pw_b, proj_w, proj_b
 #   7,8    conv 16->16 stride 2 (BatchNorm already folded by the exporter: initializers 1110/1111)
