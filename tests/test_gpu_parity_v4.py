@@ -81,17 +81,41 @@ def test_stage_taps(eng, gold, ci):
         ref = gold[f"tap{ci}_{key}"]
         scale = max(1.0, float(np.abs(ref).max()))
         assert got.shape == ref.shape
-        assert float(np.abs(got - ref).max()) < TAP_TOL * scale, stage
+        # log1p(2^20 m) amplifies the fp32 rounding noise of near-silent bins (|dm| ~ 1e-7 -> 0.1 in the log domain when
+        # m ~ 1e-6); the stages downstream are insensitive to it (their taps and the probabilities hold the tight bar)
+        tol = 2e-2 if stage == "normalized" else TAP_TOL * scale
+        err = float(np.abs(got - ref).max())
+        assert err < tol, (stage, err)
 
 
-def test_stft_magnitude_is_the_exact_tree(eng, orc, gold):
-    """the v4 front end reuses the bit-exact STFT tree kernel with the v4 geometry (pad 96, 24 frames)"""
-    x = f32(gold["pcm_speech1"])[:3 * 1536]
-    got = eng.stage_from_samples(x, "magnitude")
-    for i in range(3):
+def test_frontend_variants(eng, orc, gold):
+    """option frontend=1: the STFT tree kernel with the v4 geometry (pad 96, 24 frames) is bit-identical to the oracle's tree;
+    frontend=0 (default): the folded GEMM on the matrix cores agrees with it to fp32 rounding of a 256-tap sum"""
+    x = f32(gold["pcm_speech1"])[:7 * 1536]          # 7 chunks: ragged vs the 4-chunk workgroup iteration
+    eng.set_option("frontend", 1)
+    tree = eng.stage_from_samples(x, "magnitude")
+    tree_n = eng.stage_from_samples(x, "normalized")
+    eng.set_option("frontend", 0)
+    gemm = eng.stage_from_samples(x, "magnitude")
+    gemm_n = eng.stage_from_samples(x, "normalized")
+    for i in range(7):
         h, c = orc.new_state()
         _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
-        assert np.array_equal(got[i].view(np.uint32), taps["magnitude"].view(np.uint32))
+        assert np.array_equal(tree[i].view(np.uint32), taps["magnitude"].view(np.uint32))
+    assert float(np.abs(gemm - tree).max()) < 2e-5 * max(1.0, float(np.abs(tree).max()))
+    assert float(np.abs(gemm_n - tree_n).max()) < 5e-3     # log1p(2^20 m) amplifies rounding noise in near-silent bins
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_probabilities_both_frontends(eng, gold, variant):
+    eng.set_option("frontend", variant)
+    try:
+        for name in ("speech0", "noise"):
+            eng.reset_streams()
+            p = eng.run(gold[f"pcm_{name}"].reshape(1, -1))[0]
+            assert float(np.abs(p[:, 1] - gold[f"probs64_{name}"]).max()) < PROB_TOL
+    finally:
+        eng.set_option("frontend", 0)
 
 
 def test_state_is_carried_and_split_invariant(eng, gold):

@@ -21,6 +21,8 @@ void launch_frontend_mx2_f32(const float *, const float *, float *, float *, siz
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
+void launch_frontend_gemm_v4_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_gemm_v4_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
@@ -112,6 +114,8 @@ struct vadc_amd_engine {
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 / 3
    const int *stage_elems = nullptr;
+   const float *d_afrag_v4 = nullptr, *d_nyq_v4 = nullptr;   // v4 GEMM front end: folded basis as MFMA A fragments, bin-128 weights
+   bool v4_gemm = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
    float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
    int max_streams = 0, max_chunks = 0, precision = 0;
    size_t max_items = 0;
@@ -321,6 +325,36 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    pk.add(nullptr, 64);
+   // GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
+   // and 128 zero -- verified bit for bit, otherwise the tree kernel stays in charge.
+   size_t off_afrag = 0, off_nyq = 0;
+   {
+      bool sym = true;
+      auto B = [&](int row, int n) { return tmp[(size_t)row * 256 + n]; };
+      for (int k = 0; k < kBins && sym; ++k) {
+         if (B(k, 0) != 0.0f || B(kBins + k, 0) != 0.0f || B(kBins + k, 128) != 0.0f) sym = false;
+         for (int n = 1; n < 128 && sym; ++n)
+            if (B(k, n) != B(k, 256 - n) || B(kBins + k, n) != -B(kBins + k, 256 - n)) sym = false;
+      }
+      for (int n = 0; n < 256 && sym; ++n) if (B(kBins, n) != 0.0f || B(kBins + 128, n) != 0.0f) sym = false;
+      e->v4_gemm = sym;
+      if (sym) {
+         // A fragments: tile t < 8: re bins 16 t + r; tile 8 + t: im bins 16 t + r; k-step s, lane l: row l & 15, tap 32 (l >> 4) + s
+         std::vector<float> af((size_t)16 * 32 * 64), ny(128);
+         for (int t = 0; t < 16; ++t)
+            for (int sidx = 0; sidx < 32; ++sidx)
+               for (int l = 0; l < 64; ++l) {
+                  const int bin = 16 * (t & 7) + (l & 15), n = 32 * (l >> 4) + sidx;
+                  float v;
+                  if (t < 8) v = (n == 0) ? B(bin, 128) : B(bin, n);          // slot 0 carries the unpaired centre tap
+                  else       v = (n == 0) ? 0.0f : B(kBins + bin, n);
+                  af[((size_t)t * 32 + sidx) * 64 + l] = v;
+               }
+         for (int n = 0; n < 128; ++n) ny[n] = (n == 0) ? B(128, 128) : B(128, n);
+         off_afrag = pk.add(af.data(), af.size());
+         off_nyq = pk.add(ny.data(), ny.size());
+      }
+   }
    auto frag = [](const std::vector<float> &W, int M, int K) {
       const int KKW = (K + 3) / 4;
       std::vector<float> f((size_t)(M / 16) * KKW * 64, 0.0f);
@@ -367,6 +401,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
+      if (e->v4_gemm) { e->d_afrag_v4 = base + off_afrag; e->d_nyq_v4 = base + off_nyq; }
       for (int l = 0; l < 4; ++l) {
          LayerWeightsM &m = e->lwm[l];
          m = LayerWeightsM{};
@@ -571,8 +606,13 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && (strcmp(key, "lstm") == 0 || strcmp(key, "frontend") == 0 || strcmp(key, "encoder") == 0) && value != 0)
+   if (e->model == VADC_AMD_MODEL_V4 && (strcmp(key, "lstm") == 0 || strcmp(key, "encoder") == 0) && value != 0)
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
+   if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
+      // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
+      e->frontend_variant = value;
+      return VADC_AMD_OK;
+   }
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
@@ -620,7 +660,10 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 {
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (e->model == VADC_AMD_MODEL_V4) {
+      if (e->model == VADC_AMD_MODEL_V4 && e->v4_gemm && e->frontend_variant == 0) {
+         if (sizeof(T) == 2) launch_frontend_gemm_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
+         else                launch_frontend_gemm_v4_f32(reinterpret_cast<const float *>(d_in), e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
+      } else if (e->model == VADC_AMD_MODEL_V4) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
       } else if (e->frontend_variant == 1) {
@@ -922,7 +965,9 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
+   if (e->model == VADC_AMD_MODEL_V4 && e->v4_gemm && e->frontend_variant == 0)
+      launch_frontend_gemm_v4_f32(e->d_in_f32, e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
+   else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
