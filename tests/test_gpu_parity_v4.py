@@ -153,3 +153,21 @@ def test_device_pointer_and_graph_paths(eng, gold):
         st.synchronize()
         assert float(np.abs(d_out.cpu().numpy() - ref).max()) < 1e-6
     eng.set_option("graph", 0)
+
+
+def test_cli_with_v4_weights(gold):
+    """the POSIX CLI (host/vadc_hip.c) takes the model kind from the weights container: `--model silero_v4_16k.testtensor`"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "host", "vadc_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
+    pcm = gold["pcm_speech0"]
+    r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities"], input=pcm.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
+    assert got.size == gold["probs64_speech0"].size
+    assert float(np.abs(got - gold["probs64_speech0"]).max()) <= PROB_TOL + 5e-7        # %f quantises to 5e-7
+    r = subprocess.run([exe, "--model", V4_WEIGHTS], input=pcm.tobytes(), capture_output=True, timeout=300)
+    sec, _ = O.segments(gold["probs64_speech0"].astype(np.float32))
+    assert r.stdout.decode().splitlines() == ["%.2f,%.2f" % (a, b) for a, b in sec]
