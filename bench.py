@@ -206,6 +206,11 @@ def main():
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_s * 1e3, 4), "chunks_per_launch": int(chunks_per_launch),
                          "algorithmic_flop_per_chunk": FLOP_PER_CHUNK[dom],
+                         # blended figure over the whole path: all kernels' algorithmic FLOP per chunk
+                         # x chunks/s of the job on one GPU, against the same fp32 peak
+                         "path_flop_per_chunk": sum(FLOP_PER_CHUNK.values()),
+                         "path_achieved": round(sum(FLOP_PER_CHUNK.values()) * S * Cn * args.steps / elapsed / 1e12, 3),
+                         "path_frac": round(sum(FLOP_PER_CHUNK.values()) * S * Cn * args.steps / elapsed / 1e12 / PEAK_FP32_TFLOPS, 4),
                          "note": "dominant kernel by CU-time; fp32 peak (vector == matrix); the bit-exact STFT is unfused "
                                  "mul+add (2 VALU instructions per MAC) => its ceiling is frac 0.5"},
             "kernels": per_kernel,

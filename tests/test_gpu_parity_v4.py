@@ -72,6 +72,21 @@ def test_probabilities_match_oracle_many_streams(eng, orc):
     assert float(np.abs(got - ref).max()) < PROB_TOL
 
 
+def test_chunk_group_pipeline_matches_single_launch(eng, orc):
+    """64 streams x 64 chunks = 4096 chunks per call: the engine forks onto its two internal streams and pipelines four
+    chunk groups (front end/encoder of group g+1 under the LSTM of group g); results must not depend on the grouping"""
+    pcm = synth.make_streams(64, 64, seed0=777)
+    out = {}
+    for groups in (1, 4, 0):
+        eng.set_option("groups", groups)
+        eng.reset_streams()
+        out[groups] = eng.run(pcm)[:, :, 1]
+    eng.set_option("groups", 0)
+    assert np.array_equal(out[1], out[4]) and np.array_equal(out[1], out[0])
+    ref = orc.forward_streams(pcm[:6])
+    assert float(np.abs(out[1][:6] - ref).max()) < PROB_TOL
+
+
 @pytest.mark.parametrize("ci", [0, 20])
 def test_stage_taps(eng, gold, ci):
     x = f32(gold["pcm_speech0"])[ci * 1536:(ci + 1) * 1536]

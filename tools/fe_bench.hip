@@ -71,6 +71,12 @@ int main(int argc, char **argv)
    run<1, 256, 3, 0, 0, 0, 0, 1>("PK w3 (v_pk_mul products)", pcm, basis, Y1, FM, n, reps);
    run<1, 256, 4, 0, 0, 0, 0, 1>("PK w4", pcm, basis, Y1, FM, n, reps);
    run<1, 256, 2, 0, 0, 0, 0, 1>("PK w2", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 0, 0, 0, 0, 2>("PK2 w4 (adds packed too)", pcm, basis, Y1, FM, n, reps);     check("PK2 w4", Y1);
+   run<1, 256, 3, 0, 0, 0, 0, 2>("PK2 w3", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 5, 0, 0, 0, 0, 2>("PK2 w5", pcm, basis, Y1, FM, n, reps);
+   run<1, 256, 4, 1, 0, 0, 0, 2>("PK2 w4 dpp", pcm, basis, Y1, FM, n, reps);                   check("PK2 w4 dpp", Y1);
+   run<0, 256, 4, 0, 0, 0, 0, 2>("PK2 w4 (log mode)", pcm, basis, Y1, FM, n, reps);
+   run<0, 256, 4, 1, 0, 0, 0, 2>("PK2 w4 dpp (log mode)", pcm, basis, Y1, FM, n, reps);
    run<1, 256, 3, 1, 0, 0, 0, 1>("PK w3 dpp", pcm, basis, Y1, FM, n, reps);
    run<0, 256, 3, 0, 0, 0, 0, 1>("PK w3 (log mode)", pcm, basis, Y1, FM, n, reps);
    run<0, 256, 4, 0, 0, 0, 0, 1>("PK w4 (log mode)", pcm, basis, Y1, FM, n, reps);

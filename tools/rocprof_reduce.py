@@ -47,6 +47,7 @@ def pmc_avg(d, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel-trace"); ap.add_argument("--fetch"); ap.add_argument("--write")
+    ap.add_argument("--pmc", action="append", default=[], help="directory of an extra --pmc pass; all its counters are averaged per kernel")
     ap.add_argument("--out", required=True); ap.add_argument("--tag", required=True)
     ap.add_argument("--streams", type=int, default=256); ap.add_argument("--chunks-per-step", type=int, default=64)
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
@@ -71,6 +72,33 @@ def main():
         json.dump(out, open(p, "w"), indent=1)
         shutil.copy(p, os.path.join(os.path.dirname(os.path.abspath(a.out)), "latest_pmc_traffic.json"))
         print("wrote", p)
+    if a.pmc:
+        merged = defaultdict(dict)
+        for d in a.pmc:
+            for k, cs in pmc_all(d).items():
+                merged[k].update(cs)
+        out = {"source": f"rocprofv3 --pmc <counters> (one pass per directory, no tracing) -- {a.command}",
+               "note": "per-kernel averages per launch, summed over all XCDs/SEs as rocprofv3 reports them",
+               "streams": a.streams, "chunks_per_step": a.chunks_per_step,
+               "kernels": {k: {c: round(v, 1) for c, v in sorted(cs.items())} for k, cs in sorted(merged.items())}}
+        for k, cs in out["kernels"].items():
+            if cs.get("SQ_BUSY_CYCLES") and cs.get("SQ_ACTIVE_INST_VALU") is not None and cs.get("SQ_WAVE_CYCLES"):
+                cs["derived_valu_active_per_wave_cycle"] = round(cs["SQ_ACTIVE_INST_VALU"] / cs["SQ_WAVE_CYCLES"], 4)
+            if cs.get("SQ_INSTS_VALU") and cs.get("SQ_INSTS_VALU_MFMA_F32") is not None:
+                cs["derived_mfma_share_of_valu_insts"] = round(cs["SQ_INSTS_VALU_MFMA_F32"] / cs["SQ_INSTS_VALU"], 4)
+        p = os.path.join(a.out, a.tag + "_pmc_compute.json")
+        json.dump(out, open(p, "w"), indent=1)
+        print("wrote", p)
+
+
+def pmc_all(d):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    with open(find(d, "*_counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            k = short_name(row["Kernel_Name"])
+            if k:
+                a = acc[k][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    return {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
 
 
 if __name__ == "__main__":

@@ -101,6 +101,20 @@ typedef float f2v __attribute__((ext_vector_type(2)));
    }
 #define VADC_STAGE_PK(G, LB, CA, CB_)                                                            \
    VADC_TREE8_PK(G[(LB) + 0], G[(LB) + 1], (LB) / 2, CA) VADC_TREE8_PK(G[(LB) + 2], G[(LB) + 3], (LB) / 2 + 1, CB_)
+// The same two trees with the seven adds per level kept PACKED as well (v_pk_add_f32 on the (l, l+1) pair): component-wise
+// identical arithmetic, half the add instructions.  G2[i] = (G[2i], G[2i+1]).
+#define VADC_TREE8_PK2(dst2, LP, KV)                                                             \
+   {                                                                                             \
+      const f2v q0 = x2[0 * 4 + (LP)] * (f2v){KV[0], KV[1]},   q1 = x2[1 * 4 + (LP)] * (f2v){KV[2], KV[3]};   \
+      const f2v q2 = x2[2 * 4 + (LP)] * (f2v){KV[4], KV[5]},   q3 = x2[3 * 4 + (LP)] * (f2v){KV[6], KV[7]};   \
+      const f2v q4 = x2[4 * 4 + (LP)] * (f2v){KV[8], KV[9]},   q5 = x2[5 * 4 + (LP)] * (f2v){KV[10], KV[11]}; \
+      const f2v q6 = x2[6 * 4 + (LP)] * (f2v){KV[12], KV[13]}, q7 = x2[7 * 4 + (LP)] * (f2v){KV[14], KV[15]}; \
+      const f2v a01 = q0 + q1, a23 = q2 + q3, a45 = q4 + q5, a67 = q6 + q7;                      \
+      const f2v a0123 = a01 + a23, a4567 = a45 + a67;                                            \
+      dst2 = a0123 + a4567;                                                                      \
+   }
+#define VADC_STAGE_PK2(G2, LB, CA, CB_)                                                          \
+   VADC_TREE8_PK2(G2[(LB) / 2], (LB) / 2, CA) VADC_TREE8_PK2(G2[(LB) / 2 + 1], (LB) / 2 + 1, CB_)
 
 // one pipeline stage = 32 taps = lanes-of-the-tree l in [LB, LB+4) of one 64-tap group
 #define VADC_STAGE(G, LB, CA, CB_)                                                      \
@@ -130,9 +144,31 @@ __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *
                                              f16v &pa, f16v &pb, float vk = 1.0f)
 {
    f16v qa, qb;
-   float ga[8], gb[8], t23[8], v[8];
    const f2v *x2 = reinterpret_cast<const f2v *>(&x[0]);   // x[8 j + l], x[8 j + l + 1]  ->  x2[4 j + l / 2]
    (void)x2;
+   if constexpr (PK == 2) {
+      // everything on (l, l+1) pairs: products v_pk_mul_f32, tree adds and the cross-lane combination v_pk_add_f32
+      f2v ga[4], gb[4], t23[4], v[4];
+      VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_STAGE_PK2(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_3, l 0..3
+      VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_STAGE_PK2(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);   // G_3, l 4..7
+      VADC_SLOAD32(qa, qb, kf, BASEOFF + 3 * 128);  VADC_STAGE_PK2(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_2
+      VADC_SLOAD32(pa, pb, kf, BASEOFF + 4 * 128);  VADC_STAGE_PK2(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t23[i] = gb[i] + (f2v){lane_up1<SHIFT>(ga[i].x), lane_up1<SHIFT>(ga[i].y)};   // g_2 + g_3   (stft.c:166)
+      VADC_SLOAD32(qa, qb, kf, BASEOFF + 5 * 128);  VADC_STAGE_PK2(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_1
+      VADC_SLOAD32(pa, pb, kf, BASEOFF + 6 * 128);  VADC_STAGE_PK2(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);
+      VADC_SLOAD32(qa, qb, kf, BASEOFF + 7 * 128);  VADC_STAGE_PK2(gb, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_0
+      VADC_SLOAD32(pa, pb, next_base, NEXTOFF);     VADC_STAGE_PK2(gb, 4, qa, qb)  VADC_SWAIT(pa, pb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+         const f2v t01 = gb[i] + (f2v){lane_up1<SHIFT>(ga[i].x), lane_up1<SHIFT>(ga[i].y)};               // g_0 + g_1   (stft.c:165)
+         v[i] = t01 + (f2v){lane_up2<SHIFT>(t23[i].x), lane_up2<SHIFT>(t23[i].y)};                        // stft.c:167
+      }
+      const float s01 = v[0].x + v[0].y, s23 = v[1].x + v[1].y, s45 = v[2].x + v[2].y, s67 = v[3].x + v[3].y;   // stft.c:176-184
+      const float s0123 = s01 + s23, s4567 = s45 + s67;
+      return s0123 + s4567;
+   } else {
+   float ga[8], gb[8], t23[8], v[8];
 #define VADC_STG(G, LB, CA, CB_) if (PK) { VADC_STAGE_PK(G, LB, CA, CB_) } else { VADC_STAGE(G, LB, CA, CB_) }
    VADC_SLOAD32(qa, qb, kf, BASEOFF + 1 * 128);  VADC_STG(ga, 0, pa, pb)  VADC_SWAIT(qa, qb);   // G_3, l 0..3
    VADC_SLOAD32(pa, pb, kf, BASEOFF + 2 * 128);  VADC_STG(ga, 4, qa, qb)  VADC_SWAIT(pa, pb);   // G_3, l 4..7
@@ -153,6 +189,7 @@ __device__ __forceinline__ float stft_filter(const float (&x)[64], const float *
    const float s0123 = s01 + s23, s4567 = s45 + s67;
 #undef VADC_STG
    return s0123 + s4567;
+   }
 }
 
 // ---- PIPE = 1: mul/add interleaved software pipeline -------------------------------------------------
