@@ -148,6 +148,9 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                                      group g overlaps the front end + encoder of group g+1.
  *                             "graph"   1: capture the call's launch sequence into a hipGraph on first use and
  *                                      replay it afterwards (steady-state serving); 0 (default): eager launches
+ *                             "fe_overlap" 1: the front end runs on its own internal stream, concurrently with the encoder
+ *                                      layers of the previous call (buffers double buffered); 0: one stream.  Default: 1 for
+ *                                      the v4 model, 0 for v3.1 (measured: it helps the GEMM front end, hurts the tree one)
  *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline
  *                                      streams disjoint CU masks; 0: never mask. */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);

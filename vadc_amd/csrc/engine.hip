@@ -138,23 +138,31 @@ struct vadc_amd_engine {
    // Encoder -> LSTM hand-off buffers are double buffered over forked calls: d_act[3] / d_gx alias pair [xpar], so that
    // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
    float *d_xpair[2] = {nullptr, nullptr}, *d_gxpair[2] = {nullptr, nullptr};
+   // ... and so are the front end -> encoder buffers (d_Y / d_FM / d_MAG alias pair [xpar]): with option "fe_overlap" the front
+   // end of call k+1 runs on its own internal stream concurrently with the encoder layers of call k on the same CUs.
+   float *d_ypair[2] = {nullptr, nullptr}, *d_fmpair[2] = {nullptr, nullptr}, *d_magpair[2] = {nullptr, nullptr};
    int xpar = 0;
+   int fe_overlap = 0;                          // option "fe_overlap": 1 = front end on its own internal stream.  Measured
+                                                // (256 x 64): v3.1 2.46 -> 2.82 ms (the tree front end starves the layer kernels
+                                                // of wave slots), v4 1.43 -> 1.37 ms; default: on for v4 only.
    bool capturing = false;                      // inside hipStreamBeginCapture: no waits on events from outside the capture
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
    // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
    static constexpr int kMaxGroups = 16;
    int groups = 0;                              // 0 = auto
-   hipStream_t sA = nullptr, sB = nullptr;
+   hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
    int n_cus = 0;
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
+   bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
    struct GraphEntry { const void *in; float *out; int S, C, elem, groups; hipStream_t st; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
-   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr};
+   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_e[2] = {nullptr, nullptr}, ev_graph = nullptr,
+              ev_fe[kMaxGroups] = {nullptr}, ev_f[kMaxGroups] = {nullptr};
    bool ev_graph_valid = false;
    // profiling
    bool profiling = false;
@@ -429,15 +437,18 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
+   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_ypair[0], e->d_ypair[1], e->d_magpair[0], e->d_magpair[1],
+                   e->d_fmpair[0], e->d_fmpair[1], e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1]};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_graph}) if (ev) (void)hipEventDestroy(ev);
+   if (e->sF) (void)hipStreamDestroy(e->sF);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_e[0], e->ev_e[1], e->ev_graph}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : e->ev_f) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
 
@@ -475,19 +486,24 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
    e->stage_elems = e->model == VADC_AMD_MODEL_V4 ? kStageElemsV4 : kStageElemsV31;
+   e->fe_overlap = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_graph}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_e[0], &e->ev_e[1], &e->ev_graph}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
+   for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_f[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
-   if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
+   for (int p = 0; p < 2; ++p) {
+      if (he == hipSuccess) he = hipMalloc(&e->d_ypair[p], N * kBins * kFrames * sizeof(float));
+      if (he == hipSuccess) he = hipMalloc(&e->d_fmpair[p], kBinSplit * N * kFrames * sizeof(float));
+      if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_magpair[p], N * kBins * kFrames * sizeof(float));
+   }
+   e->d_Y = e->d_ypair[0]; e->d_FM = e->d_fmpair[0]; e->d_MAG = e->d_magpair[0];
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
-   if (he == hipSuccess) he = hipMalloc(&e->d_FM, kBinSplit * N * kFrames * sizeof(float));
-   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_MAG, N * kBins * kFrames * sizeof(float));
    for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElemsV31[2 + l] * sizeof(float));   // >= the v4 shapes
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
@@ -623,6 +639,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
 }
@@ -654,10 +671,16 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
 
 // hold_last: event the stream must wait for before the LAST layer + input projection overwrite this call's encoder-output /
 // GX pair (the LSTM of an earlier call that used the same pair may still be reading it on the other stream); nullptr = no wait
+// sf / ev_f: stream of the front end and the event that hands Y / FM over to the encoder stream `st` (sf == st: one stream);
+// hold_first: event the front end must wait for before it overwrites this call's Y / FM pair (an earlier call's encoder).
 template <typename T>
 static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, int lstm_kernel, hipStream_t st,
-                                  hipEvent_t hold_last = nullptr)
+                                  hipEvent_t hold_last = nullptr, hipStream_t sf = nullptr, hipEvent_t ev_f = nullptr,
+                                  hipEvent_t hold_first = nullptr)
 {
+   hipStream_t st_enc = st;
+   if (sf && sf != st) { st = sf; }
+   if (hold_first) (void)hipStreamWaitEvent(st, hold_first, 0);
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
       if (e->model == VADC_AMD_MODEL_V4 && e->v4_gemm && e->frontend_variant == 0) {
@@ -673,6 +696,11 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       }
+   }
+   if (st != st_enc) {
+      (void)hipEventRecord(ev_f, st);
+      (void)hipStreamWaitEvent(st_enc, ev_f, 0);
+      st = st_enc;
    }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
    if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
@@ -693,7 +721,8 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
    const int lstm_wgs = (n_streams + 15) / 16;
    int want = 0;
    if (e->cu_partition && lstm_wgs <= e->n_cus / 4) want = ((lstm_wgs + 7) / 8) * 8;   // multiples of 8: one per XCD
-   if (e->lstm_cus == want && e->sA && e->sB) return VADC_AMD_OK;
+   if (e->lstm_cus == want && e->sA && e->sB && e->sF) return VADC_AMD_OK;
+   if (e->sF) { HIP_TRY(hipStreamSynchronize(e->sF), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
    if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
    if (e->sB) { HIP_TRY(hipStreamSynchronize(e->sB), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
    bool masked = false;
@@ -703,22 +732,26 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       for (int cu = 0; cu < e->n_cus; ++cu) (cu < want ? mb : ma)[cu / 32] |= 1u << (cu % 32);
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
       hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
-      masked = (ea == hipSuccess && eb == hipSuccess);
+      hipError_t ef = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sF, (uint32_t)words, ma.data()) : eb;
+      masked = (ea == hipSuccess && eb == hipSuccess && ef == hipSuccess);
       if (!masked) {
          (void)hipGetLastError();
          if (e->sA) { (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
          if (e->sB) { (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
+         if (e->sF) { (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
       }
    }
    if (!masked) {
       want = 0;
       HIP_TRY(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamCreateWithFlags(&e->sF, hipStreamNonBlocking), VADC_AMD_EHIP);
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = highest priority
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
    }
    e->lstm_cus = want;
-   e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old stream B was drained above
+   e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
+   e->ev_e_valid[0] = e->ev_e_valid[1] = false;
    return VADC_AMD_OK;
 }
 
@@ -763,12 +796,16 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+      const bool split_fe = e->fe_overlap != 0;
+      if (split_fe) (void)hipStreamWaitEvent(e->sF, e->ev_in, 0);
       // this call's hand-off pair; its last reader was the LSTM of the forked call before the previous one
       e->xpar ^= 1;
       const int xp = e->xpar;
       e->d_act[3] = e->d_xpair[xp];
       e->d_gx = e->d_gxpair[xp];
+      e->d_Y = e->d_ypair[xp]; e->d_FM = e->d_fmpair[xp]; e->d_MAG = e->d_magpair[xp];
       hipEvent_t hold = (e->ev_b_valid[xp] && !e->capturing) ? e->ev_b[xp] : nullptr;
+      hipEvent_t hold_first = (split_fe && e->ev_e_valid[xp] && !e->capturing) ? e->ev_e[xp] : nullptr;
       // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
       int sizes[vadc_amd_engine::kMaxGroups];
       {
@@ -784,8 +821,9 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
          const int cg = sizes[gi];
          if (cg <= 0) continue;
          const ItemMap map{n_chunks, c0, cg};
-         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA, hold);
+         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA, hold, split_fe ? e->sF : nullptr, e->ev_f[gi], hold_first);
          hold = nullptr;
+         hold_first = nullptr;
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
@@ -794,6 +832,8 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
+      (void)hipEventRecord(e->ev_e[xp], e->sA);
+      e->ev_e_valid[xp] = !e->capturing;
       (void)hipEventRecord(e->ev_b[xp], e->sB);
       e->ev_b_valid[xp] = !e->capturing;
       (void)hipStreamWaitEvent(st, e->ev_a, 0);
