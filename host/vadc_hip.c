@@ -120,18 +120,50 @@ static int parse_options(int argc, char **argv, Options *o)
    return 0;
 }
 
+/* Build-time weights embedding: the counterpart of the reference's cembed.c, which turns the weights file into a C array
+ * so that vadc.exe carries its model (vadc.c:1110 default_model = embedded silero_v31_16k_weights).  Here the file is
+ * pulled in with the assembler's .incbin (`make vadc_hip_embedded WEIGHTS=path`); --model still overrides it. */
+#ifdef VADC_EMBED_WEIGHTS
+__asm__(".section .rodata\n"
+        ".balign 16\n"
+        ".global vadc_embedded_weights_begin\n"
+        "vadc_embedded_weights_begin:\n"
+        ".incbin \"" VADC_EMBED_WEIGHTS "\"\n"
+        ".global vadc_embedded_weights_end\n"
+        "vadc_embedded_weights_end:\n"
+        ".previous\n");
+extern const unsigned char vadc_embedded_weights_begin[], vadc_embedded_weights_end[];
+#endif
+
 int main(int argc, char **argv)
 {
-   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, "silero_v31_16k.testtensor"};  /* vadc.c:1110-1124 */
+#ifdef VADC_EMBED_WEIGHTS
+   const char *default_model = NULL;
+#else
+   const char *default_model = "silero_v31_16k.testtensor";
+#endif
+   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model};  /* vadc.c:1110-1124 */
    if (parse_options(argc, argv, &o)) return 2;
    if (o.batch > WINDOW_CHUNKS) o.batch = WINDOW_CHUNKS;
 
-   FILE *wf = fopen(o.model, "rb");
-   if (!wf) { fprintf(stderr, "cannot open weights %s\n", o.model); return -1; }
-   fseek(wf, 0, SEEK_END); long wlen = ftell(wf); fseek(wf, 0, SEEK_SET);
-   void *blob = malloc((size_t)wlen);
-   if (!blob || fread(blob, 1, (size_t)wlen, wf) != (size_t)wlen) { fprintf(stderr, "cannot read weights\n"); return -1; }
-   fclose(wf);
+   void *blob = NULL;
+   long wlen = 0;
+   if (o.model) {
+      FILE *wf = fopen(o.model, "rb");
+      if (!wf) { fprintf(stderr, "cannot open weights %s\n", o.model); return -1; }
+      fseek(wf, 0, SEEK_END); wlen = ftell(wf); fseek(wf, 0, SEEK_SET);
+      blob = malloc((size_t)wlen);
+      if (!blob || fread(blob, 1, (size_t)wlen, wf) != (size_t)wlen) { fprintf(stderr, "cannot read weights\n"); return -1; }
+      fclose(wf);
+   }
+#ifdef VADC_EMBED_WEIGHTS
+   else {
+      wlen = (long)(vadc_embedded_weights_end - vadc_embedded_weights_begin);
+      blob = malloc((size_t)wlen);
+      if (!blob) return -1;
+      memcpy(blob, vadc_embedded_weights_begin, (size_t)wlen);
+   }
+#endif
 
    vadc_amd_engine *eng = 0;
    if (vadc_amd_create(blob, (size_t)wlen, -1, 1, WINDOW_CHUNKS, VADC_AMD_PRECISION_FP32, &eng) != VADC_AMD_OK) {

@@ -323,6 +323,48 @@ def test_limits_are_enforced(eng):
         eng.run(np.zeros((1, 1000), np.int16))                  # ragged chunk
 
 
+def test_create_rejects_bad_input(weights_blob):
+    """vadc_amd_create fails loudly (backend_init returning NULL, vadc.c:692-695) instead of guessing"""
+    from vadc_amd import _lib
+    for blob, code in ((b"", _lib_code("EWEIGHTS")), (weights_blob[:-8], _lib_code("EWEIGHTS")), (b"\0" * 64, _lib_code("EWEIGHTS"))):
+        with pytest.raises(VadcAmdError) as ei:
+            Engine(blob, max_streams=1, max_chunks_per_call=1, device=0)
+        assert ei.value.code == code
+    # a well-formed container of the wrong model (tensor count) is a weights error too
+    ts = tt.loads(weights_blob)[:50]
+    with pytest.raises(VadcAmdError) as ei:
+        Engine(tt.dumps(ts), max_streams=1, max_chunks_per_call=1, device=0)
+    assert ei.value.code == _lib_code("EWEIGHTS")
+    with pytest.raises(VadcAmdError) as ei:
+        Engine(weights_blob, max_streams=0, max_chunks_per_call=1, device=0)
+    assert ei.value.code == _lib_code("EINVAL")
+    with pytest.raises(VadcAmdError) as ei:
+        Engine(weights_blob, max_streams=1, max_chunks_per_call=1, device=99)
+    assert ei.value.code == _lib_code("ENODEVICE")
+    with pytest.raises(VadcAmdError):
+        Engine(weights_blob, max_streams=1, max_chunks_per_call=1, device=0, precision=7)
+
+
+def _lib_code(name):
+    return {"EINVAL": -1, "EWEIGHTS": -2, "ENODEVICE": -3, "EHIP": -4, "ENOMEM": -5}[name]      # include/vadc_amd.h
+
+
+def test_partial_reset_and_unknown_option(eng, gold_py):
+    pcm = np.stack([gold_py["pcm_speech0"][:8 * 1536], gold_py["pcm_speech1"][:8 * 1536]])
+    eng.reset_streams()
+    first = eng.run(pcm)
+    eng.reset_streams(np.array([1], np.int32))                  # only stream 1 starts over
+    second = eng.run(pcm)
+    assert np.array_equal(second[1], first[1]) and not np.array_equal(second[0], first[0])
+    with pytest.raises(VadcAmdError):
+        eng.reset_streams(np.array([64], np.int32))
+    with pytest.raises(VadcAmdError):
+        eng.set_option("no_such_option", 1)
+    with pytest.raises(VadcAmdError):
+        eng.set_option("lstm", 9)
+    eng.reset_streams()
+
+
 def test_segment_indices_bit_exact(eng, gold_c, gold_py):
     """bit-exact segment chunk indices: same hysteresis decisions from HIP probabilities as from the C backend's"""
     for name in ("speech0", "speech1", "speech2"):
@@ -404,6 +446,20 @@ def test_cli_segments_match_reference_segmenter(gold_c, gold_py, args, kw):
         else:
             want = ["%.2f,%.2f" % (a, b) for a, b in sec]
         assert lines == want and len(want) > 0
+
+
+def test_cli_with_embedded_weights(gold_c, gold_py):
+    """`make -C host vadc_hip_embedded`: the weights container is linked into the binary at build time (the reference's
+    cembed.c / embedded default model, vadc.c:1110); no --model needed"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "host", "vadc_hip_embedded")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "vadc_hip_embedded"])
+    r = subprocess.run([exe, "--raw_probabilities"], input=gold_py["pcm_speech1"].tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
+    assert float(np.abs(got - gold_c["probs_speech1"][:, 1]).max()) <= PROB_TOL + 5e-7
 
 
 def test_cli_empty_and_short_input():
