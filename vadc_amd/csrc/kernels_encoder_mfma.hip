@@ -161,17 +161,20 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
    constexpr int kSlab = 32;                            // input channels per slab (slab path)
    constexpr int NSLAB = (CINP + kSlab - 1) / kSlab;
-   constexpr int ROWS_B = (DIRECT || 4 * D > 2 * kSlab) ? 4 * D : 2 * kSlab;
-   __shared__ __attribute__((aligned(16))) float Yb[D * kPitch];          // conv-block output / residual stream
-   __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // Q, K, V rows then the attention / FFN rows
-   __shared__ float mm_s[NCH];
-   float *QKV = Bb, *ATT = Bb + 3 * D * kPitch;
+   // LDS: Yb (D rows) + Bb (3D rows).  The attention output ATT reuses Yb (y is dead once QKV is formed: the residual lives
+   // in the accumulators) and relu(lin1) reuses the Q rows, so layer 4 (D = 64) needs 80 KB instead of 100 KB and TWO
+   // workgroups fit a CU's 160 KB -- with one, its single wave per SIMD had nothing to hide MFMA/LDS latency behind.
+   constexpr int ROWS_B = (DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab;
+   __shared__ __attribute__((aligned(16))) float Yb[D * kPitch];          // conv-block output / residual stream / ATT
+   __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // Q, K, V rows; then relu(lin1)
+   float *QKV = Bb, *ATT = Yb, *FFN = Bb;
    float *XS = Bb, *DWR = Bb + kSlab * kPitch;          // slab path only (aliases Q/K/V)
 
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = tid >> 6;
    const int quad = lane >> 4, lc = lane & 15;
 
+   __shared__ float mm_s[FIRST ? NCH : 1];
    if (FIRST) {
       if (tid < NCH) {
          const int it = blockIdx.x * NCH + tid;
@@ -378,13 +381,13 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
          for (int r = 0; r < 4; ++r) f[mt][r] = fmaxf(f[mt][r], 0.0f);
-      acc_store<MT>(f, ATT, lane, wave);                  // reuse the attention rows for relu(lin1)
+      acc_store<MT>(f, FFN, lane, wave);                  // relu(lin1) goes to the (dead) Q rows
    }
    __syncthreads();
    {
       f4v g[MT];
       acc_init<MT>(g, w.l2_b, lane);
-      gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, ATT, lane, wave);
+      gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, FFN, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
    }
