@@ -883,7 +883,10 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (rc) return rc;
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
    HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
-   if (e->graphs.size() >= 8) { (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin()); }
+   if (e->graphs.size() >= 8) {                            // evict the oldest signature; its last replay may still be in flight
+      (void)hipStreamSynchronize(e->graphs[0].st);
+      (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin());
+   }
    e->graphs.push_back(ge);
    return launch_graph_serialized(e, ge.x, st);
 }
