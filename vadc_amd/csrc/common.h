@@ -68,6 +68,22 @@ __host__ __device__ __forceinline__ size_t lstm_x_index(int stream, int chunk, i
    return ((((size_t)(stream / kLstmTile) * C + chunk) * steps + t) * 64 + unit) * kLstmTile + (stream % kLstmTile);
 }
 
+// log1p(x) for x >= 0 on the hardware transcendental unit instead of libm's ~50-instruction log1pf:
+//   u = fl(1 + x), c = x - (u - 1) the exact rounding error of u;  y0 = ln2 * v_log_f32(u)  (a few ulp);
+//   one Newton step on exp(y) = u:  y1 = y0 + (u * exp(-y0) - 1), the residual formed with one fma (absolute error ~6e-8);
+//   log1p(x) = y1 + c / u.
+// Absolute error <= ~1e-7 over the whole range (Y <= 16), i.e. libm-grade for what the path needs (Y enters as Y - mean);
+// neither this nor libm is bit-identical to the reference's CRT log1pf (misc.c:42-45).
+__device__ __forceinline__ float log1p_hw(float x)
+{
+   const float u = 1.0f + x;
+   const float c = x - (u - 1.0f);
+   float y = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+   const float E = __builtin_amdgcn_exp2f(y * -1.4426950408889634f);
+   y += fmaf(u, E, -1.0f);
+   return fmaf(c, __builtin_amdgcn_rcpf(u), y);
+}
+
 struct LstmWeights {
    const float *w;        // [2][256][128]  reference layout: [layer][gate*64+unit][x(64) | h(64)]
    const float *wT;       // [2][128][256]  k-major copy for the simple kernel

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
       const float mag = sqrtf(re2 + im2);                                  // stft.c:209
       float val;
       if (MODE == 0 || MODE == 2) {
-         val = log1pf(mag * 1048576.0f);                                   // misc.c:42-45
+         val = log1p_hw(mag * 1048576.0f);                                   // misc.c:42-45
          bin_sum += val;                                                   // misc.c:55-59 (channel order)
       } else {
          val = mag;
@@ -385,7 +385,7 @@ __global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *_
    float s = 0.0f;
    for (int f = 0; f < kBins; ++f) {
       const size_t idx = (size_t)chunk * kBins * kFrames + f * kFrames + t;
-      const float v = log1pf(mag[idx] * 1048576.0f);
+      const float v = log1p_hw(mag[idx] * 1048576.0f);
       Y[idx] = v;
       s += v;
    }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ p
          const float re = hi ? rb : a, im = hi ? b : ra;
          const float re2 = re * re, im2 = im * im;
          const float mag = sqrtf(re2 + im2);                                  // stft.c:209
-         const float val = (MODE == 0) ? log1pf(mag * 1048576.0f) : mag;      // misc.c:42-45
+         const float val = (MODE == 0) ? log1p_hw(mag * 1048576.0f) : mag;      // misc.c:42-45
          sy[wave][lc & 7][16 * ((e >> 2) + 2 * hi) + 4 * quad + (e & 3)] = val;
          if (e & 1) __builtin_amdgcn_sched_barrier(0);   // two elements at a time: bounds the live log1p temporaries
       }

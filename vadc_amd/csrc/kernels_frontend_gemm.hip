@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
             for (int r = 0; r < 4; ++r) {
                const float re = j == 0 ? re0[r] : re1[r], im = j == 0 ? im0[r] : im1[r];
                const float mag = sqrtf(fmaf(re, re, im * im));
-               const float val = log1pf(mag * 1048576.0f);
+               const float val = log1p_hw(mag * 1048576.0f);
                const int bin = 32 * wave + 16 * j + 4 * g + r;
                if (ok) { Y[ybase + (size_t)bin * kV4Frames] = val; MAG[ybase + (size_t)bin * kV4Frames] = mag; }
                part += val;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
             ny += __shfl_xor(ny, 16);
             ny += __shfl_xor(ny, 32);
             const float mag = fabsf(ny);
-            const float val = log1pf(mag * 1048576.0f);
+            const float val = log1p_hw(mag * 1048576.0f);
             if (g == 0) {
                if (ok) { Y[ybase + (size_t)128 * kV4Frames] = val; MAG[ybase + (size_t)128 * kV4Frames] = mag; }
                part += val;
