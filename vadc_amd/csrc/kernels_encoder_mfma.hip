@@ -127,7 +127,7 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
       for (int r = 0; r < 4; ++r) { const float d = x[mt][r] - mean; vs = fmaf(d, d, vs); }
    vs += __shfl_xor(vs, 16);
    vs += __shfl_xor(vs, 32);
-   const float rstd = 1.0f / sqrtf(vs * (1.0f / D) + 1e-5f);
+   const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / D) + 1e-5f);      // v_rsq_f32 (1 ulp)
    const float mr = mean * rstd;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt) {
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
          }
          float sum = 0.0f;                                 // tensor.h:751-784
 #pragma unroll
-         for (int j = 0; j < T; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
-         const float inv = 1.0f / sum;
+         for (int j = 0; j < T; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }   // v_exp_f32 (1 ulp); arguments <= 0
+         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
          for (int e = 0; e < HD; ++e) {
             float o = 0.0f;
