@@ -26,8 +26,9 @@
 // neighbours: lane efficiency 61/64 * 25/28 = 85 %.  ~100 VGPRs => 4-5 waves/SIMD to cover scalar-load
 // latency.  Algorithmic work: 258*25*(256 mul + 255 add) = 3.30 M VALU lane-ops per chunk, which bounds this
 // kernel at 1/2 of the FMA peak by construction (2 instructions per MAC).
-// The shipped instantiation is PK = 1 (products two at a time with v_pk_mul_f32 and an SGPR pair, see below): an
-// SGPR-operand v_mul_f32 issues at ~4.3 cycles per wave64 on gfx950, a v_pk_mul_f32 at ~4.7 for two products.
+// The shipped instantiation is PK = 2: products two at a time with v_pk_mul_f32 and an SGPR pair, and the tree adds of tree
+// lanes (l, l+1) two at a time with v_pk_add_f32 (component-wise the same IEEE operations in the same order): every VALU
+// instruction costs ~4.6 cycles per wave64 here whether packed or not (PMC), so instruction count is what matters.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -400,16 +401,16 @@ void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<float, 1, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<float, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
    const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
@@ -417,14 +418,14 @@ void launch_frontend_v4_f32(const float *pcm, const float *basis, float *Y, floa
 {
    const long waves = ((long)n * 27 + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   hipLaunchKernelGGL((k_frontend<float, 2, 256, 4, 0, 0, 0, 0, 1, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
+   hipLaunchKernelGGL((k_frontend<float, 2, 256, 4, 0, 0, 0, 0, 2, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
 }
 
 void launch_frontend_v4_s16(const int16_t *pcm, const float *basis, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map, hipStream_t st)
 {
    const long waves = ((long)n * 27 + kLanesOut - 1) / kLanesOut;
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   hipLaunchKernelGGL((k_frontend<int16_t, 2, 256, 4, 0, 0, 0, 0, 1, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
+   hipLaunchKernelGGL((k_frontend<int16_t, 2, 256, 4, 0, 0, 0, 0, 2, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, MAG);
 }
 
 void launch_normalize_tap(const float *Y, const float *FM, size_t fm_stride, float *out, int n, hipStream_t st, int frames)
