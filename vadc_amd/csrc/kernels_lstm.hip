@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ 
 // The x-part of layer 0's gates, W[0][:, 0:64] . x_t + b[0], does not depend on the recurrence: it is computed
 // for all 7 steps of every (stream tile, chunk) by the otherwise idle CUs in this small GEMM kernel and handed to
 // the recurrent kernel as the INITIAL VALUE of layer 0's accumulators (k-order x then h is unchanged, so the result
-// is bit-identical to doing both halves inside the recurrence).  Layout GX[tile][chunk][t][256 gate rows][16 streams].
+// is bit-identical to doing both halves inside the recurrence).  Layout GX[tile][chunk][t][16 row tiles][64 lanes][4]:
+// the MFMA accumulator fragment itself (row 16 mt + 4 (lane >> 4) + r, stream lane & 15).
 // TS = LSTM steps per chunk: 7 (Silero v3.1) or 3 (Silero v4)
 template <int TS>
 __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ enc,   // LSTM-native tiles
@@ -274,8 +275,9 @@ __global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ en
 #pragma unroll
          for (int kk = 0; kk < 16; ++kk)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], X[(t * 64 + 4 * kk + quad) * kLstmTile + lc], acc, 0, 0, 0);
-#pragma unroll
-         for (int r = 0; r < 4; ++r) G[((size_t)t * 256 + 16 * mt + 4 * quad + r) * kLstmTile + lc] = acc[r];
+         // GX in ACCUMULATOR-FRAGMENT order [t][mt = 4 gate + unit tile][lane][r]: one 16-byte store here, one 16-byte load per gate
+         // in the recurrent kernel (mt = 4 g + wv there), both fully coalesced
+         *reinterpret_cast<float4 *>(G + (((size_t)t * 16 + mt) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       }
    }
 }
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
    const int s0 = blockIdx.x * kTileS;
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = (s0 + col) < n_streams;
-   // this lane's 16 accumulator-init values of step (chunk, t): gx_lane[((chunk*7 + t)*256 + g*64) * 16 + r*16]
-   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + (size_t)(16 * wv + 4 * quad) * kTileS + col;
+   // this lane's accumulator-init values of step (chunk, t), gate g: float4 at gx_lane[((chunk*TS + t)*16 + 4 g) * 256]
+   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + ((size_t)wv * 64 + lane) * 4;
 
    // A fragments: layer 0 keeps only the h half (k >= 64) -- its x half was applied by k_lstm_xproj
    float a[4][32];
@@ -342,9 +344,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
    if (L == 0) {
       const float *p = gx_lane + (size_t)c0 * kGxTile;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-         for (int r = 0; r < 4; ++r) gnext[g][r] = p[(size_t)(g * 64 + r) * kTileS];
+      for (int g = 0; g < 4; ++g) {
+         const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
+         gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
+      }
    }
    __syncthreads();
 
@@ -362,9 +365,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
             if (k + 1 < total) {                // prefetch the next step's init values (latency hidden by this slot)
                const float *p = gx_lane + ((size_t)c0 * TS + (k + 1)) * (256 * kTileS);
 #pragma unroll
-               for (int g = 0; g < 4; ++g)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) gnext[g][r] = p[(size_t)(g * 64 + r) * kTileS];
+               for (int g = 0; g < 4; ++g) {
+                  const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
+                  gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
+               }
             }
             const float *hin = hb0[par0];
 #pragma unroll
