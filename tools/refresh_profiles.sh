@@ -1,0 +1,21 @@
+#!/bin/bash
+# Re-create everything under profiles/rNN from one GPU box.  Run through gpurun from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'      (outputs land in gpurun_out/, then: python tools/rocprof_reduce.py ...)
+# rocprofv3 rules on this pool: program directly after `--`, PMC passes separate from tracing, one counter group per pass.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out
+rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_kt.log 2>&1
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- $B > $O/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- $B > $O/prof_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB -- $B > $O/pmcB.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmcC -- $B > $O/pmcC.log 2>&1
+python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
+python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_4096x16.json
+python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline --graph 2>/dev/null | tail -1 > $O/bench_4096x16_graph.json
+python bench.py --model v4 2>/dev/null | tail -1 > $O/bench_v4_256x64.json
+python bench.py --model v4 --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_v4_4096x16.json
+python tools/parity_report.py > $O/parity_report.log 2>&1
+tail -1 $O/parity_report.log
