@@ -14,21 +14,37 @@ from vadc_amd import synth                # noqa: E402
 from vadc_amd.engine import Engine        # noqa: E402
 
 
+def compare(eng, orc, pcm, step, one_output=False):
+    S, n = pcm.shape[0], pcm.shape[1] // 1536
+    eng.reset_streams()
+    got = np.concatenate([eng.run(pcm[:, i * 1536:(i + step) * 1536]) for i in range(0, n, step)], axis=1)[:, :, 1]
+    want = orc.forward_streams(pcm)
+    d = np.abs(got.astype(np.float64) - want).ravel()
+    seg_equal = all(np.array_equal(O.segments(got[s])[1], O.segments(want[s])[1]) for s in range(S))
+    return {"streams": S, "chunks_per_stream": n, "max_abs_dp": float(d.max()), "p999_abs_dp": float(np.quantile(d, 0.999)),
+            "mean_abs_dp": float(d.mean()), "prob_range": [float(want.min()), float(want.max())],
+            "chunks_within_1e-3_of_threshold_0.5": int((np.abs(want - 0.5) < 1e-3).sum()),
+            "segment_chunk_indices_identical": bool(seg_equal), "tolerance": 1e-4}
+
+
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_report.json")
     blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
     orc = O.Oracle(blob)
-    S, n = 8, 1000
-    pcm = synth.make_streams(S, n, seed0=9000)
-    eng = Engine(blob, max_streams=S, max_chunks_per_call=100, device=0)
-    got = np.concatenate([eng.run(pcm[:, i * 1536:(i + 100) * 1536]) for i in range(0, n, 100)], axis=1)[:, :, 1]
-    want = orc.forward_streams(pcm)
-    d = np.abs(got.astype(np.float64) - want).ravel()
-    seg_equal = all(np.array_equal(O.segments(got[s])[1], O.segments(want[s])[1]) for s in range(S))
-    rep = {"streams": S, "chunks_per_stream": n, "max_abs_dp": float(d.max()), "p999_abs_dp": float(np.quantile(d, 0.999)),
-           "mean_abs_dp": float(d.mean()), "prob_range": [float(want.min()), float(want.max())],
-           "chunks_within_1e-3_of_threshold_0.5": int((np.abs(want - 0.5) < 1e-3).sum()),
-           "segment_chunk_indices_identical": bool(seg_equal), "tolerance": 1e-4}
+    eng = Engine(blob, max_streams=64, max_chunks_per_call=100, device=0)
+    rep = compare(eng, orc, synth.make_streams(8, 1000, seed0=9000), 100)               # 8 long streams (96 s each)
+    # a wide sweep: 64 streams x 400 chunks, different seeds, plus the control signals of SURVEY.md section 8(d)
+    wide = synth.make_streams(61, 400, seed0=31000)
+    ctrl = np.stack([synth.control_stream(k, 400 * 1536, seed=5) for k in ("zeros", "noise", "square")])
+    rep["wide_sweep"] = compare(eng, orc, np.concatenate([wide, ctrl]), 100)
+    eng.close()
+    # Silero v4 against its own restatement (PyTorch-pinned)
+    v4 = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor")
+    if os.path.exists(v4):
+        blob4 = open(v4, "rb").read()
+        e4 = Engine(blob4, max_streams=16, max_chunks_per_call=100, device=0)
+        rep["silero_v4"] = compare(e4, O.OracleV4(blob4), synth.make_streams(16, 400, seed0=52000), 100)
+        e4.close()
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(rep, open(out_path, "w"), indent=1)
     print(json.dumps(rep))
