@@ -11,14 +11,17 @@
 // Here the unit of parallelism is the STREAM: state h,c is [n_streams][2][64] in HBM, loaded once per call,
 // kept on chip while the call's n_chunks chunks of the stream are consumed in order, stored once.
 //
-// k_lstm_mfma (default): a workgroup = 16 streams x 4 waves.  Per (step, layer) the gate pre-activations are
+// The MFMA mapping (all MFMA variants): a workgroup = 16 streams.  Per (step, layer) the gate pre-activations are
 //   G[256 x 16] = W[256 x 128] . [x ; h][128 x 16]   on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).
 //   Wave w owns hidden units [16w,16w+16) for ALL four gates, so the i,f,g,o values of one (unit, stream) land in
 //   the same lane/register of its four accumulators and the cell update is register-local.  Both layers' weights
 //   live in registers as MFMA A-fragments (2 x 4 x 32 VGPRs) for the whole call; [x;h] is the B operand, read
 //   from a small LDS tile that double-buffers h: one barrier per (step, layer).
-// k_lstm_wavefront (default, variant 0): the two layers run concurrently one step apart (see below); k_lstm_mfma
-//   (variant 2) is the step-sequential version of the same MFMA mapping.
+// k_lstm_xproj + k_lstm_wavefront (default while the recurrence is latency-bound, variant 0/4): layer 0's input projection
+//   hoisted into a GEMM, the two layers of the recurrence run concurrently one step apart (see below);
+//   k_lstm_wavefront_fused (default for many stream tiles, variant 3): the same with the projection inside the recurrence;
+//   k_lstm_mfma (variant 2): the step-sequential version of the same MFMA mapping.  Template parameters TS / DEC select the
+//   steps per chunk and the decoder of Silero v3.1 (7, two-output mean-then-sigmoid) or v4 (3, one-output sigmoid-then-mean).
 // k_lstm_simple: bring-up/reference variant (one wave per stream, weights streamed from L2), selectable with
 //   vadc_amd_set_option(e, "lstm", 1); used by the tests to A/B the MFMA kernel on the device.
 #include "common.h"
