@@ -323,6 +323,25 @@ def test_limits_are_enforced(eng):
         eng.run(np.zeros((1, 1000), np.int16))                  # ragged chunk
 
 
+def test_calls_are_ordered_whatever_stream_the_caller_uses(weights_blob, gold_py):
+    """per-stream LSTM state makes consecutive calls dependent: the engine orders them itself (events), also when a caller
+    alternates HIP streams without synchronising and the calls are small enough to run on the caller's stream"""
+    import torch
+    pcm = gold_py["pcm_speech0"][:40 * 1536].reshape(1, -1)
+    e = Engine(weights_blob, max_streams=1, max_chunks_per_call=8, device=0)
+    ref = np.concatenate([e.run(pcm[:, i * 1536:(i + 4) * 1536]) for i in range(0, 40, 4)], axis=1)      # synchronous calls
+    e.reset_streams()
+    d_in = torch.from_numpy(pcm.copy()).to("cuda:0")
+    d_out = torch.zeros((10, 1, 4, 2), dtype=torch.float32, device="cuda:0")
+    sts = [torch.cuda.Stream(device="cuda:0") for _ in range(3)]
+    for k in range(10):                                         # ten dependent calls round-robin over three streams, no host sync
+        e.run_device(d_in.data_ptr() + k * 4 * 1536 * 2, np.int16, 1, 4, d_out[k].data_ptr(), hip_stream=sts[k % 3].cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(1, 40, 2)
+    e.close()
+    assert np.array_equal(got, ref)
+
+
 def test_create_rejects_bad_input(weights_blob):
     """vadc_amd_create fails loudly (backend_init returning NULL, vadc.c:692-695) instead of guessing"""
     from vadc_amd import _lib

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path versus the number of concurrent streams (report at B in {1, 256, 4096},
+sweep 1..4096).  Runs bench.py once per point on this GPU and writes gpurun_out/sweep_streams.json.
+   python tools/sweep_streams.py [--model v31|v4]"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+model = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "v31"
+POINTS = [(1, 96), (4, 96), (16, 96), (64, 64), (256, 64), (1024, 32), (4096, 16)]     # (streams, chunks per step)
+rows = []
+for S, C in POINTS:
+    for graph in ((False, True) if S <= 16 else (False,)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--streams", str(S), "--chunks-per-step", str(C), "--no-cpu-baseline",
+               "--model", model, "--steps", "20", "--warmup", "3"] + (["--graph"] if graph else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print("FAILED", S, C, out.stderr[-400:], file=sys.stderr); continue
+        d = json.loads(line[-1])
+        rows.append({"streams": S, "chunks_per_step": C, "hipgraph": graph, "audio_seconds_per_sec": d["value"], "ms_per_step": d["ms_per_step"],
+                     "path_frac_of_fp32_peak": d["roofline"].get("path_frac")})
+        print(rows[-1], flush=True)
+json.dump({"model": model, "unit": "audio-seconds/sec (= real-time streams), one MI355X, fp32", "points": rows},
+          open(os.path.join(ROOT, "gpurun_out", f"sweep_streams_{model}.json"), "w"), indent=1)

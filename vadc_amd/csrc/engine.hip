@@ -164,6 +164,11 @@ struct vadc_amd_engine {
    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_e[2] = {nullptr, nullptr}, ev_graph = nullptr,
               ev_fe[kMaxGroups] = {nullptr}, ev_f[kMaxGroups] = {nullptr};
    bool ev_graph_valid = false;
+   // Call-to-call ordering that does not depend on which stream the caller used: ev_last_a = the last work that touched the
+   // front-end / encoder buffers, ev_last_b = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
+   // stream(s) that touch these wait for them first (free when it is the same stream) and re-records them.
+   hipEvent_t ev_last_a = nullptr, ev_last_b = nullptr;
+   bool ev_last_valid = false;
    // profiling
    bool profiling = false;
    struct EvPair { hipEvent_t a, b; };
@@ -446,7 +451,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
    if (e->sF) (void)hipStreamDestroy(e->sF);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_e[0], e->ev_e[1], e->ev_graph}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_e[0], e->ev_e[1], e->ev_graph, e->ev_last_a, e->ev_last_b}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_f) if (ev) (void)hipEventDestroy(ev);
    delete e;
@@ -492,7 +497,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_e[0], &e->ev_e[1], &e->ev_graph}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_e[0], &e->ev_e[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_f[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
@@ -784,11 +789,16 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
    // with one group: the internal streams are in-order across calls, so a caller that alternates between two
    // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
    // while every call keeps strict stream semantics (its results are complete when its own stream reaches the join).
+   const bool order = e->ev_last_valid && !e->capturing;
    if (G == 1 && (long)n_streams * n_chunks < 2048) {
       const ItemMap map{n_chunks, 0, n_chunks};
+      if (order) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); }
       run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
-      KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-      launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+      {
+         KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
+         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+      }
+      if (!e->capturing) { (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true; }
    } else {
       int rc = ensure_pipeline_streams(e, n_streams);
       if (rc) return rc;
@@ -798,6 +808,11 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
       const bool split_fe = e->fe_overlap != 0;
       if (split_fe) (void)hipStreamWaitEvent(e->sF, e->ev_in, 0);
+      if (order) {
+         (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
+         (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
+         if (split_fe) (void)hipStreamWaitEvent(e->sF, e->ev_last_a, 0);
+      }
       // this call's hand-off pair; its last reader was the LSTM of the forked call before the previous one
       e->xpar ^= 1;
       const int xp = e->xpar;
@@ -832,6 +847,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
+      if (!e->capturing) { (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); e->ev_last_valid = true; }
       (void)hipEventRecord(e->ev_e[xp], e->sA);
       e->ev_e_valid[xp] = !e->capturing;
       (void)hipEventRecord(e->ev_b[xp], e->sB);
@@ -854,8 +870,15 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
 static int launch_graph_serialized(vadc_amd_engine *e, hipGraphExec_t x, hipStream_t st)
 {
    if (e->ev_graph_valid) HIP_TRY(hipStreamWaitEvent(st, e->ev_graph, 0), VADC_AMD_EHIP);
+   if (e->ev_last_valid) {                                  // eager calls issued before this replay
+      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_a, 0), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_b, 0), VADC_AMD_EHIP);
+   }
    HIP_TRY(hipGraphLaunch(x, st), VADC_AMD_EHIP);
    HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
+   HIP_TRY(hipEventRecord(e->ev_last_a, st), VADC_AMD_EHIP);
+   HIP_TRY(hipEventRecord(e->ev_last_b, st), VADC_AMD_EHIP);
+   e->ev_last_valid = true;
    e->ev_graph_valid = true;
    return VADC_AMD_OK;
 }
@@ -950,10 +973,19 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
 // ---------------------------------------------------------------------------------------------------
 // per-stream state
 // ---------------------------------------------------------------------------------------------------
+// state accessors are synchronous; they first wait for the last LSTM enqueued through ANY stream
+static int wait_last_lstm(vadc_amd_engine *e)
+{
+   if (e->ev_last_valid) HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
 extern "C" int vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *ids, int n)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "reset_streams: NULL engine");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    if (!ids) {
       HIP_TRY(hipMemsetAsync(e->d_h, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_c, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
@@ -972,7 +1004,7 @@ extern "C" int vadc_amd_get_state(vadc_amd_engine *e, int stream, float *h, floa
 {
    if (!e || !h || !c || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "get_state: bad argument");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
-   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    HIP_TRY(hipMemcpy(h, e->d_h + (size_t)stream * 128, 128 * sizeof(float), hipMemcpyDeviceToHost), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpy(c, e->d_c + (size_t)stream * 128, 128 * sizeof(float), hipMemcpyDeviceToHost), VADC_AMD_EHIP);
    return VADC_AMD_OK;
@@ -982,7 +1014,7 @@ extern "C" int vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h
 {
    if (!e || !h || !c || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "set_state: bad argument");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
-   HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    HIP_TRY(hipMemcpy(e->d_h + (size_t)stream * 128, h, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpy(e->d_c + (size_t)stream * 128, c, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    return VADC_AMD_OK;
