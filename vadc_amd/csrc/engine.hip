@@ -716,6 +716,28 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    }
 }
 
+// How many CUs the LSTM chain gets (0 = no partition).  Its workgroups (one per 16-stream tile) are latency-bound -- a slot
+// costs the same whether a CU hosts one tile or takes several in turn -- while the front end + encoder scale with the CUs
+// they are given.  So the partition is the SMALLEST multiple of 8 CUs (one per XCD) on which the chain still finishes inside
+// the front-end/encoder time of the same call: tiles/want rounds x steps x ~3.9 us per slot versus ~0.12 us (v3.1) / 0.07 us
+// (v4) of whole-chip front-end + encoder time per chunk (both sides are per chunk of the call).
+static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
+{
+   if (!e->cu_partition) return 0;
+   const int lstm_wgs = (n_streams + 15) / 16;
+   // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
+   // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
+   if (lstm_wgs > e->n_cus / 4) return 0;
+   const double slot_us = 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
+   for (int w = 8; w <= e->n_cus / 4; w += 8) {
+      const int rounds = (lstm_wgs + w - 1) / w;
+      const double t_lstm = rounds * e->lstm_steps * slot_us;
+      const double t_enc = 0.9 * n_streams * per_chunk_us * e->n_cus / (double)(e->n_cus - w);
+      if (rounds == 1 || t_lstm <= t_enc) return w;
+   }
+   return 0;
+}
+
 // Streams A (front end + encoder) and B (LSTM) of the chunk-group pipeline.  The LSTM of a small batch is
 // latency-bound on a handful of workgroups (16 streams each) while the front end wants every CU, and a
 // front-end grid that already fills the machine would keep the LSTM workgroups waiting for a free CU.  So
@@ -723,9 +745,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 // LSTM chain owns `want` CUs outright and runs truly concurrently with the next group's front end.
 static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 {
-   const int lstm_wgs = (n_streams + 15) / 16;
-   int want = 0;
-   if (e->cu_partition && lstm_wgs <= e->n_cus / 4) want = ((lstm_wgs + 7) / 8) * 8;   // multiples of 8: one per XCD
+   int want = lstm_partition_cus(e, n_streams);
    if (e->lstm_cus == want && e->sA && e->sB && e->sF) return VADC_AMD_OK;
    if (e->sF) { HIP_TRY(hipStreamSynchronize(e->sF), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
    if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
@@ -765,7 +785,8 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
 {
    if (e->model == VADC_AMD_MODEL_V4) return 0;            // v4: hoisted wavefront only
-   if (e->lstm_variant == 0) return ((n_streams + 15) / 16 <= e->n_cus / 2) ? 0 : 3;
+   if (e->lstm_variant == 0)      // hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
+      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 0 : 3;
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
 }
