@@ -184,12 +184,13 @@ def main():
         chunks_per_step = S * Cn * world
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
         kt = eng.kernel_times()
-        # The LSTM chain runs concurrently on its own small CU partition (ceil(S/16) workgroups); weigh every kernel's
+        # The LSTM chain runs concurrently on its own small CU partition; weigh every kernel's
         # time by the share of the chip it occupies so that "dominant" means dominant in CU-time, not in wall time
         # of a kernel that leaves 240 CUs to the others.
         n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         cu_share = {k: 1.0 for k in kt}
-        cu_share["k_lstm"] = min(1.0, ((S + 15) // 16) / n_cus)
+        lstm_cus = eng.get_option("lstm_cus")                     # CUs the engine reserved for the LSTM chain (0: whole chip)
+        cu_share["k_lstm"] = (lstm_cus / n_cus) if lstm_cus > 0 else 1.0
         dom = max(kt, key=lambda k: kt[k][1] * cu_share[k])
         launches, total_ms = kt[dom]
         avg_s = total_ms / max(launches, 1) / 1e3

@@ -137,10 +137,13 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront MFMA kernel, input projection hoisted
- *                                      into a GEMM while the recurrence is latency-bound (few stream tiles);
- *                                      1 = simple reference kernel, 2 = step-sequential MFMA, 3 = wavefront with
- *                                      fused input projection, 4 = wavefront with hoisted input projection
+/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront kernel with the input projection hoisted into a
+ *                                      GEMM and the recurrent GEMMs on the fp16 matrix pipe with split-fp16 operands (fp32
+ *                                      accuracy, variant 5) while the recurrence is latency-bound or CU-partitioned; fused fp32
+ *                                      wavefront (3) when it owns the chip;
+ *                                      1 = simple reference kernel, 2 = step-sequential fp32 MFMA, 3 = fp32 wavefront with
+ *                                      fused input projection, 4 = fp32 wavefront with hoisted input projection,
+ *                                      5 = split-fp16 wavefront with hoisted input projection
  *                             "frontend" 0 = k_frontend (VALU tree, default), 1 = k_frontend_mx2 (products issued as MFMA K=1;
  *                                      experimental, bit-identical, not faster: fp32 MFMA shares the vector ALU lanes)
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels
@@ -154,6 +157,9 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline
  *                                      streams disjoint CU masks; 0: never mask. */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
+/* Reads a switch back, plus two read-only facts about the last forked call: "lstm_cus" = CUs reserved for the LSTM chain
+ * (0 = no partition) and "lstm_kernel" = the LSTM variant "lstm"=0 resolved to. */
+int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
 enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "vadc_amd_run_f32", "vadc_amd_run_s16", "vadc_amd_run_device_f32", "vadc_amd_run_device_s16",
     "vadc_amd_synchronize", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
     "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder",
-    "vadc_amd_set_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
+    "vadc_amd_set_option", "vadc_amd_get_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
     "vadc_amd_kernel_name",
 ]
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     L.vadc_amd_debug_stage_from_stage.argtypes = [vp, vp, i32, i32, i32, vp]
     L.vadc_amd_debug_lstm_decoder.argtypes = [vp, vp, i32, i32, vp]
     L.vadc_amd_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.vadc_amd_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
     L.vadc_amd_set_profiling.argtypes = [vp, i32]
     L.vadc_amd_get_kernel_time.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]
     L.vadc_amd_reset_kernel_times.argtypes = [vp]

@@ -154,6 +154,7 @@ struct vadc_amd_engine {
    hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
    int n_cus = 0;
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
+   int last_lstm_kernel = -1;                   // what resolve_lstm chose for the last call
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
@@ -627,14 +628,14 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && (strcmp(key, "lstm") == 0 || strcmp(key, "encoder") == 0) && value != 0)
+   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5) || (strcmp(key, "encoder") == 0 && value != 0)))
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 4) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 5) { e->lstm_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
          return fail(VADC_AMD_EINVAL, "set_option: frontend=1 indexes Y with 32-bit offsets; workspace too large");
@@ -647,6 +648,22 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
+}
+
+extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value)
+{
+   if (!e || !key || !value) return fail(VADC_AMD_EINVAL, "get_option: NULL argument");
+   if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
+   else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
+   else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
+   else if (strcmp(key, "groups") == 0) *value = e->groups;
+   else if (strcmp(key, "graph") == 0) *value = e->use_graph;
+   else if (strcmp(key, "fe_overlap") == 0) *value = e->fe_overlap;
+   else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
+   else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
+   else if (strcmp(key, "lstm_kernel") == 0) *value = e->last_lstm_kernel;
+   else return fail(VADC_AMD_EINVAL, "get_option: unknown option %s", key);
+   return VADC_AMD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -710,7 +727,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    run_encoder_layers(e, 0, 2, n, map, 0, st);
    if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
    run_encoder_layers(e, 3, 3, n, map, 1, st);
-   if (lstm_kernel == 0) {
+   if (lstm_kernel == 0 || lstm_kernel == 5) {
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM_XPROJ, st);
       launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st, e->model);
    }
@@ -728,7 +745,8 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 4) return 0;
-   const double slot_us = 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
+   // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
+   const double slot_us = (e->lstm_variant == 0 || e->lstm_variant == 5) ? 1.6 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -780,13 +798,15 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
    return VADC_AMD_OK;
 }
 
-// LSTM kernel for this call: option "lstm" 0 = auto (hoisted input projection while the recurrence is latency-bound,
-// i.e. few stream tiles; fused otherwise), 1 = simple, 2 = step-sequential MFMA, 3 = fused wavefront, 4 = hoisted wavefront
+// LSTM kernel for this call: option "lstm" 0 = auto (hoisted input projection + split-fp16 wavefront while the recurrence is
+// latency-bound or partitioned, i.e. few stream tiles; fused fp32 wavefront otherwise), 1 = simple, 2 = step-sequential MFMA,
+// 3 = fused fp32 wavefront, 4 = hoisted fp32 wavefront, 5 = hoisted split-fp16 wavefront
 static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
 {
-   if (e->model == VADC_AMD_MODEL_V4) return 0;            // v4: hoisted wavefront only
+   if (e->lstm_variant == 5) return 5;                     // hoisted wavefront on the fp16 matrix pipe (split-fp16, fp32 accuracy)
+   if (e->model == VADC_AMD_MODEL_V4) return 5;            // v4: hoisted wavefront only
    if (e->lstm_variant == 0)      // hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
-      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 0 : 3;
+      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 5 : 3;
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
 }
@@ -806,6 +826,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
 {
    const int G = pick_groups(e, n_chunks);
    const int lk = resolve_lstm(e, n_streams);
+   e->last_lstm_kernel = lk;
    // Small calls run straight on the caller's stream.  Larger ones always fork onto the two internal streams, even
    // with one group: the internal streams are in-order across calls, so a caller that alternates between two
    // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
@@ -1125,7 +1146,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
       HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    }
    const int lk = resolve_lstm(e, n_streams);
-   if (lk == 0) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st, e->model);
+   if (lk == 0 || lk == 5) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st, e->model);
    launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);

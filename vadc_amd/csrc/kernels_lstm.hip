@@ -457,6 +457,202 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restri
    }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_lstm_wavefront_h3: the same recurrence with the gate GEMMs on the fp16 matrix pipe, at fp32 accuracy
+// ------------------------------------------------------------------------------------------------
+// k_lstm_wavefront is bound by 192 fp32 MFMAs per SIMD and slot at 32 cycles each.  An fp32
+// product splits exactly into fp16 pieces, a = ah + al with ah = (half)a, al = (half)(a - ah) (22 significant bits), and
+//     W . h  ~=  Wl . hh  +  Wh . hl  +  Wh . hh            (the dropped Wl . hl term is ~2^-22 relative)
+// is three v_mfma_f32_16x16x32_f16 (K = 32, 16 cycles each, fp32 accumulation of exact fp16 x fp16 products) instead of
+// eight v_mfma_f32_16x16x4_f32 (K = 4 x 8, 32 cycles each): 5.3x fewer matrix cycles.  Measured error of a K = 128 dot product
+// against float64: 6.0e-7 for this form, 1.07e-6 for the plain fp32 FMA chain (tools/mfma_f16_probe.hip) -- it is not a
+// reduced-precision mode.  Weights are split once per call into registers (same 128 VGPRs as the fp32 fragments); h is
+// split by the wave that produces it and lives in LDS as two fp16 tiles [stream][unit] (pitch 72: conflict-free 16-byte
+// B-fragment reads).  Operand layout (verified on the device): lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15].
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+constexpr int kHPitch = 72;                     // fp16 elements per stream row of an h tile (64 units + 8 pad)
+
+template <int TS, int DEC>
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__restrict__ gx,    // GX tiles from k_lstm_xproj
+                                                              LstmWeights w,
+                                                              float *__restrict__ hs, float *__restrict__ cs,
+                                                              float *__restrict__ probs,
+                                                              int n_streams, int n_chunks, int c0, int cg)
+{
+   // [layer][parity][hi / lo][stream][unit]: the CURRENT h of each layer as split fp16
+   __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][2][kTileS * kHPitch];
+   __shared__ float pd[2][4][2][kTileS];
+   constexpr int kGxTile = TS * 256 * kLstmTile;
+   __shared__ __attribute__((aligned(16))) float bl1[256];
+
+   const int tid = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = tid >> 6;
+   const int L = wave >> 2;
+   const int wv = wave & 3;
+   const int col = lane & 15;
+   const int quad = lane >> 4;
+   const int s0 = blockIdx.x * kTileS;
+   const int s_col = min(s0 + col, n_streams - 1);
+   const bool col_ok = (s0 + col) < n_streams;
+   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + ((size_t)wv * 64 + lane) * 4;
+
+   // A fragments, split: k-block kb covers k in [32 kb, 32 kb + 32) of this layer's K (layer 0: the h half only, K = 64;
+   // layer 1: [h0 ; h1], K = 128); lane holds row 16 wv + (lane & 15) of gate g, k = 32 kb + 8 quad + e
+   constexpr int KB1 = 4, KB0 = 2;
+   h8v ah[4][KB1], al[4][KB1];
+#pragma unroll
+   for (int g = 0; g < 4; ++g) {
+      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + (L == 0 ? 64 : 0) + 8 * quad;
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb) {
+#pragma unroll
+         for (int e = 0; e < 8; ++e) {
+            const float v = (L == 0 && kb >= KB0) ? 0.0f : row[32 * kb + e];
+            const _Float16 hi = (_Float16)v;
+            ah[g][kb][e] = hi;
+            al[g][kb][e] = (_Float16)(v - (float)hi);
+         }
+      }
+   }
+   float c[4], dw[2][4], hlast[4];
+   if (tid < 256) bl1[tid] = w.b[256 + tid];
+   {
+      h4v hi4, lo4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wv + 4 * quad + r;
+         dw[0][r] = w.dec_w[u];
+         dw[1][r] = w.dec_w[64 + u];
+         c[r] = cs[(size_t)s_col * 128 + L * 64 + u];
+         hlast[r] = hs[(size_t)s_col * 128 + L * 64 + u];
+         hi4[r] = (_Float16)hlast[r];
+         lo4[r] = (_Float16)(hlast[r] - (float)hi4[r]);
+      }
+      *reinterpret_cast<h4v *>(&hb[L][0][0][col * kHPitch + 16 * wv + 4 * quad]) = hi4;
+      *reinterpret_cast<h4v *>(&hb[L][0][1][col * kHPitch + 16 * wv + 4 * quad]) = lo4;
+   }
+   int par0 = 0, par1 = 0;
+   float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+   float gnext[4][4];
+   if (L == 0) {
+      const float *p = gx_lane + (size_t)c0 * kGxTile;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+         const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
+         gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
+      }
+   }
+   __syncthreads();
+
+   const int total = TS * cg;
+   float psum = 0.0f;
+   for (int k = 0; k <= total; ++k) {
+      const bool active = (L == 0) ? (k < total) : (k >= 1);
+      const int step = (L == 0) ? k : k - 1;
+      const int chi = step / TS, t = step - chi * TS;
+      if (active) {
+         f4v acc[4];
+         if (L == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
+            if (k + 1 < total) {
+               const float *p = gx_lane + ((size_t)c0 * TS + (k + 1)) * (256 * kTileS);
+#pragma unroll
+               for (int g = 0; g < 4; ++g) {
+                  const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
+                  gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
+               }
+            }
+         } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+               const float4 b4 = *reinterpret_cast<const float4 *>(&bl1[g * 64 + 16 * wv + 4 * quad]);
+               acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
+            }
+         }
+         // B fragments: k-blocks 0,1 = h0 (both layers), 2,3 = h1 (layer 1 only); lane reads units 32 kb' + 8 quad .. +7 of stream col
+         const int nkb = (L == 0) ? KB0 : KB1;
+#pragma unroll
+         for (int kb = 0; kb < KB1; ++kb) {
+            if (kb < nkb) {
+               const _Float16 *base = (kb < 2) ? hb[0][par0][0] : hb[1][par1][0];
+               const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
+               const h8v bh = *reinterpret_cast<const h8v *>(base + off);
+               const h8v bl = *reinterpret_cast<const h8v *>(base + kTileS * kHPitch + off);
+#pragma unroll
+               for (int g = 0; g < 4; ++g) {
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kb], bh, acc[g], 0, 0, 0);
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bl, acc[g], 0, 0, 0);
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bh, acc[g], 0, 0, 0);
+               }
+            }
+         }
+         h4v hi4, lo4;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) {
+            const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
+            const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
+            c[r] = fg * c[r] + ig * gg;
+            const float hn = og * fast_tanh(c[r]);
+            hlast[r] = hn;
+            hi4[r] = (_Float16)hn;
+            lo4[r] = (_Float16)(hn - (float)hi4[r]);
+            if (L == 1) rsum[r] = (DEC == 0 ? rsum[r] : 0.0f) + fmaxf(hn, 0.0f);
+         }
+         _Float16 *hout = (L == 0) ? hb[0][par0 ^ 1][0] : hb[1][par1 ^ 1][0];
+         *reinterpret_cast<h4v *>(hout + col * kHPitch + 16 * wv + 4 * quad) = hi4;
+         *reinterpret_cast<h4v *>(hout + kTileS * kHPitch + col * kHPitch + 16 * wv + 4 * quad) = lo4;
+      }
+      const bool chunk_done = (L == 1) && active && (t == TS - 1);
+      if (DEC == 1 && L == 1 && active) {
+         float d0 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) d0 = fmaf(dw[0][r], rsum[r], d0);
+         d0 += __shfl_xor(d0, 16);
+         d0 += __shfl_xor(d0, 32);
+         if (quad == 0) pd[k & 1][wv][0][col] = d0;
+      }
+      if (DEC == 0 && chunk_done) {
+         float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
+         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
+         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
+         if (quad == 0) { pd[0][wv][0][col] = d0; pd[0][wv][1][col] = d1; }
+      }
+      __syncthreads();
+      if (k < total) par0 ^= 1;
+      if (k >= 1) par1 ^= 1;
+      if (DEC == 0 && chunk_done && wv == 0 && lane < 2 * kTileS) {
+         const int sc = lane & 15, f = lane >> 4;
+         const float m = ((pd[0][0][f][sc] + pd[0][1][f][sc]) + (pd[0][2][f][sc] + pd[0][3][f][sc])) / (float)TS + w.dec_b[f];
+         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
+      }
+      if (DEC == 1 && L == 1 && active && wv == 0 && lane < kTileS) {
+         const int q = k & 1;
+         psum += sigmoidf_(((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + w.dec_b[0]);
+         if (t == TS - 1) {
+            const float pr = psum / (float)TS;
+            if (s0 + lane < n_streams) {
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 0] = pr;
+               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 1] = pr;
+            }
+            psum = 0.0f;
+         }
+      }
+   }
+   if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wv + 4 * quad + r;
+         cs[(size_t)s_col * 128 + L * 64 + u] = c[r];
+         hs[(size_t)s_col * 128 + L * 64 + u] = hlast[r];      // fp32 value of the last step (LDS holds only the split form)
+      }
+   }
+}
+
 // Same layer-wavefront schedule with layer 0's input projection done INSIDE the recurrence (x frames staged by
 // LDS-DMA).  Used when there are many stream tiles (the LSTM is throughput- not latency-bound and the extra GX round
 // trip of the hoisted form does not pay).
@@ -606,8 +802,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 void launch_lstm(int variant, const float *enc, float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
                  int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
-   if (model == 1)
+   if (model == 1 && variant == 5)
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (model == 1)
       hipLaunchKernelGGL((k_lstm_wavefront<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 5)
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 1)
       hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 3)

@@ -155,6 +155,11 @@ class Engine:
     def set_option(self, key: str, value: int):
         self._check(self._L.vadc_amd_set_option(self._h, key.encode(), value))
 
+    def get_option(self, key: str) -> int:
+        v = C.c_int32()
+        self._check(self._L.vadc_amd_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     # ---- measurement ----
     def set_profiling(self, on: bool):
         self._check(self._L.vadc_amd_set_profiling(self._h, int(on)))
