@@ -26,10 +26,10 @@ def short_name(full):
 
 
 def find(d, pat):
-    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
     if not hits:
         sys.exit(f"no {pat} under {d}")
-    return hits[-1]
+    return max(hits, key=os.path.getmtime)        # gpurun merges runs into the same directory: take the newest
 
 
 def pmc_avg(d, counter):
