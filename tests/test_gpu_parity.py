@@ -384,6 +384,15 @@ def test_auto_lstm_choice_and_partition_are_reported(weights_blob):
     e.close()
 
 
+def test_split_fp16_lstm_is_not_used_for_weights_outside_fp16_range(weights_blob):
+    ts = tt.loads(weights_blob)
+    w = ts[95][1].copy(); w[0, 0, 0] = 7.0e4                   # does not fit fp16
+    e = Engine(_blob_with(weights_blob, {95: w}), max_streams=16, max_chunks_per_call=4, device=0)
+    e.run(np.zeros((16, 4 * 1536), np.int16))
+    assert e.get_option("lstm_kernel") == 0                    # the fp32 wavefront
+    e.close()
+
+
 def test_partial_reset_and_unknown_option(eng, gold_py):
     pcm = np.stack([gold_py["pcm_speech0"][:8 * 1536], gold_py["pcm_speech1"][:8 * 1536]])
     eng.reset_streams()

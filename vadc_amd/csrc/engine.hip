@@ -155,6 +155,7 @@ struct vadc_amd_engine {
    int n_cus = 0;
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
    int last_lstm_kernel = -1;                   // what resolve_lstm chose for the last call
+   bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
@@ -288,6 +289,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 128) || !need(idx + 3, 2)) goto bad;
       std::vector<float> W, B, dw, db;
       copy_unaligned(W, ts[idx]); copy_unaligned(B, ts[idx + 1]); copy_unaligned(dw, ts[idx + 2]); copy_unaligned(db, ts[idx + 3]);
+      for (float v : W) if (!(fabsf(v) < 3.0e4f)) e->lstm_h3_ok = false;      // also catches NaN / inf
       std::vector<float> WT(W.size());
       for (int l = 0; l < 2; ++l)
          for (int r = 0; r < 256; ++r)
@@ -404,6 +406,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 64) || !need(idx + 3, 1) || !need(idx + 4, 7)) goto bad;
       std::vector<float> W, B, dw, db;
       copy_unaligned(W, ts[idx]); copy_unaligned(B, ts[idx + 1]); copy_unaligned(dw, ts[idx + 2]); copy_unaligned(db, ts[idx + 3]);
+      for (float v : W) if (!(fabsf(v) < 3.0e4f)) e->lstm_h3_ok = false;
       dw.resize(128, 0.0f); db.resize(2, 0.0f);            // LstmWeights carries room for the v3.1 two-output decoder
       std::vector<float> WT(W.size());
       for (int l = 0; l < 2; ++l)
@@ -746,7 +749,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 4) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   const double slot_us = (e->lstm_variant == 0 || e->lstm_variant == 5) ? 1.6 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
+   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5) && e->lstm_h3_ok) ? 1.6 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -803,10 +806,11 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 // 3 = fused fp32 wavefront, 4 = hoisted fp32 wavefront, 5 = hoisted split-fp16 wavefront
 static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
 {
-   if (e->lstm_variant == 5) return 5;                     // hoisted wavefront on the fp16 matrix pipe (split-fp16, fp32 accuracy)
-   if (e->model == VADC_AMD_MODEL_V4) return 5;            // v4: hoisted wavefront only
+   const int hoisted = e->lstm_h3_ok ? 5 : 0;              // split-fp16 needs every weight inside fp16's range; else the fp32 form
+   if (e->lstm_variant == 5) return hoisted;               // hoisted wavefront on the fp16 matrix pipe (split-fp16, fp32 accuracy)
+   if (e->model == VADC_AMD_MODEL_V4) return hoisted;      // v4: hoisted wavefront only
    if (e->lstm_variant == 0)      // hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
-      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 5 : 3;
+      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? hoisted : 3;
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
 }
