@@ -234,7 +234,8 @@ def main():
         if args.model == "v4":
             out["roofline"]["note"] = ("dominant kernel by CU-time; fp32 peak (vector == matrix).  FLOP are counted for the DENSE basis "
                                        "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm_v4 folds the "
-                                       "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, so its hardware utilisation is frac / 2")
+                                       "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, as split-fp16 products on the fp16 matrix pipe "
+                                       "(3 x v_mfma_f32_16x16x32_f16 per k-block), so frac is not a utilisation of the fp32 roof")
             out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * 24
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)

@@ -355,17 +355,19 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       for (int n = 0; n < 256 && sym; ++n) if (B(kBins, n) != 0.0f || B(kBins + 128, n) != 0.0f) sym = false;
       e->v4_gemm = sym;
       if (sym) {
-         // A fragments: tile t < 8: re bins 16 t + r; tile 8 + t: im bins 16 t + r; k-step s, lane l: row l & 15, tap 32 (l >> 4) + s
-         std::vector<float> af((size_t)16 * 32 * 64), ny(128);
+         // A fragments (v_mfma_f32_16x16x32_f16 operand order): tile t < 8: re bins 16 t + r; tile 8 + t: im bins 16 t + r;
+         // k-block kb, lane l, element e: row l & 15, tap 32 kb + 8 (l >> 4) + e
+         std::vector<float> af((size_t)16 * 4 * 64 * 8), ny(128);
          for (int t = 0; t < 16; ++t)
-            for (int sidx = 0; sidx < 32; ++sidx)
-               for (int l = 0; l < 64; ++l) {
-                  const int bin = 16 * (t & 7) + (l & 15), n = 32 * (l >> 4) + sidx;
-                  float v;
-                  if (t < 8) v = (n == 0) ? B(bin, 128) : B(bin, n);          // slot 0 carries the unpaired centre tap
-                  else       v = (n == 0) ? 0.0f : B(kBins + bin, n);
-                  af[((size_t)t * 32 + sidx) * 64 + l] = v;
-               }
+            for (int kb = 0; kb < 4; ++kb)
+               for (int l = 0; l < 64; ++l)
+                  for (int el = 0; el < 8; ++el) {
+                     const int bin = 16 * (t & 7) + (l & 15), n = 32 * kb + 8 * (l >> 4) + el;
+                     float v;
+                     if (t < 8) v = (n == 0) ? B(bin, 128) : B(bin, n);          // slot 0 carries the unpaired centre tap
+                     else       v = (n == 0) ? 0.0f : B(kBins + bin, n);
+                     af[(((size_t)t * 4 + kb) * 64 + l) * 8 + el] = v;
+                  }
          for (int n = 0; n < 128; ++n) ny[n] = (n == 0) ? B(128, 128) : B(128, n);
          off_afrag = pk.add(af.data(), af.size());
          off_nyq = pk.add(ny.data(), ny.size());

@@ -21,7 +21,7 @@
 // A fragments of bins [32w, 32w+32) -- two re and two im row tiles, 128 VGPRs -- for the whole kernel.  The 4 chunks are
 // staged twice in LDS (block pitch 68 floats: the 16 frames of a column tile hit disjoint banks): X0[i] = x[i] and X1[i] =
 // x[i+1], so that both the direct taps x[p+32g+4q..+3] and the mirrored taps x[p+256-32g-4q-3..] are ALIGNED ds_read_b128.
-// Lane (f = l & 15, g = l >> 4) supplies B[k = g][col = f] = xs/xd of position f at tap 32g + s for k-step s.  re and im of
+// Lane (f = l & 15, g = l >> 4) supplies the B fragment of position f: taps 32 kb + 8 g + e of k-block kb.  re and im of
 // one (bin, position) land in the same lane and register of their accumulators, so magnitude/log1p are register-local; the
 // stores run along the frames of a chunk.  Bin 128 (re only) is one extra dot product on the vector ALU, taken by a different
 // wave for every column tile.  Per-frame bin sums: one partial per wave = the 4 partials of FM (common.h kBinSplit).
@@ -30,6 +30,14 @@
 namespace vadc {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+// a = ah + al exactly to 22 bits; x = s16 / 32768 and x[n] +- x[256-n] (17 bits) split EXACTLY
+__device__ __forceinline__ void split8(const float (&v)[8], h8v &hi, h8v &lo)
+{
+#pragma unroll
+   for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+}
 
 constexpr int kV4Pad = 96, kV4Frames = 24, kV4Padded = kChunk + 2 * kV4Pad;   // 1728 samples = 27 blocks of 64
 constexpr int kGBlockPitch = 68;
@@ -40,7 +48,12 @@ constexpr int kGTiles = kGChunks * kV4Frames / 16;                            //
 __device__ __forceinline__ float g_sample(float v) { return v; }
 __device__ __forceinline__ float g_sample(int16_t v) { return (float)v * (1.0f / 32768.0f); }
 
-// afrag: [tile 0..15 (0-7 re bins 16t.., 8-15 im)][s 0..31][lane]   = A[16 t' + (lane & 15)][32 (lane >> 4) + s]
+// MATRIX PIPE.  The two K = 128 contractions run as v_mfma_f32_16x16x32_f16 with SPLIT-fp16 operands (a = ah + al, three MFMAs
+// per k-block: al.bh + ah.bl + ah.bh, fp32 accumulation; see k_lstm_wavefront_h3 in kernels_lstm.hip): 48 matrix instructions
+// of 16 cycles per column tile and wave instead of 128 fp32 MFMAs of 32 cycles, on the fp16 pipe that does not share lanes
+// with the vector ALU.  s16 input and the folded sums split exactly; the basis keeps 22 of its 24 bits (error ~2e-7 relative,
+// the level of fp32 accumulation itself).  Operand layout: lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15].
+// afrag: [tile 0..15 (0-7 re bins 16t.., 8-15 im)][kb 0..3][lane][8]  = A[16 t' + (lane & 15)][32 kb + 8 (lane >> 4) + e]  (fp32; split in-kernel)
 // nyq:   [128] folded weights of bin 128 (re)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict__ pcm, const float *__restrict__ afrag,
@@ -55,14 +68,19 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int f = lane & 15, g = lane >> 4;
 
-   // this wave's A fragments: re tiles 2w, 2w+1 and im tiles 8+2w, 8+2w+1
-   float are0[32], are1[32], aim0[32], aim1[32];
+   // this wave's A fragments, split once: re tiles 2w, 2w+1 and im tiles 8+2w, 8+2w+1; [tile][kb] -> 8 halves hi + 8 halves lo
+   h8v ah[4][4], al[4][4];
 #pragma unroll
-   for (int s = 0; s < 32; ++s) {
-      are0[s] = afrag[((size_t)(2 * wave) * 32 + s) * 64 + lane];
-      are1[s] = afrag[((size_t)(2 * wave + 1) * 32 + s) * 64 + lane];
-      aim0[s] = afrag[((size_t)(8 + 2 * wave) * 32 + s) * 64 + lane];
-      aim1[s] = afrag[((size_t)(8 + 2 * wave + 1) * 32 + s) * 64 + lane];
+   for (int ti = 0; ti < 4; ++ti) {
+      const int tile = (ti < 2 ? 0 : 8) + 2 * wave + (ti & 1);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+         float v[8];
+         const float *src = afrag + (((size_t)tile * 4 + kb) * 64 + lane) * 8;
+#pragma unroll
+         for (int e = 0; e < 8; ++e) v[e] = src[e];
+         split8(v, ah[ti][kb], al[ti][kb]);
+      }
    }
    if (tid < 128) nyq_s[tid] = nyq[tid];
 
@@ -91,45 +109,44 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
          // column tile ct: positions 16 ct + f of the group; position -> (chunk c, frame fr)
          const int pos = 16 * ct + f;
          const int c = pos / kV4Frames, fr = pos - c * kV4Frames;
-         // direct taps 32 g + 4 q + {0..3}: sample 64 fr + 32 g + 4 q   -> block fr + (g >> 1), offset 32 (g & 1) + 4 q
-         const float *pd = X0 + c * kGChunkPitch + (fr + (g >> 1)) * kGBlockPitch + 32 * (g & 1);
-         // mirrored taps: samples 64 fr + 256 - 32 g - 4 q - {0..3} = X1[64 fr + 252 - 32 g - 4 q + {3,2,1,0}]
-         //   252 - 32 g - 4 q stays inside block 3 - (g >> 1) for q = 0..7; offset inside the block 60 - 32 (g & 1) - 4 q
-         const float *pm = X1 + c * kGChunkPitch + (fr + 3 - (g >> 1)) * kGBlockPitch + 60 - 32 * (g & 1);
+         // k-block kb, lane group g, element e  <->  tap n = 32 kb + 8 g + e
+         //   direct   x[64 fr + n]              = X0[block fr + (kb >> 1)][32 (kb & 1) + 8 g + e]
+         //   mirrored x[64 fr + 256 - n]        = X1[block fr + 3 - (kb >> 1)][56 - 32 (kb & 1) - 8 g + (7 - e)]
+         const float *pd = X0 + c * kGChunkPitch + fr * kGBlockPitch + 8 * g;
+         const float *pm = X1 + c * kGChunkPitch + (fr + 3) * kGBlockPitch + 56 - 8 * g;
          const float center = X0[c * kGChunkPitch + (fr + 2) * kGBlockPitch];       // sample 64 fr + 128
-         f4v re0 = {0, 0, 0, 0}, re1 = {0, 0, 0, 0}, im0 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0};
+         f4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};       // re0, re1, im0, im1
          float ny = 0.0f;
          const bool do_ny = (ct & 3) == wave;
-         // operands of k-steps 4q..4q+3 are fetched one q ahead of the MFMAs that consume them
-         float4 d = *reinterpret_cast<const float4 *>(pd), m = *reinterpret_cast<const float4 *>(pm);
 #pragma unroll
-         for (int q = 0; q < 8; ++q) {
-            float xs[4], xd[4];
-            xs[0] = d.x + m.w; xs[1] = d.y + m.z; xs[2] = d.z + m.y; xs[3] = d.w + m.x;
-            xd[0] = d.x - m.w; xd[1] = d.y - m.z; xd[2] = d.z - m.y; xd[3] = d.w - m.x;
-            if (q == 0 && g == 0) { xs[0] = center; xd[0] = 0.0f; }                 // tap 0 carries the unpaired centre tap 128
-            if (q < 7) {
-               d = *reinterpret_cast<const float4 *>(pd + 4 * (q + 1));
-               m = *reinterpret_cast<const float4 *>(pm - 4 * (q + 1));
+         for (int kb = 0; kb < 4; ++kb) {
+            const float *pdk = pd + (kb >> 1) * kGBlockPitch + 32 * (kb & 1);
+            const float *pmk = pm - (kb >> 1) * kGBlockPitch - 32 * (kb & 1);
+            const float4 d0 = *reinterpret_cast<const float4 *>(pdk), d1 = *reinterpret_cast<const float4 *>(pdk + 4);
+            const float4 m0 = *reinterpret_cast<const float4 *>(pmk), m1 = *reinterpret_cast<const float4 *>(pmk + 4);
+            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            const float mv[8] = {m1.w, m1.z, m1.y, m1.x, m0.w, m0.z, m0.y, m0.x};   // mirrored element of tap e is index 7 - e
+            float xs[8], xd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xs[e] = dv[e] + mv[e]; xd[e] = dv[e] - mv[e]; }
+            if (kb == 0 && g == 0) { xs[0] = center; xd[0] = 0.0f; }                // tap 0 carries the unpaired centre tap 128
+            h8v sh, sl, dh, dl;
+            split8(xs, sh, sl);
+            split8(xd, dh, dl);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+               const h8v bh = ti < 2 ? sh : dh, bl = ti < 2 ? sl : dl;
+               acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ti][kb], bh, acc[ti], 0, 0, 0);
+               acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bl, acc[ti], 0, 0, 0);
+               acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bh, acc[ti], 0, 0, 0);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-               const int s = 4 * q + t;
-               re0 = __builtin_amdgcn_mfma_f32_16x16x4f32(are0[s], xs[t], re0, 0, 0, 0);
-               re1 = __builtin_amdgcn_mfma_f32_16x16x4f32(are1[s], xs[t], re1, 0, 0, 0);
-               im0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aim0[s], xd[t], im0, 0, 0, 0);
-               im1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aim1[s], xd[t], im1, 0, 0, 0);
+            if (do_ny) {                                   // bin 128 (re only) on the vector ALU, fp32
+               const float4 w0 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g), w1 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g + 4);
+               ny = fmaf(w0.x, xs[0], ny); ny = fmaf(w0.y, xs[1], ny); ny = fmaf(w0.z, xs[2], ny); ny = fmaf(w0.w, xs[3], ny);
+               ny = fmaf(w1.x, xs[4], ny); ny = fmaf(w1.y, xs[5], ny); ny = fmaf(w1.z, xs[6], ny); ny = fmaf(w1.w, xs[7], ny);
             }
          }
-         if (do_ny) {                                      // bin 128 on the vector ALU: its own pass over the operands, so that its
-#pragma unroll                                             // LDS reads do not serialise the MFMA loop's prefetch
-            for (int q = 0; q < 8; ++q) {
-               const float4 dq = *reinterpret_cast<const float4 *>(pd + 4 * q), mq = *reinterpret_cast<const float4 *>(pm - 4 * q);
-               const float4 wq = *reinterpret_cast<const float4 *>(nyq_s + 32 * g + 4 * q);
-               const float x0 = (q == 0 && g == 0) ? center : dq.x + mq.w;
-               ny = fmaf(wq.x, x0, ny); ny = fmaf(wq.y, dq.y + mq.z, ny); ny = fmaf(wq.z, dq.z + mq.y, ny); ny = fmaf(wq.w, dq.w + mq.x, ny);
-            }
-         }
+         const f4v re0 = acc[0], re1 = acc[1], im0 = acc[2], im1 = acc[3];
          // ---- epilogue: D rows = bins 32 w + 16 j + 4 g + r, column = position f ----
          const int item = grp * kGChunks + c;
          const bool ok = item < n_chunks;
