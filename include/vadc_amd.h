@@ -137,13 +137,13 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront kernel with the input projection hoisted into a
- *                                      GEMM and the recurrent GEMMs on the fp16 matrix pipe with split-fp16 operands (fp32
- *                                      accuracy, variant 5) while the recurrence is latency-bound or CU-partitioned; fused fp32
- *                                      wavefront (3) when it owns the chip;
+/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront kernel with all gate GEMMs on the fp16 matrix pipe
+ *                                      with split-fp16 operands (fp32 accuracy; variant 6); the fp32 kernels (0/3) if an LSTM
+ *                                      weight does not fit fp16's range;
  *                                      1 = simple reference kernel, 2 = step-sequential fp32 MFMA, 3 = fp32 wavefront with
  *                                      fused input projection, 4 = fp32 wavefront with hoisted input projection,
- *                                      5 = split-fp16 wavefront with hoisted input projection
+ *                                      5 = split-fp16 wavefront with hoisted input projection, 6 = split-fp16 wavefront with the
+ *                                      projection inside (the last encoder stage hands over split-fp16 tiles; what auto picks)
  *                             "frontend" 0 = k_frontend (VALU tree, default), 1 = k_frontend_mx2 (products issued as MFMA K=1;
  *                                      experimental, bit-identical, not faster: fp32 MFMA shares the vector ALU lanes)
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels

@@ -165,7 +165,7 @@ def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):     
     assert float(np.abs(got - ref).max()) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_reference_fixture_lstm(weights_blob, fixture_path, variant):                     # test.c:243
     x, h0, c0, w, b, ref = [a for _, a in tt.load(fixture_path("lstm_nito_reference_randn"))]
     e = Engine(_blob_with(weights_blob, {95: w, 96: b}), max_streams=1, max_chunks_per_call=4, device=0)
@@ -273,14 +273,18 @@ def test_encoder_variants_agree(eng, gold_py, stage):
 
 def test_lstm_variants_agree(eng):
     pcm = synth.make_streams(19, 6, seed0=5)
-    eng.set_option("lstm", 0); eng.reset_streams(); a = eng.run(pcm)     # layer-wavefront MFMA
+    eng.set_option("lstm", 4); eng.reset_streams(); a = eng.run(pcm)     # fp32 layer-wavefront MFMA, hoisted input projection
     eng.set_option("lstm", 1); eng.reset_streams(); b = eng.run(pcm)     # libm-grade reference kernel
     eng.set_option("lstm", 2); eng.reset_streams(); c = eng.run(pcm)     # step-sequential MFMA
     eng.set_option("lstm", 5); eng.reset_streams(); d = eng.run(pcm)     # wavefront on the fp16 matrix pipe, split-fp16 operands
+    eng.set_option("lstm", 6); eng.reset_streams(); f = eng.run(pcm)     # the same with the input projection inside (default)
+    eng.set_option("lstm", 3); eng.reset_streams(); g = eng.run(pcm)     # fp32 wavefront with the input projection inside
     eng.set_option("lstm", 0)
     assert float(np.abs(a - b).max()) < 2e-5
     assert float(np.abs(a - c).max()) < 1e-6                             # same arithmetic, different schedule
+    assert float(np.abs(a - g).max()) < 1e-6
     assert float(np.abs(a - d).max()) < 2e-5                             # fp32-grade: 22-bit operands, fp32 accumulation
+    assert float(np.abs(a - f).max()) < 2e-5
 
 
 @pytest.mark.parametrize("groups", [1, 2, 3, 4, 8])
@@ -371,12 +375,12 @@ def _lib_code(name):
 
 
 def test_auto_lstm_choice_and_partition_are_reported(weights_blob):
-    """vadc_amd_get_option: "lstm"=0 resolves to the split-fp16 wavefront (5) for few stream tiles; the CU partition of the
-    LSTM chain is the smallest one that keeps it inside the front-end/encoder time"""
+    """vadc_amd_get_option: "lstm"=0 resolves to the fused split-fp16 wavefront (6); the CU partition of the LSTM chain is the
+    smallest one that keeps it inside the front-end/encoder time"""
     e = Engine(weights_blob, max_streams=256, max_chunks_per_call=16, device=0)
     assert e.get_option("lstm") == 0 and e.get_option("cu_partition") == 1
     e.run(np.zeros((256, 16 * 1536), np.int16))                 # 4096 chunks: forked path
-    assert e.get_option("lstm_kernel") == 5
+    assert e.get_option("lstm_kernel") == 6
     assert e.get_option("lstm_cus") in (8, 16)
     e.set_option("lstm", 4)
     e.run(np.zeros((256, 16 * 1536), np.int16))

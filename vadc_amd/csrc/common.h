@@ -84,6 +84,14 @@ __device__ __forceinline__ float log1p_hw(float x)
    return fmaf(c, __builtin_amdgcn_rcpf(u), y);
 }
 
+// Split-fp16 hand-off ("h3-native"): one (tile, chunk, step) block = [hi | lo][stream-in-tile 16][unit 64] halves (4 KB, the size
+// of the fp32 block), i.e. a stream's 64 units are one 128-byte row: the B fragment of v_mfma_f32_16x16x32_f16 for
+// k-block kb is the 16 bytes at unit 32 kb + 8 (lane >> 4).  Index in HALVES of the hi row; the lo row is + 16 * 64.
+__host__ __device__ __forceinline__ size_t lstm_xh_index(int stream, int chunk, int C, int t, int unit, int steps)
+{
+   return ((((size_t)(stream / kLstmTile) * C + chunk) * steps + t) * 2 * kLstmTile + (stream % kLstmTile)) * 64 + unit;
+}
+
 struct LstmWeights {
    const float *w;        // [2][256][128]  reference layout: [layer][gate*64+unit][x(64) | h(64)]
    const float *wT;       // [2][128][256]  k-major copy for the simple kernel

@@ -633,14 +633,14 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5) || (strcmp(key, "encoder") == 0 && value != 0)))
+   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && value != 0)))
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 5) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 6) { e->lstm_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
          return fail(VADC_AMD_EINVAL, "set_option: frontend=1 indexes Y with 32-bit offsets; workspace too large");
@@ -731,7 +731,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
    if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
-   run_encoder_layers(e, 3, 3, n, map, 1, st);
+   run_encoder_layers(e, 3, 3, n, map, lstm_kernel == 6 ? 2 : 1, st);      // 2: split-fp16 tiles for the fused split-fp16 LSTM
    if (lstm_kernel == 0 || lstm_kernel == 5) {
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM_XPROJ, st);
       launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st, e->model);
@@ -751,7 +751,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 4) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5) && e->lstm_h3_ok) ? 1.6 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
+   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.9 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -808,11 +808,15 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 // 3 = fused fp32 wavefront, 4 = hoisted fp32 wavefront, 5 = hoisted split-fp16 wavefront
 static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
 {
-   const int hoisted = e->lstm_h3_ok ? 5 : 0;              // split-fp16 needs every weight inside fp16's range; else the fp32 form
-   if (e->lstm_variant == 5) return hoisted;               // hoisted wavefront on the fp16 matrix pipe (split-fp16, fp32 accuracy)
-   if (e->model == VADC_AMD_MODEL_V4) return hoisted;      // v4: hoisted wavefront only
-   if (e->lstm_variant == 0)      // hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
-      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? hoisted : 3;
+   // split-fp16 needs every weight inside fp16's range; else the fp32 forms
+   if (e->lstm_variant == 5) return e->lstm_h3_ok ? 5 : 0;    // hoisted input projection + split-fp16 wavefront
+   if (e->lstm_variant == 6) return e->lstm_h3_ok ? 6 : 0;    // fused split-fp16 wavefront (x arrives as split-fp16 tiles, no GX)
+   if (e->model == VADC_AMD_MODEL_V4) return e->lstm_h3_ok ? 6 : 0;
+   if (e->lstm_variant == 0) {
+      if (e->lstm_h3_ok) return 6;
+      // fp32: hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
+      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 0 : 3;
+   }
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
 }
@@ -1139,19 +1143,34 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    hipStream_t st = e->stream;
    const size_t n = (size_t)n_streams * n_chunks;
+   const int lk = resolve_lstm(e, n_streams);
    {
-      // pure data movement: reference layout [S][C][64][7] -> LSTM-native tiles (common.h)
+      // pure data movement: reference layout [S][C][64][steps] -> LSTM-native tiles (common.h), fp32 or split fp16
       const size_t padded = (size_t)((n_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
       const int TS = e->lstm_steps;
-      std::vector<float> tiles(padded * n_chunks * 64 * TS, 0.0f);
-      for (int s = 0; s < n_streams; ++s)
-         for (int c = 0; c < n_chunks; ++c)
-            for (int u = 0; u < 64; ++u)
-               for (int t = 0; t < TS; ++t)
-                  tiles[lstm_x_index(s, c, n_chunks, t, u, TS)] = x[(((size_t)s * n_chunks + c) * 64 + u) * TS + t];
-      HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      if (lk == 6) {
+         std::vector<_Float16> tiles(padded * n_chunks * 64 * TS * 2, (_Float16)0.0f);
+         for (int s = 0; s < n_streams; ++s)
+            for (int c = 0; c < n_chunks; ++c)
+               for (int u = 0; u < 64; ++u)
+                  for (int t = 0; t < TS; ++t) {
+                     const float v = x[(((size_t)s * n_chunks + c) * 64 + u) * TS + t];
+                     const _Float16 hi = (_Float16)v;
+                     const size_t i = lstm_xh_index(s, c, n_chunks, t, u, TS);
+                     tiles[i] = hi;
+                     tiles[i + kLstmTile * 64] = (_Float16)(v - (float)hi);
+                  }
+         HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(_Float16), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      } else {
+         std::vector<float> tiles(padded * n_chunks * 64 * TS, 0.0f);
+         for (int s = 0; s < n_streams; ++s)
+            for (int c = 0; c < n_chunks; ++c)
+               for (int u = 0; u < 64; ++u)
+                  for (int t = 0; t < TS; ++t)
+                     tiles[lstm_x_index(s, c, n_chunks, t, u, TS)] = x[(((size_t)s * n_chunks + c) * 64 + u) * TS + t];
+         HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      }
    }
-   const int lk = resolve_lstm(e, n_streams);
    if (lk == 0 || lk == 5) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st, e->model);
    launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);

@@ -144,7 +144,10 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 //        2 = Silero v4 first block: input = concat(magnitude `in2` [n][129][T], Y - mm) = 258 channels (silero_vad.py:212).
 // HAS_TF: false = Silero v4 encoder stage (ConvBlock -> strided 1x1 conv with folded BatchNorm -> ReLU, no transformer
 //        block; silero_vad.py:157-189 with is_v4).
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, bool LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true>
+// LSTM_OUT: 0 = [n][D][TOUT] (next layer / stage taps); 1 = fp32 LSTM-native tiles (common.h lstm_x_index); 2 = split-fp16
+//        LSTM-native tiles (common.h lstm_xh_index): what k_lstm_wavefront_h3f reads as MFMA B fragments, written through an
+//        LDS transpose so that every (chunk, step) leaves as two contiguous 128-byte rows (hi, lo) -- D == 64 only.
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true>
 __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
@@ -406,6 +409,37 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       const int ocol = 16 * wave + lc;
       const int ocb = ocol / T, ot = ocol - ocb * T;
       const int oitem = blockIdx.x * NCH + ocb;
+      if constexpr (LSTM_OUT == 2) {
+         static_assert(D == 64 || LSTM_OUT != 2, "split-fp16 LSTM hand-off is the last stage (64 units)");
+         // transpose through LDS (Bb is dead here): Zs[column][unit], then every thread converts 16 consecutive units of one
+         // column and stores 32 contiguous bytes of the hi row and of the lo row
+         float *Zs = Bb;                                   // 64 columns x pitch 65
+         __syncthreads();                                  // all waves are past their last read of Bb
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zs[ocol * 65 + 16 * mt + 4 * quad + r] = fmaxf(z[mt][r], 0.0f);
+         __syncthreads();
+         const int tcol = tid >> 2, u0 = 16 * (tid & 3);
+         const int tcb = tcol / T, tt = tcol - tcb * T;
+         const int titem = blockIdx.x * NCH + tcb;
+         if (tcol < NCOLV && titem < n_chunks && (tt % STRIDE) == 0) {
+            int st_, ch_;
+            map.split(titem, st_, ch_);
+            typedef _Float16 h8o __attribute__((ext_vector_type(8)));
+            _Float16 *dsth = reinterpret_cast<_Float16 *>(out) + lstm_xh_index(st_, ch_, map.C, tt / STRIDE, u0, TOUT);
+            h8o hi[2], lo[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+               const float v = Zs[tcol * 65 + u0 + e];
+               const _Float16 h = (_Float16)v;
+               hi[e >> 3][e & 7] = h;
+               lo[e >> 3][e & 7] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<h8o *>(dsth) = hi[0]; *reinterpret_cast<h8o *>(dsth + 8) = hi[1];
+            *reinterpret_cast<h8o *>(dsth + kLstmTile * 64) = lo[0]; *reinterpret_cast<h8o *>(dsth + kLstmTile * 64 + 8) = lo[1];
+         }
+      } else
       if (ocol < NCOLV && oitem < n_chunks && (ot % STRIDE) == 0) {
          constexpr int ostride = LSTM_OUT ? kLstmTile : TOUT;
          float *dst;
@@ -433,8 +467,9 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 3:
-      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, true, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 2, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 1, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 0, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
       break;
    }
 }
@@ -449,8 +484,9 @@ void launch_layer_v4(int layer, const float *in, const float *in2, const float *
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 12, 2, true, 0, false, 5, true, false>), dim3((n + 4) / 5), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 6, 2, false, 0, false, 10, true, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
-      if (lstm_layout) hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, true, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else             hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, false, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 2, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 1, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 0, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
       break;
    }
 }

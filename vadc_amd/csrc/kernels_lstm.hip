@@ -473,8 +473,12 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 constexpr int kHPitch = 72;                     // fp16 elements per stream row of an h tile (64 units + 8 pad)
 
-template <int TS, int DEC>
-__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__restrict__ gx,    // GX tiles from k_lstm_xproj
+// FUSED = false: layer 0's input projection arrives as GX (k_lstm_xproj), its recurrent K is the h half (64).
+// FUSED = true : no GX -- `gx` points at the encoder output in split-fp16 LSTM-native tiles (common.h lstm_xh_index, written by
+//                the last encoder stage), layer 0 runs the full K = 128 = [x_t ; h0] like layer 1, its x fragments are fetched
+//                from global one slot ahead (four 16-byte loads per lane), the accumulators start at the bias.
+template <int TS, int DEC, bool FUSED>
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__restrict__ gx,    // GX tiles, or split-fp16 X tiles (FUSED)
                                                               LstmWeights w,
                                                               float *__restrict__ hs, float *__restrict__ cs,
                                                               float *__restrict__ probs,
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    __shared__ float pd[2][4][2][kTileS];
    constexpr int kGxTile = TS * 256 * kLstmTile;
    __shared__ __attribute__((aligned(16))) float bl1[256];
+   __shared__ __attribute__((aligned(16))) float bl0[256];   // FUSED: layer-0 fused biases
 
    const int tid = threadIdx.x;
    const int lane = tid & 63;
@@ -504,12 +509,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    h8v ah[4][KB1], al[4][KB1];
 #pragma unroll
    for (int g = 0; g < 4; ++g) {
-      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + (L == 0 ? 64 : 0) + 8 * quad;
+      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + ((L == 0 && !FUSED) ? 64 : 0) + 8 * quad;
 #pragma unroll
       for (int kb = 0; kb < KB1; ++kb) {
 #pragma unroll
          for (int e = 0; e < 8; ++e) {
-            const float v = (L == 0 && kb >= KB0) ? 0.0f : row[32 * kb + e];
+            const float v = (L == 0 && !FUSED && kb >= KB0) ? 0.0f : row[32 * kb + e];
             const _Float16 hi = (_Float16)v;
             ah[g][kb][e] = hi;
             al[g][kb][e] = (_Float16)(v - (float)hi);
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
       }
    }
    float c[4], dw[2][4], hlast[4];
-   if (tid < 256) bl1[tid] = w.b[256 + tid];
+   if (tid < 256) { bl1[tid] = w.b[256 + tid]; bl0[tid] = w.b[tid]; }
    {
       h4v hi4, lo4;
 #pragma unroll
@@ -536,12 +541,23 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    int par0 = 0, par1 = 0;
    float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
    float gnext[4][4];
-   if (L == 0) {
+   // FUSED: this lane's x fragments of the NEXT step: k-blocks 0,1 (units 32 kb + 8 quad .. +7 of stream col), hi and lo
+   const _Float16 *xh_lane = reinterpret_cast<const _Float16 *>(gx) + (size_t)blockIdx.x * n_chunks * (TS * 2 * kTileS * 64) + col * 64 + 8 * quad;
+   h8v xnh[2], xnl[2];
+   if (L == 0 && !FUSED) {
       const float *p = gx_lane + (size_t)c0 * kGxTile;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
          const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
          gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
+      }
+   }
+   if (L == 0 && FUSED) {
+      const _Float16 *p = xh_lane + (size_t)c0 * TS * (2 * kTileS * 64);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+         xnh[kb] = *reinterpret_cast<const h8v *>(p + 32 * kb);
+         xnl[kb] = *reinterpret_cast<const h8v *>(p + kTileS * 64 + 32 * kb);
       }
    }
    __syncthreads();
@@ -554,7 +570,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
       const int chi = step / TS, t = step - chi * TS;
       if (active) {
          f4v acc[4];
-         if (L == 0) {
+         h8v xch[2], xcl[2];
+         if (L == 0 && !FUSED) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
             if (k + 1 < total) {
@@ -566,21 +583,39 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
                }
             }
          } else {
+            const float *bias = (L == 0) ? bl0 : bl1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-               const float4 b4 = *reinterpret_cast<const float4 *>(&bl1[g * 64 + 16 * wv + 4 * quad]);
+               const float4 b4 = *reinterpret_cast<const float4 *>(&bias[g * 64 + 16 * wv + 4 * quad]);
                acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
             }
+            if (L == 0) {                       // FUSED: take this step's x fragments, request the next step's
+               xch[0] = xnh[0]; xch[1] = xnh[1]; xcl[0] = xnl[0]; xcl[1] = xnl[1];
+               if (k + 1 < total) {
+                  const _Float16 *p = xh_lane + ((size_t)c0 * TS + (k + 1)) * (2 * kTileS * 64);
+#pragma unroll
+                  for (int kb = 0; kb < 2; ++kb) {
+                     xnh[kb] = *reinterpret_cast<const h8v *>(p + 32 * kb);
+                     xnl[kb] = *reinterpret_cast<const h8v *>(p + kTileS * 64 + 32 * kb);
+                  }
+               }
+            }
          }
-         // B fragments: k-blocks 0,1 = h0 (both layers), 2,3 = h1 (layer 1 only); lane reads units 32 kb' + 8 quad .. +7 of stream col
-         const int nkb = (L == 0) ? KB0 : KB1;
+         // B fragments.  Layer 1: k-blocks 0,1 = h0, 2,3 = h1.  Layer 0: (hoisted) k-blocks 0,1 = h0; (FUSED) 0,1 = x_t from global,
+         // 2,3 = h0.  A lane reads units 32 kb' + 8 quad .. +7 of stream col.
+         const int nkb = (L == 0 && !FUSED) ? KB0 : KB1;
 #pragma unroll
          for (int kb = 0; kb < KB1; ++kb) {
             if (kb < nkb) {
-               const _Float16 *base = (kb < 2) ? hb[0][par0][0] : hb[1][par1][0];
-               const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
-               const h8v bh = *reinterpret_cast<const h8v *>(base + off);
-               const h8v bl = *reinterpret_cast<const h8v *>(base + kTileS * kHPitch + off);
+               h8v bh, bl;
+               if (L == 0 && FUSED && kb < 2) { bh = xch[kb]; bl = xcl[kb]; }
+               else {
+                  const bool from_h1 = (L == 1) && (kb >= 2);
+                  const _Float16 *base = from_h1 ? hb[1][par1][0] : hb[0][par0][0];
+                  const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
+                  bh = *reinterpret_cast<const h8v *>(base + off);
+                  bl = *reinterpret_cast<const h8v *>(base + kTileS * kHPitch + off);
+               }
 #pragma unroll
                for (int g = 0; g < 4; ++g) {
                   acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kb], bh, acc[g], 0, 0, 0);
@@ -802,12 +837,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 void launch_lstm(int variant, const float *enc, float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
                  int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
-   if (model == 1 && variant == 5)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   if (model == 1 && variant == 6)
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1, true>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (variant == 6)
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0, true>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else if (model == 1 && variant == 5)
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1, false>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (model == 1)
       hipLaunchKernelGGL((k_lstm_wavefront<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 5)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0, false>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 1)
       hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    else if (variant == 3)
