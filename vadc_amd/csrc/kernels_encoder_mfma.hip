@@ -68,6 +68,16 @@ __device__ __forceinline__ float norm_offset_m(const float *__restrict__ fmp, si
    return total / (float)kFrames;
 }
 
+// full-wave lane shifts (gfx9 DPP wave_shr / wave_shl): lane i <- lane i-1 / lane i+1, 0 shifted in at the ends
+__device__ __forceinline__ float dpp_wave_shr1(float v)
+{
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v)
+{
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // acc[mt] (+)= W[16mt.., :] . X[:, wave's 16 columns]   for mt < MT, K = 4*KK rows of X starting at xrow0.
 // wf: fragment-major weights [MT][KKW][64] (KKW = k-steps per M-tile in memory), kk0 = first k-step to use.
 template <int MT, int KK>
@@ -258,30 +268,34 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    for (int s = 0; s < NSLAB; ++s) {
       const int c0 = s * kSlab;
       if (s > 0) __syncthreads();                        // previous slab fully consumed
+      // In the slab path a wave's 64 lanes ARE the 64 columns, so the depthwise conv's time neighbours are the adjacent
+      // lanes: x(t-1), x(t-2), x(t+1), x(t+2) come from DPP wave shifts of the value that is in a register anyway, not from
+      // an LDS round trip behind a barrier.  depthwise k5 pad2 + ReLU: conv.c:17-53.
+      float xc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
          const int r = wave * 8 + i, ch = c0 + r;
-         XS[r * kPitch + col] = (cvalid && ch < CIN) ? xv[i] - ((FIRST == 2 && ch < kBins) ? 0.0f : mm) : 0.0f;  // misc.c:84-96
+         xc[i] = (cvalid && ch < CIN) ? xv[i] - ((FIRST == 2 && ch < kBins) ? 0.0f : mm) : 0.0f;  // misc.c:84-96
+         XS[r * kPitch + col] = xc[i];
       }
-      __syncthreads();
       if (s + 1 < NSLAB) {
 #pragma unroll
          for (int i = 0; i < 8; ++i) xv[i] = load_x(c0 + kSlab + wave * 8 + i);
       }
-      // depthwise k5 pad2 + ReLU (conv.c:17-53): neighbours are adjacent columns of the same chunk
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
          const int r = wave * 8 + i, ch = c0 + r;
+         const float xm1 = dpp_wave_shr1(xc[i]), xm2 = dpp_wave_shr1(xm1);
+         const float xp1 = dpp_wave_shl1(xc[i]), xp2 = dpp_wave_shl1(xp1);
          float dv = 0.0f;
-         if (ch < CIN) {
+         if (ch < CIN) {                                 // wave-uniform
             const float *k = w.dw_w + ch * 5;
-            const float *xr = XS + r * kPitch + col;
             dv = w.dw_b[ch];
-            dv = fmaf(t >= 2 ? xr[-2] : 0.0f, k[0], dv);
-            dv = fmaf(t >= 1 ? xr[-1] : 0.0f, k[1], dv);
-            dv = fmaf(xr[0], k[2], dv);
-            dv = fmaf(t + 1 < T ? xr[1] : 0.0f, k[3], dv);
-            dv = fmaf(t + 2 < T ? xr[2] : 0.0f, k[4], dv);
+            dv = fmaf(t >= 2 ? xm2 : 0.0f, k[0], dv);
+            dv = fmaf(t >= 1 ? xm1 : 0.0f, k[1], dv);
+            dv = fmaf(xc[i], k[2], dv);
+            dv = fmaf(t + 1 < T ? xp1 : 0.0f, k[3], dv);
+            dv = fmaf(t + 2 < T ? xp2 : 0.0f, k[4], dv);
             dv = fmaxf(dv, 0.0f);
          }
          DWR[r * kPitch + col] = cvalid ? dv : 0.0f;
