@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    float *XS = Bb, *DWR = Bb + kSlab * kPitch;          // slab path only (aliases Q/K/V)
 
    const int tid = threadIdx.x;
-   const int lane = tid & 63, wave = tid >> 6;
+   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: per-row weights become scalar loads
    const int quad = lane >> 4, lc = lane & 15;
 
    __shared__ float mm_s[FIRST ? NCH : 1];
