@@ -517,6 +517,28 @@ def test_cli_empty_and_short_input():
     assert lines == []
 
 
+@pytest.mark.parametrize("S,C,groups,calls", [
+    (1, 1, 0, 5), (3, 2, 0, 4), (17, 5, 0, 3), (33, 31, 2, 2), (100, 24, 0, 2), (130, 16, 4, 2), (257, 8, 0, 2), (520, 4, 1, 2),
+    (1030, 2, 0, 2), (2049, 1, 0, 3),
+])
+def test_shapes_sweep_against_oracle(weights_blob, orc, S, C, groups, calls):
+    """ragged stream counts (vs the 16-stream LSTM tile, the CU-partition thresholds at 256 / 1024 streams, the 2048-chunk
+    fork threshold), several calls with carried state: a sample of streams is checked against the oracle"""
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=C, device=0)
+    e.set_option("groups", groups)
+    base = synth.make_streams(min(S, 8), C * calls, seed0=1000 + S)
+    pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+    got = np.concatenate([e.run(pcm[:, k * C * 1536:(k + 1) * C * 1536]) for k in range(calls)], axis=1)[:, :, 1]
+    e.close()
+    pick = sorted({0, S - 1, S // 2, min(S - 1, 15), min(S - 1, 16)})
+    for s in pick:
+        want = orc.forward_stream(pcm[s])[:, 1]
+        assert float(np.abs(got[s] - want).max()) < PROB_TOL, (s, float(np.abs(got[s] - want).max()))
+    # identical input streams must give identical outputs wherever they sit (tile position, partition round)
+    for s in range(base.shape[0], S, max(1, S // 7)):
+        assert np.array_equal(got[s], got[s % base.shape[0]])
+
+
 # ---------------------------------------------------------------------------------------------- long streams
 def test_long_stream_statistics(weights_blob, orc):
     """2000 chunks (192 s) of one stream against the oracle: the 1e-4 bar sits at the reference's own fp32 noise floor

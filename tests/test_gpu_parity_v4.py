@@ -87,6 +87,21 @@ def test_chunk_group_pipeline_matches_single_launch(eng, orc):
     assert float(np.abs(out[1][:6] - ref).max()) < PROB_TOL
 
 
+@pytest.mark.parametrize("S,C,calls", [(1, 3, 3), (18, 7, 2), (129, 16, 2), (700, 3, 2), (2049, 1, 2)])
+def test_shapes_sweep_against_oracle(blob, orc, S, C, calls):
+    """ragged stream counts and several calls with carried state (ragged vs the 4-chunk front-end groups and 21-chunk last stage)"""
+    e = Engine(blob, max_streams=S, max_chunks_per_call=C, device=0)
+    base = synth.make_streams(min(S, 6), C * calls, seed0=2000 + S)
+    pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+    got = np.concatenate([e.run(pcm[:, k * C * 1536:(k + 1) * C * 1536]) for k in range(calls)], axis=1)[:, :, 1]
+    e.close()
+    for s in sorted({0, S - 1, S // 2, min(S - 1, 16)}):
+        want = orc.forward_stream(pcm[s])
+        assert float(np.abs(got[s] - want).max()) < PROB_TOL, (s, float(np.abs(got[s] - want).max()))
+    for s in range(base.shape[0], S, max(1, S // 7)):
+        assert np.array_equal(got[s], got[s % base.shape[0]])
+
+
 @pytest.mark.parametrize("ci", [0, 20])
 def test_stage_taps(eng, gold, ci):
     x = f32(gold["pcm_speech0"])[ci * 1536:(ci + 1) * 1536]
