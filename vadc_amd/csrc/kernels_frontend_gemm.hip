@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
    __shared__ __attribute__((aligned(16))) float X1[kGChunks * kGChunkPitch];
    __shared__ __attribute__((aligned(16))) float nyq_s[128];
    __shared__ float bsum[4][kGChunks * kV4Frames];
+   __shared__ float nyv[kGChunks * kV4Frames];          // log value of bin 128 per position (whichever wave computed it)
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int f = lane & 15, g = lane >> 4;
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
             const float val = log1p_hw(mag * 1048576.0f);
             if (g == 0) {
                if (ok) { Y[ybase + (size_t)128 * kV4Frames] = val; MAG[ybase + (size_t)128 * kV4Frames] = mag; }
-               part += val;
+               nyv[pos] = val;                             // added to partial 3 below: the sum must not depend on which wave took it
             }
          }
          part += __shfl_xor(part, 16);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
          const int wv = i / (kGChunks * kV4Frames), pos = i - wv * (kGChunks * kV4Frames);
          const int c = pos / kV4Frames, fr = pos - c * kV4Frames;
          const int item = grp * kGChunks + c;
-         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kV4Frames + fr] = bsum[wv][pos];
+         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kV4Frames + fr] = (wv == 3) ? bsum[3][pos] + nyv[pos] : bsum[wv][pos];
       }
    }
 }
