@@ -144,8 +144,9 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                                      fused input projection, 4 = fp32 wavefront with hoisted input projection,
  *                                      5 = split-fp16 wavefront with hoisted input projection, 6 = split-fp16 wavefront with the
  *                                      projection inside (the last encoder stage hands over split-fp16 tiles; what auto picks)
- *                             "frontend" v3.1: 0 = k_frontend (bit-exact VALU tree, default), 1 = k_frontend_mx2 (products issued as MFMA
- *                                      K=1; experimental, bit-identical, not faster: fp32 MFMA shares the vector ALU lanes);
+ *                             "frontend" v3.1: 0 = k_frontend_fl (bit-exact VALU tree, one lane per frame, default), 1 = k_frontend_mx2
+ *                                      (products issued as MFMA K=1; experimental, bit-identical, not faster: fp32 MFMA shares the
+ *                                      vector ALU lanes), 2 = k_frontend (the same tree with one lane per 64-sample block and wave shifts);
  *                                      v4: 0 = k_frontend_gemm_v4 (folded STFT GEMM on the fp16 matrix pipe, default),
  *                                      1 = the tree kernel with the v4 geometry
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels

@@ -83,9 +83,10 @@ def test_stft_edge_inputs_bit_exact(eng, orc, kind):
         assert np.array_equal(bits(got[i]), bits(taps["magnitude"]))
 
 
-@pytest.mark.parametrize("variant", [1])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_frontend_variants_bit_identical(eng, gold_py, variant):
-    """k_frontend_mx2 (products on v_mfma_f32_16x16x1 with C = 0) and k_frontend (VALU) evaluate the same fp32 tree"""
+    """k_frontend_fl (default: one lane per frame), k_frontend_mx2 (1: products on v_mfma_f32_16x16x1 with C = 0) and k_frontend
+    (2: one lane per block + wave shifts) evaluate the same fp32 tree"""
     x = f32(gold_py["pcm_speech1"])[: 37 * 1536]
     eng.set_option("frontend", 0); a = eng.stage_from_samples(x, "magnitude"); an = eng.stage_from_samples(x, "normalized")
     eng.set_option("frontend", variant); b = eng.stage_from_samples(x, "magnitude"); bn = eng.stage_from_samples(x, "normalized")

@@ -38,6 +38,28 @@ static float run(const char *name, const int16_t *pcm, const float *basis, float
    return ms;
 }
 
+template <int MODE, int NB, int MINW>
+static float run_fl(const char *name, const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int reps)
+{
+   const dim3 blocks((unsigned)(((long)n * kFrames + 63) / 64));
+   const size_t fm_stride = (size_t)n * kFrames;
+   const ItemMap map{n, 0, n};
+   hipEvent_t a, b;
+   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+   hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW>), blocks, dim3(256), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
+   CK(hipDeviceSynchronize());
+   CK(hipEventRecord(a, 0));
+   for (int r = 0; r < reps; ++r)
+      hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW>), blocks, dim3(256), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
+   CK(hipEventRecord(b, 0));
+   CK(hipEventSynchronize(b));
+   float ms = 0;
+   CK(hipEventElapsedTime(&ms, a, b));
+   ms /= reps;
+   printf("%-44s mode %d  %8.4f ms  %7.2f Mchunks/s\n", name, MODE, ms, n / ms / 1e3);
+   return ms;
+}
+
 int main(int argc, char **argv)
 {
    const int n = argc > 1 ? atoi(argv[1]) : 16384;
@@ -45,7 +67,7 @@ int main(int argc, char **argv)
    std::vector<int16_t> h_pcm((size_t)n * kChunk);
    srand(1);
    for (auto &v : h_pcm) v = (int16_t)((rand() % 20001) - 10000);
-   std::vector<float> h_basis((size_t)kFilters * kFilterLen + 64);
+   std::vector<float> h_basis((size_t)kFilters * kFilterLen + 1024);   // slack: the pipelines prefetch past the last filter
    for (auto &v : h_basis) v = (float)((rand() % 2001) - 1000) / 1000.0f;
    int16_t *pcm; float *basis, *Y0, *Y1, *FM;
    CK(hipMalloc(&pcm, h_pcm.size() * 2)); CK(hipMalloc(&basis, h_basis.size() * 4));
@@ -61,6 +83,33 @@ int main(int argc, char **argv)
       printf("   %-41s %s (%zu mismatching words)\n", name, bad ? "MISMATCH" : "bit-identical to baseline", bad);
    };
    printf("n_chunks = %d\n", n);
+   if (argc > 2 && !strcmp(argv[2], "fl")) {          // frame-lane kernel against the shipped k_frontend: magnitudes, log values and FM
+      float *FM1;
+      CK(hipMalloc(&FM1, (size_t)kBinSplit * n * kFrames * 4));
+      std::vector<float> fref((size_t)kBinSplit * n * kFrames), fgot(fref.size());
+      auto check_fm = [&](const char *name) {
+         CK(hipMemcpy(fgot.data(), FM1, fgot.size() * 4, hipMemcpyDeviceToHost));
+         size_t bad = 0;
+         for (size_t i = 0; i < fgot.size(); ++i) if (memcmp(&fgot[i], &fref[i], 4)) ++bad;
+         printf("   %-41s FM %s (%zu mismatching words)\n", name, bad ? "MISMATCH" : "bit-identical to baseline", bad);
+      };
+      run<1, 256, 4, 0, 0, 0, 0, 2>("k_frontend PK2 w4 (shipped), magnitude", pcm, basis, Y0, FM, n, reps);
+      CK(hipMemcpy(ref.data(), Y0, ref.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      run_fl<1, 3, 4>("fl nb3 w4, magnitude", pcm, basis, Y1, FM1, n, reps);          check("fl nb3 w4", Y1);
+      run_fl<1, 3, 3>("fl nb3 w3, magnitude", pcm, basis, Y1, FM1, n, reps);          check("fl nb3 w3", Y1);
+      run_fl<1, 3, 2>("fl nb3 w2, magnitude", pcm, basis, Y1, FM1, n, reps);          check("fl nb3 w2", Y1);
+      run_fl<1, 1, 4>("fl nb1 w4, magnitude", pcm, basis, Y1, FM1, n, reps);          check("fl nb1 w4", Y1);
+      run_fl<1, 1, 5>("fl nb1 w5, magnitude", pcm, basis, Y1, FM1, n, reps);          check("fl nb1 w5", Y1);
+      run<0, 256, 4, 0, 0, 0, 0, 2>("k_frontend PK2 w4 (shipped), log mode", pcm, basis, Y0, FM, n, reps);
+      CK(hipMemcpy(ref.data(), Y0, ref.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(fref.data(), FM, fref.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      run_fl<0, 3, 4>("fl nb3 w4, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb3 w4 log", Y1); check_fm("fl nb3 w4 log");
+      run_fl<0, 3, 3>("fl nb3 w3, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb3 w3 log", Y1); check_fm("fl nb3 w3 log");
+      run_fl<0, 1, 4>("fl nb1 w4, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb1 w4 log", Y1); check_fm("fl nb1 w4 log");
+      return 0;
+   }
    //            MODE NT  MINW SHIFT LOCK STAG
    run<1, 256, 3, 0, 0, 0>("baseline nt256 w3 bperm", pcm, basis, Y0, FM, n, reps);
    CK(hipMemcpy(ref.data(), Y0, ref.size() * 4, hipMemcpyDeviceToHost));

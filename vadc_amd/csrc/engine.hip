@@ -17,6 +17,8 @@
 namespace vadc {
 void launch_frontend_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
@@ -123,7 +125,7 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    const float *d_basis_mx2 = nullptr;          // k_frontend_mx2: [17 tiles][l][i][j/4][16 filters][j%4]
-   int frontend_variant = 0;                    // 0 = k_frontend (all VALU, default), 1 = k_frontend_mx2 (products issued as MFMA, experimental)
+   int frontend_variant = 0;                    // v3.1: 0 = k_frontend_fl (one lane per frame, default), 1 = k_frontend_mx2 (products issued as MFMA, experimental), 2 = k_frontend (one lane per block + wave shifts)
    LayerWeights lw[4];
    LayerWeightsM lwm[4];
    int encoder_variant = 0;                     // 0 = MFMA layers, 1 = VALU bring-up layers
@@ -224,7 +226,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                   }
       off_basis_mx2 = pk.add(bt.data(), bt.size());
    }
-   pk.add(nullptr, 64);   // the pipeline's final prefetch reads 32 floats past filter 129's start: keep slack anyway
+   pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
                  size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f; } lo[4];
@@ -641,7 +643,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return VADC_AMD_OK;
    }
    if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 6) { e->lstm_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
+   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 2) {
       if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
          return fail(VADC_AMD_EINVAL, "set_option: frontend=1 indexes Y with 32-bit offsets; workspace too large");
       e->frontend_variant = value;
@@ -719,9 +721,12 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       } else if (e->frontend_variant == 1) {
          if (sizeof(T) == 2) launch_frontend_mx2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_mx2_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-      } else {
+      } else if (e->frontend_variant == 2) {
          if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+      } else {
+         if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+         else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       }
    }
    if (st != st_enc) {
@@ -1096,7 +1101,8 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
       launch_frontend_gemm_v4_f32(e->d_in_f32, e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   else launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   else if (e->frontend_variant == 2) launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);

@@ -340,6 +340,208 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
 }
 
 
+
+// =====================================================================================================
+// k_frontend_fl -- the same bit-exact tree with one LANE per FRAME ("frame-lane"), no halo, no wave shifts
+// =====================================================================================================
+// k_frontend gives a lane one 64-sample block and moves group sums between lanes: 3 halo lanes per wave and the 3 blocks of
+// a chunk that only feed their neighbours leave 85 % of the lanes producing outputs, and every filter pair costs 48
+// ds_bpermute.  Here a lane owns one (chunk, frame) POSITION and evaluates the whole 256-tap tree of stft.c:115-184 itself:
+//     for l-pair LP (tree lanes 2LP, 2LP+1), group i:  g_i = tree8_j( x[64 (n+i) + 8 j + l] * k[64 i + 8 j + l] )   (packed pair)
+//     v = (g_0 + g_1) + (g_2 + g_3) ;  y = ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7))  accumulated as the l-pairs complete
+// -- the same IEEE operations in the same order, so Y and FM are bit-identical to k_frontend's.  The 16 samples a step
+// (LP, i) needs are four ds_read_b128 from the workgroup's tile of reflect-padded chunks (block pitch 68 floats: the
+// 16 lanes of a read phase hit disjoint banks; inside a block sample 8 j + l sits at 16 (l/2) + 2 j + l%2, so an l-pair's
+// taps for j, j+1 are one aligned 16-byte read = two v_pk operands), prefetched one step ahead into the other register
+// set, and are shared by the 2 NB filters of a bin batch, whose partial trees stay in registers (6 VGPRs per filter).
+// The basis taps stay wave-uniform SCALAR loads from the same permuted basis k_frontend uses (one s_load_dwordx16 = the
+// 16 taps of one (filter, i, LP)), software-pipelined one stage (= re + im of one bin) ahead.
+// A workgroup = 64 consecutive positions (at most 4 chunks staged once) x 4 waves = the 4 bin splits of common.h, so FM
+// keeps the partial-sum order the first encoder layer expects.  Every lane produces an output: lane efficiency ~100 %.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int kFlBlockPitch = 68;
+constexpr int kFlChunks = 4;                                  // 64 consecutive positions span at most 4 chunks
+
+#define VADC_FL_SLOAD2(A, B, BASE, OFFA, OFFB)                                          \
+   asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"              \
+                : "=&s"(A), "=&s"(B)                                                     \
+                : "s"(BASE), "n"(OFFA), "n"(OFFB));                                       \
+   __builtin_amdgcn_sched_barrier(0)
+#define VADC_FL_LDS16(X, ADDR, OFF)                                                     \
+   asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"    \
+                "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"        \
+                : "=&v"(X[0]), "=&v"(X[1]), "=&v"(X[2]), "=&v"(X[3])                     \
+                : "v"(ADDR), "n"(OFF), "n"((OFF) + 16), "n"((OFF) + 32), "n"((OFF) + 48)); \
+   __builtin_amdgcn_sched_barrier(0)
+
+// g = ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)),  q_j = (x[8j+l], x[8j+l+1]) * (k[j][l], k[j][l+1])   (stft.c:141-160)
+__device__ __forceinline__ f2v fl_tree8(const f4v (&xq)[4], const f16v &kv)
+{
+   const f2v q0 = __builtin_shufflevector(xq[0], xq[0], 0, 1) * (f2v){kv[0], kv[1]};
+   const f2v q1 = __builtin_shufflevector(xq[0], xq[0], 2, 3) * (f2v){kv[2], kv[3]};
+   const f2v q2 = __builtin_shufflevector(xq[1], xq[1], 0, 1) * (f2v){kv[4], kv[5]};
+   const f2v q3 = __builtin_shufflevector(xq[1], xq[1], 2, 3) * (f2v){kv[6], kv[7]};
+   const f2v q4 = __builtin_shufflevector(xq[2], xq[2], 0, 1) * (f2v){kv[8], kv[9]};
+   const f2v q5 = __builtin_shufflevector(xq[2], xq[2], 2, 3) * (f2v){kv[10], kv[11]};
+   const f2v q6 = __builtin_shufflevector(xq[3], xq[3], 0, 1) * (f2v){kv[12], kv[13]};
+   const f2v q7 = __builtin_shufflevector(xq[3], xq[3], 2, 3) * (f2v){kv[14], kv[15]};
+   const f2v a01 = q0 + q1, a23 = q2 + q3, a45 = q4 + q5, a67 = q6 + q7;
+   const f2v a0123 = a01 + a23, a4567 = a45 + a67;
+   return a0123 + a4567;
+}
+
+// per-filter partial trees of a bin batch (filter 2b = re of bin b, 2b+1 = im)
+template <int NB>
+struct FlState {
+   f2v ta[2 * NB], tb[2 * NB];      // g_0 (+ g_1), g_2 (+ g_3) of the current l-pair
+   float sa[2 * NB], sb[2 * NB];    // (v0+v1) (+ (v2+v3)),  (v4+v5)
+   float y[2 * NB];
+};
+
+template <int I, int LP, int NB>
+__device__ __forceinline__ void fl_accumulate(FlState<NB> &st, int fi, f2v g)
+{
+   if (I == 0) st.ta[fi] = g;
+   else if (I == 1) st.ta[fi] = st.ta[fi] + g;                   // g_0 + g_1   (stft.c:165)
+   else if (I == 2) st.tb[fi] = g;
+   else {
+      const f2v t23 = st.tb[fi] + g;                             // g_2 + g_3   (stft.c:166)
+      const f2v v = st.ta[fi] + t23;                             // stft.c:167
+      const float s = v.x + v.y;                                 // stft.c:176-184, as the l-pairs complete
+      if (LP == 0) st.sa[fi] = s;
+      else if (LP == 1) st.sa[fi] = st.sa[fi] + s;
+      else if (LP == 2) st.sb[fi] = s;
+      else { const float s4567 = st.sb[fi] + s; st.y[fi] = st.sa[fi] + s4567; }
+   }
+}
+
+// byte offset of the 16 taps of (bin b of the batch, group i, l-pair lp) from the batch's first filter; basis layout
+// [f][ii = 3 - i][lp][j][l % 2] (engine.hip), re and im rows of a bin are kBins rows apart
+constexpr int fl_tap_off(int b, int i, int lp) { return b * 1024 + (3 - i) * 256 + lp * 64; }
+
+// Stage K of a batch = (step S = K / NB = 4 LP + I, bin B = K % NB).  On entry ca/cb hold the taps of this stage (waited
+// for) and xc the samples of this step; the stage requests the next stage's taps into na/nb and, at B == 0, the next
+// step's samples into xn.  After the last stage ca/cb and xc are again "current" for the next batch (16 NB stages and 16
+// steps are even counts, so the buffers end where they started).
+template <int NB, int K>
+struct FlStages {
+   static __device__ __forceinline__ void run(FlState<NB> &st, const float *kf, unsigned xaddr, f16v &ca, f16v &cb, f16v &na, f16v &nb,
+                                              f4v (&xc)[4], f4v (&xn)[4])
+   {
+      constexpr int S = K / NB, B = K % NB, LP = S / 4, I = S % 4;
+      constexpr int Kn = K + 1;
+      constexpr int Sn = (Kn / NB) % 16, Bn = Kn % NB, LPn = Sn / 4, In = Sn % 4;
+      constexpr int noff = (Kn == 16 * NB ? NB * 1024 : 0) + fl_tap_off(Bn, In, LPn);
+      constexpr int kImOffB = kBins * kFilterLen * 4;
+      if constexpr (B == 0) {
+         constexpr int S1 = (S + 1) % 16;
+         VADC_FL_LDS16(xn, xaddr, ((S1 % 4) * kFlBlockPitch + (S1 / 4) * 16) * 4);
+      }
+      VADC_FL_SLOAD2(na, nb, kf, noff, noff + kImOffB);
+      fl_accumulate<I, LP, NB>(st, 2 * B, fl_tree8(xc, ca));
+      fl_accumulate<I, LP, NB>(st, 2 * B + 1, fl_tree8(xc, cb));
+      if constexpr (B == NB - 1) {
+         // two statements: an asm with SGPR and VGPR outputs counts as a divergent source and its taps would be copied to VGPRs
+         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
+         __builtin_amdgcn_sched_barrier(0);
+         FlStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
+      } else {
+         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         __builtin_amdgcn_sched_barrier(0);
+         FlStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
+      }
+   }
+};
+template <int NB>
+struct FlStages<NB, 16 * NB> {
+   static __device__ __forceinline__ void run(FlState<NB> &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
+};
+
+// MODE as k_frontend (0: Y = log1p(2^20 m) + FM partial bin sums; 1: Y = magnitude).  NB = bins per batch; kBinsPerSplit = 33 and
+// the last split's 30 bins are both multiples of 3.
+template <typename T, int MODE, int NB = 3, int MINW = 4>
+__global__ __launch_bounds__(256, MINW) void k_frontend_fl(const T *__restrict__ pcm,          // [n_chunks][1536]
+                                                           const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
+                                                           float *__restrict__ Y,              // [n_chunks][129][25]
+                                                           float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
+                                                           int n_chunks, ItemMap map, size_t fm_stride)
+{
+   static_assert(kBinsPerSplit % NB == 0 && (kBins - 3 * kBinsPerSplit) % NB == 0, "bin batches must tile every split");
+   static_assert((16 * NB) % 2 == 0, "tap buffers must end where they started");
+   constexpr int kChunkPitch = kBlocks * kFlBlockPitch;          // 1904 floats per chunk
+   __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kChunkPitch];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const long total_pos = (long)n_chunks * kFrames;
+   const long p0 = (long)blockIdx.x * 64;
+   const int item0 = (int)(p0 / kFrames);
+
+   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954), l-pair-major inside a block
+   for (int c = 0; c < kFlChunks; ++c) {
+      const int it = min(item0 + c, n_chunks - 1);
+      const T *src = pcm + (size_t)map(it) * kChunk;
+      for (int idx = tid; idx < kPadded; idx += 256) {
+         int s = idx - kPad;
+         s = s < 0 ? -s : s;
+         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
+         const int k = idx & 63, j = k >> 3, l = k & 7;
+         xs[c * kChunkPitch + (idx >> 6) * kFlBlockPitch + (l >> 1) * 16 + j * 2 + (l & 1)] = sample_to_f32(src[s]);
+      }
+   }
+   __syncthreads();
+
+   const long pe = p0 + lane;
+   const bool writer = pe < total_pos;
+   const long pa_ = writer ? pe : total_pos - 1;
+   const int item = (int)(pa_ / kFrames), n = (int)(pa_ - (long)item * kFrames);
+   const int chunk = map(item);
+   typedef __attribute__((address_space(3))) float lds_f;
+   const unsigned xaddr = (unsigned)(uintptr_t)(lds_f *)(xs + (item - item0) * kChunkPitch + kFlBlockPitch * n);
+
+   const int f_start = wave * kBinsPerSplit;
+   const int f_end = min(f_start + kBinsPerSplit, kBins);
+   float *yout = Y + (size_t)chunk * (kBins * kFrames) + n;
+   float bin_sum = 0.0f;
+   constexpr int kImOffB = kBins * kFilterLen * 4;
+
+   f16v ca, cb, na, nb;
+   f4v xc[4], xn[4];
+   {
+      const float *k0 = basis + (size_t)f_start * kFilterLen;
+      VADC_FL_LDS16(xc, xaddr, 0);
+      VADC_FL_SLOAD2(ca, cb, k0, fl_tap_off(0, 0, 0), fl_tap_off(0, 0, 0) + kImOffB);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
+      asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
+      __builtin_amdgcn_sched_barrier(0);
+   }
+#pragma unroll 1
+   for (int f = f_start; f < f_end; f += NB) {
+      const float *kf = basis + (size_t)f * kFilterLen;          // wave-uniform
+      FlState<NB> st;
+      FlStages<NB, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
+      // pin the trees here: with the stores below under `if (writer)`, machine sinking would otherwise move the arithmetic
+      // of a whole bin into the epilogue's blocks, far below the taps it consumes (spilling every tap on the way)
+#pragma unroll
+      for (int b = 0; b < 2 * NB; ++b) asm volatile("" : "+v"(st.y[b]));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+         const float re = st.y[2 * b], im = st.y[2 * b + 1];
+         const float re2 = re * re, im2 = im * im;
+         const float mag = sqrtf(re2 + im2);                                  // stft.c:209
+         float val;
+         if (MODE == 0) {
+            val = log1p_hw(mag * 1048576.0f);                                 // misc.c:42-45
+            bin_sum += val;                                                   // misc.c:55-59 (channel order)
+         } else {
+            val = mag;
+         }
+         if (writer) yout[(f + b) * kFrames] = val;
+      }
+   }
+   if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
+}
+
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
 template <int kFrames>
@@ -411,6 +613,20 @@ void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float
    const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
    if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
    else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+}
+
+void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_fl<float, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+}
+
+void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+{
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
