@@ -5,6 +5,7 @@
 // bits (magnitudes in MODE 1; MODE 0 outputs except the rotated-order mean of STAGGER variants).
 #include "../vadc_amd/csrc/kernels_frontend.hip"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,23 +39,63 @@ static float run(const char *name, const int16_t *pcm, const float *basis, float
    return ms;
 }
 
-template <int MODE, int NB, int MINW>
-static float run_fl(const char *name, const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int reps)
+// "lstm": a latency-bound MFMA + LDS chain on 16 workgroups of 512 threads on CUs 0..7, concurrently with every timed launch
+__global__ __launch_bounds__(512) void k_dummy_chain(float *out, int iters)
 {
-   const dim3 blocks((unsigned)(((long)n * kFrames + 63) / 64));
+   __shared__ float sh[8192];
+   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+   typedef float f4 __attribute__((ext_vector_type(4)));
+   f4 acc = {0, 0, 0, 0};
+   h8 a, b;
+   for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f); b[e] = (_Float16)0.5f; }
+   for (int i = threadIdx.x; i < 8192; i += 512) sh[i] = i;
+   __syncthreads();
+   for (int it = 0; it < iters; ++it) {
+      for (int j = 0; j < 12; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+      sh[(threadIdx.x * 4 + it) & 8191] = acc[0];
+      __syncthreads();
+      acc[1] += sh[(threadIdx.x * 7 + it) & 8191];
+   }
+   out[blockIdx.x * 512 + threadIdx.x] = acc[0] + acc[1];
+}
+static hipStream_t g_stb = 0;
+static float *g_dummy_out = nullptr;
+static int g_dummy_iters = 0;
+static hipStream_t g_st = 0;                     // "mask": a stream restricted to CUs 8..255 like the engine's stream A
+static bool g_cold = false;
+static void *g_scratch = nullptr;
+template <int MODE, int NB, int MINW, int ABL = 0, int NPS = 1>
+static float run_fl(const char *name, const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int reps, int dyn_lds = 0)
+{
+   const dim3 blocks((unsigned)(((long)n * kFrames + 64 * NPS - 1) / (64 * NPS)));
    const size_t fm_stride = (size_t)n * kFrames;
    const ItemMap map{n, 0, n};
    hipEvent_t a, b;
    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-   hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW>), blocks, dim3(256), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
+   hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, 0, pcm, basis, Y, FM, n, map, fm_stride);
    CK(hipDeviceSynchronize());
-   CK(hipEventRecord(a, 0));
-   for (int r = 0; r < reps; ++r)
-      hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW>), blocks, dim3(256), 0, 0, pcm, basis, Y, FM, n, map, fm_stride);
-   CK(hipEventRecord(b, 0));
-   CK(hipEventSynchronize(b));
    float ms = 0;
-   CK(hipEventElapsedTime(&ms, a, b));
+   if (g_cold) {                                  // single launches, each after an unrelated 256 MB memset (cold caches, no back-to-back overlap)
+      for (int r = 0; r < reps; ++r) {
+         CK(hipMemsetAsync(g_scratch, r, (size_t)256 << 20, g_st));
+         CK(hipStreamSynchronize(g_st));
+         if (g_dummy_iters) hipLaunchKernelGGL(k_dummy_chain, dim3(16), dim3(512), 0, g_stb, g_dummy_out, g_dummy_iters);
+         CK(hipEventRecord(a, g_st));
+         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride);
+         CK(hipEventRecord(b, g_st));
+         CK(hipEventSynchronize(b));
+         float t = 0;
+         CK(hipEventElapsedTime(&t, a, b));
+         ms += t;
+      }
+   } else {
+      CK(hipEventRecord(a, g_st));
+      for (int r = 0; r < reps; ++r)
+         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride);
+      CK(hipEventRecord(b, g_st));
+      CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms, a, b));
+   }
    ms /= reps;
    printf("%-44s mode %d  %8.4f ms  %7.2f Mchunks/s\n", name, MODE, ms, n / ms / 1e3);
    return ms;
@@ -69,6 +110,23 @@ int main(int argc, char **argv)
    for (auto &v : h_pcm) v = (int16_t)((rand() % 20001) - 10000);
    std::vector<float> h_basis((size_t)kFilters * kFilterLen + 1024);   // slack: the pipelines prefetch past the last filter
    for (auto &v : h_basis) v = (float)((rand() % 2001) - 1000) / 1000.0f;
+   if (argc > 4 && !strcmp(argv[4], "real")) {     // a windowed-DFT basis in the engine's permuted layout and speech-like input (low level, silences)
+      for (int f = 0; f < kFilters; ++f)
+         for (int ii = 0; ii < 4; ++ii)
+            for (int lp = 0; lp < 4; ++lp)
+               for (int j = 0; j < 8; ++j)
+                  for (int b = 0; b < 2; ++b) {
+                     const int t = 64 * (3 - ii) + 8 * j + (2 * lp + b), bin = f % kBins;
+                     const double w = 0.5 - 0.5 * cos(2.0 * M_PI * t / 256.0), ph = 2.0 * M_PI * bin * t / 256.0;
+                     h_basis[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = (float)(f < kBins ? w * cos(ph) : -w * sin(ph));
+                  }
+      for (size_t i = 0; i < h_pcm.size(); ++i) {
+         const size_t seg = i / 8000;
+         const double amp = (seg % 3 == 0) ? 3.0 : 2500.0;
+         h_pcm[i] = (int16_t)(amp * sin(0.02 * (double)(i % 16000)) + amp * 0.3 * ((rand() % 2001) - 1000) / 1000.0);
+      }
+      printf("real-like basis and input\n");
+   }
    int16_t *pcm; float *basis, *Y0, *Y1, *FM;
    CK(hipMalloc(&pcm, h_pcm.size() * 2)); CK(hipMalloc(&basis, h_basis.size() * 4));
    CK(hipMalloc(&Y0, (size_t)n * kBins * kFrames * 4)); CK(hipMalloc(&Y1, (size_t)n * kBins * kFrames * 4));
@@ -83,6 +141,29 @@ int main(int argc, char **argv)
       printf("   %-41s %s (%zu mismatching words)\n", name, bad ? "MISMATCH" : "bit-identical to baseline", bad);
    };
    printf("n_chunks = %d\n", n);
+   if (argc > 5 && !strncmp(argv[5], "mask", 4)) {  // maskN: the first N CUs (mask bit order) are taken away, "mask" = 8
+      const int removed = argv[5][4] ? atoi(argv[5] + 4) : 8;
+      uint32_t m[8];
+      for (int w = 0; w < 8; ++w) m[w] = 0xffffffffu;
+      for (int cu = 0; cu < removed; ++cu) m[cu / 32] &= ~(1u << (cu % 32));
+      CK(hipExtStreamCreateWithCUMask(&g_st, 8, m));
+      printf("stream masked to CUs %d..255\n", removed);
+   }
+   if (argc > 6 && !strcmp(argv[6], "lstm")) {
+      uint32_t m[8] = {0xffu, 0, 0, 0, 0, 0, 0, 0};
+      CK(hipExtStreamCreateWithCUMask(&g_stb, 8, m));
+      CK(hipMalloc(&g_dummy_out, 16 * 512 * 4));
+      g_dummy_iters = 1000;
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      hipLaunchKernelGGL(k_dummy_chain, dim3(16), dim3(512), 0, g_stb, g_dummy_out, 100);
+      CK(hipEventRecord(a, g_stb));
+      hipLaunchKernelGGL(k_dummy_chain, dim3(16), dim3(512), 0, g_stb, g_dummy_out, g_dummy_iters);
+      CK(hipEventRecord(b, g_stb)); CK(hipEventSynchronize(b));
+      float t; CK(hipEventElapsedTime(&t, a, b));
+      g_dummy_iters = (int)(g_dummy_iters * 1.5f / t);           // ~1.5 ms
+      printf("concurrent chain kernel on CUs 0..7: %d iterations (~1.5 ms)\n", g_dummy_iters);
+   }
+   if (argc > 3 && !strcmp(argv[3], "cold")) { g_cold = true; CK(hipMalloc(&g_scratch, (size_t)256 << 20)); }
    if (argc > 2 && !strcmp(argv[2], "fl")) {          // frame-lane kernel against the shipped k_frontend: magnitudes, log values and FM
       float *FM1;
       CK(hipMalloc(&FM1, (size_t)kBinSplit * n * kFrames * 4));
@@ -108,6 +189,21 @@ int main(int argc, char **argv)
       run_fl<0, 3, 4>("fl nb3 w4, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb3 w4 log", Y1); check_fm("fl nb3 w4 log");
       run_fl<0, 3, 3>("fl nb3 w3, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb3 w3 log", Y1); check_fm("fl nb3 w3 log");
       run_fl<0, 1, 4>("fl nb1 w4, log mode", pcm, basis, Y1, FM1, n, reps);           check("fl nb1 w4 log", Y1); check_fm("fl nb1 w4 log");
+      run_fl<0, 3, 4, 1>("fl ABL1: no tap loads/waits", pcm, basis, Y1, FM1, n, reps);
+      run_fl<0, 3, 4, 2>("fl ABL2: no sample loads", pcm, basis, Y1, FM1, n, reps);
+      run_fl<0, 3, 4, 3>("fl ABL3: neither", pcm, basis, Y1, FM1, n, reps);
+      run_fl<0, 3, 4, 8>("fl ABL8: same 6 KB of taps for every batch", pcm, basis, Y1, FM1, n, reps);
+      run_fl<0, 3, 4, 10>("fl ABL10: same taps, no sample loads", pcm, basis, Y1, FM1, n, reps);
+      run_fl<0, 3, 4, 16>("fl ABL16: the 4 waves of a WG read the same taps", pcm, basis, Y1, FM1, n, reps);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      run_fl<0, 3, 4, 0, 2>("fl nps2 (512 threads)", pcm, basis, Y1, FM1, n, reps);   check("fl nps2", Y1); check_fm("fl nps2");
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      run_fl<0, 3, 4, 0, 4>("fl nps4 (1024 threads)", pcm, basis, Y1, FM1, n, reps);  check("fl nps4", Y1); check_fm("fl nps4");
+      run_fl<0, 3, 4, 0>("fl +23 KB LDS: 3 WG/CU", pcm, basis, Y1, FM1, n, reps, 23 * 1024);
+      run_fl<0, 3, 4, 0>("fl +50 KB LDS: 2 WG/CU", pcm, basis, Y1, FM1, n, reps, 50 * 1024);
+      run_fl<0, 3, 4, 16>("fl ABL16 +23 KB LDS: 3 WG/CU", pcm, basis, Y1, FM1, n, reps, 23 * 1024);
+      run_fl<0, 3, 4, 16>("fl ABL16 +50 KB LDS: 2 WG/CU", pcm, basis, Y1, FM1, n, reps, 50 * 1024);
+      run_fl<0, 3, 4, 8>("fl ABL8 +50 KB LDS: 2 WG/CU", pcm, basis, Y1, FM1, n, reps, 50 * 1024);
       return 0;
    }
    //            MODE NT  MINW SHIFT LOCK STAG

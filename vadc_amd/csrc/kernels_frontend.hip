@@ -356,11 +356,18 @@ __global__ __launch_bounds__(NT, MINW) void k_frontend(const T *__restrict__ pcm
 // set, and are shared by the 2 NB filters of a bin batch, whose partial trees stay in registers (6 VGPRs per filter).
 // The basis taps stay wave-uniform SCALAR loads from the same permuted basis k_frontend uses (one s_load_dwordx16 = the
 // 16 taps of one (filter, i, LP)), software-pipelined one stage (= re + im of one bin) ahead.
-// A workgroup = 64 consecutive positions (at most 4 chunks staged once) x 4 waves = the 4 bin splits of common.h, so FM
+// A workgroup = NPS x 64 consecutive positions (their chunks staged once) x 4 waves = the 4 bin splits of common.h, so FM
 // keeps the partial-sum order the first encoder layer expects.  Every lane produces an output: lane efficiency ~100 %.
+// What bounds it (tools/fe_bench.hip ablations, 16,384 chunks, kernel alone on the chip): 1.03 ms as shipped (NPS = 1); 0.89 ms
+// with every tap load hitting the scalar cache (the 264 KB basis streams through a 16 KB scalar cache); the packed-instruction
+// issue floor of the 518 VALU instructions per (bin, wave) is ~0.79 ms (4.3 cycles per v_pk_*_f32 at the ~2.25 GHz the chip
+// sustains under this load, tools/pk_rate.hip).  NPS = 2 (512 threads: the two waves of a bin split share their tap lines)
+// runs 0.90 ms alone -- but inside the engine, next to the LSTM chain on its own CUs, it is 5 % SLOWER than NPS = 1 (1.14 vs
+// 1.08 ms, rocprofv3): the chip is power-limited under this kernel (clocks 2.0-2.4 GHz depending on the instruction mix,
+// 32 CUs fewer cost 7 % not 14 %), so the in-engine A/B decides, and NPS = 1 ships (option "fe_nps").
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kFlBlockPitch = 68;
-constexpr int kFlChunks = 4;                                  // 64 consecutive positions span at most 4 chunks
+constexpr int fl_chunks(int nps) { return (kFrames - 1 + 64 * nps - 1) / kFrames + 1; }   // 64 nps consecutive positions span at most this many chunks
 
 #define VADC_FL_SLOAD2(A, B, BASE, OFFA, OFFB)                                          \
    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"              \
@@ -375,8 +382,14 @@ constexpr int kFlChunks = 4;                                  // 64 consecutive 
    __builtin_amdgcn_sched_barrier(0)
 
 // g = ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)),  q_j = (x[8j+l], x[8j+l+1]) * (k[j][l], k[j][l+1])   (stft.c:141-160)
-__device__ __forceinline__ f2v fl_tree8(const f4v (&xq)[4], const f16v &kv)
+template <int ABL = 0>
+__device__ __forceinline__ f2v fl_tree8(const f4v (&xq)[4], const f16v &kv_)
 {
+   f4v kvv[4] = {xq[1], xq[2], xq[3], xq[0]};                    // ABL & 4 (tools/fe_bench.hip only): VGPR operands instead of the SGPR taps
+   const float *kx = reinterpret_cast<const float *>(&kvv[0]);
+   float kv[16];
+#pragma unroll
+   for (int e = 0; e < 16; ++e) kv[e] = (ABL & 4) ? kx[e] : kv_[e];
    const f2v q0 = __builtin_shufflevector(xq[0], xq[0], 0, 1) * (f2v){kv[0], kv[1]};
    const f2v q1 = __builtin_shufflevector(xq[0], xq[0], 2, 3) * (f2v){kv[2], kv[3]};
    const f2v q2 = __builtin_shufflevector(xq[1], xq[1], 0, 1) * (f2v){kv[4], kv[5]};
@@ -423,7 +436,9 @@ constexpr int fl_tap_off(int b, int i, int lp) { return b * 1024 + (3 - i) * 256
 // for) and xc the samples of this step; the stage requests the next stage's taps into na/nb and, at B == 0, the next
 // step's samples into xn.  After the last stage ca/cb and xc are again "current" for the next batch (16 NB stages and 16
 // steps are even counts, so the buffers end where they started).
-template <int NB, int K>
+// ABL (timing ablations for tools/fe_bench.hip, 0 in the product; results are garbage otherwise): 1 = no tap loads / waits,
+// 2 = no sample loads, 4 = products by VGPR pairs instead of SGPR pairs, 8 = every batch reads the taps of the first one
+template <int NB, int K, int ABL = 0>
 struct FlStages {
    static __device__ __forceinline__ void run(FlState<NB> &st, const float *kf, unsigned xaddr, f16v &ca, f16v &cb, f16v &na, f16v &nb,
                                               f4v (&xc)[4], f4v (&xn)[4])
@@ -433,35 +448,40 @@ struct FlStages {
       constexpr int Sn = (Kn / NB) % 16, Bn = Kn % NB, LPn = Sn / 4, In = Sn % 4;
       constexpr int noff = (Kn == 16 * NB ? NB * 1024 : 0) + fl_tap_off(Bn, In, LPn);
       constexpr int kImOffB = kBins * kFilterLen * 4;
-      if constexpr (B == 0) {
+      if constexpr (B == 0 && !(ABL & 2)) {
          constexpr int S1 = (S + 1) % 16;
          VADC_FL_LDS16(xn, xaddr, ((S1 % 4) * kFlBlockPitch + (S1 / 4) * 16) * 4);
       }
-      VADC_FL_SLOAD2(na, nb, kf, noff, noff + kImOffB);
-      fl_accumulate<I, LP, NB>(st, 2 * B, fl_tree8(xc, ca));
-      fl_accumulate<I, LP, NB>(st, 2 * B + 1, fl_tree8(xc, cb));
+      if constexpr (!(ABL & 1)) { VADC_FL_SLOAD2(na, nb, kf, noff, noff + kImOffB); }
+      fl_accumulate<I, LP, NB>(st, 2 * B, fl_tree8<ABL>(xc, ca));
+      fl_accumulate<I, LP, NB>(st, 2 * B + 1, fl_tree8<ABL>(xc, cb));
       if constexpr (B == NB - 1) {
          // two statements: an asm with SGPR and VGPR outputs counts as a divergent source and its taps would be copied to VGPRs
-         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         if constexpr (!(ABL & 1)) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         else if constexpr (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         else asm volatile("" : "+s"(na), "+s"(nb));
          asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
          __builtin_amdgcn_sched_barrier(0);
-         FlStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
+         FlStages<NB, K + 1, ABL>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
       } else {
-         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         if constexpr (!(ABL & 1)) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+         else asm volatile("" : "+s"(na), "+s"(nb));
          __builtin_amdgcn_sched_barrier(0);
-         FlStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
+         FlStages<NB, K + 1, ABL>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
       }
    }
 };
-template <int NB>
-struct FlStages<NB, 16 * NB> {
+template <int NB, int ABL>
+struct FlStages<NB, 16 * NB, ABL> {
    static __device__ __forceinline__ void run(FlState<NB> &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
 };
 
 // MODE as k_frontend (0: Y = log1p(2^20 m) + FM partial bin sums; 1: Y = magnitude).  NB = bins per batch; kBinsPerSplit = 33 and
 // the last split's 30 bins are both multiples of 3.
-template <typename T, int MODE, int NB = 3, int MINW = 4>
-__global__ __launch_bounds__(256, MINW) void k_frontend_fl(const T *__restrict__ pcm,          // [n_chunks][1536]
+// NPS = position sets (of 64) per workgroup: the NPS waves that work on the same bin split start together and read the same
+// taps at about the same time, so all but the first of them hit the scalar cache.
+template <typename T, int MODE, int NB = 3, int MINW = 4, int ABL = 0, int NPS = 1>
+__global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                            const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
                                                            float *__restrict__ Y,              // [n_chunks][129][25]
                                                            float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
@@ -470,18 +490,20 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_fl(const T *__restrict__
    static_assert(kBinsPerSplit % NB == 0 && (kBins - 3 * kBinsPerSplit) % NB == 0, "bin batches must tile every split");
    static_assert((16 * NB) % 2 == 0, "tap buffers must end where they started");
    constexpr int kChunkPitch = kBlocks * kFlBlockPitch;          // 1904 floats per chunk
+   constexpr int kFlChunks = fl_chunks(NPS);
    __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kChunkPitch];
    const int tid = threadIdx.x, lane = tid & 63;
-   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;          // bin split
+   const int pset = __builtin_amdgcn_readfirstlane(tid >> 8);              // position set
    const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * 64;
+   const long p0 = (long)blockIdx.x * (64 * NPS);
    const int item0 = (int)(p0 / kFrames);
 
    // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954), l-pair-major inside a block
    for (int c = 0; c < kFlChunks; ++c) {
       const int it = min(item0 + c, n_chunks - 1);
       const T *src = pcm + (size_t)map(it) * kChunk;
-      for (int idx = tid; idx < kPadded; idx += 256) {
+      for (int idx = tid; idx < kPadded; idx += 256 * NPS) {
          int s = idx - kPad;
          s = s < 0 ? -s : s;
          s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_fl(const T *__restrict__
    }
    __syncthreads();
 
-   const long pe = p0 + lane;
+   const long pe = p0 + pset * 64 + lane;
    const bool writer = pe < total_pos;
    const long pa_ = writer ? pe : total_pos - 1;
    const int item = (int)(pa_ / kFrames), n = (int)(pa_ - (long)item * kFrames);
@@ -517,9 +539,11 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_fl(const T *__restrict__
    }
 #pragma unroll 1
    for (int f = f_start; f < f_end; f += NB) {
-      const float *kf = basis + (size_t)f * kFilterLen;          // wave-uniform
+      const float *kf = basis + (size_t)((ABL & 8) ? 0 : (ABL & 16) ? f - f_start : f) * kFilterLen;          // wave-uniform  (ABL & 8: every batch reads the same taps = scalar-cache hits)
       FlState<NB> st;
-      FlStages<NB, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
+      if (ABL & 1) { na = ca; nb = cb; }
+      if (ABL & 2) { xn[0] = xc[0]; xn[1] = xc[1]; xn[2] = xc[2]; xn[3] = xc[3]; }
+      FlStages<NB, 0, ABL>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
       // pin the trees here: with the stores below under `if (writer)`, machine sinking would otherwise move the arithmetic
       // of a whole bin into the epilogue's blocks, far below the taps it consumes (spilling every tap on the way)
 #pragma unroll
@@ -615,18 +639,31 @@ void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float
    else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+constexpr int kFlNps = 2;   // the alternative to nps == 1 (engine option "fe_nps"); 4 (1024 threads) measured 1.21 ms
+void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps)
 {
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_fl<float, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (nps == 1) {
+      const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+      if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+      else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+      return;
+   }
+   const dim3 grid((unsigned)(((long)n * kFrames + 64 * kFlNps - 1) / (64 * kFlNps)));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps)
 {
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (nps == 1) {
+      const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+      if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+      else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+      return;
+   }
+   const dim3 grid((unsigned)(((long)n * kFrames + 64 * kFlNps - 1) / (64 * kFlNps)));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
