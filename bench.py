@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["v31", "v4"], default="v31",
                     help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
+    ap.add_argument("--precision", choices=["fp32", "split16"], default="fp32",
+                    help="fp32 = the parity mode (default, BASELINE config 2); split16 = BASELINE config 3: STFT as a split-fp16 GEMM on "
+                         "the matrix pipe instead of the reference's reduction tree (|dp| up to ~1e-4, see include/vadc_amd.h)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -110,7 +113,8 @@ def main():
         FLOP_PER_CHUNK.clear(); FLOP_PER_CHUNK.update(FLOP_PER_CHUNK_V4)
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
-    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=1 if args.precision == "split16" else 0)
+    split16 = args.precision == "split16" and eng.caps()["precision"] == 1
     eng.set_option("groups", args.groups)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -217,8 +221,9 @@ def main():
                       "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, fp32, s16le input resident in HBM",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not split16 else "split-f16 (2 x fp16, fp32 accumulate) front end + f32", "data": "synthetic",
+            "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
+                                   f"{'fp32' if not split16 else 'SPLIT16 precision mode (BASELINE config 3; not the parity mode)'}, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
@@ -234,12 +239,12 @@ def main():
             "kernels": per_kernel,
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
         }
-        if args.model == "v4":
+        if args.model == "v4" or split16:
             out["roofline"]["note"] = ("dominant kernel by CU-time; fp32 peak (vector == matrix).  FLOP are counted for the DENSE basis "
-                                       "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm_v4 folds the "
+                                       "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm folds the "
                                        "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, as split-fp16 products on the fp16 matrix pipe "
                                        "(3 x v_mfma_f32_16x16x32_f16 per k-block), so frac is not a utilisation of the fp32 roof")
-            out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * 24
+            out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * (24 if args.model == "v4" else 25)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)
         print(json.dumps(out), flush=True)

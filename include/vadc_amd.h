@@ -57,9 +57,15 @@ enum {
                                 to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */
 };
 
-/* precision selector for vadc_amd_create (room for the bf16x3 variant of BASELINE config 3) */
+/* precision selector for vadc_amd_create */
 enum {
-   VADC_AMD_PRECISION_FP32 = 0   /* fp32 everywhere, STFT with the reference's exact reduction tree */
+   VADC_AMD_PRECISION_FP32 = 0,   /* fp32 everywhere, STFT with the reference's exact reduction tree: the parity mode (|dp| <= 1e-4 vs the C backend) */
+   VADC_AMD_PRECISION_SPLIT16 = 1 /* BASELINE config 3 ("reduced-precision compute + fp32 LSTM state"): the STFT runs as a folded GEMM on the
+                                     fp16 matrix pipe with 2-term split-fp16 operands (~22 significant bits, fp32 accumulation) instead of the
+                                     reference's reduction tree -- 3x faster front end; probabilities deviate from the C backend by up to
+                                     ~1e-4 on long streams (measured distribution: DESIGN.md).  Everything behind the front end is the
+                                     FP32 mode's code.  Silero v4 uses this front end in both modes.  If the loaded basis lacks the real-DFT
+                                     symmetries the folding needs, the engine keeps the tree and caps.precision reports FP32. */
 };
 
 typedef struct vadc_amd_engine vadc_amd_engine;

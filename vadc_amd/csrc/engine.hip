@@ -23,8 +23,8 @@ void launch_frontend_mx2_f32(const float *, const float *, float *, float *, siz
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
-void launch_frontend_gemm_v4_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_gemm_v4_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
+void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
@@ -116,8 +116,9 @@ struct vadc_amd_engine {
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 / 3
    const int *stage_elems = nullptr;
-   const float *d_afrag_v4 = nullptr, *d_nyq_v4 = nullptr;   // v4 GEMM front end: folded basis as MFMA A fragments, bin-128 weights
-   bool v4_gemm = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
+   const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in SPLIT16 precision): folded basis as MFMA A fragments, bin-128 weights
+   bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
+   bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_SPLIT16)); }
    float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
    int max_streams = 0, max_chunks = 0, precision = 0;
    size_t max_items = 0;
@@ -189,6 +190,36 @@ static void copy_unaligned(std::vector<float> &dst, const HostTensor &t)
    memcpy(dst.data(), t.data, (size_t)t.size * 4);
 }
 
+// GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
+// and 128 zero -- verified bit for bit on the loaded basis [258][256]; otherwise the tree kernel stays in charge.
+static bool build_gemm_frontend(const std::vector<float> &basis, Packer &pk, size_t &off_afrag, size_t &off_nyq)
+{
+   auto B = [&](int row, int n) { return basis[(size_t)row * 256 + n]; };
+   for (int k = 0; k < kBins; ++k) {
+      if (B(k, 0) != 0.0f || B(kBins + k, 0) != 0.0f || B(kBins + k, 128) != 0.0f) return false;
+      for (int n = 1; n < 128; ++n)
+         if (B(k, n) != B(k, 256 - n) || B(kBins + k, n) != -B(kBins + k, 256 - n)) return false;
+   }
+   for (int n = 0; n < 256; ++n) if (B(kBins, n) != 0.0f || B(kBins + 128, n) != 0.0f) return false;
+   // A fragments (v_mfma_f32_16x16x32_f16 operand order): tile t < 8: re bins 16 t + r; tile 8 + t: im bins 16 t + r;
+   // k-block kb, lane l, element e: row l & 15, tap 32 kb + 8 (l >> 4) + e
+   std::vector<float> af((size_t)16 * 4 * 64 * 8), ny(128);
+   for (int t = 0; t < 16; ++t)
+      for (int kb = 0; kb < 4; ++kb)
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el) {
+               const int bin = 16 * (t & 7) + (l & 15), n = 32 * kb + 8 * (l >> 4) + el;
+               float v;
+               if (t < 8) v = (n == 0) ? B(bin, 128) : B(bin, n);          // slot 0 carries the unpaired centre tap
+               else       v = (n == 0) ? 0.0f : B(kBins + bin, n);
+               af[(((size_t)t * 4 + kb) * 64 + l) * 8 + el] = v;
+            }
+   for (int n = 0; n < 128; ++n) ny[n] = (n == 0) ? B(128, 128) : B(128, n);
+   off_afrag = pk.add(af.data(), af.size());
+   off_nyq = pk.add(ny.data(), ny.size());
+   return true;
+}
+
 static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
 {
    if (ts.size() != 99) return fail(VADC_AMD_EWEIGHTS, "weights: expected 99 tensors, found %zu", ts.size());
@@ -227,6 +258,8 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                   }
       off_basis_mx2 = pk.add(bt.data(), bt.size());
    }
+   size_t off_afrag = 0, off_nyq = 0;
+   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // SPLIT16 precision mode (BASELINE config 3)
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
@@ -305,6 +338,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
       e->d_basis_mx2 = base + off_basis_mx2;
+      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
       for (int l = 0; l < 4; ++l) {
          LayerWeights &w = e->lw[l];
          w.dw_w = base + lo[l].dw_w; w.dw_b = base + lo[l].dw_b; w.pwT = base + lo[l].pwT; w.pw_b = base + lo[l].pw_b;
@@ -344,38 +378,8 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    pk.add(nullptr, 64);
-   // GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
-   // and 128 zero -- verified bit for bit, otherwise the tree kernel stays in charge.
    size_t off_afrag = 0, off_nyq = 0;
-   {
-      bool sym = true;
-      auto B = [&](int row, int n) { return tmp[(size_t)row * 256 + n]; };
-      for (int k = 0; k < kBins && sym; ++k) {
-         if (B(k, 0) != 0.0f || B(kBins + k, 0) != 0.0f || B(kBins + k, 128) != 0.0f) sym = false;
-         for (int n = 1; n < 128 && sym; ++n)
-            if (B(k, n) != B(k, 256 - n) || B(kBins + k, n) != -B(kBins + k, 256 - n)) sym = false;
-      }
-      for (int n = 0; n < 256 && sym; ++n) if (B(kBins, n) != 0.0f || B(kBins + 128, n) != 0.0f) sym = false;
-      e->v4_gemm = sym;
-      if (sym) {
-         // A fragments (v_mfma_f32_16x16x32_f16 operand order): tile t < 8: re bins 16 t + r; tile 8 + t: im bins 16 t + r;
-         // k-block kb, lane l, element e: row l & 15, tap 32 kb + 8 (l >> 4) + e
-         std::vector<float> af((size_t)16 * 4 * 64 * 8), ny(128);
-         for (int t = 0; t < 16; ++t)
-            for (int kb = 0; kb < 4; ++kb)
-               for (int l = 0; l < 64; ++l)
-                  for (int el = 0; el < 8; ++el) {
-                     const int bin = 16 * (t & 7) + (l & 15), n = 32 * kb + 8 * (l >> 4) + el;
-                     float v;
-                     if (t < 8) v = (n == 0) ? B(bin, 128) : B(bin, n);          // slot 0 carries the unpaired centre tap
-                     else       v = (n == 0) ? 0.0f : B(kBins + bin, n);
-                     af[(((size_t)t * 4 + kb) * 64 + l) * 8 + el] = v;
-                  }
-         for (int n = 0; n < 128; ++n) ny[n] = (n == 0) ? B(128, 128) : B(128, n);
-         off_afrag = pk.add(af.data(), af.size());
-         off_nyq = pk.add(ny.data(), ny.size());
-      }
-   }
+   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);
    auto frag = [](const std::vector<float> &W, int M, int K) {
       const int KKW = (K + 3) / 4;
       std::vector<float> f((size_t)(M / 16) * KKW * 64, 0.0f);
@@ -423,7 +427,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
-      if (e->v4_gemm) { e->d_afrag_v4 = base + off_afrag; e->d_nyq_v4 = base + off_nyq; }
+      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
       for (int l = 0; l < 4; ++l) {
          LayerWeightsM &m = e->lwm[l];
          m = LayerWeightsM{};
@@ -474,7 +478,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (!blob || len < 8) return fail(VADC_AMD_EWEIGHTS, "create: empty weights blob");
    if (max_streams <= 0 || max_chunks <= 0 || (long)max_streams * max_chunks > (1L << 24))
       return fail(VADC_AMD_EINVAL, "create: max_streams=%d max_chunks_per_call=%d out of range", max_streams, max_chunks);
-   if (precision != VADC_AMD_PRECISION_FP32) return fail(VADC_AMD_EINVAL, "create: unsupported precision %d", precision);
+   if (precision != VADC_AMD_PRECISION_FP32 && precision != VADC_AMD_PRECISION_SPLIT16) return fail(VADC_AMD_EINVAL, "create: unsupported precision %d", precision);
 
    std::vector<HostTensor> ts;
    if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
@@ -557,7 +561,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    caps->max_streams = e->max_streams;
    caps->max_chunks_per_call = e->max_chunks;
    caps->device = e->device;
-   caps->precision = e->precision;
+   caps->precision = (e->precision == VADC_AMD_PRECISION_SPLIT16 && e->model != VADC_AMD_MODEL_V4 && !e->gemm_ok) ? VADC_AMD_PRECISION_FP32 : e->precision;
    caps->model_kind = e->model;
    caps->lstm_steps_per_chunk = e->lstm_steps;
    return VADC_AMD_OK;
@@ -715,9 +719,10 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    if (hold_first) (void)hipStreamWaitEvent(st, hold_first, 0);
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      if (e->model == VADC_AMD_MODEL_V4 && e->v4_gemm && e->frontend_variant == 0) {
-         if (sizeof(T) == 2) launch_frontend_gemm_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
-         else                launch_frontend_gemm_v4_f32(reinterpret_cast<const float *>(d_in), e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
+      if (e->use_gemm_frontend()) {
+         const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
+         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
+         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
       } else if (e->model == VADC_AMD_MODEL_V4) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
@@ -759,7 +764,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 4) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.9 : 3.9, per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.07 : 0.122;
+   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured steps: v3.1 1.73 ms, v3.1 SPLIT16 0.9 ms, v4 0.7 ms per 16,384 chunks)
+   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
+   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.043 : (e->use_gemm_frontend() ? 0.055 : 0.105);
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -946,6 +953,8 @@ static int launch_graph_serialized(vadc_amd_engine *e, hipGraphExec_t x, hipStre
 template <typename T>
 static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
 {
+   if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
+      return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
    if (!e->use_graph || e->profiling) return run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
    for (auto &ge : e->graphs)
       if (ge.in == d_in && ge.out == d_probs && ge.S == n_streams && ge.C == n_chunks && ge.elem == (int)sizeof(T) &&
@@ -1100,8 +1109,8 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
-   if (e->model == VADC_AMD_MODEL_V4 && e->v4_gemm && e->frontend_variant == 0)
-      launch_frontend_gemm_v4_f32(e->d_in_f32, e->d_afrag_v4, e->d_nyq_v4, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st);
+   if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
+      launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, e->model == VADC_AMD_MODEL_V4 ? 1 : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else if (e->frontend_variant == 2) launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);

@@ -1,30 +1,42 @@
-// kernels_frontend_gemm.hip -- Silero v4 front end: reflect pad 96 + STFT + magnitude + log1p + bin means as an fp32 GEMM on
-// v_mfma_f32_16x16x4_f32.
+// kernels_frontend_gemm.hip -- the STFT front end as a folded GEMM on the fp16 matrix pipe with split-fp16 operands:
+// reflect pad + STFT + magnitude + log1p + per-frame bin sums.
 //
-// Replaces, for the v4 model (reference arithmetic: silero_vad.py:22-66, STFT_conv with is_v4 + AdaptiveAudioNormalization;
-// the reference itself runs it through onnxruntime, onnx_helpers.c:83-115): pad_reflect(96), conv1d with the [258,1,256]
-// basis at hop 64 (24 frames per 1536-sample chunk), sqrt(re^2 + im^2), log1p(2^20 m) and the per-frame bin sums.
+// Used for (a) the Silero v4 model (default front end there; reference arithmetic: silero_vad.py:22-66, STFT_conv with is_v4 +
+// AdaptiveAudioNormalization; the reference itself runs it through onnxruntime, onnx_helpers.c:83-115): pad_reflect(96), conv1d
+// with the [258,1,256] basis at hop 64 (24 frames per 1536-sample chunk), sqrt(re^2 + im^2), log1p(2^20 m), bin sums; and
+// (b) Silero v3.1 in the engine's SPLIT16 precision mode (BASELINE config 3; replaces tensor.h:912-958, stft.c:15-224,
+// misc.c:40-63 with pad 128 and 25 frames).
 //
-// Why a GEMM here and the bit-exact tree (kernels_frontend.hip) for v3.1: v3.1 parity is defined against the reference C
-// backend, whose fp32 reduction tree is part of what the model sees (tools/stft_sensitivity.py).  v4
-// has no C implementation in the reference -- its parity target is the PyTorch/onnxruntime convolution, any fp32 order --
-// and its probabilities move by <= 1e-6 between fp32 and fp64 evaluation (tests/golden/gen_golden_v4_from_python_reference.py).
+// Why a GEMM is the default for v4 but an opt-in precision mode for v3.1: v3.1 parity is defined against the reference C
+// backend, whose fp32 reduction tree is part of what the model sees (tools/stft_sensitivity.py), so the
+// fp32 mode keeps the bit-exact tree (kernels_frontend.hip).  v4 has no C implementation in the reference -- its parity target
+// is the PyTorch/onnxruntime convolution, any fp32 order -- and its probabilities move by <= 1e-6 between fp32 and fp64
+// evaluation (tests/golden/gen_golden_v4_from_python_reference.py).
 //
 // REAL-INPUT FOLDING.  The basis rows are a windowed DFT: re rows are even about tap 128, im rows odd, tap 0 is zero (periodic
 // Hann), and the im rows of bins 0 and 128 vanish.  vadc_amd_create VERIFIES these identities bit for bit on the loaded basis
-// (engine.hip: v4_basis_is_symmetric) and otherwise keeps the tree kernel.  With them
+// (engine.hip) and otherwise keeps the tree kernel.  With them
 //     re_k = sum_{n=0..127} Are[k][n] xs[n],   xs[n] = x[n] + x[256-n] (n >= 1),  xs[0] = x[128],  Are[k][0] = basis[k][128]
 //     im_k = sum_{n=1..127} Aim[k][n] xd[n],   xd[n] = x[n] - x[256-n],           xd[0] = 0
 // i.e. two K = 128 contractions instead of one K = 256: half the MACs of the dense conv.
 //
-// MAPPING.  Workgroup = 4 waves, persistent over groups of 4 chunks (96 positions = 6 MFMA column tiles).  Wave w keeps the
-// A fragments of bins [32w, 32w+32) -- two re and two im row tiles, 128 VGPRs -- for the whole kernel.  The 4 chunks are
-// staged twice in LDS (block pitch 68 floats: the 16 frames of a column tile hit disjoint banks): X0[i] = x[i] and X1[i] =
-// x[i+1], so that both the direct taps x[p+32g+4q..+3] and the mirrored taps x[p+256-32g-4q-3..] are ALIGNED ds_read_b128.
-// Lane (f = l & 15, g = l >> 4) supplies the B fragment of position f: taps 32 kb + 8 g + e of k-block kb.  re and im of
-// one (bin, position) land in the same lane and register of their accumulators, so magnitude/log1p are register-local; the
-// stores run along the frames of a chunk.  Bin 128 (re only) is one extra dot product on the vector ALU, taken by a different
-// wave for every column tile.  Per-frame bin sums: one partial per wave = the 4 partials of FM (common.h kBinSplit).
+// MATRIX PIPE.  The contractions run as v_mfma_f32_16x16x32_f16 with SPLIT-fp16 operands (a = ah + al, three MFMAs per k-block:
+// al.bh + ah.bl + ah.bh, fp32 accumulation; see k_lstm_wavefront_h3 in kernels_lstm.hip) on the fp16 pipe, which does not
+// share lanes with the vector ALU.  s16 input and the folded sums split exactly; the basis keeps 22 of its 24 bits (error
+// ~2e-7 relative, the level of fp32 accumulation itself).  Operand layout: lane l holds A[l & 15][8 (l >> 4) + e],
+// B[8 (l >> 4) + e][l & 15].
+//
+// MAPPING.  Workgroup = 4 waves, persistent over groups of G = 4 chunks (4 x frames positions = 6 or 7 column tiles of 16).
+// Wave w keeps the split A fragments of bins [32w, 32w+32) -- two re and two im row tiles, 128 VGPRs -- for the whole kernel.
+// The group's chunks are staged once in LDS as fp32 (16-byte global loads, block pitch 68 floats: the 16 frames of a column tile
+// hit disjoint banks).  The B operand of a column tile -- folded sums/differences, split into fp16 hi/lo -- is the same for all
+// four waves, so it is PREPARED ONCE: wave w folds and splits k-block w of the next tile into an LDS fragment buffer (double
+// buffered, one barrier per tile) while the matrix pipe works on the current one, and every wave then fetches its 16 fragments
+// with conflict-free ds_read_b128.  re and im of one (bin, position) land in the same lane and register of their
+// accumulators, so magnitude/log1p are register-local; the stores run along the frames of a chunk.  Bin 128 (re only) is a
+// K = 128 dot product on the vector ALU: the wave that prepares k-block kb accumulates that block's share (reduced over the
+// four lane groups with two shuffles), a rotating wave adds the four shares in fixed order.  Per-frame bin sums: one partial
+// per wave = the 4 partials of FM (common.h kBinSplit).
 #include "common.h"
 
 namespace vadc {
@@ -39,33 +51,54 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8v &hi, h8v &lo)
    for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
 }
 
-constexpr int kV4Pad = 96, kV4Frames = 24, kV4Padded = kChunk + 2 * kV4Pad;   // 1728 samples = 27 blocks of 64
 constexpr int kGBlockPitch = 68;
 constexpr int kGChunks = 4;                                                   // chunks per workgroup iteration
-constexpr int kGChunkPitch = (kV4Padded / 64 + 1) * kGBlockPitch;             // 28 blocks (one spare: X1 reads sample 1728)
-constexpr int kGTiles = kGChunks * kV4Frames / 16;                            // 6 column tiles of 16 positions
 
+// GEO 0: Silero v3.1 (reflect pad 128, 25 frames, 28 blocks; Y + FM);  GEO 1: Silero v4 (pad 96, 24 frames, 27 blocks; Y + MAG + FM)
+template <int GEO> struct GemmGeo;
+template <> struct GemmGeo<0> { static constexpr int pad = 128, frames = 25, blocks = 28; static constexpr bool mag = false; };
+template <> struct GemmGeo<1> { static constexpr int pad = 96, frames = 24, blocks = 27; static constexpr bool mag = true; };
+
+__device__ __forceinline__ void g_stage8(const float *src, float (&v)[8])
+{
+   const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void g_stage8(const int16_t *src, float (&v)[8])
+{
+   const uint4 r = *reinterpret_cast<const uint4 *>(src);                       // 8 samples; chunks are 3072-byte aligned
+   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+   for (int i = 0; i < 4; ++i) {
+      v[2 * i] = (float)(int16_t)(w[i] & 0xffffu) * (1.0f / 32768.0f);          // exact
+      v[2 * i + 1] = (float)(int16_t)(w[i] >> 16) * (1.0f / 32768.0f);
+   }
+}
 __device__ __forceinline__ float g_sample(float v) { return v; }
 __device__ __forceinline__ float g_sample(int16_t v) { return (float)v * (1.0f / 32768.0f); }
 
-// MATRIX PIPE.  The two K = 128 contractions run as v_mfma_f32_16x16x32_f16 with SPLIT-fp16 operands (a = ah + al, three MFMAs
-// per k-block: al.bh + ah.bl + ah.bh, fp32 accumulation; see k_lstm_wavefront_h3 in kernels_lstm.hip): 48 matrix instructions
-// of 16 cycles per column tile and wave instead of 128 fp32 MFMAs of 32 cycles, on the fp16 pipe that does not share lanes
-// with the vector ALU.  s16 input and the folded sums split exactly; the basis keeps 22 of its 24 bits (error ~2e-7 relative,
-// the level of fp32 accumulation itself).  Operand layout: lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15].
 // afrag: [tile 0..15 (0-7 re bins 16t.., 8-15 im)][kb 0..3][lane][8]  = A[16 t' + (lane & 15)][32 kb + 8 (lane >> 4) + e]  (fp32; split in-kernel)
 // nyq:   [128] folded weights of bin 128 (re)
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict__ pcm, const float *__restrict__ afrag,
-                                                             const float *__restrict__ nyq,
-                                                             float *__restrict__ Y, float *__restrict__ MAG, float *__restrict__ FM,
-                                                             int n_chunks, ItemMap map, size_t fm_stride)
+template <typename T, int GEO>
+__global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ pcm, const float *__restrict__ afrag,
+                                                          const float *__restrict__ nyq,
+                                                          float *__restrict__ Y, float *__restrict__ MAG, float *__restrict__ FM,
+                                                          int n_chunks, ItemMap map, size_t fm_stride)
 {
-   __shared__ __attribute__((aligned(16))) float X0[kGChunks * kGChunkPitch];
-   __shared__ __attribute__((aligned(16))) float X1[kGChunks * kGChunkPitch];
+   typedef GemmGeo<GEO> Geo;
+   constexpr int kPadG = Geo::pad, kFr = Geo::frames, kBlk = Geo::blocks;
+   constexpr int kPaddedG = kChunk + 2 * kPadG;
+   constexpr int kChunkPitch = (kBlk + 1) * kGBlockPitch;                       // one spare block: the mirror of tap 0 is read (unused)
+   constexpr int kPos = kGChunks * kFr;                                         // positions per group (96 | 100)
+   constexpr int kTiles = (kPos + 15) / 16;                                     // 6 | 7 column tiles
+   constexpr int kPosPad = kTiles * 16;
+
+   __shared__ __attribute__((aligned(16))) float X0[kGChunks * kChunkPitch];
+   __shared__ __attribute__((aligned(16))) _Float16 Bf[2][4][4][64][8];         // [buffer][kb][sh, sl, dh, dl][lane][8]: 32 KB
    __shared__ __attribute__((aligned(16))) float nyq_s[128];
-   __shared__ float bsum[4][kGChunks * kV4Frames];
-   __shared__ float nyv[kGChunks * kV4Frames];          // log value of bin 128 per position (whichever wave computed it)
+   __shared__ float nyp[2][4][16];                                             // bin 128: share of k-block kb, per buffer and position
+   __shared__ float bsum[4][kPosPad];
+   __shared__ float nyv[kPosPad];                                              // log value of bin 128 per position
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int f = lane & 15, g = lane >> 4;
 
@@ -77,63 +110,92 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
          float v[8];
-         const float *src = afrag + (((size_t)tile * 4 + kb) * 64 + lane) * 8;
-#pragma unroll
-         for (int e = 0; e < 8; ++e) v[e] = src[e];
+         g_stage8(afrag + (((size_t)tile * 4 + kb) * 64 + lane) * 8, v);
          split8(v, ah[ti][kb], al[ti][kb]);
       }
    }
    if (tid < 128) nyq_s[tid] = nyq[tid];
+   if (tid < kGChunks) X0[tid * kChunkPitch + kBlk * kGBlockPitch] = 0.0f;       // the spare sample (index kPaddedG) that tap 0's mirror touches
+
+   // fold + split k-block `wave` of column tile ct into fragment buffer ct & 1 (all four waves: one k-block each)
+   auto prepare = [&](int ct) {
+      const int kb = wave;
+      const int pos = min(16 * ct + f, kPos - 1);
+      const int c = pos / kFr, fr = pos - c * kFr;
+      // tap n = 32 kb + 8 g + e:  direct x[64 fr + n] = block fr + (kb >> 1), offset 32 (kb & 1) + 8 g + e;  mirrored x[64 fr + 256 - n]
+      const float *row = X0 + c * kChunkPitch + fr * kGBlockPitch;
+      const float *pd = row + (kb >> 1) * kGBlockPitch + 32 * (kb & 1) + 8 * g;
+      const float4 d0 = *reinterpret_cast<const float4 *>(pd), d1 = *reinterpret_cast<const float4 *>(pd + 4);
+      const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float xs[8], xd[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+         const int m = 256 - 32 * kb - 8 * g - e;                               // 1..256
+         const float mv = row[(m >> 6) * kGBlockPitch + (m & 63)];
+         xs[e] = dv[e] + mv;
+         xd[e] = dv[e] - mv;
+      }
+      if (kb == 0 && g == 0) { xs[0] = row[2 * kGBlockPitch]; xd[0] = 0.0f; }   // tap 0 carries the unpaired centre tap 128
+      h8v sh, sl, dh, dl;
+      split8(xs, sh, sl);
+      split8(xd, dh, dl);
+      const int buf = ct & 1;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][0][lane][0]) = sh;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][1][lane][0]) = sl;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][2][lane][0]) = dh;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][3][lane][0]) = dl;
+      // bin 128 (re only): this k-block's share, fp32 on the vector ALU
+      const float4 w0 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g), w1 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g + 4);
+      float ny = w0.x * xs[0];
+      ny = fmaf(w0.y, xs[1], ny); ny = fmaf(w0.z, xs[2], ny); ny = fmaf(w0.w, xs[3], ny);
+      ny = fmaf(w1.x, xs[4], ny); ny = fmaf(w1.y, xs[5], ny); ny = fmaf(w1.z, xs[6], ny); ny = fmaf(w1.w, xs[7], ny);
+      ny += __shfl_xor(ny, 16);
+      ny += __shfl_xor(ny, 32);
+      if (g == 0) nyp[buf][kb][f] = ny;
+   };
 
    const int n_groups = (n_chunks + kGChunks - 1) / kGChunks;
 #pragma unroll 1
    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
       __syncthreads();                                   // previous iteration's readers are done
-      // ---- stage 4 chunks: reflect pad 96 (no edge repeat), block pitch 68, X1 = X0 shifted by one sample ----
-      for (int c = 0; c < kGChunks; ++c) {
+      // ---- stage the group's chunks: reflect pad (no edge repeat), block pitch 68 ----
+      for (int i = tid; i < kGChunks * (kChunk / 8); i += 256) {
+         const int c = i / (kChunk / 8), q = i - c * (kChunk / 8);
+         const int it = min(grp * kGChunks + c, n_chunks - 1);
+         float v[8];
+         g_stage8(pcm + (size_t)map(it) * kChunk + 8 * q, v);
+         const int p = kPadG + 8 * q;
+         float *dst = X0 + c * kChunkPitch + (p >> 6) * kGBlockPitch + (p & 63);
+         *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+         *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      for (int i = tid; i < kGChunks * 2 * kPadG; i += 256) {
+         const int c = i / (2 * kPadG), j = i - c * (2 * kPadG);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
          const T *src = pcm + (size_t)map(it) * kChunk;
-         for (int idx = tid; idx < kV4Padded + 1; idx += 256) {
-            int sidx = idx - kV4Pad;
-            sidx = sidx < 0 ? -sidx : sidx;
-            sidx = sidx >= kChunk ? 2 * (kChunk - 1) - sidx : sidx;
-            const float v = (idx < kV4Padded) ? g_sample(src[sidx]) : 0.0f;
-            if (idx < kV4Padded) X0[c * kGChunkPitch + (idx >> 6) * kGBlockPitch + (idx & 63)] = v;
-            if (idx >= 1) { const int j = idx - 1; X1[c * kGChunkPitch + (j >> 6) * kGBlockPitch + (j & 63)] = v; }
-         }
+         const int p = j < kPadG ? j : kChunk + j;                             // padded index: left pad | right pad
+         const int sidx = j < kPadG ? kPadG - j : 2 * (kChunk - 1) - (p - kPadG);
+         X0[c * kChunkPitch + (p >> 6) * kGBlockPitch + (p & 63)] = g_sample(src[sidx]);
       }
-      for (int i = tid; i < 4 * kGChunks * kV4Frames; i += 256) (&bsum[0][0])[i] = 0.0f;
+      static_assert(kPaddedG == kBlk * 64, "padded chunk must be whole blocks");
+      __syncthreads();
+      prepare(0);
       __syncthreads();
 
 #pragma unroll 1
-      for (int ct = 0; ct < kGTiles; ++ct) {
+      for (int ct = 0; ct < kTiles; ++ct) {
+         if (ct + 1 < kTiles) prepare(ct + 1);           // into the other buffer; its last readers passed the barrier below
          // column tile ct: positions 16 ct + f of the group; position -> (chunk c, frame fr)
+         const int buf = ct & 1;
          const int pos = 16 * ct + f;
-         const int c = pos / kV4Frames, fr = pos - c * kV4Frames;
-         // k-block kb, lane group g, element e  <->  tap n = 32 kb + 8 g + e
-         //   direct   x[64 fr + n]              = X0[block fr + (kb >> 1)][32 (kb & 1) + 8 g + e]
-         //   mirrored x[64 fr + 256 - n]        = X1[block fr + 3 - (kb >> 1)][56 - 32 (kb & 1) - 8 g + (7 - e)]
-         const float *pd = X0 + c * kGChunkPitch + fr * kGBlockPitch + 8 * g;
-         const float *pm = X1 + c * kGChunkPitch + (fr + 3) * kGBlockPitch + 56 - 8 * g;
-         const float center = X0[c * kGChunkPitch + (fr + 2) * kGBlockPitch];       // sample 64 fr + 128
+         const bool pos_ok = pos < kPos;
+         const int posc = pos_ok ? pos : kPos - 1;
+         const int c = posc / kFr, fr = posc - c * kFr;
          f4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};       // re0, re1, im0, im1
-         float ny = 0.0f;
-         const bool do_ny = (ct & 3) == wave;
 #pragma unroll
          for (int kb = 0; kb < 4; ++kb) {
-            const float *pdk = pd + (kb >> 1) * kGBlockPitch + 32 * (kb & 1);
-            const float *pmk = pm - (kb >> 1) * kGBlockPitch - 32 * (kb & 1);
-            const float4 d0 = *reinterpret_cast<const float4 *>(pdk), d1 = *reinterpret_cast<const float4 *>(pdk + 4);
-            const float4 m0 = *reinterpret_cast<const float4 *>(pmk), m1 = *reinterpret_cast<const float4 *>(pmk + 4);
-            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-            const float mv[8] = {m1.w, m1.z, m1.y, m1.x, m0.w, m0.z, m0.y, m0.x};   // mirrored element of tap e is index 7 - e
-            float xs[8], xd[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { xs[e] = dv[e] + mv[e]; xd[e] = dv[e] - mv[e]; }
-            if (kb == 0 && g == 0) { xs[0] = center; xd[0] = 0.0f; }                // tap 0 carries the unpaired centre tap 128
-            h8v sh, sl, dh, dl;
-            split8(xs, sh, sl);
-            split8(xd, dh, dl);
+            const h8v sh = *reinterpret_cast<const h8v *>(&Bf[buf][kb][0][lane][0]), sl = *reinterpret_cast<const h8v *>(&Bf[buf][kb][1][lane][0]);
+            const h8v dh = *reinterpret_cast<const h8v *>(&Bf[buf][kb][2][lane][0]), dl = *reinterpret_cast<const h8v *>(&Bf[buf][kb][3][lane][0]);
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) {
                const h8v bh = ti < 2 ? sh : dh, bl = ti < 2 ? sl : dl;
@@ -141,17 +203,12 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bl, acc[ti], 0, 0, 0);
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bh, acc[ti], 0, 0, 0);
             }
-            if (do_ny) {                                   // bin 128 (re only) on the vector ALU, fp32
-               const float4 w0 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g), w1 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g + 4);
-               ny = fmaf(w0.x, xs[0], ny); ny = fmaf(w0.y, xs[1], ny); ny = fmaf(w0.z, xs[2], ny); ny = fmaf(w0.w, xs[3], ny);
-               ny = fmaf(w1.x, xs[4], ny); ny = fmaf(w1.y, xs[5], ny); ny = fmaf(w1.z, xs[6], ny); ny = fmaf(w1.w, xs[7], ny);
-            }
          }
          const f4v re0 = acc[0], re1 = acc[1], im0 = acc[2], im1 = acc[3];
          // ---- epilogue: D rows = bins 32 w + 16 j + 4 g + r, column = position f ----
          const int item = grp * kGChunks + c;
-         const bool ok = item < n_chunks;
-         const size_t ybase = (size_t)map(ok ? item : n_chunks - 1) * (kBins * kV4Frames) + fr;
+         const bool ok = pos_ok && item < n_chunks;
+         const size_t ybase = (size_t)map(item < n_chunks ? item : n_chunks - 1) * (kBins * kFr) + fr;
          float part = 0.0f;
 #pragma unroll
          for (int j = 0; j < 2; ++j)
@@ -161,48 +218,58 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm_v4(const T *__restrict
                const float mag = sqrtf(fmaf(re, re, im * im));
                const float val = log1p_hw(mag * 1048576.0f);
                const int bin = 32 * wave + 16 * j + 4 * g + r;
-               if (ok) { Y[ybase + (size_t)bin * kV4Frames] = val; MAG[ybase + (size_t)bin * kV4Frames] = mag; }
+               if (ok) {
+                  Y[ybase + (size_t)bin * kFr] = val;
+                  if (Geo::mag) MAG[ybase + (size_t)bin * kFr] = mag;
+               }
                part += val;
             }
-         if (do_ny) {                                      // bin 128: re only (its im row is identically zero)
-            ny += __shfl_xor(ny, 16);
-            ny += __shfl_xor(ny, 32);
+         if ((ct & 3) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
+            const float ny = (nyp[buf][0][f] + nyp[buf][1][f]) + (nyp[buf][2][f] + nyp[buf][3][f]);
             const float mag = fabsf(ny);
             const float val = log1p_hw(mag * 1048576.0f);
-            if (g == 0) {
-               if (ok) { Y[ybase + (size_t)128 * kV4Frames] = val; MAG[ybase + (size_t)128 * kV4Frames] = mag; }
-               nyv[pos] = val;                             // added to partial 3 below: the sum must not depend on which wave took it
+            if (ok) {
+               Y[ybase + (size_t)128 * kFr] = val;
+               if (Geo::mag) MAG[ybase + (size_t)128 * kFr] = mag;
             }
+            nyv[pos] = val;                                // added to partial 3 below: the sum must not depend on which wave took it
          }
          part += __shfl_xor(part, 16);
          part += __shfl_xor(part, 32);
          if (g == 0) bsum[wave][pos] = part;               // one writer per (wave, position)
+         __syncthreads();                                  // fragment buffer ct & 1 and nyp[ct & 1] are free again; ct + 1 is ready
       }
-      __syncthreads();
       // FM partial w = this wave's 32 (+ Nyquist) bins; the consumer adds the 4 partials in fixed order
-      for (int i = tid; i < 4 * kGChunks * kV4Frames; i += 256) {
-         const int wv = i / (kGChunks * kV4Frames), pos = i - wv * (kGChunks * kV4Frames);
-         const int c = pos / kV4Frames, fr = pos - c * kV4Frames;
+      for (int i = tid; i < 4 * kPos; i += 256) {
+         const int wv = i / kPos, pos = i - wv * kPos;
+         const int c = pos / kFr, fr = pos - c * kFr;
          const int item = grp * kGChunks + c;
-         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kV4Frames + fr] = (wv == 3) ? bsum[3][pos] + nyv[pos] : bsum[wv][pos];
+         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kFr + fr] = (wv == 3) ? bsum[3][pos] + nyv[pos] : bsum[wv][pos];
       }
    }
 }
 
-void launch_frontend_gemm_v4_f32(const float *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
-                                 int n, ItemMap map, int n_cus, hipStream_t st)
+template <typename T>
+static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
+                        int n_cus, hipStream_t st, int geo)
 {
    const int groups = (n + kGChunks - 1) / kGChunks;
    const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
-   hipLaunchKernelGGL(k_frontend_gemm_v4<float>, dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   if (geo == 1) hipLaunchKernelGGL((k_frontend_gemm<T, 1>), dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   else          hipLaunchKernelGGL((k_frontend_gemm<T, 0>), dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
 }
 
-void launch_frontend_gemm_v4_s16(const int16_t *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
-                                 int n, ItemMap map, int n_cus, hipStream_t st)
+// geo: 0 = Silero v3.1 geometry (MAG unused), 1 = Silero v4
+void launch_frontend_gemm_f32(const float *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
+                              int n, ItemMap map, int n_cus, hipStream_t st, int geo)
 {
-   const int groups = (n + kGChunks - 1) / kGChunks;
-   const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
-   hipLaunchKernelGGL(k_frontend_gemm_v4<int16_t>, dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   launch_gemm<float>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo);
+}
+
+void launch_frontend_gemm_s16(const int16_t *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
+                              int n, ItemMap map, int n_cus, hipStream_t st, int geo)
+{
+   launch_gemm<int16_t>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo);
 }
 
 }  // namespace vadc
