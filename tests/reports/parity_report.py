@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Parity statistics of the HIP engine against the CPU oracle on long synthetic speech streams (GPU box).
-Writes profiles/<round>/parity_report.json.   python tools/parity_report.py [out.json]"""
+Writes profiles/<round>/parity_report.json.   python tests/reports/parity_report.py [out.json]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O            # noqa: E402  (checker)
 from vadc_amd import synth                # noqa: E402

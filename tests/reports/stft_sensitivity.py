@@ -10,7 +10,7 @@ folded evaluation with a different order.  Test infrastructure only (imports ora
 """
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O
 from vadc_amd import synth

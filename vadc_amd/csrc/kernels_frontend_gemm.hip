@@ -8,7 +8,7 @@
 // misc.c:40-63 with pad 128 and 25 frames).
 //
 // Why a GEMM is the default for v4 but an opt-in precision mode for v3.1: v3.1 parity is defined against the reference C
-// backend, whose fp32 reduction tree is part of what the model sees (tools/stft_sensitivity.py), so the
+// backend, whose fp32 reduction tree is part of what the model sees (tests/reports/stft_sensitivity.py), so the
 // fp32 mode keeps the bit-exact tree (kernels_frontend.hip).  v4 has no C implementation in the reference -- its parity target
 // is the PyTorch/onnxruntime convolution, any fp32 order -- and its probabilities move by <= 1e-6 between fp32 and fp64
 // evaluation (tests/golden/gen_golden_v4_from_python_reference.py).
