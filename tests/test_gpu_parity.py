@@ -272,6 +272,15 @@ def test_encoder_variants_agree(eng, gold_py, stage):
     assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
 
 
+def test_first_stage_forms_agree(eng, gold_py):
+    """first encoder stage: K = 1 MFMA form (default) vs the LDS slab path (option encoder=2): same fp32 math, other summation order"""
+    x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
+    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
+    eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")
+    eng.set_option("encoder", 0)
+    assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
+
+
 def test_lstm_variants_agree(eng):
     pcm = synth.make_streams(19, 6, seed0=5)
     eng.set_option("lstm", 4); eng.reset_streams(); a = eng.run(pcm)     # fp32 layer-wavefront MFMA, hoisted input projection

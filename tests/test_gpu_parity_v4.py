@@ -136,6 +136,15 @@ def test_frontend_variants(eng, orc, gold):
     assert float(np.abs(gemm_n - tree_n).max()) < 5e-3     # log1p(2^20 m) amplifies rounding noise in near-silent bins
 
 
+def test_first_stage_forms_agree(eng, gold):
+    """first encoder stage (258 channels): LDS slab path (default) vs the K = 1 MFMA form (option encoder=2)"""
+    x = f32(gold["pcm_speech1"])[:11 * 1536]
+    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
+    eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")
+    eng.set_option("encoder", 0)
+    assert float(np.abs(a - b).max()) < 5e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_probabilities_both_frontends(eng, gold, variant):
     eng.set_option("frontend", variant)

@@ -32,10 +32,10 @@ void launch_lstm(int, const float *, float *, const LstmWeights &, float *, floa
 void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, hipStream_t, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
-      *n2_w, *n2_b, *cv_f, *cv_b;
+      *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
 };
-void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
-void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
+void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
+void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
 }  // namespace vadc
 
 using namespace vadc;
@@ -190,6 +190,16 @@ static void copy_unaligned(std::vector<float> &dst, const HostTensor &t)
    memcpy(dst.data(), t.data, (size_t)t.size * 4);
 }
 
+// first encoder stage, K = 1 MFMA form (kernels_encoder_mfma.hip): per input channel the 16 pointwise and the 16 projection
+// weights as one 128-byte row [ch][pw 0..15 | proj 0..15]
+static std::vector<float> k1_pack(const std::vector<float> &pw, const std::vector<float> &pj, int D, int C)
+{
+   std::vector<float> r((size_t)C * 2 * D);
+   for (int c = 0; c < C; ++c)
+      for (int o = 0; o < D; ++o) { r[((size_t)c * 2 + 0) * D + o] = pw[(size_t)o * C + c]; r[((size_t)c * 2 + 1) * D + o] = pj[(size_t)o * C + c]; }
+   return r;
+}
+
 // GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
 // and 128 zero -- verified bit for bit on the loaded basis [258][256]; otherwise the tree kernel stays in charge.
 static bool build_gemm_frontend(const std::vector<float> &basis, Packer &pk, size_t &off_afrag, size_t &off_nyq)
@@ -263,7 +273,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
-                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f; } lo[4];
+                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f, pwj_k1; } lo[4];
    // MFMA A-fragment order for v_mfma_f32_16x16x4_f32: [m-tile][k-step][lane], lane l holds W[16mt + (l&15)][4kk + (l>>4)]
    auto frag = [](const std::vector<float> &W, int M, int K) {
       const int KKW = (K + 3) / 4;
@@ -285,11 +295,13 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
       if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
       std::vector<float> cbb;
-      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); }
+      std::vector<float> pwm;
+      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; }
       if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size()); cbb = v;
       lo[l].pjT = lo[l].pj_b = lo[l].pj_f = (size_t)-1;
       if (s.proj) {
          if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
+         if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); }
          if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size());
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
@@ -349,6 +361,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          w.cv_w = base + lo[l].cv_w; w.cv_b = base + lo[l].cv_b;
          LayerWeightsM &m = e->lwm[l];
          m.dw_w = w.dw_w; m.dw_b = w.dw_b; m.pw_f = base + lo[l].pw_f; m.pj_f = kLayers[l].proj ? base + lo[l].pj_f : nullptr;
+         m.pwj_k1 = (l == 0) ? base + lo[l].pwj_k1 : nullptr;
          m.cb_b = base + lo[l].cb_b; m.qkv_f = base + lo[l].qkv_f; m.qkv_b = w.qkv_b; m.out_f = base + lo[l].out_f; m.out_b = w.out_b;
          m.n1_w = w.n1_w; m.n1_b = w.n1_b; m.l1_f = base + lo[l].l1_f; m.l1_b = w.l1_b; m.l2_f = base + lo[l].l2_f; m.l2_b = w.l2_b;
          m.n2_w = w.n2_w; m.n2_b = w.n2_b; m.cv_f = base + lo[l].cv_f; m.cv_b = w.cv_b;
@@ -391,7 +404,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
             }
       return f;
    };
-   struct LOff { size_t dw_w, dw_b, pw_f, pj_f, cb_b, cv_f, cv_b; } lo[4];
+   struct LOff { size_t dw_w, dw_b, pw_f, pj_f, cb_b, cv_f, cv_b, pwj_k1; } lo[4];
    for (int l = 0; l < 4; ++l) {
       const LayerShape &s = kLayersV4[l];
       const int D = s.d, C = s.cin;
@@ -399,11 +412,13 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       std::vector<float> v, cbb;
       if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
       if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
-      if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); }
+      std::vector<float> pwm;
+      if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; }
       if (!take(D, v)) goto bad;     cbb = v;
       lo[l].pj_f = (size_t)-1;
       if (s.proj) {
          if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
+         if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); }
          if (!take(D, v)) goto bad;
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
@@ -433,6 +448,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
          m = LayerWeightsM{};
          m.dw_w = base + lo[l].dw_w; m.dw_b = base + lo[l].dw_b; m.pw_f = base + lo[l].pw_f;
          m.pj_f = kLayersV4[l].proj ? base + lo[l].pj_f : nullptr;
+         m.pwj_k1 = (l == 0) ? base + lo[l].pwj_k1 : nullptr;
          m.cb_b = base + lo[l].cb_b; m.cv_f = base + lo[l].cv_f; m.cv_b = base + lo[l].cv_b;
       }
       e->lstm.w = base + o_w; e->lstm.wT = base + o_wT; e->lstm.b = base + o_b; e->lstm.dec_w = base + o_dw; e->lstm.dec_b = base + o_db;
@@ -640,7 +656,7 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && value != 0)))
+   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && value == 1)))
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
@@ -655,7 +671,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return VADC_AMD_OK;
    }
    if (strcmp(key, "fe_nps") == 0 && (value == 1 || value == 2)) { e->fe_nps = value; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 1)) { e->encoder_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && value >= 0 && value <= 2) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
@@ -699,9 +715,9 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant != 2);   // v4: the slab path is the default first stage (258 channels: the K = 1 form needs 168 VGPRs)
       else if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
-      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
+      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
    }
 }
 

@@ -43,6 +43,7 @@ struct LayerWeightsM {
    const float *l2_f, *l2_b;
    const float *n2_w, *n2_b;
    const float *cv_f, *cv_b;          // strided conv with BatchNorm folded
+   const float *pwj_k1;               // first stage only: [cin][pw 0..15 | proj 0..15] (K = 1 MFMA form)
 };
 
 template <int kFrames>
@@ -157,7 +158,11 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 // LSTM_OUT: 0 = [n][D][TOUT] (next layer / stage taps); 1 = fp32 LSTM-native tiles (common.h lstm_x_index); 2 = split-fp16
 //        LSTM-native tiles (common.h lstm_xh_index): what k_lstm_wavefront_h3f reads as MFMA B fragments, written through an
 //        LDS transpose so that every (chunk, step) leaves as two contiguous 128-byte rows (hi, lo) -- D == 64 only.
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true>
+// K1 (with !DIRECT): first stage in the K = 1 MFMA form instead of the LDS slab path.  Measured per 16,384 / 65,536 chunks: v3.1
+// 0.182 / 0.633 ms (K = 1) vs 0.188 / 0.653 (slab); v4 0.283 / 0.936 vs 0.248 / 0.823 -- so v3.1 ships K = 1, v4 the slab path,
+// option "encoder" = 2 selects the other one.  Both read the 211 MB (v4: 406 MB) hand-off at 1.5-2 TB/s; the read alone takes
+// 0.033 ms from the infinity cache and 0.077 ms from HBM (tools/yread_probe.hip).
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false>
 __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
@@ -187,11 +192,65 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: per-row weights become scalar loads
    const int quad = lane >> 4, lc = lane & 15;
 
+   // K = 1 form: this wave's input channels are requested from memory FIRST -- before the normalization prologue and its
+   // barrier, which do not depend on them -- so that the whole first-stage input of the workgroup (26 KB) is in flight at
+   // once; with a group of 8 channels per wave in flight the stage ran at 1.2 TB/s of a 2.7 (HBM) .. 6.4 (infinity cache) TB/s
+   // read ceiling (tools/yread_probe.hip).
+   constexpr int CPW = K1 ? (CIN + 3) / 4 : 1;           // input channels per wave
+   float xv[CPW];
+   if constexpr (K1) {
+      const int cb0 = lane / T, t0 = lane - cb0 * T;
+      const int item0 = blockIdx.x * NCH + cb0;
+      const bool cv0 = (lane < NCOLV) && (item0 < n_chunks);
+      const int chunk0 = map(cv0 ? item0 : min(blockIdx.x * NCH, n_chunks - 1));
+      const float *xa = in + (size_t)chunk0 * (FIRST == 2 ? kBins : CIN) * T + t0;
+      const float *xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;
+      const int c0 = wave * CPW, c1 = min(c0 + CPW, CIN);
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+         const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
+         const bool first_half = FIRST == 2 && ch < kBins;  // magnitude half of the v4 input
+         xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)(FIRST == 2 ? ch - kBins : ch) * T];
+      }
+   }
    __shared__ float mm_s[FIRST ? NCH : 1];
+   // K = 1 form: depthwise weights [ch][k0..k4, bias] in LDS, so that a channel's six values are broadcast LDS reads that sit in
+   // the same batch as its global loads (as scalar loads they cost one exposed scalar-cache round trip per channel)
+   __shared__ __attribute__((aligned(8))) float dws[K1 ? CIN * 6 : 2];
+   if (K1) {
+      for (int i = tid; i < CIN; i += 256) {
+#pragma unroll
+         for (int j = 0; j < 5; ++j) dws[i * 6 + j] = w.dw_w[i * 5 + j];
+         dws[i * 6 + 5] = w.dw_b[i];
+      }
+      if (!FIRST) __syncthreads();
+   }
    if (FIRST) {
-      if (tid < NCH) {
-         const int it = blockIdx.x * NCH + tid;
-         mm_s[tid] = norm_offset_m<T>(fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * T, fm_stride);   // misc.c:65-82
+      // adaptive normalization offset mm per chunk (misc.c:65-82), spread over the first wave: lane = (chunk, frame) computes its
+      // frame mean and its smoothed value; one lane per chunk adds the T smoothed values in the reference's order
+      __shared__ float fms[NCH * T], rs[NCH * T];
+      if (tid < NCOLV) {
+         const int cbp = tid / T, q = tid - cbp * T;
+         const int it = blockIdx.x * NCH + cbp;
+         const float *fmp = fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * T + q;
+         fms[tid] = ((fmp[0] + fmp[fm_stride]) + (fmp[2 * fm_stride] + fmp[3 * fm_stride])) / 129.0f;
+         const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
+                                0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
+                                0.03663284704089164733887f};
+         float r = 0.0f;
+#pragma unroll
+         for (int i = 0; i < 7; ++i) {
+            int qq = q + i - 3;                           // reflect pad 3, no edge repeat
+            qq = qq < 0 ? -qq : qq;
+            qq = qq >= T ? 2 * (T - 1) - qq : qq;
+            r += fms[cbp * T + qq] * filt[i];             // same wave: LDS is in order
+         }
+         rs[tid] = r;
+         if (q == 0) {
+            float total = 0.0f;
+            for (int tt = 0; tt < T; ++tt) total += rs[cbp * T + tt];
+            mm_s[cbp] = total / (float)T;
+         }
       }
       __syncthreads();
    }
@@ -239,6 +298,64 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   __syncthreads();
+
+   } else if constexpr (K1) {
+   // ---- first stage (129 / 258 input channels -> 16), K = 1 form: one lane per COLUMN, one input channel per MFMA --------
+   // v_mfma_f32_16x16x1_4b_f32 multiplies, in each of its 4 blocks, a 16x1 column of A with a 1x16 row of B: with the same 16
+   // weights W[0..15][ch] in every block and lane l's value as B of (block l / 16, column l % 16), ONE instruction adds
+   // channel ch's contribution for all 64 columns of the workgroup.  So x[ch] is loaded straight from global along the frames
+   // (coalesced), its time neighbours for the depthwise conv are wave shifts of that register (a wave's 64 lanes are the 64
+   // columns), relu(dw(x)) feeds the pointwise MFMA and x the projection MFMA -- no LDS, no barriers, 32 channels in flight.
+   // The 4 waves split the input channels; their partial accumulators meet once in LDS (alias of the Q/K/V rows).
+   static_assert(!K1 || (D == 16 && HAS_PROJ), "K = 1 form: 16 output channels with projection");
+   typedef float f16acc __attribute__((ext_vector_type(16)));
+   const int col = lane;
+   const int cb = col / T, t = col - cb * T;
+   const int item_raw = blockIdx.x * NCH + cb;
+   const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
+   const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
+   const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
+   const bool l2 = t >= 2, l1 = t >= 1, r1 = t + 1 < T, r2 = t + 2 < T;
+   const int ch0 = wave * CPW, ch1 = min(ch0 + CPW, CIN);
+   f16acc P = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+   for (int i = 0; i < CPW; ++i) {
+      const bool on = ch0 + i < ch1;                       // wave-uniform
+      const int ch = on ? ch0 + i : ch1 - 1;
+      const bool first_half = FIRST == 2 && ch < kBins;    // magnitude half of the v4 input: no mean removed
+      const float x = cvalid ? (first_half ? xv[i] : xv[i] - mm) : 0.0f;                               // misc.c:84-96
+      const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
+      const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
+      const float2 k01 = *reinterpret_cast<const float2 *>(&dws[ch * 6]), k23 = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 2]);
+      const float2 k45 = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 4]);
+      float dv = k45.y;                                    // conv.c:17-53
+      dv = fmaf(l2 ? xm2 : 0.0f, k01.x, dv);
+      dv = fmaf(l1 ? xm1 : 0.0f, k01.y, dv);
+      dv = fmaf(x, k23.x, dv);
+      dv = fmaf(r1 ? xp1 : 0.0f, k23.y, dv);
+      dv = fmaf(r2 ? xp2 : 0.0f, k45.x, dv);
+      dv = cvalid ? fmaxf(dv, 0.0f) : 0.0f;
+      const float a = w.pwj_k1[ch * 32 + lc], b = w.pwj_k1[ch * 32 + 16 + lc];
+      P = __builtin_amdgcn_mfma_f32_16x16x1f32(on ? a : 0.0f, dv, P, 0, 0, 0);
+      P = __builtin_amdgcn_mfma_f32_16x16x1f32(on ? b : 0.0f, x, P, 0, 0, 0);
+   }
+   // P[4 b + r] = partial y[row 4 quad + r][column 16 b + lc]; consumer wave b wants rows 4 quad + r of ITS 16 columns in the
+   // same lane: partial buffer [producer wave][register][lane]
+   float *PB = Bb;                                        // 4 x 16 x 64 floats = 16 KB (Q/K/V rows are not live yet)
+   static_assert(!K1 || ROWS_B * kPitch >= 4 * 16 * 64, "partial buffer must fit the Q/K/V rows");
+#pragma unroll
+   for (int e = 0; e < 16; ++e) PB[(wave * 16 + e) * 64 + lane] = P[e];
+   __syncthreads();
+#pragma unroll
+   for (int r = 0; r < 4; ++r) {
+      float v = acc[0][r];                                // bias (acc_init)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v += PB[(p * 16 + 4 * wave + r) * 64 + lane];
+      acc[0][r] = fmaxf(v, 0.0f);
+   }
+   __syncthreads();                                       // partial buffer consumed before anyone writes Q/K/V
    acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
    __syncthreads();
 
@@ -474,10 +591,13 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
 
 // chunks per workgroup: L1 T=25 -> 2 (50 of 64 columns), L2 T=13 -> 4 (52), L3/L4 T=7 -> 9 (63)
 void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                       int lstm_layout, size_t fm_stride, hipStream_t st)
+                       int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
 {
    switch (layer) {
-   case 0: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
+   case 0:
+      if (slab) hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      else      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 3:
@@ -491,10 +611,13 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
 // Silero v4 encoder stages (silero_vad.py:157-189, is_v4): T = 24 -> 12 -> 6 -> 3 -> 3
 // chunks per workgroup: 2 (48 of 64 columns), 5 (60), 10 (60), 21 (63)
 void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st)
+                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
 {
    switch (layer) {
-   case 0: hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 0:
+      if (slab) hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else      hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 12, 2, true, 0, false, 5, true, false>), dim3((n + 4) / 5), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 6, 2, false, 0, false, 10, true, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
