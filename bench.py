@@ -43,6 +43,7 @@ FLOP_PER_CHUNK_V4 = {
 }
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
+PEAK_FP16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
 def cpu_baseline(blob, weights_path, seconds_budget=12.0, model="v31"):
@@ -239,11 +240,23 @@ def main():
             "kernels": per_kernel,
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
         }
+        gemm_fe = (args.model == "v4" and eng.get_option("frontend") == 0) or split16
+        if gemm_fe and dom == "k_frontend":
+            # the GEMM front end executes the FOLDED real-input DFT as split-fp16 products on the fp16 matrix pipe: 3 MFMAs per
+            # k-block, 256 rows (8 re + 8 im tiles) x K = 128 per position -- price it on what it executes against that pipe's peak
+            frames = 24 if args.model == "v4" else 25
+            executed = 3 * 2 * 256 * 128 * frames
+            ach = executed * chunks_per_launch / avg_s / 1e12
+            out["roofline"].update({"achieved": round(ach, 3), "peak": PEAK_FP16_TFLOPS, "frac": round(ach / PEAK_FP16_TFLOPS, 4),
+                                    "executed_mfma_flop_per_chunk": executed,
+                                    "algorithmic_tflops_dense_basis": round(achieved, 3)})
         if args.model == "v4" or split16:
             out["roofline"]["note"] = ("dominant kernel by CU-time; fp32 peak (vector == matrix).  FLOP are counted for the DENSE basis "
                                        "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm folds the "
                                        "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, as split-fp16 products on the fp16 matrix pipe "
-                                       "(3 x v_mfma_f32_16x16x32_f16 per k-block), so frac is not a utilisation of the fp32 roof")
+                                       "(3 x v_mfma_f32_16x16x32_f16 per k-block).  When k_frontend is the dominant kernel its achieved / peak / frac are EXECUTED "
+                                       "split-fp16 MFMA FLOP against the fp16 dense peak (the kernel is bound by its vector-ALU epilogue -- sqrt, log1p, "
+                                       "fold + split -- not by the matrix pipe); path_frac stays algorithmic FLOP (dense basis) against the fp32 roof")
             out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * (24 if args.model == "v4" else 25)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)
