@@ -5,7 +5,8 @@
 
 A "step" = one pass of the hot path (front end -> 4 encoder layers -> LSTM+decoder) over one batch of
 synthetic 16 kHz s16le audio: S independent streams x C consecutive 1536-sample chunks per stream, LSTM state
-carried on the device from step to step.  Inputs are resident in HBM before the timed region.
+carried on the device from step to step.  Defaults: S = 256 (BASELINE config 2), C = 96 = the window vadc hands its backend per
+stream and call (`chunks_count = 96` vadc.c:799, `--batch` default 96 vadc.c:1116).  Inputs are resident in HBM before the timed region.
 value = streams x chunks x 0.096 s / wall_s  (audio-seconds per second == concurrent real-time streams),
 whole job over all ranks.  For N > 1 the driver launches one rank per GPU (torch.distributed, RCCL); streams
 are sharded across ranks with no data-path collective; the per-step speech probabilities are gathered to
@@ -75,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
-    ap.add_argument("--chunks-per-step", type=int, default=64)
+    ap.add_argument("--chunks-per-step", type=int, default=96, help="chunks per stream and step (default 96 = vadc's window, vadc.c:799)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["v31", "v4"], default="v31",
                     help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")

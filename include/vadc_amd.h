@@ -156,6 +156,8 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                                      v4: 0 = k_frontend_gemm_v4 (folded STFT GEMM on the fp16 matrix pipe, default),
  *                                      1 = the tree kernel with the v4 geometry
  *                             "fe_nps" k_frontend_fl workgroup size: 1 = 64 positions / 256 threads (default), 2 = 128 positions / 512 threads
+ *                             "fe_persist" k_frontend_fl grid: 0 = one workgroup per 64 positions (default), 1 = persistent workgroups drawing
+ *                                      their units from a work counter (faster alone on the chip, not inside the engine)
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels (v3.1), 2 = MFMA layer kernels with
  *                                      the other first-stage form (v3.1: LDS slab path instead of the K = 1 MFMA form; v4: the reverse)
  *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of

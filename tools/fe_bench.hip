@@ -61,10 +61,13 @@ __global__ __launch_bounds__(512) void k_dummy_chain(float *out, int iters)
 static hipStream_t g_stb = 0;
 static float *g_dummy_out = nullptr;
 static int g_dummy_iters = 0;
+static int g_removed = 0;
 static hipStream_t g_st = 0;                     // "mask": a stream restricted to CUs 8..255 like the engine's stream A
 static bool g_cold = false;
 static void *g_scratch = nullptr;
-template <int MODE, int NB, int MINW, int ABL = 0, int NPS = 1>
+static int *g_counter = nullptr;
+static int g_slots = 0;                          // persistent variants: workgroups in the grid
+template <int MODE, int NB, int MINW, int ABL = 0, int NPS = 1, bool PERSIST = false>
 static float run_fl(const char *name, const int16_t *pcm, const float *basis, float *Y, float *FM, int n, int reps, int dyn_lds = 0)
 {
    const dim3 blocks((unsigned)(((long)n * kFrames + 64 * NPS - 1) / (64 * NPS)));
@@ -72,7 +75,7 @@ static float run_fl(const char *name, const int16_t *pcm, const float *basis, fl
    const ItemMap map{n, 0, n};
    hipEvent_t a, b;
    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-   hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, 0, pcm, basis, Y, FM, n, map, fm_stride);
+   hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS, PERSIST>), PERSIST ? dim3(g_slots / NPS) : blocks, dim3(256 * NPS), dyn_lds, 0, pcm, basis, Y, FM, n, map, fm_stride, g_counter);
    CK(hipDeviceSynchronize());
    float ms = 0;
    if (g_cold) {                                  // single launches, each after an unrelated 256 MB memset (cold caches, no back-to-back overlap)
@@ -81,7 +84,8 @@ static float run_fl(const char *name, const int16_t *pcm, const float *basis, fl
          CK(hipStreamSynchronize(g_st));
          if (g_dummy_iters) hipLaunchKernelGGL(k_dummy_chain, dim3(16), dim3(512), 0, g_stb, g_dummy_out, g_dummy_iters);
          CK(hipEventRecord(a, g_st));
-         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride);
+         if (PERSIST) CK(hipMemsetAsync(g_counter, 0, 4, g_st));
+         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS, PERSIST>), PERSIST ? dim3(g_slots / NPS) : blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride, g_counter);
          CK(hipEventRecord(b, g_st));
          CK(hipEventSynchronize(b));
          float t = 0;
@@ -90,8 +94,10 @@ static float run_fl(const char *name, const int16_t *pcm, const float *basis, fl
       }
    } else {
       CK(hipEventRecord(a, g_st));
-      for (int r = 0; r < reps; ++r)
-         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS>), blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride);
+      for (int r = 0; r < reps; ++r) {
+         if (PERSIST) CK(hipMemsetAsync(g_counter, 0, 4, g_st));
+         hipLaunchKernelGGL((k_frontend_fl<int16_t, MODE, NB, MINW, ABL, NPS, PERSIST>), PERSIST ? dim3(g_slots / NPS) : blocks, dim3(256 * NPS), dyn_lds, g_st, pcm, basis, Y, FM, n, map, fm_stride, g_counter);
+      }
       CK(hipEventRecord(b, g_st));
       CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&ms, a, b));
@@ -143,6 +149,7 @@ int main(int argc, char **argv)
    printf("n_chunks = %d\n", n);
    if (argc > 5 && !strncmp(argv[5], "mask", 4)) {  // maskN: the first N CUs (mask bit order) are taken away, "mask" = 8
       const int removed = argv[5][4] ? atoi(argv[5] + 4) : 8;
+      g_removed = removed;
       uint32_t m[8];
       for (int w = 0; w < 8; ++w) m[w] = 0xffffffffu;
       for (int cu = 0; cu < removed; ++cu) m[cu / 32] &= ~(1u << (cu % 32));
@@ -196,6 +203,13 @@ int main(int argc, char **argv)
       run_fl<0, 3, 4, 10>("fl ABL10: same taps, no sample loads", pcm, basis, Y1, FM1, n, reps);
       run_fl<0, 3, 4, 16>("fl ABL16: the 4 waves of a WG read the same taps", pcm, basis, Y1, FM1, n, reps);
       CK(hipMemset(Y1, 0, ref.size() * 4));
+      CK(hipMalloc(&g_counter, 4)); CK(hipMemset(g_counter, 0, 4));
+      g_slots = 4 * (256 - g_removed);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      run_fl<0, 3, 4, 0, 1, true>("fl persistent, work counter", pcm, basis, Y1, FM1, n, reps);   check("fl persistent", Y1); check_fm("fl persistent");
+      g_slots = 5 * (256 - g_removed);
+      run_fl<0, 3, 4, 0, 1, true>("fl persistent, 5 per CU", pcm, basis, Y1, FM1, n, reps);
+      g_slots = 4 * (256 - g_removed);
       run_fl<0, 3, 4, 0, 2>("fl nps2 (512 threads)", pcm, basis, Y1, FM1, n, reps);   check("fl nps2", Y1); check_fm("fl nps2");
       CK(hipMemset(Y1, 0, ref.size() * 4));
       run_fl<0, 3, 4, 0, 4>("fl nps4 (1024 threads)", pcm, basis, Y1, FM1, n, reps);  check("fl nps4", Y1); check_fm("fl nps4");

@@ -15,10 +15,10 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SM
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_4096x16.json
 python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline --graph 2>/dev/null | tail -1 > $O/bench_4096x16_graph.json
-python bench.py --precision split16 2>/dev/null | tail -1 > $O/bench_split16_256x64.json
+python bench.py --precision split16 2>/dev/null | tail -1 > $O/bench_split16_256x96.json
 python bench.py --precision split16 --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_split16_4096x16.json
 python tools/split16_report.py 64 64 564 > $O/split16_report.json 2>$O/split16_report.err
-python bench.py --model v4 2>/dev/null | tail -1 > $O/bench_v4_256x64.json
+python bench.py --model v4 2>/dev/null | tail -1 > $O/bench_v4_256x96.json
 python bench.py --model v4 --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_v4_4096x16.json
 python tests/reports/parity_report.py > $O/parity_report.log 2>&1
 tail -1 $O/parity_report.log

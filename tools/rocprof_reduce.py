@@ -2,7 +2,7 @@
 """Reduce rocprofv3 output directories into the small summaries kept under profiles/.
 
   python tools/rocprof_reduce.py --kernel-trace gpurun_out/prof_kt --fetch gpurun_out/prof_fetch --write gpurun_out/prof_write \
-         --out profiles/r01 --tag bench_256x64 --streams 256 --chunks-per-step 64
+         --out profiles/r01 --tag bench_256x96 --streams 256 --chunks-per-step 96
 
 * kernel trace:  <dir>/**/*_kernel_stats.csv  -> <out>/<tag>_kernel_stats.csv (copied, vadc kernels + totals only)
 * PMC passes  :  FETCH_SIZE and WRITE_SIZE were collected in SEPARATE runs (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE);
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--kernel-trace"); ap.add_argument("--fetch"); ap.add_argument("--write")
     ap.add_argument("--pmc", action="append", default=[], help="directory of an extra --pmc pass; all its counters are averaged per kernel")
     ap.add_argument("--out", required=True); ap.add_argument("--tag", required=True)
-    ap.add_argument("--streams", type=int, default=256); ap.add_argument("--chunks-per-step", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=256); ap.add_argument("--chunks-per-step", type=int, default=96)
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)

@@ -5,7 +5,7 @@ sweep 1..4096).  Runs bench.py once per point on this GPU and writes gpurun_out/
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 model = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "v31"
-POINTS = [(1, 96), (4, 96), (16, 96), (64, 64), (256, 64), (1024, 32), (4096, 16),      # (streams, chunks per step)
+POINTS = [(1, 96), (4, 96), (16, 96), (64, 96), (256, 96), (1024, 32), (4096, 16),      # (streams, chunks per step)
           (1024, 1), (4096, 1), (4096, 4), (16384, 1)]   # serving with minimum latency: one (or four) 96-ms chunks per call
 rows = []
 for S, C in POINTS:

@@ -17,8 +17,8 @@
 namespace vadc {
 void launch_frontend_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
-void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
+void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int *, int);
+void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int *, int);
 void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
@@ -126,6 +126,8 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    const float *d_basis_mx2 = nullptr;          // k_frontend_mx2: [17 tiles][l][i][j/4][16 filters][j%4]
+   int *d_fe_counter = nullptr;                 // k_frontend_fl persistent grid: work counter (zeroed on the launch's stream before every launch)
+   int fe_persist = 0;                          // option "fe_persist": 1 = persistent grid + work counter, 0 = one workgroup per unit (default: see kernels_frontend.hip)
    int fe_nps = 1;                              // k_frontend_fl: position sets per workgroup (1 = 256 threads, 2 = 512 threads; see kernels_frontend.hip)
    int frontend_variant = 0;                    // v3.1: 0 = k_frontend_fl (one lane per frame, default), 1 = k_frontend_mx2 (products issued as MFMA, experimental), 2 = k_frontend (one lane per block + wave shifts)
    LayerWeights lw[4];
@@ -473,7 +475,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_ypair[0], e->d_ypair[1], e->d_magpair[0], e->d_magpair[1],
                    e->d_fmpair[0], e->d_fmpair[1], e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1]};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1], e->d_fe_counter};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -549,6 +551,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->d_act[3] = e->d_xpair[0];
    e->d_gx = e->d_gxpair[0];
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_fe_counter, 64);
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMemset(e->d_h, 0, (size_t)max_streams * 128 * sizeof(float));
@@ -671,6 +674,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return VADC_AMD_OK;
    }
    if (strcmp(key, "fe_nps") == 0 && (value == 1 || value == 2)) { e->fe_nps = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_persist") == 0 && (value == 0 || value == 1)) { e->fe_persist = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && value >= 0 && value <= 2) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
@@ -685,6 +689,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "fe_nps") == 0) *value = e->fe_nps;
+   else if (strcmp(key, "fe_persist") == 0) *value = e->fe_persist;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
@@ -735,6 +740,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    if (hold_first) (void)hipStreamWaitEvent(st, hold_first, 0);
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
+      // workgroups that fit the CUs this stream may use (4 per CU); the internal streams lose the LSTM partition's CUs
+      const int fe_slots = 4 * ((st == e->sA || st == e->sF) && e->lstm_cus > 0 ? e->n_cus - e->lstm_cus : e->n_cus);
       if (e->use_gemm_frontend()) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
          if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
@@ -749,8 +756,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
          else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
       } else {
-         if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps);
-         else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps);
+         if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps, e->fe_persist ? e->d_fe_counter : nullptr, fe_slots);
+         else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps, e->fe_persist ? e->d_fe_counter : nullptr, fe_slots);
       }
    }
    if (st != st_enc) {
@@ -780,9 +787,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 4) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured steps: v3.1 1.73 ms, v3.1 SPLIT16 0.9 ms, v4 0.7 ms per 16,384 chunks)
+   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
    const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
-   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.043 : (e->use_gemm_frontend() ? 0.055 : 0.105);
+   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : 0.100);
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -1130,7 +1137,8 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else if (e->frontend_variant == 2) launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_nps);
+   else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_nps,
+                               e->fe_persist ? e->d_fe_counter : nullptr, 4 * e->n_cus);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);

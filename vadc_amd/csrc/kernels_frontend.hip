@@ -480,12 +480,17 @@ struct FlStages<NB, 16 * NB, ABL> {
 // the last split's 30 bins are both multiples of 3.
 // NPS = position sets (of 64) per workgroup: the NPS waves that work on the same bin split start together and read the same
 // taps at about the same time, so all but the first of them hit the scalar cache.
-template <typename T, int MODE, int NB = 3, int MINW = 4, int ABL = 0, int NPS = 1>
+// PERSIST (option "fe_persist"): the grid is as large as the chip (slots), every workgroup draws its units of 64 NPS positions from
+// `work_counter` (zeroed by the host before the launch) until they run out.  Alone on the chip this is 8-12 % faster (16,384 chunks:
+// 1.05 -> 0.96 ms, on a stream masked to 248 CUs 1.16 -> 1.03; 65,536 chunks 4.12 -> 3.60: tools/fe_bench.hip) -- but inside the
+// engine the plain grid already runs at that rate (3.53 ms per 65,536 chunks, 1.07 per 16,384 next to the LSTM chain) and the
+// persistent one is no faster (3.57 / 1.08), so the plain grid stays the default.
+template <typename T, int MODE, int NB = 3, int MINW = 4, int ABL = 0, int NPS = 1, bool PERSIST = false>
 __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__restrict__ pcm,          // [n_chunks][1536]
                                                            const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
                                                            float *__restrict__ Y,              // [n_chunks][129][25]
                                                            float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
-                                                           int n_chunks, ItemMap map, size_t fm_stride)
+                                                           int n_chunks, ItemMap map, size_t fm_stride, int *__restrict__ work_counter = nullptr)
 {
    static_assert(kBinsPerSplit % NB == 0 && (kBins - 3 * kBinsPerSplit) % NB == 0, "bin batches must tile every split");
    static_assert((16 * NB) % 2 == 0, "tap buffers must end where they started");
@@ -496,7 +501,19 @@ __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__rest
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;          // bin split
    const int pset = __builtin_amdgcn_readfirstlane(tid >> 8);              // position set
    const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * (64 * NPS);
+   __shared__ int unit_s;
+   const int n_units = (int)((total_pos + 64 * NPS - 1) / (64 * NPS));
+#pragma unroll 1
+   for (int round = 0;; ++round) {
+   int unit = blockIdx.x;
+   if (PERSIST) {
+      if (round) __syncthreads();                          // the previous unit's readers of xs / unit_s are done
+      if (tid == 0) unit_s = atomicAdd(work_counter, 1);
+      __syncthreads();
+      unit = unit_s;
+      if (unit >= n_units) break;
+   } else if (round) break;
+   const long p0 = (long)unit * (64 * NPS);
    const int item0 = (int)(p0 / kFrames);
 
    // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954), l-pair-major inside a block
@@ -564,6 +581,7 @@ __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__rest
       }
    }
    if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
+   }
 }
 
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
@@ -640,8 +658,15 @@ void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float
 }
 
 constexpr int kFlNps = 2;   // the alternative to nps == 1 (engine option "fe_nps"); 4 (1024 threads) measured 1.21 ms
-void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps)
+void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps,
+                            int *work_counter, int slots)
 {
+   if (work_counter && mode == 0) {                     // persistent grid (option "fe_persist"): units of 64 positions drawn from a counter
+      const int units = (int)(((long)n * kFrames + 63) / 64);
+      (void)hipMemsetAsync(work_counter, 0, sizeof(int), st);
+      hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1, true>), dim3(units < slots ? units : slots), dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, work_counter);
+      return;
+   }
    if (nps == 1) {
       const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
       if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
@@ -653,8 +678,15 @@ void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, floa
    else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps)
+void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps,
+                            int *work_counter, int slots)
 {
+   if (work_counter && mode == 0) {                     // persistent grid (option "fe_persist"): units of 64 positions drawn from a counter
+      const int units = (int)(((long)n * kFrames + 63) / 64);
+      (void)hipMemsetAsync(work_counter, 0, sizeof(int), st);
+      hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1, true>), dim3(units < slots ? units : slots), dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, work_counter);
+      return;
+   }
    if (nps == 1) {
       const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
       if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);

@@ -26,17 +26,20 @@
 // ~2e-7 relative, the level of fp32 accumulation itself).  Operand layout: lane l holds A[l & 15][8 (l >> 4) + e],
 // B[8 (l >> 4) + e][l & 15].
 //
-// MAPPING.  Workgroup = 4 waves, persistent over groups of G = 4 chunks (4 x frames positions = 6 or 7 column tiles of 16).
-// Wave w keeps the split A fragments of bins [32w, 32w+32) -- two re and two im row tiles, 128 VGPRs -- for the whole kernel.
+// MAPPING.  Workgroup = 8 waves, persistent over groups of G = 4 chunks (4 x frames positions = 6 or 7 column tiles of 16).
+// Wave w keeps the split A fragments of bins [16w, 16w+16) -- one re and one im row tile, 64 VGPRs -- for the whole kernel
+// (4 waves with 32 bins each need 128 VGPRs and leave two waves per SIMD; measured the two layouts are within 4 % of each
+// other -- the kernel is bound by the vector-ALU epilogue, ~20 instructions per output with four transcendentals, not by
+// latency).
 // The group's chunks are staged once in LDS as fp32 (16-byte global loads, block pitch 68 floats: the 16 frames of a column tile
 // hit disjoint banks).  The B operand of a column tile -- folded sums/differences, split into fp16 hi/lo -- is the same for all
-// four waves, so it is PREPARED ONCE: wave w folds and splits k-block w of the next tile into an LDS fragment buffer (double
-// buffered, one barrier per tile) while the matrix pipe works on the current one, and every wave then fetches its 16 fragments
-// with conflict-free ds_read_b128.  re and im of one (bin, position) land in the same lane and register of their
+// waves, so it is PREPARED ONCE: wave w folds k-block w % 4 of the next tile -- waves 0-3 the sums (re operand), waves 4-7 the
+// differences (im operand) -- and splits it into an LDS fragment buffer (double buffered, one barrier per tile) while the matrix
+// pipe works on the current one, and every wave then fetches its 16 fragments with conflict-free ds_read_b128.  re and im of one (bin, position) land in the same lane and register of their
 // accumulators, so magnitude/log1p are register-local; the stores run along the frames of a chunk.  Bin 128 (re only) is a
-// K = 128 dot product on the vector ALU: the wave that prepares k-block kb accumulates that block's share (reduced over the
-// four lane groups with two shuffles), a rotating wave adds the four shares in fixed order.  Per-frame bin sums: one partial
-// per wave = the 4 partials of FM (common.h kBinSplit).
+// K = 128 dot product on the vector ALU: the wave that prepares the sums of k-block kb accumulates that block's share (reduced
+// over the four lane groups with two shuffles), a rotating wave adds the four shares in fixed order.  Per-frame bin sums: one
+// partial per wave; waves 2p and 2p+1 make up partial p of FM (common.h kBinSplit), added in that order.
 #include "common.h"
 
 namespace vadc {
@@ -80,7 +83,7 @@ __device__ __forceinline__ float g_sample(int16_t v) { return (float)v * (1.0f /
 // afrag: [tile 0..15 (0-7 re bins 16t.., 8-15 im)][kb 0..3][lane][8]  = A[16 t' + (lane & 15)][32 kb + 8 (lane >> 4) + e]  (fp32; split in-kernel)
 // nyq:   [128] folded weights of bin 128 (re)
 template <typename T, int GEO>
-__global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ pcm, const float *__restrict__ afrag,
+__global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ pcm, const float *__restrict__ afrag,
                                                           const float *__restrict__ nyq,
                                                           float *__restrict__ Y, float *__restrict__ MAG, float *__restrict__ FM,
                                                           int n_chunks, ItemMap map, size_t fm_stride)
@@ -97,16 +100,16 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
    __shared__ __attribute__((aligned(16))) _Float16 Bf[2][4][4][64][8];         // [buffer][kb][sh, sl, dh, dl][lane][8]: 32 KB
    __shared__ __attribute__((aligned(16))) float nyq_s[128];
    __shared__ float nyp[2][4][16];                                             // bin 128: share of k-block kb, per buffer and position
-   __shared__ float bsum[4][kPosPad];
+   __shared__ float bsum[8][kPosPad];
    __shared__ float nyv[kPosPad];                                              // log value of bin 128 per position
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int f = lane & 15, g = lane >> 4;
 
-   // this wave's A fragments, split once: re tiles 2w, 2w+1 and im tiles 8+2w, 8+2w+1; [tile][kb] -> 8 halves hi + 8 halves lo
-   h8v ah[4][4], al[4][4];
+   // this wave's A fragments, split once: re tile w and im tile 8 + w; [tile][kb] -> 8 halves hi + 8 halves lo
+   h8v ah[2][4], al[2][4];
 #pragma unroll
-   for (int ti = 0; ti < 4; ++ti) {
-      const int tile = (ti < 2 ? 0 : 8) + 2 * wave + (ti & 1);
+   for (int ti = 0; ti < 2; ++ti) {
+      const int tile = (ti < 1 ? 0 : 8) + wave;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
          float v[8];
@@ -117,9 +120,10 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
    if (tid < 128) nyq_s[tid] = nyq[tid];
    if (tid < kGChunks) X0[tid * kChunkPitch + kBlk * kGBlockPitch] = 0.0f;       // the spare sample (index kPaddedG) that tap 0's mirror touches
 
-   // fold + split k-block `wave` of column tile ct into fragment buffer ct & 1 (all four waves: one k-block each)
+   // fold + split k-block `wave & 3` of column tile ct into fragment buffer ct & 1: waves 0-3 the sums, waves 4-7 the differences
    auto prepare = [&](int ct) {
-      const int kb = wave;
+      const int kb = wave & 3;
+      const bool sums = wave < 4;
       const int pos = min(16 * ct + f, kPos - 1);
       const int c = pos / kFr, fr = pos - c * kFr;
       // tap n = 32 kb + 8 g + e:  direct x[64 fr + n] = block fr + (kb >> 1), offset 32 (kb & 1) + 8 g + e;  mirrored x[64 fr + 256 - n]
@@ -127,31 +131,29 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
       const float *pd = row + (kb >> 1) * kGBlockPitch + 32 * (kb & 1) + 8 * g;
       const float4 d0 = *reinterpret_cast<const float4 *>(pd), d1 = *reinterpret_cast<const float4 *>(pd + 4);
       const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      float xs[8], xd[8];
+      float xv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
          const int m = 256 - 32 * kb - 8 * g - e;                               // 1..256
          const float mv = row[(m >> 6) * kGBlockPitch + (m & 63)];
-         xs[e] = dv[e] + mv;
-         xd[e] = dv[e] - mv;
+         xv[e] = sums ? dv[e] + mv : dv[e] - mv;
       }
-      if (kb == 0 && g == 0) { xs[0] = row[2 * kGBlockPitch]; xd[0] = 0.0f; }   // tap 0 carries the unpaired centre tap 128
-      h8v sh, sl, dh, dl;
-      split8(xs, sh, sl);
-      split8(xd, dh, dl);
+      if (kb == 0 && g == 0) xv[0] = sums ? row[2 * kGBlockPitch] : 0.0f;       // tap 0 carries the unpaired centre tap 128
+      h8v vh, vl;
+      split8(xv, vh, vl);
       const int buf = ct & 1;
-      *reinterpret_cast<h8v *>(&Bf[buf][kb][0][lane][0]) = sh;
-      *reinterpret_cast<h8v *>(&Bf[buf][kb][1][lane][0]) = sl;
-      *reinterpret_cast<h8v *>(&Bf[buf][kb][2][lane][0]) = dh;
-      *reinterpret_cast<h8v *>(&Bf[buf][kb][3][lane][0]) = dl;
-      // bin 128 (re only): this k-block's share, fp32 on the vector ALU
-      const float4 w0 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g), w1 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g + 4);
-      float ny = w0.x * xs[0];
-      ny = fmaf(w0.y, xs[1], ny); ny = fmaf(w0.z, xs[2], ny); ny = fmaf(w0.w, xs[3], ny);
-      ny = fmaf(w1.x, xs[4], ny); ny = fmaf(w1.y, xs[5], ny); ny = fmaf(w1.z, xs[6], ny); ny = fmaf(w1.w, xs[7], ny);
-      ny += __shfl_xor(ny, 16);
-      ny += __shfl_xor(ny, 32);
-      if (g == 0) nyp[buf][kb][f] = ny;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][sums ? 0 : 2][lane][0]) = vh;
+      *reinterpret_cast<h8v *>(&Bf[buf][kb][sums ? 1 : 3][lane][0]) = vl;
+      if (sums) {                                                              // wave-uniform
+         // bin 128 (re only): this k-block's share, fp32 on the vector ALU
+         const float4 w0 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g), w1 = *reinterpret_cast<const float4 *>(nyq_s + 32 * kb + 8 * g + 4);
+         float ny = w0.x * xv[0];
+         ny = fmaf(w0.y, xv[1], ny); ny = fmaf(w0.z, xv[2], ny); ny = fmaf(w0.w, xv[3], ny);
+         ny = fmaf(w1.x, xv[4], ny); ny = fmaf(w1.y, xv[5], ny); ny = fmaf(w1.z, xv[6], ny); ny = fmaf(w1.w, xv[7], ny);
+         ny += __shfl_xor(ny, 16);
+         ny += __shfl_xor(ny, 32);
+         if (g == 0) nyp[buf][kb][f] = ny;
+      }
    };
 
    const int n_groups = (n_chunks + kGChunks - 1) / kGChunks;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
       __syncthreads();                                   // previous iteration's readers are done
       // ---- stage the group's chunks: reflect pad (no edge repeat), block pitch 68 ----
-      for (int i = tid; i < kGChunks * (kChunk / 8); i += 256) {
+      for (int i = tid; i < kGChunks * (kChunk / 8); i += 512) {
          const int c = i / (kChunk / 8), q = i - c * (kChunk / 8);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
          float v[8];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
          *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
          *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
-      for (int i = tid; i < kGChunks * 2 * kPadG; i += 256) {
+      for (int i = tid; i < kGChunks * 2 * kPadG; i += 512) {
          const int c = i / (2 * kPadG), j = i - c * (2 * kPadG);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
          const T *src = pcm + (size_t)map(it) * kChunk;
@@ -191,40 +193,37 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
          const bool pos_ok = pos < kPos;
          const int posc = pos_ok ? pos : kPos - 1;
          const int c = posc / kFr, fr = posc - c * kFr;
-         f4v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};       // re0, re1, im0, im1
+         f4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};       // re, im
 #pragma unroll
          for (int kb = 0; kb < 4; ++kb) {
             const h8v sh = *reinterpret_cast<const h8v *>(&Bf[buf][kb][0][lane][0]), sl = *reinterpret_cast<const h8v *>(&Bf[buf][kb][1][lane][0]);
             const h8v dh = *reinterpret_cast<const h8v *>(&Bf[buf][kb][2][lane][0]), dl = *reinterpret_cast<const h8v *>(&Bf[buf][kb][3][lane][0]);
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-               const h8v bh = ti < 2 ? sh : dh, bl = ti < 2 ? sl : dl;
+            for (int ti = 0; ti < 2; ++ti) {
+               const h8v bh = ti < 1 ? sh : dh, bl = ti < 1 ? sl : dl;
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ti][kb], bh, acc[ti], 0, 0, 0);
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bl, acc[ti], 0, 0, 0);
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bh, acc[ti], 0, 0, 0);
             }
          }
-         const f4v re0 = acc[0], re1 = acc[1], im0 = acc[2], im1 = acc[3];
-         // ---- epilogue: D rows = bins 32 w + 16 j + 4 g + r, column = position f ----
+         // ---- epilogue: D rows = bins 16 w + 4 g + r, column = position f ----
          const int item = grp * kGChunks + c;
          const bool ok = pos_ok && item < n_chunks;
          const size_t ybase = (size_t)map(item < n_chunks ? item : n_chunks - 1) * (kBins * kFr) + fr;
          float part = 0.0f;
 #pragma unroll
-         for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-               const float re = j == 0 ? re0[r] : re1[r], im = j == 0 ? im0[r] : im1[r];
-               const float mag = sqrtf(fmaf(re, re, im * im));
-               const float val = log1p_hw(mag * 1048576.0f);
-               const int bin = 32 * wave + 16 * j + 4 * g + r;
-               if (ok) {
-                  Y[ybase + (size_t)bin * kFr] = val;
-                  if (Geo::mag) MAG[ybase + (size_t)bin * kFr] = mag;
-               }
-               part += val;
+         for (int r = 0; r < 4; ++r) {
+            const float re = acc[0][r], im = acc[1][r];
+            const float mag = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));    // v_sqrt_f32 (1 ulp): this front end is not the bit-exact one
+            const float val = log1p_hw(mag * 1048576.0f);
+            const int bin = 16 * wave + 4 * g + r;
+            if (ok) {
+               Y[ybase + (size_t)bin * kFr] = val;
+               if (Geo::mag) MAG[ybase + (size_t)bin * kFr] = mag;
             }
-         if ((ct & 3) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
+            part += val;
+         }
+         if ((ct & 7) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
             const float ny = (nyp[buf][0][f] + nyp[buf][1][f]) + (nyp[buf][2][f] + nyp[buf][3][f]);
             const float mag = fabsf(ny);
             const float val = log1p_hw(mag * 1048576.0f);
@@ -239,12 +238,13 @@ __global__ __launch_bounds__(256, 2) void k_frontend_gemm(const T *__restrict__ 
          if (g == 0) bsum[wave][pos] = part;               // one writer per (wave, position)
          __syncthreads();                                  // fragment buffer ct & 1 and nyp[ct & 1] are free again; ct + 1 is ready
       }
-      // FM partial w = this wave's 32 (+ Nyquist) bins; the consumer adds the 4 partials in fixed order
-      for (int i = tid; i < 4 * kPos; i += 256) {
+      // FM partial p = the 32 bins of waves 2p, 2p+1 (+ Nyquist for p = 3); the consumer adds the 4 partials in fixed order
+      for (int i = tid; i < 4 * kPos; i += 512) {
          const int wv = i / kPos, pos = i - wv * kPos;
          const int c = pos / kFr, fr = pos - c * kFr;
          const int item = grp * kGChunks + c;
-         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kFr + fr] = (wv == 3) ? bsum[3][pos] + nyv[pos] : bsum[wv][pos];
+         const float v = bsum[2 * wv][pos] + bsum[2 * wv + 1][pos];
+         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kFr + fr] = (wv == 3) ? v + nyv[pos] : v;
       }
    }
 }
@@ -255,8 +255,8 @@ static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, floa
 {
    const int groups = (n + kGChunks - 1) / kGChunks;
    const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
-   if (geo == 1) hipLaunchKernelGGL((k_frontend_gemm<T, 1>), dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
-   else          hipLaunchKernelGGL((k_frontend_gemm<T, 0>), dim3(grid), dim3(256), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   if (geo == 1) hipLaunchKernelGGL((k_frontend_gemm<T, 1>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   else          hipLaunchKernelGGL((k_frontend_gemm<T, 0>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
 }
 
 // geo: 0 = Silero v3.1 geometry (MAG unused), 1 = Silero v4
