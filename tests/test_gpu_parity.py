@@ -95,6 +95,26 @@ def test_frontend_variants_bit_identical(eng, gold_py, variant):
     assert float(np.abs(an - bn).max()) < 2e-5          # bin means are summed in a different (fixed) order
 
 
+@pytest.mark.parametrize("opt", ["fe_nps", "fe_persist"])
+def test_frontend_grid_options_bit_identical(weights_blob, opt):
+    """k_frontend_fl with 512-thread workgroups (fe_nps=2) or as a persistent grid drawing units from a work counter (fe_persist=1):
+    the same arithmetic per (chunk, frame, bin), so probabilities and the normalized tap are bit-identical -- ragged sizes, repeated
+    calls (the work counter is re-armed by every launch) and a call large enough for the forked two-stream path"""
+    e = Engine(weights_blob, max_streams=40, max_chunks_per_call=64, device=0)
+    try:
+        for S, Cn in ((1, 1), (3, 5), (7, 33), (40, 64)):
+            pcm = synth.make_streams(S, Cn, seed0=900 + S)
+            e.set_option(opt, 1 if opt == "fe_nps" else 0); e.reset_streams(); a = e.run(pcm); a2 = e.run(pcm)
+            e.set_option(opt, 2 if opt == "fe_nps" else 1); e.reset_streams(); b = e.run(pcm); b2 = e.run(pcm)
+            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a2), bits(b2)), (S, Cn)
+        x = f32(synth.speech_like(5 * 1536, seed=5))
+        e.set_option(opt, 1 if opt == "fe_nps" else 0); ta = e.stage_from_samples(x, "normalized")
+        e.set_option(opt, 2 if opt == "fe_nps" else 1); tb = e.stage_from_samples(x, "normalized")
+        assert np.array_equal(bits(ta), bits(tb))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 61, 64, 123])
 def test_stft_ragged_counts(eng, orc, n):
     """wave tiling (61 producing lanes, 28 blocks/chunk) must not depend on the chunk count"""
