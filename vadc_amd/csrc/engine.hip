@@ -901,7 +901,8 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       if (order) {
          (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
          (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
-         if (split_fe) (void)hipStreamWaitEvent(e->sF, e->ev_last_a, 0);
+         // the front end stream does NOT wait for the previous call's encoder (ev_last_a): it is in order with the previous front
+         // end, its Y / FM pair is guarded by hold_first below, and overlapping that encoder is the point of the third stream
       }
       // this call's hand-off pair; its last reader was the LSTM of the forked call before the previous one
       e->xpar ^= 1;
