@@ -23,8 +23,17 @@
 // The conv block needs no LDS at all: a lane's B-fragment element for k-step kk is channel 4kk+quad at its own
 // column, so x and its time neighbours are loaded from global/L1 straight into fragment registers.
 #include "common.h"
+#include <cstdio>
 
 namespace vadc {
+
+#ifdef VADC_PHASE_PROF
+__device__ unsigned long long g_phase[4][16];      // [layer][phase] accumulated cycles of (workgroup 0 mod 64, thread 0)
+__device__ unsigned int g_phase_n[4];
+#define PH(i) do { if (ph_on) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[ph_layer][i], t_ - ph_t); ph_t = t_; } } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -191,6 +200,12 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: per-row weights become scalar loads
    const int quad = lane >> 4, lc = lane & 15;
+#ifdef VADC_PHASE_PROF
+   const bool ph_on = tid == 0 && (blockIdx.x & 63) == 7;
+   const int ph_layer = CIN > 100 ? 0 : (D == 32 && CIN == 16 ? 1 : (D == 32 ? 2 : 3));
+   unsigned long long ph_t = __builtin_readcyclecounter();
+   if (ph_on) atomicAdd(&g_phase_n[ph_layer], 1u);
+#endif
 
    // K = 1 form: this wave's input channels are requested from memory FIRST -- before the normalization prologue and its
    // barrier, which do not depend on them -- so that the whole first-stage input of the workgroup (26 KB) is in flight at
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       }
       __syncthreads();
    }
+   PH(0);
    f4v acc[MT];
    acc_init<MT>(acc, w.cb_b, lane);
    if constexpr (DIRECT) {
@@ -269,6 +285,44 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const float *mx = in + (size_t)map(mvalid ? mitem : min(blockIdx.x * NCH, n_chunks - 1)) * CIN * T + mt_;
    const float mmm = FIRST ? mm_s[mcb < NCH ? mcb : 0] : 0.0f;
    const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < T, tr2 = mvalid && mt_ + 2 < T;
+   // HOIST: request ALL of the conv block's inputs (unconditionally, from clamped addresses) before anything is computed, instead of
+   // 4 k-steps at a time under lane conditions.  Measured per instantiation (16,384 / 65,536 chunks): layer 2 0.134 -> 0.125 / 0.316 ->
+   // 0.289 ms, layer 4 0.220 -> 0.215, v4 stage 2 0.082 -> 0.071; layer 3 and v4 stages 3, 4 (32 input channels, few frames: many
+   // short segments per load) get slower (0.081 -> 0.086, 0.083 -> 0.108), so they keep the batched form.
+   constexpr bool HOIST = (CIN == 16) || (CIN == 32 && D == 64 && T == 7);
+   if constexpr (HOIST) {
+   float xin[KKW][5], kw[KKW][6];
+   const int om2 = tl2 ? -2 : 0, om1 = tl1 ? -1 : 0, op1 = tr1 ? 1 : 0, op2 = tr2 ? 2 : 0;
+#pragma unroll
+   for (int kk = 0; kk < KKW; ++kk) {
+      const int ch = 4 * kk + quad;
+      const bool chv = ch < CIN;
+      const float *xr = mx + (size_t)(chv ? ch : 0) * T;
+      const float v0 = xr[0], vm2 = xr[om2], vm1 = xr[om1], vp1 = xr[op1], vp2 = xr[op2];
+      xin[kk][2] = (mvalid && chv) ? v0 - mmm : 0.0f;                    // misc.c:84-96
+      xin[kk][0] = (tl2 && chv) ? vm2 - mmm : 0.0f; xin[kk][1] = (tl1 && chv) ? vm1 - mmm : 0.0f;
+      xin[kk][3] = (tr1 && chv) ? vp1 - mmm : 0.0f; xin[kk][4] = (tr2 && chv) ? vp2 - mmm : 0.0f;
+      const float *k5 = w.dw_w + (chv ? ch : 0) * 5;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) kw[kk][j] = k5[j];
+      kw[kk][5] = w.dw_b[chv ? ch : 0];                                  // conv.c:17-53
+   }
+#pragma unroll
+   for (int kk = 0; kk < KKW; ++kk) {
+      const int ch = 4 * kk + quad;
+      const bool chv = ch < CIN;
+      const float x0 = xin[kk][2];
+      float dv = kw[kk][5];
+      dv = fmaf(xin[kk][0], kw[kk][0], dv); dv = fmaf(xin[kk][1], kw[kk][1], dv); dv = fmaf(x0, kw[kk][2], dv);
+      dv = fmaf(xin[kk][3], kw[kk][3], dv); dv = fmaf(xin[kk][4], kw[kk][4], dv);
+      dv = (mvalid && chv) ? fmaxf(dv, 0.0f) : 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pw_f[((size_t)mt * KKW + kk) * 64 + lane], dv, acc[mt], 0, 0, 0);
+         if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
+      }
+   }
+   } else {
 #pragma unroll 4
    for (int kk = 0; kk < KKW; ++kk) {
       const int ch = 4 * kk + quad;
@@ -288,6 +342,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
          if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
       }
    }
+   }
    if (!HAS_PROJ) {                                       // identity residual (CIN == D): + x
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -298,7 +353,12 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+#ifdef VADC_PHASE_PROF
+   asm volatile("" :: "v"(acc[0][0]), "v"(acc[MT - 1][3]));
+   PH(9);
+#endif
    acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   PH(10);
    __syncthreads();
 
    } else if constexpr (K1) {
@@ -442,6 +502,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    __syncthreads();                                       // slab buffers free, Yb visible
 
    }
+   PH(1);
    if constexpr (HAS_TF) {
    // ---- QKV = W y + b  -> LDS rows [0,D) Q, [D,2D) K, [2D,3D) V      transformer.c:69-99 -----------------
    {
@@ -451,6 +512,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       acc_store<3 * MT>(q, QKV, lane, wave);
    }
    __syncthreads();
+   PH(2);
 
    // ---- attention per (column i, head h): a = softmax_j(k_i . q_j / sqrt(hd)), att_i = sum_j a_j v_j ----------
    //      (K Q^T, not Q K^T: transformer.c:104-105)
@@ -492,6 +554,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       }
    }
    __syncthreads();
+   PH(3);
 
    // ---- out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220 -------------------
    {
@@ -502,11 +565,12 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       for (int mt = 0; mt < MT; ++mt) acc[mt] += p[mt];
    }
    layer_norm_acc<MT>(acc, w.n1_w, w.n1_b, lane);
-   // the wave's own 16 columns only from here on: a wave-level LDS round trip turns the accumulator layout
-   // into the next GEMM's B fragments (workgroup barriers are kept for simplicity; they cost little here)
-   __syncthreads();                                       // everyone is done reading ATT / Yb
+   PH(4);
+   // The wave's own 16 columns only from here on: a WAVE-level LDS round trip turns the accumulator layout into the next GEMM's B
+   // fragments.  A wave's LDS instructions execute in order, every element a wave reads below was written by the same wave (rows
+   // of its own columns), and no other wave touches those columns after the attention barrier -- so no workgroup barrier is
+   // needed until the epilogue, and the four waves drift apart instead of meeting five times.
    acc_store<MT>(acc, Yb, lane, wave);
-   __syncthreads();
    {
       f4v f[MT];
       acc_init<MT>(f, w.l1_b, lane);
@@ -517,7 +581,7 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
          for (int r = 0; r < 4; ++r) f[mt][r] = fmaxf(f[mt][r], 0.0f);
       acc_store<MT>(f, FFN, lane, wave);                  // relu(lin1) goes to the (dead) Q rows
    }
-   __syncthreads();
+   PH(5);
    {
       f4v g[MT];
       acc_init<MT>(g, w.l2_b, lane);
@@ -526,9 +590,8 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
    }
    layer_norm_acc<MT>(acc, w.n2_w, w.n2_b, lane);
-   __syncthreads();
    acc_store<MT>(acc, Yb, lane, wave);
-   __syncthreads();
+   PH(6);
    }  // HAS_TF
 
    // ---- conv k=1 stride s (+ folded BatchNorm) -> ReLU; only surviving time steps are stored -----------------
@@ -587,7 +650,26 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
             for (int r = 0; r < 4; ++r) dst[(size_t)(16 * mt + 4 * quad + r) * ostride] = fmaxf(z[mt][r], 0.0f);
       }
    }
+   PH(7);
 }
+
+#ifdef VADC_PHASE_PROF
+extern "C" void vadc_phase_report(void)
+{
+   unsigned long long h[4][16]; unsigned int n[4];
+   (void)hipDeviceSynchronize();
+   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
+   (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_phase_n), sizeof(n));
+   const char *names[8] = {"prologue", "conv block", "QKV", "attention", "out-proj+LN1", "FFN lin1", "lin2+LN2+store", "strided conv+out"};
+   for (int l = 0; l < 4; ++l) {
+      if (!n[l]) continue;
+      printf("layer %d (%u workgroups sampled):", l + 1, n[l]);
+      for (int i = 0; i < 8; ++i) printf("  %s %.0f", names[i], (double)h[l][i] / n[l]);
+      printf("  | conv block: inputs arrived %.0f, MFMAs + residual %.0f, acc_store %.0f (barrier wait is the rest)", (double)h[l][8] / n[l], (double)h[l][9] / n[l], (double)h[l][10] / n[l]);
+      printf("   [cycles of s_memtime/readcyclecounter]\n");
+   }
+}
+#endif
 
 // chunks per workgroup: L1 T=25 -> 2 (50 of 64 columns), L2 T=13 -> 4 (52), L3/L4 T=7 -> 9 (63)
 void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
