@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    static_assert(NCOLV <= kCol, "too many chunks per workgroup");
    constexpr int TOUT = 1 + (T - 1) / STRIDE;
    constexpr int HD = D / 2;
+   constexpr int TP = (T + 3) / 4 * 4;                  // chunk stride of the Q / V rows in LDS (attention layout)
+   static_assert(!HAS_TF || (63 / T) * TP + (63 % T) < kPitch, "padded Q / V rows must fit the LDS row pitch");
    constexpr int MT = D / 16;
    constexpr int CINP = (CIN + 3) / 4 * 4;
    constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
@@ -509,32 +511,55 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
       f4v q[3 * MT];
       acc_init<3 * MT>(q, w.qkv_b, lane);
       gemm_acc<3 * MT, D / 4>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
-      acc_store<3 * MT>(q, QKV, lane, wave);
+      // K rows keep the column layout (attention reads K at its own column).  Q and V rows are stored with every chunk's T steps
+      // padded to TP = a multiple of 4 (the row pitch has room: NCH TP <= 72), so that the attention below fetches a row's T
+      // values of one chunk with T/4 aligned 16-byte reads instead of T scalar ones -- that phase is bound by LDS instructions.
+      const int qcol = 16 * wave + lc;
+      const int qcb = qcol / T;
+      const int qcolp = qcb * TP + (qcol - qcb * T);
+#pragma unroll
+      for (int mt = 0; mt < 3 * MT; ++mt) {
+         const int cdst = (mt >= MT && mt < 2 * MT) ? qcol : qcolp;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) QKV[(16 * mt + 4 * quad + r) * kPitch + cdst] = q[mt][r];
+      }
    }
    __syncthreads();
    PH(2);
 
    // ---- attention per (column i, head h): a = softmax_j(k_i . q_j / sqrt(hd)), att_i = sum_j a_j v_j ----------
    //      (K Q^T, not Q K^T: transformer.c:104-105)
-   for (int it = tid; it < 2 * kCol; it += 256) {
-      const int h = it >> 6, i = it & 63;
+   // All 256 threads: a PAIR of adjacent lanes shares one (head, column) task -- lane p takes half of the head's hd dimensions:
+   // its part of the k.q dot products (summed across the pair with a quad-permute shuffle) and its hd/2 output rows.  Q and V rows
+   // are read as whole padded chunks (16-byte reads).  One thread per task with scalar reads made 2 T hd LDS instructions per task
+   // on two of the four waves: the longest phase of the transformer block.
+   {
+      const int p = tid & 1, task = tid >> 1;
+      const int h = task >> 6, i = task & 63;
       const int icb = i / T;
-      float *dst = ATT + (h * HD) * kPitch + i;
+      constexpr int HH = HD / 2, TQ = TP / 4;
+      float *dst = ATT + (h * HD + p * HH) * kPitch + i;
       if (i < NCOLV) {
-         const int j0 = icb * T;
-         const float *Q = QKV + (h * HD) * kPitch, *K = QKV + (D + h * HD) * kPitch, *V = QKV + (2 * D + h * HD) * kPitch;
-         float kreg[HD];
+         const float *Q = QKV + (h * HD + p * HH) * kPitch + icb * TP, *K = QKV + (D + h * HD + p * HH) * kPitch + i;
+         const float *V = QKV + (2 * D + h * HD + p * HH) * kPitch + icb * TP;
+         float sc[TP];
 #pragma unroll
-         for (int e = 0; e < HD; ++e) kreg[e] = K[e * kPitch + i];
-         float sc[T];
-         float mx = -3.0e38f;
+         for (int j = 0; j < TP; ++j) sc[j] = 0.0f;
+#pragma unroll
+         for (int e = 0; e < HH; ++e) {
+            const float ke = K[e * kPitch];
+#pragma unroll
+            for (int q4 = 0; q4 < TQ; ++q4) {
+               const float4 qv = *reinterpret_cast<const float4 *>(Q + e * kPitch + 4 * q4);
+               sc[4 * q4 + 0] = fmaf(ke, qv.x, sc[4 * q4 + 0]); sc[4 * q4 + 1] = fmaf(ke, qv.y, sc[4 * q4 + 1]);
+               sc[4 * q4 + 2] = fmaf(ke, qv.z, sc[4 * q4 + 2]); sc[4 * q4 + 3] = fmaf(ke, qv.w, sc[4 * q4 + 3]);
+            }
+         }
          const float scale = 1.0f / sqrtf((float)HD);      // transformer.c:114
+         float mx = -3.0e38f;
 #pragma unroll
          for (int j = 0; j < T; ++j) {
-            float a = 0.0f;
-#pragma unroll
-            for (int e = 0; e < HD; ++e) a = fmaf(kreg[e], Q[e * kPitch + j0 + j], a);
-            sc[j] = a * scale;
+            sc[j] = (sc[j] + __shfl_xor(sc[j], 1)) * scale;
             mx = fmaxf(mx, sc[j]);
          }
          float sum = 0.0f;                                 // tensor.h:751-784
@@ -542,15 +567,21 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
          for (int j = 0; j < T; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }   // v_exp_f32 (1 ulp); arguments <= 0
          const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-         for (int e = 0; e < HD; ++e) {
+         for (int e = 0; e < HH; ++e) {
             float o = 0.0f;
 #pragma unroll
-            for (int j = 0; j < T; ++j) o = fmaf(sc[j], V[e * kPitch + j0 + j], o);
+            for (int q4 = 0; q4 < TQ; ++q4) {
+               const float4 vv = *reinterpret_cast<const float4 *>(V + e * kPitch + 4 * q4);
+               if (4 * q4 + 0 < T) o = fmaf(sc[4 * q4 + 0], vv.x, o);
+               if (4 * q4 + 1 < T) o = fmaf(sc[4 * q4 + 1], vv.y, o);
+               if (4 * q4 + 2 < T) o = fmaf(sc[4 * q4 + 2], vv.z, o);
+               if (4 * q4 + 3 < T) o = fmaf(sc[4 * q4 + 3], vv.w, o);
+            }
             dst[e * kPitch] = o * inv;
          }
       } else {
 #pragma unroll
-         for (int e = 0; e < HD; ++e) dst[e * kPitch] = 0.0f;
+         for (int e = 0; e < HH; ++e) dst[e * kPitch] = 0.0f;
       }
    }
    __syncthreads();
