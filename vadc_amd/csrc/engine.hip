@@ -159,6 +159,7 @@ struct vadc_amd_engine {
    int groups = 0;                              // 0 = auto
    hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
    int n_cus = 0;
+   int lstm_cus_forced = 0;                     // option "lstm_cus": CUs for the LSTM partition (0 = sized by lstm_partition_cus)
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
    int last_lstm_kernel = -1;                   // what resolve_lstm chose for the last call
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
@@ -679,6 +680,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
 }
@@ -782,6 +784,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
 {
    if (!e->cu_partition) return 0;
+   if (e->lstm_cus_forced > 0) return e->lstm_cus_forced;      // option "lstm_cus" (experiments)
    const int lstm_wgs = (n_streams + 15) / 16;
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
@@ -794,7 +797,10 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
       const double t_enc = 0.9 * n_streams * per_chunk_us * e->n_cus / (double)(e->n_cus - w);
-      if (rounds == 1 || t_lstm <= t_enc) return w;
+      // the chain must finish well inside the front end + encoder time, not just inside it: with the two equal (256 streams on 8 CUs:
+      // 2.20 vs 2.19 ms) every hiccup of the chain delays the next step -- 16 CUs: 0.995 M -> 1.040 M, 512 streams 16 -> 32 CUs: 1.070 -> 1.087 M;
+      // giving CUs away costs the front end little (power-limited clocks: 32 CUs fewer, same front-end time)
+      if (rounds == 1 || t_lstm <= 0.4 * t_enc) return w;
    }
    return 0;
 }
