@@ -197,7 +197,7 @@ static void copy_unaligned(std::vector<float> &dst, const HostTensor &t)
 // weights as one 128-byte row [ch][pw 0..15 | proj 0..15]
 static std::vector<float> k1_pack(const std::vector<float> &pw, const std::vector<float> &pj, int D, int C)
 {
-   std::vector<float> r((size_t)C * 2 * D);
+   std::vector<float> r((size_t)((C + 3) / 4 * 4) * 2 * D, 0.0f);      // zero rows up to 4 x (channels per wave): the kernel's last wave reads them
    for (int c = 0; c < C; ++c)
       for (int o = 0; o < D; ++o) { r[((size_t)c * 2 + 0) * D + o] = pw[(size_t)o * C + c]; r[((size_t)c * 2 + 1) * D + o] = pj[(size_t)o * C + c]; }
    return r;

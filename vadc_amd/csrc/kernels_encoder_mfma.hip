@@ -81,11 +81,11 @@ __device__ __forceinline__ float norm_offset_m(const float *__restrict__ fmp, si
 // full-wave lane shifts (gfx9 DPP wave_shr / wave_shl): lane i <- lane i-1 / lane i+1, 0 shifted in at the ends
 __device__ __forceinline__ float dpp_wave_shr1(float v)
 {
-   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));   // bound_ctrl: 0 shifted in, no v_mov of the old value
 }
 __device__ __forceinline__ float dpp_wave_shl1(float v)
 {
-   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
 // acc[mt] (+)= W[16mt.., :] . X[:, wave's 16 columns]   for mt < MT, K = 4*KK rows of X starting at xrow0.
@@ -233,12 +233,12 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    __shared__ float mm_s[FIRST ? NCH : 1];
    // K = 1 form: depthwise weights [ch][k0..k4, bias] in LDS, so that a channel's six values are broadcast LDS reads that sit in
    // the same batch as its global loads (as scalar loads they cost one exposed scalar-cache round trip per channel)
-   __shared__ __attribute__((aligned(8))) float dws[K1 ? CIN * 6 : 2];
+   __shared__ __attribute__((aligned(8))) float dws[K1 ? 4 * CPW * 6 : 2];
    if (K1) {
-      for (int i = tid; i < CIN; i += 256) {
+      for (int i = tid; i < 4 * CPW; i += 256) {
 #pragma unroll
-         for (int j = 0; j < 5; ++j) dws[i * 6 + j] = w.dw_w[i * 5 + j];
-         dws[i * 6 + 5] = w.dw_b[i];
+         for (int j = 0; j < 5; ++j) dws[i * 6 + j] = i < CIN ? w.dw_w[i * 5 + j] : 0.0f;
+         dws[i * 6 + 5] = i < CIN ? w.dw_b[i] : 0.0f;
       }
       if (!FIRST) __syncthreads();
    }
@@ -377,34 +377,56 @@ __global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in
    const int cb = col / T, t = col - cb * T;
    const int item_raw = blockIdx.x * NCH + cb;
    const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
-   const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
    const bool l2 = t >= 2, l1 = t >= 1, r1 = t + 1 < T, r2 = t + 2 < T;
    const int ch0 = wave * CPW, ch1 = min(ch0 + CPW, CIN);
    f16acc P = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef VADC_PHASE_PROF
+   { float sink = 0; for (int i = 0; i < CPW; ++i) sink += xv[i]; asm volatile("" :: "v"(sink)); }
+   PH(8);
+#endif
+   // Everything a channel needs besides x -- its two weight rows (global) and its six depthwise values (LDS broadcast) -- travels
+   // through rings of registers, requested WR channels ahead, and the pointwise and projection products accumulate in two independent
+   // accumulators: left to the compiler each channel's loads sat right in front of its two dependent MFMAs (600 cycles per channel,
+   // 20 K of the workgroup's 45 K cycles: VADC_PHASE_PROF).
+   constexpr int WR = 4;
+   float wra[WR], wrb[WR];
+   float2 k01r[WR], k23r[WR], k45r[WR];
+   auto request = [&](int i, int slot) {
+      const int ch = ch0 + i;                              // < 4 CPW: pwj_k1 and dws are zero-padded to that many channels
+      wra[slot] = w.pwj_k1[ch * 32 + lc]; wrb[slot] = w.pwj_k1[ch * 32 + 16 + lc];
+      k01r[slot] = *reinterpret_cast<const float2 *>(&dws[ch * 6]); k23r[slot] = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 2]);
+      k45r[slot] = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 4]);
+   };
+#pragma unroll
+   for (int i = 0; i < WR; ++i) request(i, i);
+   f16acc P2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
    for (int i = 0; i < CPW; ++i) {
-      const bool on = ch0 + i < ch1;                       // wave-uniform
-      const int ch = on ? ch0 + i : ch1 - 1;
+      const int ch = min(ch0 + i, ch1 - 1);                // wave-uniform
       const bool first_half = FIRST == 2 && ch < kBins;    // magnitude half of the v4 input: no mean removed
       const float x = cvalid ? (first_half ? xv[i] : xv[i] - mm) : 0.0f;                               // misc.c:84-96
       const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
       const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
-      const float2 k01 = *reinterpret_cast<const float2 *>(&dws[ch * 6]), k23 = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 2]);
-      const float2 k45 = *reinterpret_cast<const float2 *>(&dws[ch * 6 + 4]);
+      const float2 k01 = k01r[i % WR], k23 = k23r[i % WR], k45 = k45r[i % WR];
+      const float a = wra[i % WR], b = wrb[i % WR];
+      if (i + WR < CPW) request(i + WR, i % WR);
       float dv = k45.y;                                    // conv.c:17-53
       dv = fmaf(l2 ? xm2 : 0.0f, k01.x, dv);
       dv = fmaf(l1 ? xm1 : 0.0f, k01.y, dv);
       dv = fmaf(x, k23.x, dv);
       dv = fmaf(r1 ? xp1 : 0.0f, k23.y, dv);
       dv = fmaf(r2 ? xp2 : 0.0f, k45.x, dv);
-      dv = cvalid ? fmaxf(dv, 0.0f) : 0.0f;
-      const float a = w.pwj_k1[ch * 32 + lc], b = w.pwj_k1[ch * 32 + 16 + lc];
-      P = __builtin_amdgcn_mfma_f32_16x16x1f32(on ? a : 0.0f, dv, P, 0, 0, 0);
-      P = __builtin_amdgcn_mfma_f32_16x16x1f32(on ? b : 0.0f, x, P, 0, 0, 0);
+      dv = fmaxf(dv, 0.0f);          // not masked for invalid columns: columns never mix outside a chunk's attention, dead columns stay dead
+      P = __builtin_amdgcn_mfma_f32_16x16x1f32(a, dv, P, 0, 0, 0);      // channels past CIN: zero weight rows (host padding)
+      P2 = __builtin_amdgcn_mfma_f32_16x16x1f32(b, x, P2, 0, 0, 0);
    }
-   // P[4 b + r] = partial y[row 4 quad + r][column 16 b + lc]; consumer wave b wants rows 4 quad + r of ITS 16 columns in the
-   // same lane: partial buffer [producer wave][register][lane]
+#pragma unroll
+   for (int e = 0; e < 16; ++e) P[e] += P2[e];
+#ifdef VADC_PHASE_PROF
+   asm volatile("" :: "v"(P[0]), "v"(P[15]));
+   PH(9);
+#endif
    float *PB = Bb;                                        // 4 x 16 x 64 floats = 16 KB (Q/K/V rows are not live yet)
    static_assert(!K1 || ROWS_B * kPitch >= 4 * 16 * 64, "partial buffer must fit the Q/K/V rows");
 #pragma unroll
