@@ -484,6 +484,29 @@ def test_large_batch_properties(weights_blob, orc):
     e.close()
 
 
+@pytest.mark.parametrize("precision,tol", [(0, PROB_TOL), (1, 1e-3)])
+def test_full_size_4096_streams_properties(weights_blob, orc, precision, tol):
+    """BASELINE config 3 / 5 size (4096 streams x 16 chunks per GPU): determinism, range, stream independence (the same audio in two
+    slots gives the same bits), state carry over two calls = one call of twice the length, and a spot check against the oracle"""
+    S, Cn = 4096, 16
+    base = synth.make_streams(64, 2 * Cn, seed0=7000)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 64, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=2 * Cn, device=0, precision=precision)
+    try:
+        a1 = e.run(pcm[:, : Cn * 1536]); a2 = e.run(pcm[:, Cn * 1536:])
+        a = np.concatenate([a1, a2], axis=1)
+        e.reset_streams()
+        b = e.run(pcm)                                       # one call of 32 chunks
+        assert np.array_equal(bits(a), bits(b))
+        assert np.isfinite(a).all() and (a >= 0).all() and (a <= 1).all()
+        assert np.array_equal(bits(a[:64]), bits(a[64 * 17: 64 * 18])) and np.array_equal(bits(a[:64]), bits(a[S - 64:]))
+        idx = [0, 1, 15, 16, 63]
+        want = orc.forward_streams(base[idx])
+        assert float(np.abs(a[idx, :, 1] - want).max()) <= tol
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------------------------------------- C host CLI
 def _run_cli(pcm, *args):
     import subprocess
