@@ -172,7 +172,7 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 // option "encoder" = 2 selects the other one.  Both read the 211 MB (v4: 406 MB) hand-off at 1.5-2 TB/s; the read alone takes
 // 0.033 ms from the infinity cache and 0.077 ms from HBM (tools/yread_probe.hip).
 template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false>
-__global__ __launch_bounds__(256) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
+__global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
