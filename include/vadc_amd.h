@@ -167,8 +167,10 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                             "fe_overlap" 1: the front end runs on its own internal stream, concurrently with the encoder
  *                                      layers of the previous call (buffers double buffered); 0: one stream.  Default: 1 for
  *                                      the v4 model, 0 for v3.1 (measured: it helps the GEMM front end, hurts the tree one)
- *                             "cu_partition" 1 (default): when the LSTM needs few CUs, give the two pipeline
- *                                      streams disjoint CU masks; 0: never mask. */
+ *                             "cu_partition" 1 (default): when the LSTM needs few CUs it gets CUs of its own (CU masks): shared with
+ *                                      the front end + encoder stream when every 16-stream tile has a CU to itself and the chain has
+ *                                      slack, disjoint otherwise; 2: always shared; 0: never mask.
+ *                             "lstm_cus" size of that partition in CUs (multiple of 8; 0 = sized by the engine) */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
 /* Reads a switch back, plus two read-only facts about the last forked call: "lstm_cus" = CUs reserved for the LSTM chain
  * (0 = no partition) and "lstm_kernel" = the LSTM variant "lstm"=0 resolved to. */

@@ -159,6 +159,7 @@ struct vadc_amd_engine {
    int groups = 0;                              // 0 = auto
    hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
    int n_cus = 0;
+   bool lstm_shared = false;                    // the LSTM partition's CUs are also in the other streams' mask
    int lstm_cus_forced = 0;                     // option "lstm_cus": CUs for the LSTM partition (0 = sized by lstm_partition_cus)
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
    int last_lstm_kernel = -1;                   // what resolve_lstm chose for the last call
@@ -681,7 +682,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
-   if (strcmp(key, "cu_partition") == 0 && (value == 0 || value == 1)) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
+   if (strcmp(key, "cu_partition") == 0 && value >= 0 && value <= 2) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
 }
 
@@ -743,7 +744,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
       // workgroups that fit the CUs this stream may use (4 per CU); the internal streams lose the LSTM partition's CUs
-      const int fe_slots = 4 * ((st == e->sA || st == e->sF) && e->lstm_cus > 0 ? e->n_cus - e->lstm_cus : e->n_cus);
+      const int fe_slots = 4 * ((st == e->sA || st == e->sF) && e->lstm_cus > 0 && !e->lstm_shared ? e->n_cus - e->lstm_cus : e->n_cus);
       if (e->use_gemm_frontend()) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
          if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
@@ -781,8 +782,10 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 // they are given.  So the partition is the SMALLEST multiple of 8 CUs (one per XCD) on which the chain still finishes inside
 // the front-end/encoder time of the same call: tiles/want rounds x steps x ~3.9 us per slot versus ~0.12 us (v3.1) / 0.07 us
 // (v4) of whole-chip front-end + encoder time per chunk (both sides are per chunk of the call).
-static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
+// *shared = true: the chain's CUs stay in the other streams' mask too (see ensure_pipeline_streams)
+static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *shared)
 {
+   *shared = e->cu_partition == 2;
    if (!e->cu_partition) return 0;
    if (e->lstm_cus_forced > 0) return e->lstm_cus_forced;      // option "lstm_cus" (experiments)
    const int lstm_wgs = (n_streams + 15) / 16;
@@ -793,6 +796,17 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
    // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
    const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
    const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : 0.100);
+   // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.6 of the other stream's time), the
+   // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
+   // resident LSTM workgroup leaves of those CUs, no shader engine is a CU short, and the chain is not slowed measurably
+   // (256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
+   // several tiles per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
+   // streams: 955 K -> 943 K), not for v4, whose front end runs on a third stream (2.63 M -> 2.22 M).
+   if (e->cu_partition == 1 && e->model != VADC_AMD_MODEL_V4) {
+      const int w1 = (lstm_wgs + 7) / 8 * 8;
+      const double t_enc1 = 0.9 * n_streams * per_chunk_us;
+      if (w1 <= e->n_cus / 4 && e->lstm_steps * slot_us <= 0.6 * t_enc1) { *shared = true; return w1; }
+   }
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
@@ -812,8 +826,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams)
 // LSTM chain owns `want` CUs outright and runs truly concurrently with the next group's front end.
 static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 {
-   int want = lstm_partition_cus(e, n_streams);
-   if (e->lstm_cus == want && e->sA && e->sB && e->sF) return VADC_AMD_OK;
+   bool shared = false;
+   int want = lstm_partition_cus(e, n_streams, &shared);
+   if (e->lstm_cus == want && e->lstm_shared == shared && e->sA && e->sB && e->sF) return VADC_AMD_OK;
    if (e->sF) { HIP_TRY(hipStreamSynchronize(e->sF), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
    if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
    if (e->sB) { HIP_TRY(hipStreamSynchronize(e->sB), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
@@ -822,6 +837,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       const int words = (e->n_cus + 31) / 32;
       std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
       for (int cu = 0; cu < e->n_cus; ++cu) (cu < want ? mb : ma)[cu / 32] |= 1u << (cu % 32);
+      if (shared) for (int cu = 0; cu < want; ++cu) ma[cu / 32] |= 1u << (cu % 32);   // the LSTM keeps its CUs, the other streams may use them too
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
       hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
       hipError_t ef = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sF, (uint32_t)words, ma.data()) : eb;
@@ -842,6 +858,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
    }
    e->lstm_cus = want;
+   e->lstm_shared = shared && want > 0;
    e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
    e->ev_e_valid[0] = e->ev_e_valid[1] = false;
    return VADC_AMD_OK;
@@ -859,7 +876,8 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
    if (e->lstm_variant == 0) {
       if (e->lstm_h3_ok) return 6;
       // fp32: hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
-      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams) > 0) ? 0 : 3;
+      bool sh_ = false;
+      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams, &sh_) > 0) ? 0 : 3;
    }
    if (e->lstm_variant == 4) return 0;
    return e->lstm_variant;
