@@ -673,6 +673,28 @@ def test_split16_long_stream_statistics_and_segments(weights_blob, orc):
         assert np.array_equal(O.segments(got)[1], O.segments(want)[1])
 
 
+def test_split16_device_path_and_alignment_rule(eng16):
+    """device-resident buffers in the SPLIT16 mode: same bits as the host path; the GEMM front end stages the input with 16-byte loads, so a
+    misaligned device pointer is refused (EINVAL), not read"""
+    import torch
+    pcm = synth.make_streams(8, 4, seed0=23)
+    eng16.reset_streams()
+    want = eng16.run(pcm)
+    eng16.reset_streams()
+    d_buf = torch.zeros(pcm.size + 8, dtype=torch.int16, device="cuda:0")
+    d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream()
+    d_buf[:pcm.size].copy_(torch.from_numpy(pcm.reshape(-1)))
+    eng16.run_device(d_buf.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
+    d_buf[1:pcm.size + 1].copy_(torch.from_numpy(pcm.reshape(-1)))
+    with pytest.raises(VadcAmdError) as ei:
+        eng16.run_device(d_buf.data_ptr() + 2, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
+    assert ei.value.code == _lib_code("EINVAL")
+    eng16.reset_streams()
+
+
 def test_split16_state_carry_and_call_split_invariance(eng16, gold_py):
     pcm = gold_py["pcm_speech2"][: 24 * 1536].reshape(1, -1)
     eng16.reset_streams()
