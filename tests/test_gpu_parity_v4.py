@@ -137,7 +137,7 @@ def test_frontend_variants(eng, orc, gold):
 
 
 def test_first_stage_forms_agree(eng, gold):
-    """first encoder stage (258 channels): LDS slab path (default) vs the K = 1 MFMA form (option encoder=2)"""
+    """first encoder stage (258 channels): K = 1 MFMA form (default) vs the LDS slab path (option encoder=2)"""
     x = f32(gold["pcm_speech1"])[:11 * 1536]
     eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
     eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")

@@ -167,10 +167,10 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 // LSTM_OUT: 0 = [n][D][TOUT] (next layer / stage taps); 1 = fp32 LSTM-native tiles (common.h lstm_x_index); 2 = split-fp16
 //        LSTM-native tiles (common.h lstm_xh_index): what k_lstm_wavefront_h3f reads as MFMA B fragments, written through an
 //        LDS transpose so that every (chunk, step) leaves as two contiguous 128-byte rows (hi, lo) -- D == 64 only.
-// K1 (with !DIRECT): first stage in the K = 1 MFMA form instead of the LDS slab path.  Measured per 16,384 / 65,536 chunks: v3.1
-// 0.182 / 0.633 ms (K = 1) vs 0.188 / 0.653 (slab); v4 0.283 / 0.936 vs 0.248 / 0.823 -- so v3.1 ships K = 1, v4 the slab path,
-// option "encoder" = 2 selects the other one.  Both read the 211 MB (v4: 406 MB) hand-off at 1.5-2 TB/s; the read alone takes
-// 0.033 ms from the infinity cache and 0.077 ms from HBM (tools/yread_probe.hip).
+// K1 (with !DIRECT): first stage in the K = 1 MFMA form instead of the LDS slab path (option "encoder" = 2 selects the slab path).
+// Measured per 24,576 / 65,536 chunks: v3.1 0.21 / 0.52 ms (K = 1) vs 0.23 / 0.56 (slab); v4 0.39 / 0.78 vs 0.43 / 0.85.  Both read the
+// 211 MB (v4: 406 MB) per 16,384 chunks of hand-off at 1.5-2 TB/s; the read alone takes 0.033 ms from the infinity cache and 0.077 ms
+// from HBM (tools/yread_probe.hip).
 template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false>
 __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
@@ -214,17 +214,21 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // once; with a group of 8 channels per wave in flight the stage ran at 1.2 TB/s of a 2.7 (HBM) .. 6.4 (infinity cache) TB/s
    // read ceiling (tools/yread_probe.hip).
    constexpr int CPW = K1 ? (CIN + 3) / 4 : 1;           // input channels per wave
-   float xv[CPW];
+   // x travels through a ring of XR registers: the first XR channels are requested here, channel i + XR when channel i has been
+   // consumed (v3.1: XR = CPW = 33, everything up front; v4's 65 channels per wave would cost 65 VGPRs and an occupancy step)
+   constexpr int XR = K1 ? (CPW <= 40 ? CPW : 24) : 1;
+   float xv[XR];
+   const float *xa = in, *xb = in;
    if constexpr (K1) {
       const int cb0 = lane / T, t0 = lane - cb0 * T;
       const int item0 = blockIdx.x * NCH + cb0;
       const bool cv0 = (lane < NCOLV) && (item0 < n_chunks);
       const int chunk0 = map(cv0 ? item0 : min(blockIdx.x * NCH, n_chunks - 1));
-      const float *xa = in + (size_t)chunk0 * (FIRST == 2 ? kBins : CIN) * T + t0;
-      const float *xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;
+      xa = in + (size_t)chunk0 * (FIRST == 2 ? kBins : CIN) * T + t0;
+      xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;
       const int c0 = wave * CPW, c1 = min(c0 + CPW, CIN);
 #pragma unroll
-      for (int i = 0; i < CPW; ++i) {
+      for (int i = 0; i < XR; ++i) {
          const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
          const bool first_half = FIRST == 2 && ch < kBins;  // magnitude half of the v4 input
          xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)(FIRST == 2 ? ch - kBins : ch) * T];
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    const int ch0 = wave * CPW, ch1 = min(ch0 + CPW, CIN);
    f16acc P = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef VADC_PHASE_PROF
-   { float sink = 0; for (int i = 0; i < CPW; ++i) sink += xv[i]; asm volatile("" :: "v"(sink)); }
+   { float sink = 0; for (int i = 0; i < XR; ++i) sink += xv[i]; asm volatile("" :: "v"(sink)); }
    PH(8);
 #endif
    // Everything a channel needs besides x -- its two weight rows (global) and its six depthwise values (LDS broadcast) -- travels
@@ -405,7 +409,13 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    for (int i = 0; i < CPW; ++i) {
       const int ch = min(ch0 + i, ch1 - 1);                // wave-uniform
       const bool first_half = FIRST == 2 && ch < kBins;    // magnitude half of the v4 input: no mean removed
-      const float x = cvalid ? (first_half ? xv[i] : xv[i] - mm) : 0.0f;                               // misc.c:84-96
+      const float xraw = xv[i % XR];
+      if (i + XR < CPW) {                                  // the ring slot is free: request channel i + XR
+         const int chn = min(ch0 + i + XR, ch1 - 1);
+         const bool fh = FIRST == 2 && chn < kBins;
+         xv[i % XR] = fh ? xb[(size_t)chn * T] : xa[(size_t)(FIRST == 2 ? chn - kBins : chn) * T];
+      }
+      const float x = cvalid ? (first_half ? xraw : xraw - mm) : 0.0f;                                 // misc.c:84-96
       const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
       const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
       const float2 k01 = k01r[i % WR], k23 = k23r[i % WR], k45 = k45r[i % WR];
