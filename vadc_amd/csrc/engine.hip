@@ -791,7 +791,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    const int lstm_wgs = (n_streams + 15) / 16;
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
-   if (lstm_wgs > e->n_cus / 4) return 0;
+   if (lstm_wgs > e->n_cus / 2) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
    // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
    const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
@@ -805,8 +805,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    if (e->cu_partition == 1 && e->model != VADC_AMD_MODEL_V4) {
       const int w1 = (lstm_wgs + 7) / 8 * 8;
       const double t_enc1 = 0.9 * n_streams * per_chunk_us;
-      if (w1 <= e->n_cus / 4 && e->lstm_steps * slot_us <= 0.6 * t_enc1) { *shared = true; return w1; }
+      if (w1 <= e->n_cus / 2 && e->lstm_steps * slot_us <= 0.6 * t_enc1) { *shared = true; return w1; }   // 2048 streams on 128 shared CUs: 1.18 M -> 1.25 M
    }
+   if (lstm_wgs > e->n_cus / 4) return 0;
    for (int w = 8; w <= e->n_cus / 4; w += 8) {
       const int rounds = (lstm_wgs + w - 1) / w;
       const double t_lstm = rounds * e->lstm_steps * slot_us;
