@@ -84,6 +84,16 @@ __device__ __forceinline__ float log1p_hw(float x)
    return fmaf(c, __builtin_amdgcn_rcpf(u), y);
 }
 
+// The same without the Newton step: y = ln2 * v_log_f32(u) + c / u.  v_log_f32 is good to ~1 ulp of log2(u), i.e. an absolute error of
+// up to ~1e-6 at Y ~ 16 (ten times log1p_hw's).  Used by the GEMM front end only (Silero v4, SPLIT16 mode), whose own deviation from a
+// correctly rounded STFT moves Y by up to 4e-2 in near-silent bins: one transcendental and three more instructions less per output.
+__device__ __forceinline__ float log1p_hw_fast(float x)
+{
+   const float u = 1.0f + x;
+   const float c = x - (u - 1.0f);
+   return fmaf(c, __builtin_amdgcn_rcpf(u), __builtin_amdgcn_logf(u) * 0.6931471805599453f);
+}
+
 // Split-fp16 hand-off ("h3-native"): one (tile, chunk, step) block = [hi | lo][stream-in-tile 16][unit 64] halves (4 KB, the size
 // of the fp32 block), i.e. a stream's 64 units are one 128-byte row: the B fragment of v_mfma_f32_16x16x32_f16 for
 // k-block kb is the 16 bytes at unit 32 kb + 8 (lane >> 4).  Index in HALVES of the hi row; the lo row is + 16 * 64.

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          for (int r = 0; r < 4; ++r) {
             const float re = acc[0][r], im = acc[1][r];
             const float mag = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));    // v_sqrt_f32 (1 ulp): this front end is not the bit-exact one
-            const float val = log1p_hw(mag * 1048576.0f);
+            const float val = log1p_hw_fast(mag * 1048576.0f);
             const int bin = 16 * wave + 4 * g + r;
             if (ok) {
                Y[ybase + (size_t)bin * kFr] = val;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          if ((ct & 7) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
             const float ny = (nyp[buf][0][f] + nyp[buf][1][f]) + (nyp[buf][2][f] + nyp[buf][3][f]);
             const float mag = fabsf(ny);
-            const float val = log1p_hw(mag * 1048576.0f);
+            const float val = log1p_hw_fast(mag * 1048576.0f);
             if (ok) {
                Y[ybase + (size_t)128 * kFr] = val;
                if (Geo::mag) MAG[ybase + (size_t)128 * kFr] = mag;
