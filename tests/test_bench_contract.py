@@ -1,0 +1,55 @@
+"""The bench line the driver parses: the committed profiles/rNN/bench_default.json (a verbatim `python bench.py` output) must carry every
+field of the contract, with consistent arithmetic.  CPU-only: checks the artifact, does not run the bench."""
+import glob
+import json
+import os
+
+import pytest
+
+from conftest import ROOT
+
+
+def _latest_default():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")))
+    assert files, "no profiles/rNN/bench_default.json committed"
+    return json.load(open(files[-1]))
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _latest_default()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "audio-seconds/sec" and d["dtype"] == "f32"
+    # value = streams x chunks x 0.096 s / step time
+    cfg = d["config"]
+    want = cfg["streams_per_gpu"] * cfg["chunks_per_step"] * 0.096 / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value"] - want) / want < 1e-3
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _latest_default()
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic FLOP per launch / average launch duration of the dominant kernel
+    want = r["algorithmic_flop_per_chunk"] * r["chunks_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
+    assert abs(r["achieved"] - want) / want < 1e-2
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+@pytest.mark.parametrize("name", ["bench_256x96_kernel_stats.csv", "bench_256x96_pmc_traffic.json"])
+def test_rocprof_summaries_are_committed(name):
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", name))
+    assert files, name
+    if name.endswith(".csv"):
+        txt = open(sorted(files)[-1]).read()
+        assert "k_frontend" in txt and "AverageNs" in txt
