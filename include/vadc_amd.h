@@ -159,7 +159,8 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                             "fe_persist" k_frontend_fl grid: 0 = one workgroup per 64 positions (default), 1 = persistent workgroups drawing
  *                                      their units from a work counter (faster alone on the chip, not inside the engine)
  *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels (v3.1), 2 = MFMA layer kernels with
- *                                      the first stage as the LDS slab path instead of the K = 1 MFMA form
+ *                                      the first stage as the LDS slab path instead of the K = 1 MFMA form, 3 = MFMA layer kernels with fp32
+ *                                      MFMA for the GEMMs of layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16)
  *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
  *                                      group g overlaps the front end + encoder of group g+1.
  *                             "graph"   1: capture the call's launch sequence into a hipGraph on first use and

@@ -427,6 +427,34 @@ def test_split_fp16_lstm_is_not_used_for_weights_outside_fp16_range(weights_blob
     e.close()
 
 
+@pytest.mark.parametrize("stage", ["layer2", "layer3", "layer4"])
+def test_encoder_gemm_forms_agree(eng, gold_py, stage):
+    """layers 2-4: GEMMs as split-fp16 MFMA (default: 3 x v_mfma_f32_16x16x32_f16 per k-block, 22-bit operands, fp32 accumulation) vs fp32
+    MFMA (option encoder=3): the same math to fp32 rounding"""
+    x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
+    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 3); b = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 0)
+    assert not np.array_equal(bits(a), bits(b))                       # two different kernels did run
+    assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
+
+
+def test_split_fp16_encoder_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):
+    """a layer GEMM weight that does not fit fp16: the engine keeps the fp32 MFMA form for the encoder (bit-identical to option encoder=3)"""
+    ts = tt.loads(weights_blob)
+    idx = next(i for i, (_, a) in enumerate(ts) if a.size == 3 * 32 * 32)      # a QKV weight of a 32-channel layer
+    w = ts[idx][1].copy(); w.reshape(-1)[5] = 7.0e4
+    blob = _blob_with(weights_blob, {idx: w})
+    x = f32(gold_py["pcm_speech2"])[: 5 * 1536]
+    e = Engine(blob, max_streams=4, max_chunks_per_call=8, device=0)
+    try:
+        a = e.stage_from_samples(x, "layer4")
+        e.set_option("encoder", 3); b = e.stage_from_samples(x, "layer4")
+        assert np.array_equal(bits(a), bits(b)) and np.isfinite(a).all()
+    finally:
+        e.close()
+
+
 def test_partial_reset_and_unknown_option(eng, gold_py):
     pcm = np.stack([gold_py["pcm_speech0"][:8 * 1536], gold_py["pcm_speech1"][:8 * 1536]])
     eng.reset_streams()

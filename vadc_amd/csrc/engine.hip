@@ -33,8 +33,9 @@ void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, in
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
+   const _Float16 *qkv_h, *out_h, *l1_h, *l2_h, *cv_h;
 };
-void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
+void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
 }  // namespace vadc
 
@@ -159,6 +160,7 @@ struct vadc_amd_engine {
    int groups = 0;                              // 0 = auto
    hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
    int n_cus = 0;
+   bool enc_h3_ok = false;                      // every encoder GEMM weight fits fp16's range: layers 2-4 run their GEMMs in the split-fp16 form
    bool lstm_shared = false;                    // the LSTM partition's CUs are also in the other streams' mask
    int lstm_cus_forced = 0;                     // option "lstm_cus": CUs for the LSTM partition (0 = sized by lstm_partition_cus)
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
@@ -277,7 +279,27 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
-                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f, pwj_k1; } lo[4];
+                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f, pwj_k1, qkv_h, out_h, l1_h, l2_h, cv_h; } lo[4];
+   // split-fp16 A fragments for v_mfma_f32_16x16x32_f16 (kernels_encoder_mfma.hip, H3): [m-tile][k-block][lane][hi 8 | lo 8] halves, lane l holds
+   // W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + e]; two halves per float slot of the packer.  `h3_ok` = every weight fits fp16's range.
+   bool h3_ok = true;
+   auto frag_h3 = [&h3_ok](const std::vector<float> &W, int M, int K) {
+      const int KB = K / 32;
+      std::vector<_Float16> h((size_t)(M / 16) * KB * 64 * 16);
+      for (int mt = 0; mt < M / 16; ++mt)
+         for (int kb = 0; kb < KB; ++kb)
+            for (int l = 0; l < 64; ++l)
+               for (int el = 0; el < 8; ++el) {
+                  const float v = W[(size_t)(16 * mt + (l & 15)) * K + 32 * kb + 8 * (l >> 4) + el];
+                  if (!(fabsf(v) < 60000.0f)) h3_ok = false;
+                  const _Float16 hi = (_Float16)v;
+                  h[(((size_t)mt * KB + kb) * 64 + l) * 16 + el] = hi;
+                  h[(((size_t)mt * KB + kb) * 64 + l) * 16 + 8 + el] = (_Float16)(v - (float)hi);
+               }
+      std::vector<float> f(h.size() / 2);
+      memcpy(f.data(), h.data(), h.size() * sizeof(_Float16));
+      return f;
+   };
    // MFMA A-fragment order for v_mfma_f32_16x16x4_f32: [m-tile][k-step][lane], lane l holds W[16mt + (l&15)][4kk + (l>>4)]
    auto frag = [](const std::vector<float> &W, int M, int K) {
       const int KKW = (K + 3) / 4;
@@ -310,15 +332,15 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
       lo[l].cb_b = pk.add(cbb.data(), cbb.size());
-      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size()); { auto f = frag(v, 3 * D, D); lo[l].qkv_f = pk.add(f.data(), f.size()); }
+      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size()); { auto f = frag(v, 3 * D, D); lo[l].qkv_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, 3 * D, D); lo[l].qkv_h = pk.add(h.data(), h.size()); } }
       if (!take(3 * D, v)) goto bad;     lo[l].qkv_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].out_f = pk.add(f.data(), f.size()); }
+      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].out_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].out_h = pk.add(h.data(), h.size()); } }
       if (!take(D, v)) goto bad;         lo[l].out_b = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n1_w = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l1_f = pk.add(f.data(), f.size()); }
+      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l1_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l1_h = pk.add(h.data(), h.size()); } }
       if (!take(D, v)) goto bad;         lo[l].l1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l2_f = pk.add(f.data(), f.size()); }
+      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l2_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l2_h = pk.add(h.data(), h.size()); } }
       if (!take(D, v)) goto bad;         lo[l].l2_b = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n2_w = pk.add(v.data(), v.size());
       if (!take(D, v)) goto bad;         lo[l].n2_b = pk.add(v.data(), v.size());
@@ -334,9 +356,10 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          }
          lo[l].cv_w = pk.add(cw.data(), cw.size());
          lo[l].cv_b = pk.add(cb.data(), cb.size());
-         { auto f = frag(cw, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); }
+         { auto f = frag(cw, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(cw, D, D); lo[l].cv_h = pk.add(h.data(), h.size()); } }
       }
    }
+   e->enc_h3_ok = h3_ok;
    {
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 128) || !need(idx + 3, 2)) goto bad;
       std::vector<float> W, B, dw, db;
@@ -366,6 +389,11 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          LayerWeightsM &m = e->lwm[l];
          m.dw_w = w.dw_w; m.dw_b = w.dw_b; m.pw_f = base + lo[l].pw_f; m.pj_f = kLayers[l].proj ? base + lo[l].pj_f : nullptr;
          m.pwj_k1 = (l == 0) ? base + lo[l].pwj_k1 : nullptr;
+         if (kLayers[l].d % 32 == 0 && e->enc_h3_ok) {
+            m.qkv_h = reinterpret_cast<const _Float16 *>(base + lo[l].qkv_h); m.out_h = reinterpret_cast<const _Float16 *>(base + lo[l].out_h);
+            m.l1_h = reinterpret_cast<const _Float16 *>(base + lo[l].l1_h);   m.l2_h = reinterpret_cast<const _Float16 *>(base + lo[l].l2_h);
+            m.cv_h = reinterpret_cast<const _Float16 *>(base + lo[l].cv_h);
+         } else m.qkv_h = m.out_h = m.l1_h = m.l2_h = m.cv_h = nullptr;
          m.cb_b = base + lo[l].cb_b; m.qkv_f = base + lo[l].qkv_f; m.qkv_b = w.qkv_b; m.out_f = base + lo[l].out_f; m.out_b = w.out_b;
          m.n1_w = w.n1_w; m.n1_b = w.n1_b; m.l1_f = base + lo[l].l1_f; m.l1_b = w.l1_b; m.l2_f = base + lo[l].l2_f; m.l2_b = w.l2_b;
          m.n2_w = w.n2_w; m.n2_b = w.n2_b; m.cv_f = base + lo[l].cv_f; m.cv_b = w.cv_b;
@@ -661,7 +689,7 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && value == 1)))
+   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && (value == 1 || value == 3))))
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
@@ -677,7 +705,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "fe_nps") == 0 && (value == 1 || value == 2)) { e->fe_nps = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_persist") == 0 && (value == 0 || value == 1)) { e->fe_persist = value; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder") == 0 && value >= 0 && value <= 2) { e->encoder_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && value >= 0 && value <= 3) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
@@ -725,7 +753,8 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
       if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
       else if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
-      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
+      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
+                                                     e->encoder_variant != 3 && e->enc_h3_ok);
    }
 }
 

@@ -53,6 +53,7 @@ struct LayerWeightsM {
    const float *n2_w, *n2_b;
    const float *cv_f, *cv_b;          // strided conv with BatchNorm folded
    const float *pwj_k1;               // first stage only: [cin][pw 0..15 | proj 0..15] (K = 1 MFMA form)
+   const _Float16 *qkv_h, *out_h, *l1_h, *l2_h, *cv_h;   // H3: host-split fp16 fragments [M / 16][K / 32][64 lanes][hi 8 | lo 8] (or null)
 };
 
 template <int kFrames>
@@ -103,6 +104,56 @@ __device__ __forceinline__ void gemm_acc(f4v (&acc)[MT], const float *__restrict
       const float *wp = wf + ((size_t)mt * KKW + kk0) * 64 + lane;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[kk * 64], b[kk], acc[mt], 0, 0, 0);
+   }
+}
+
+// ---- split-fp16 form of the layer GEMMs (H3; the LSTM's trick, kernels_lstm.hip): W . X ~= Wl . Xh + Wh . Xl + Wh . Xh as three
+// v_mfma_f32_16x16x32_f16 (K = 32, 16 cycles, fp32 accumulation of exact fp16 x fp16 products) instead of eight
+// v_mfma_f32_16x16x4_f32 (32 cycles each, on the vector ALU's lanes): 5.3x fewer matrix cycles at fp32 accuracy (22 significant
+// bits per operand).  Activations live in LDS as two fp16 tiles [column][k] (k contiguous, pitch K + 8 halves: a wave's 16-byte
+// B-fragment reads and 8-byte accumulator stores are conflict-free within a 16-lane phase); a lane's B fragment of k-block kb is the
+// 16 bytes at k = 32 kb + 8 (lane >> 4) of column 16 wave + (lane & 15).  Weights come host-split: [M tile][kb][lane][hi 8 | lo 8].
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+template <int KB>
+__device__ __forceinline__ void load_b_h3(h8v (&bh)[KB], h8v (&bl)[KB], const _Float16 *Sh, const _Float16 *Sl, int pitch, int lane, int wave)
+{
+   const int off = (16 * wave + (lane & 15)) * pitch + 8 * (lane >> 4);
+#pragma unroll
+   for (int kb = 0; kb < KB; ++kb) {
+      bh[kb] = *reinterpret_cast<const h8v *>(Sh + off + 32 * kb);
+      bl[kb] = *reinterpret_cast<const h8v *>(Sl + off + 32 * kb);
+   }
+}
+
+template <int MT, int KB>
+__device__ __forceinline__ void gemm_acc_h3(f4v (&acc)[MT], const _Float16 *__restrict__ wf, const h8v (&bh)[KB], const h8v (&bl)[KB], int lane)
+{
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+         const h8v *p = reinterpret_cast<const h8v *>(wf + (((size_t)mt * KB + kb) * 64 + lane) * 16);
+         const h8v ah = p[0], al = p[1];
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kb], acc[mt], 0, 0, 0);
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kb], acc[mt], 0, 0, 0);
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kb], acc[mt], 0, 0, 0);
+      }
+}
+
+// accumulator layout -> split tiles: lane (quad, lc), acc[mt][r]  ->  column 16 wave + lc, k = 16 mt + 4 quad + r
+template <int MT>
+__device__ __forceinline__ void acc_store_h3(const f4v (&acc)[MT], _Float16 *Sh, _Float16 *Sl, int pitch, int lane, int wave)
+{
+   const int off = (16 * wave + (lane & 15)) * pitch + 4 * (lane >> 4);
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      h4v hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hi[r] = (_Float16)acc[mt][r]; lo[r] = (_Float16)(acc[mt][r] - (float)hi[r]); }
+      *reinterpret_cast<h4v *>(Sh + off + 16 * mt) = hi;
+      *reinterpret_cast<h4v *>(Sl + off + 16 * mt) = lo;
    }
 }
 
@@ -171,7 +222,8 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 // Measured per 24,576 / 65,536 chunks: v3.1 0.21 / 0.52 ms (K = 1) vs 0.23 / 0.56 (slab); v4 0.39 / 0.78 vs 0.43 / 0.85.  Both read the
 // 211 MB (v4: 406 MB) per 16,384 chunks of hand-off at 1.5-2 TB/s; the read alone takes 0.033 ms from the infinity cache and 0.077 ms
 // from HBM (tools/yread_probe.hip).
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false>
+// H3: the transformer block's GEMMs and the strided conv in the split-fp16 form above (D = 32 / 64 layers; option "encoder" = 3 keeps fp32 MFMA)
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false, bool H3 = false>
 __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
@@ -194,7 +246,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // in the accumulators) and relu(lin1) reuses the Q rows, so layer 4 (D = 64) needs 80 KB instead of 100 KB and TWO
    // workgroups fit a CU's 160 KB -- with one, its single wave per SIMD had nothing to hide MFMA/LDS latency behind.
    constexpr int ROWS_B = (DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab;
-   __shared__ __attribute__((aligned(16))) float Yb[D * kPitch];          // conv-block output / residual stream / ATT
+   static_assert(!H3 || (DIRECT && HAS_TF && D % 32 == 0), "split-fp16 layer GEMMs: transformer layers with D = 32 / 64");
+   constexpr int HP = D + 8, KB = H3 ? D / 32 : 1;       // H3: pitch (halves) of the split activation tiles, k-blocks per GEMM
+   __shared__ __attribute__((aligned(16))) _Float16 SH[H3 ? 2 * kCol * HP : 8];   // H3: [hi | lo][column][k]: the B operand of every GEMM of the block, reused in place
+   _Float16 *Sh = SH, *Sl = SH + (H3 ? kCol * HP : 0);
+   __shared__ __attribute__((aligned(16))) float Yb[H3 ? 4 : D * kPitch];   // conv-block output / residual stream / ATT (fp32 MFMA form)
    __shared__ __attribute__((aligned(16))) float Bb[ROWS_B * kPitch];     // Q, K, V rows; then relu(lin1)
    float *QKV = Bb, *ATT = Yb, *FFN = Bb;
    float *XS = Bb, *DWR = Bb + kSlab * kPitch;          // slab path only (aliases Q/K/V)
@@ -363,7 +419,8 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    asm volatile("" :: "v"(acc[0][0]), "v"(acc[MT - 1][3]));
    PH(9);
 #endif
-   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave);
+   else acc_store<MT>(acc, Yb, lane, wave);               // y: B operand of QKV; also kept in acc as the residual
    PH(10);
    __syncthreads();
 
@@ -542,7 +599,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    {
       f4v q[3 * MT];
       acc_init<3 * MT>(q, w.qkv_b, lane);
-      gemm_acc<3 * MT, D / 4>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
+      if constexpr (H3) {
+         h8v bh[KB], bl[KB];
+         load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
+         gemm_acc_h3<3 * MT, KB>(q, w.qkv_h, bh, bl, lane);
+      } else gemm_acc<3 * MT, D / 4>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
       // K rows keep the column layout (attention reads K at its own column).  Q and V rows are stored with every chunk's T steps
       // padded to TP = a multiple of 4 (the row pitch has room: NCH TP <= 72), so that the attention below fetches a row's T
       // values of one chunk with T/4 aligned 16-byte reads instead of T scalar ones -- that phase is bound by LDS instructions.
@@ -571,6 +632,8 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
       const int icb = i / T;
       constexpr int HH = HD / 2, TQ = TP / 4;
       float *dst = ATT + (h * HD + p * HH) * kPitch + i;
+      _Float16 *dsh = Sh + i * HP + h * HD + p * HH, *dsl = Sl + i * HP + h * HD + p * HH;    // H3: this lane's HH consecutive k of column i
+      float ov[HH];
       if (i < NCOLV) {
          const float *Q = QKV + (h * HD + p * HH) * kPitch + icb * TP, *K = QKV + (D + h * HD + p * HH) * kPitch + i;
          const float *V = QKV + (2 * D + h * HD + p * HH) * kPitch + icb * TP;
@@ -609,11 +672,21 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
                if (4 * q4 + 2 < T) o = fmaf(sc[4 * q4 + 2], vv.z, o);
                if (4 * q4 + 3 < T) o = fmaf(sc[4 * q4 + 3], vv.w, o);
             }
-            dst[e * kPitch] = o * inv;
+            if constexpr (H3) ov[e] = o * inv; else dst[e * kPitch] = o * inv;
          }
       } else {
 #pragma unroll
-         for (int e = 0; e < HH; ++e) dst[e * kPitch] = 0.0f;
+         for (int e = 0; e < HH; ++e) { if constexpr (H3) ov[e] = 0.0f; else dst[e * kPitch] = 0.0f; }
+      }
+      if constexpr (H3) {
+#pragma unroll
+         for (int e8 = 0; e8 < HH / 8; ++e8) {
+            h8v hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)ov[8 * e8 + e]; lo[e] = (_Float16)(ov[8 * e8 + e] - (float)hi[e]); }
+            *reinterpret_cast<h8v *>(dsh + 8 * e8) = hi;
+            *reinterpret_cast<h8v *>(dsl + 8 * e8) = lo;
+         }
       }
    }
    __syncthreads();
@@ -623,7 +696,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    {
       f4v p[MT];
       acc_init<MT>(p, w.out_b, lane);
-      gemm_acc<MT, D / 4>(p, w.out_f, D / 4, 0, ATT, lane, wave);
+      if constexpr (H3) {
+         h8v bh[KB], bl[KB];
+         load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
+         gemm_acc_h3<MT, KB>(p, w.out_h, bh, bl, lane);
+      } else gemm_acc<MT, D / 4>(p, w.out_f, D / 4, 0, ATT, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += p[mt];
    }
@@ -633,27 +710,38 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // fragments.  A wave's LDS instructions execute in order, every element a wave reads below was written by the same wave (rows
    // of its own columns), and no other wave touches those columns after the attention barrier -- so no workgroup barrier is
    // needed until the epilogue, and the four waves drift apart instead of meeting five times.
-   acc_store<MT>(acc, Yb, lane, wave);
+   // (H3: one pair of split tiles serves the whole chain in place -- a wave holds ALL of its B fragments of a GEMM in registers
+   // before it stores that GEMM's output over them)
+   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT>(acc, Yb, lane, wave);
    {
       f4v f[MT];
       acc_init<MT>(f, w.l1_b, lane);
-      gemm_acc<MT, D / 4>(f, w.l1_f, D / 4, 0, Yb, lane, wave);
+      if constexpr (H3) {
+         h8v bh[KB], bl[KB];
+         load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
+         gemm_acc_h3<MT, KB>(f, w.l1_h, bh, bl, lane);
+      } else gemm_acc<MT, D / 4>(f, w.l1_f, D / 4, 0, Yb, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
          for (int r = 0; r < 4; ++r) f[mt][r] = fmaxf(f[mt][r], 0.0f);
-      acc_store<MT>(f, FFN, lane, wave);                  // relu(lin1) goes to the (dead) Q rows
+      if constexpr (H3) acc_store_h3<MT>(f, Sh, Sl, HP, lane, wave);
+      else acc_store<MT>(f, FFN, lane, wave);             // relu(lin1) goes to the (dead) Q rows
    }
    PH(5);
    {
       f4v g[MT];
       acc_init<MT>(g, w.l2_b, lane);
-      gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, FFN, lane, wave);
+      if constexpr (H3) {
+         h8v bh[KB], bl[KB];
+         load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
+         gemm_acc_h3<MT, KB>(g, w.l2_h, bh, bl, lane);
+      } else gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, FFN, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
    }
    layer_norm_acc<MT>(acc, w.n2_w, w.n2_b, lane);
-   acc_store<MT>(acc, Yb, lane, wave);
+   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT>(acc, Yb, lane, wave);
    PH(6);
    }  // HAS_TF
 
@@ -661,7 +749,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    {
       f4v z[MT];
       acc_init<MT>(z, w.cv_b, lane);
-      gemm_acc<MT, D / 4>(z, w.cv_f, D / 4, 0, Yb, lane, wave);
+      if constexpr (H3) {
+         h8v bh[KB], bl[KB];
+         load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
+         gemm_acc_h3<MT, KB>(z, w.cv_h, bh, bl, lane);
+      } else gemm_acc<MT, D / 4>(z, w.cv_f, D / 4, 0, Yb, lane, wave);
       // this lane's column in the accumulator layout
       const int ocol = 16 * wave + lc;
       const int ocb = ocol / T, ot = ocol - ocb * T;
@@ -736,8 +828,20 @@ extern "C" void vadc_phase_report(void)
 
 // chunks per workgroup: L1 T=25 -> 2 (50 of 64 columns), L2 T=13 -> 4 (52), L3/L4 T=7 -> 9 (63)
 void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                       int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
+                       int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, bool h3)
 {
+   if (h3 && w.qkv_h) {
+      switch (layer) {
+      case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true, true, false, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); return;
+      case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); return;
+      case 3:
+         if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 2, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+         else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 1, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+         else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 0, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+         return;
+      default: break;
+      }
+   }
    switch (layer) {
    case 0:
       if (slab) hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
