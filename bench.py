@@ -213,7 +213,8 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
             prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
-            if prof.get("streams") == S and prof.get("chunks_per_step") == Cn and dom in prof.get("kernels", {}):
+            # the committed passes were collected with the default command (Silero v3.1, fp32 mode): only that workload gets their bytes
+            if args.model == "v31" and not split16 and prof.get("streams") == S and prof.get("chunks_per_step") == Cn and dom in prof.get("kernels", {}):
                 traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass
