@@ -149,9 +149,10 @@ struct vadc_amd_engine {
    // end of call k+1 runs on its own internal stream concurrently with the encoder layers of call k on the same CUs.
    float *d_ypair[2] = {nullptr, nullptr}, *d_fmpair[2] = {nullptr, nullptr}, *d_magpair[2] = {nullptr, nullptr};
    int xpar = 0;
-   int fe_overlap = 0;                          // option "fe_overlap": 1 = front end on its own internal stream.  Measured
-                                                // (256 x 64): v3.1 2.46 -> 2.82 ms (the tree front end starves the layer kernels
-                                                // of wave slots), v4 1.43 -> 1.37 ms; default: on for v4 only.
+   int fe_overlap = 0;                          // option "fe_overlap": 1 = front end on its own internal stream, overlapping the previous
+                                                // call's encoder.  Off by default: the front end's grid starves the layer kernels of
+                                                // workgroup slots (v3.1 -10 %); for v4 it was worth +3 % until the shared LSTM partition,
+                                                // which needs the two-stream form, was worth more (256 streams: 2.66 M -> 2.81 M).
    bool capturing = false;                      // inside hipStreamBeginCapture: no waits on events from outside the capture
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
@@ -552,7 +553,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
    e->stage_elems = e->model == VADC_AMD_MODEL_V4 ? kStageElemsV4 : kStageElemsV31;
-   e->fe_overlap = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
+   e->fe_overlap = 0;
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    const size_t N = e->max_items;
@@ -825,16 +826,16 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
    const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
    const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : 0.100);
-   // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.6 of the other stream's time), the
+   // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
    // resident LSTM workgroup leaves of those CUs, no shader engine is a CU short, and the chain is not slowed measurably
    // (256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
    // several tiles per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
-   // streams: 955 K -> 943 K), not for v4, whose front end runs on a third stream (2.63 M -> 2.22 M).
-   if (e->cu_partition == 1 && e->model != VADC_AMD_MODEL_V4) {
+   // streams: 955 K -> 943 K), not with the front end on a third stream (option "fe_overlap": v4 2.63 M -> 2.22 M).
+   if (e->cu_partition == 1 && !e->fe_overlap) {
       const int w1 = (lstm_wgs + 7) / 8 * 8;
       const double t_enc1 = 0.9 * n_streams * per_chunk_us;
-      if (w1 <= e->n_cus / 2 && e->lstm_steps * slot_us <= 0.6 * t_enc1) { *shared = true; return w1; }   // 2048 streams on 128 shared CUs: 1.18 M -> 1.25 M
+      if (w1 <= e->n_cus / 2 && e->lstm_steps * slot_us <= 0.7 * t_enc1) { *shared = true; return w1; }   // 2048 streams on 128 shared CUs: 1.18 M -> 1.25 M
    }
    if (lstm_wgs > e->n_cus / 4) return 0;
    for (int w = 8; w <= e->n_cus / 4; w += 8) {

@@ -336,63 +336,46 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    acc_init<MT>(acc, w.cb_b, lane);
    if constexpr (DIRECT) {
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
-   // Direct-to-fragment: for k-step kk this lane's B-fragment element is channel 4kk+quad at ITS OWN column, so x
-   // (and its 4 time neighbours for the depthwise conv) is loaded straight from global/L1 into the fragment
-   // registers -- no LDS staging, no barriers, the 4 waves run independently.  x feeds the projection MFMA,
-   // relu(dw(x)) the pointwise MFMA.
+   // The workgroup's input tile -- NCH chunks x CIN channels x T steps, one CONTIGUOUS run of CIN T floats per chunk -- is staged once
+   // with 16-byte loads into LDS as [channel][column] (the rows of the Q / K / V area, not live yet); a lane's B-fragment element for k-step
+   // kk is channel 4 kk + quad at its own column, and x with its 4 time neighbours for the depthwise conv are five LDS reads.  x feeds the
+   // projection MFMA, relu(dw(x)) the pointwise MFMA.  (Loaded straight from global, every lane fetched x and its four neighbours itself:
+   // 40-48 load instructions per lane over 28-byte segments, and the texture path, not memory latency, made the block the longest phase of
+   // layers 2-4: 7 / 13 / 15 K cycles per workgroup.)
+   static_assert((CIN * T) % 4 == 0, "a chunk's input tile must be whole 16-byte pieces");
+   float *XT = Bb;                                        // [CIN][kPitch]
+   {
+      constexpr int Q4 = CIN * T / 4;                     // 16-byte pieces per chunk
+      for (int i = tid; i < NCH * Q4; i += 256) {
+         const int cbs = i / Q4, q = i - cbs * Q4;
+         const int its = blockIdx.x * NCH + cbs;
+         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+         if (its < n_chunks) v = *reinterpret_cast<const float4 *>(in + (size_t)map(its) * (CIN * T) + 4 * q);
+         const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+         for (int e = 0; e < 4; ++e) {
+            const int idx = 4 * q + e, ch = idx / T, tt = idx - ch * T;
+            XT[ch * kPitch + cbs * T + tt] = ve[e];
+         }
+      }
+   }
+   __syncthreads();
    const int mcol = 16 * wave + lc;                       // this lane's column in every MFMA phase
    const int mcb = mcol / T, mt_ = mcol - mcb * T;
    const int mitem = blockIdx.x * NCH + mcb;
    const bool mvalid = (mcol < NCOLV) && (mitem < n_chunks);
-   const float *mx = in + (size_t)map(mvalid ? mitem : min(blockIdx.x * NCH, n_chunks - 1)) * CIN * T + mt_;
    const float mmm = FIRST ? mm_s[mcb < NCH ? mcb : 0] : 0.0f;
    const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < T, tr2 = mvalid && mt_ + 2 < T;
-   // HOIST: request ALL of the conv block's inputs (unconditionally, from clamped addresses) before anything is computed, instead of
-   // 4 k-steps at a time under lane conditions.  Measured per instantiation (16,384 / 65,536 chunks): layer 2 0.134 -> 0.125 / 0.316 ->
-   // 0.289 ms, layer 4 0.220 -> 0.215, v4 stage 2 0.082 -> 0.071; layer 3 and v4 stages 3, 4 (32 input channels, few frames: many
-   // short segments per load) get slower (0.081 -> 0.086, 0.083 -> 0.108), so they keep the batched form.
-   constexpr bool HOIST = (CIN == 16) || (CIN == 32 && D == 64 && T == 7);
-   if constexpr (HOIST) {
-   float xin[KKW][5], kw[KKW][6];
+   const int ccol = mvalid ? mcol : 0;                    // invalid columns read a valid slot and are zeroed
    const int om2 = tl2 ? -2 : 0, om1 = tl1 ? -1 : 0, op1 = tr1 ? 1 : 0, op2 = tr2 ? 2 : 0;
 #pragma unroll
    for (int kk = 0; kk < KKW; ++kk) {
       const int ch = 4 * kk + quad;
       const bool chv = ch < CIN;
-      const float *xr = mx + (size_t)(chv ? ch : 0) * T;
-      const float v0 = xr[0], vm2 = xr[om2], vm1 = xr[om1], vp1 = xr[op1], vp2 = xr[op2];
-      xin[kk][2] = (mvalid && chv) ? v0 - mmm : 0.0f;                    // misc.c:84-96
-      xin[kk][0] = (tl2 && chv) ? vm2 - mmm : 0.0f; xin[kk][1] = (tl1 && chv) ? vm1 - mmm : 0.0f;
-      xin[kk][3] = (tr1 && chv) ? vp1 - mmm : 0.0f; xin[kk][4] = (tr2 && chv) ? vp2 - mmm : 0.0f;
-      const float *k5 = w.dw_w + (chv ? ch : 0) * 5;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) kw[kk][j] = k5[j];
-      kw[kk][5] = w.dw_b[chv ? ch : 0];                                  // conv.c:17-53
-   }
-#pragma unroll
-   for (int kk = 0; kk < KKW; ++kk) {
-      const int ch = 4 * kk + quad;
-      const bool chv = ch < CIN;
-      const float x0 = xin[kk][2];
-      float dv = kw[kk][5];
-      dv = fmaf(xin[kk][0], kw[kk][0], dv); dv = fmaf(xin[kk][1], kw[kk][1], dv); dv = fmaf(x0, kw[kk][2], dv);
-      dv = fmaf(xin[kk][3], kw[kk][3], dv); dv = fmaf(xin[kk][4], kw[kk][4], dv);
-      dv = (mvalid && chv) ? fmaxf(dv, 0.0f) : 0.0f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pw_f[((size_t)mt * KKW + kk) * 64 + lane], dv, acc[mt], 0, 0, 0);
-         if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
-      }
-   }
-   } else {
-#pragma unroll 4
-   for (int kk = 0; kk < KKW; ++kk) {
-      const int ch = 4 * kk + quad;
-      const bool chv = ch < CIN;
-      const float *xr = mx + (size_t)(chv ? ch : 0) * T;
+      const float *xr = XT + (chv ? ch : 0) * kPitch + ccol;
       const float x0 = (mvalid && chv) ? xr[0] - mmm : 0.0f;             // misc.c:84-96
-      const float xm2 = (tl2 && chv) ? xr[-2] - mmm : 0.0f, xm1 = (tl1 && chv) ? xr[-1] - mmm : 0.0f;
-      const float xp1 = (tr1 && chv) ? xr[1] - mmm : 0.0f, xp2 = (tr2 && chv) ? xr[2] - mmm : 0.0f;
+      const float xm2 = (tl2 && chv) ? xr[om2] - mmm : 0.0f, xm1 = (tl1 && chv) ? xr[om1] - mmm : 0.0f;
+      const float xp1 = (tr1 && chv) ? xr[op1] - mmm : 0.0f, xp2 = (tr2 && chv) ? xr[op2] - mmm : 0.0f;
       const float *k5 = w.dw_w + (chv ? ch : 0) * 5;
       float dv = w.dw_b[chv ? ch : 0];                                   // conv.c:17-53
       dv = fmaf(xm2, k5[0], dv); dv = fmaf(xm1, k5[1], dv); dv = fmaf(x0, k5[2], dv);
@@ -404,13 +387,13 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
       }
    }
-   }
    if (!HAS_PROJ) {                                       // identity residual (CIN == D): + x
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-         for (int r = 0; r < 4; ++r) acc[mt][r] += mvalid ? mx[(size_t)(16 * mt + 4 * quad + r) * T] : 0.0f;
+         for (int r = 0; r < 4; ++r) acc[mt][r] += mvalid ? XT[(16 * mt + 4 * quad + r) * kPitch + ccol] : 0.0f;
    }
+   __syncthreads();                                       // every wave is done with the input tile before Q / K / V rows are written
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
