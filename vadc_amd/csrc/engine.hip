@@ -34,6 +34,7 @@ struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
    const _Float16 *qkv_h, *out_h, *l1_h, *l2_h, *cv_h;
+   const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
@@ -280,7 +281,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
-                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f, pwj_k1, qkv_h, out_h, l1_h, l2_h, cv_h; } lo[4];
+                 size_t pw_f, pj_f, cb_b, qkv_f, out_f, l1_f, l2_f, cv_f, pwj_k1, qkv_h, out_h, l1_h, l2_h, cv_h, pw_h, pj_h; } lo[4];
    // split-fp16 A fragments for v_mfma_f32_16x16x32_f16 (kernels_encoder_mfma.hip, H3): [m-tile][k-block][lane][hi 8 | lo 8] halves, lane l holds
    // W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + e]; two halves per float slot of the packer.  `h3_ok` = every weight fits fp16's range.
    bool h3_ok = true;
@@ -323,11 +324,11 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
       std::vector<float> cbb;
       std::vector<float> pwm;
-      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; }
+      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pw_h = pk.add(h.data(), h.size()); } }
       if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size()); cbb = v;
       lo[l].pjT = lo[l].pj_b = lo[l].pj_f = (size_t)-1;
       if (s.proj) {
-         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
+         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pj_h = pk.add(h.data(), h.size()); } }
          if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); }
          if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size());
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
@@ -394,7 +395,9 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
             m.qkv_h = reinterpret_cast<const _Float16 *>(base + lo[l].qkv_h); m.out_h = reinterpret_cast<const _Float16 *>(base + lo[l].out_h);
             m.l1_h = reinterpret_cast<const _Float16 *>(base + lo[l].l1_h);   m.l2_h = reinterpret_cast<const _Float16 *>(base + lo[l].l2_h);
             m.cv_h = reinterpret_cast<const _Float16 *>(base + lo[l].cv_h);
-         } else m.qkv_h = m.out_h = m.l1_h = m.l2_h = m.cv_h = nullptr;
+            m.pw_h = kLayers[l].cin == 32 ? reinterpret_cast<const _Float16 *>(base + lo[l].pw_h) : nullptr;
+            m.pj_h = (kLayers[l].cin == 32 && kLayers[l].proj) ? reinterpret_cast<const _Float16 *>(base + lo[l].pj_h) : nullptr;
+         } else m.qkv_h = m.out_h = m.l1_h = m.l2_h = m.cv_h = m.pw_h = m.pj_h = nullptr;
          m.cb_b = base + lo[l].cb_b; m.qkv_f = base + lo[l].qkv_f; m.qkv_b = w.qkv_b; m.out_f = base + lo[l].out_f; m.out_b = w.out_b;
          m.n1_w = w.n1_w; m.n1_b = w.n1_b; m.l1_f = base + lo[l].l1_f; m.l1_b = w.l1_b; m.l2_f = base + lo[l].l2_f; m.l2_b = w.l2_b;
          m.n2_w = w.n2_w; m.n2_b = w.n2_b; m.cv_f = base + lo[l].cv_f; m.cv_b = w.cv_b;

@@ -54,6 +54,7 @@ struct LayerWeightsM {
    const float *cv_f, *cv_b;          // strided conv with BatchNorm folded
    const float *pwj_k1;               // first stage only: [cin][pw 0..15 | proj 0..15] (K = 1 MFMA form)
    const _Float16 *qkv_h, *out_h, *l1_h, *l2_h, *cv_h;   // H3: host-split fp16 fragments [M / 16][K / 32][64 lanes][hi 8 | lo 8] (or null)
+   const _Float16 *pw_h, *pj_h;                          // H3, 32 input channels: the conv block's pointwise / projection weights in the same form
 };
 
 template <int kFrames>
@@ -343,7 +344,13 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // 40-48 load instructions per lane over 28-byte segments, and the texture path, not memory latency, made the block the longest phase of
    // layers 2-4: 7 / 13 / 15 K cycles per workgroup.)
    static_assert((CIN * T) % 4 == 0, "a chunk's input tile must be whole 16-byte pieces");
-   float *XT = Bb;                                        // [CIN][kPitch]
+   // H3C: the conv block's two GEMMs in the split-fp16 form as well (32 input channels = one k-block): a lane then owns 8 CONSECUTIVE
+   // channels of its column (the B fragment's k = 8 (lane >> 4) + e), so the tile's row pitch is 66: rows 8 apart land 16 banks apart
+   constexpr bool H3C = H3 && CIN == 32;
+   constexpr int XP = H3C ? 66 : kPitch;
+   float *XT = Bb;                                        // [CIN][XP]
+   float *DWS = Bb + CIN * XP;                            // [CIN][6]
+   static_assert(CIN * XP + CIN * 6 <= ROWS_B * kPitch, "input tile + depthwise weights must fit the Q / K / V area");
    {
       constexpr int Q4 = CIN * T / 4;                     // 16-byte pieces per chunk
       for (int i = tid; i < NCH * Q4; i += 256) {
@@ -355,8 +362,15 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
 #pragma unroll
          for (int e = 0; e < 4; ++e) {
             const int idx = 4 * q + e, ch = idx / T, tt = idx - ch * T;
-            XT[ch * kPitch + cbs * T + tt] = ve[e];
+            XT[ch * XP + cbs * T + tt] = ve[e];
          }
+      }
+      // depthwise weights [ch][k0..k4, bias] next to the tile (rows CIN.. of the same area): six LDS reads per k-step instead of six
+      // per-lane global loads
+      for (int i = tid; i < CIN; i += 256) {
+#pragma unroll
+         for (int j = 0; j < 5; ++j) DWS[i * 6 + j] = w.dw_w[i * 5 + j];
+         DWS[i * 6 + 5] = w.dw_b[i];
       }
    }
    __syncthreads();
@@ -368,18 +382,57 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < T, tr2 = mvalid && mt_ + 2 < T;
    const int ccol = mvalid ? mcol : 0;                    // invalid columns read a valid slot and are zeroed
    const int om2 = tl2 ? -2 : 0, om1 = tl1 ? -1 : 0, op1 = tr1 ? 1 : 0, op2 = tr2 ? 2 : 0;
+   if constexpr (H3C) {
+      float dvv[8], xvv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+         const int ch = 8 * quad + e;
+         const float *xr = XT + ch * XP + ccol;
+         const float x0 = mvalid ? xr[0] : 0.0f;
+         const float xm2 = tl2 ? xr[om2] : 0.0f, xm1 = tl1 ? xr[om1] : 0.0f, xp1 = tr1 ? xr[op1] : 0.0f, xp2 = tr2 ? xr[op2] : 0.0f;
+         const float *k5 = DWS + ch * 6;
+         const float2 k01 = *reinterpret_cast<const float2 *>(k5), k23 = *reinterpret_cast<const float2 *>(k5 + 2), k45 = *reinterpret_cast<const float2 *>(k5 + 4);
+         float dv = k45.y;                                               // conv.c:17-53
+         dv = fmaf(xm2, k01.x, dv); dv = fmaf(xm1, k01.y, dv); dv = fmaf(x0, k23.x, dv);
+         dv = fmaf(xp1, k23.y, dv); dv = fmaf(xp2, k45.x, dv);
+         dvv[e] = mvalid ? fmaxf(dv, 0.0f) : 0.0f;
+         xvv[e] = x0;
+      }
+      h8v dh, dl, xh, xl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+         dh[e] = (_Float16)dvv[e]; dl[e] = (_Float16)(dvv[e] - (float)dh[e]);
+         xh[e] = (_Float16)xvv[e]; xl[e] = (_Float16)(xvv[e] - (float)xh[e]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+         const h8v *pp = reinterpret_cast<const h8v *>(w.pw_h + ((size_t)mt * 64 + lane) * 16);
+         const h8v ah = pp[0], al = pp[1];
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, dh, acc[mt], 0, 0, 0);
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, dl, acc[mt], 0, 0, 0);
+         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, dh, acc[mt], 0, 0, 0);
+         if (HAS_PROJ) {
+            const h8v *pq = reinterpret_cast<const h8v *>(w.pj_h + ((size_t)mt * 64 + lane) * 16);
+            const h8v bh_ = pq[0], bl_ = pq[1];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl_, xh, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh_, xl, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh_, xh, acc[mt], 0, 0, 0);
+         }
+      }
+   } else {
 #pragma unroll
    for (int kk = 0; kk < KKW; ++kk) {
       const int ch = 4 * kk + quad;
       const bool chv = ch < CIN;
-      const float *xr = XT + (chv ? ch : 0) * kPitch + ccol;
+      const float *xr = XT + (chv ? ch : 0) * XP + ccol;
       const float x0 = (mvalid && chv) ? xr[0] - mmm : 0.0f;             // misc.c:84-96
       const float xm2 = (tl2 && chv) ? xr[om2] - mmm : 0.0f, xm1 = (tl1 && chv) ? xr[om1] - mmm : 0.0f;
       const float xp1 = (tr1 && chv) ? xr[op1] - mmm : 0.0f, xp2 = (tr2 && chv) ? xr[op2] - mmm : 0.0f;
-      const float *k5 = w.dw_w + (chv ? ch : 0) * 5;
-      float dv = w.dw_b[chv ? ch : 0];                                   // conv.c:17-53
-      dv = fmaf(xm2, k5[0], dv); dv = fmaf(xm1, k5[1], dv); dv = fmaf(x0, k5[2], dv);
-      dv = fmaf(xp1, k5[3], dv); dv = fmaf(xp2, k5[4], dv);
+      const float *k5 = DWS + (chv ? ch : 0) * 6;
+      const float2 k01 = *reinterpret_cast<const float2 *>(k5), k23 = *reinterpret_cast<const float2 *>(k5 + 2), k45 = *reinterpret_cast<const float2 *>(k5 + 4);
+      float dv = k45.y;                                                  // conv.c:17-53
+      dv = fmaf(xm2, k01.x, dv); dv = fmaf(xm1, k01.y, dv); dv = fmaf(x0, k23.x, dv);
+      dv = fmaf(xp1, k23.y, dv); dv = fmaf(xp2, k45.x, dv);
       dv = (mvalid && chv) ? fmaxf(dv, 0.0f) : 0.0f;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -387,11 +440,12 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          if (HAS_PROJ) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.pj_f[((size_t)mt * KKW + kk) * 64 + lane], x0, acc[mt], 0, 0, 0);
       }
    }
+   }
    if (!HAS_PROJ) {                                       // identity residual (CIN == D): + x
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-         for (int r = 0; r < 4; ++r) acc[mt][r] += mvalid ? XT[(16 * mt + 4 * quad + r) * kPitch + ccol] : 0.0f;
+         for (int r = 0; r < 4; ++r) acc[mt][r] += mvalid ? XT[(16 * mt + 4 * quad + r) * XP + ccol] : 0.0f;
    }
    __syncthreads();                                       // every wave is done with the input tile before Q / K / V rows are written
 #pragma unroll
