@@ -2,7 +2,7 @@
 //
 // Same arithmetic as kernels_encoder.hip (the VALU bring-up variant kept for A/B tests), re-mapped so that every
 // dense contraction of the layer -- pointwise + projection conv, QKV, attention out-projection, both FFN linears
-// and the strided 1x1 conv -- runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains):
+// and the strided 1x1 conv -- runs on the matrix instructions:
 //
 //   Y[Cout x cols] = W[Cout x K] . X[K x cols]        cols = (chunk, time-step) of the workgroup's NCH chunks
 //
@@ -12,16 +12,18 @@
 // adaptive_audio_normalization_inplace misc.c:65-96.
 //
 // MAPPING.  A workgroup (4 waves) owns 64 columns; WAVE w owns the 16-column MFMA N-tile [16w,16w+16) for the whole
-// layer.  Activations live in LDS as [channel][column] (pitch 80 floats: the four k-rows an MFMA B-fragment reads
-// fall into different banks).  For a GEMM the wave reads its B fragments once (K/4 ds_read_b32), streams the weight
-// A-fragments from L2 in a host-prepacked fragment-major layout (one coalesced 256-B load per MFMA) and loops over the
-// Cout/16 M-tiles; accumulators start at the bias; epilogues (ReLU, residual) are applied in the accumulator layout
-// and written back to LDS.  LayerNorm reduces over channels = over the accumulator registers and the 4 lane-quads of
-// the wave (two DPP/permute shuffles), never across waves.  Only the depthwise conv (time neighbours) and attention
-// (all 7..25 steps of a chunk) look across columns, so those are the only phases that need workgroup barriers for
-// correctness; the VALU work there is spread over all 256 threads.
-// The conv block needs no LDS at all: a lane's B-fragment element for k-step kk is channel 4kk+quad at its own
-// column, so x and its time neighbours are loaded from global/L1 straight into fragment registers.
+// layer; accumulators start at the bias; epilogues (ReLU, residual) are applied in the accumulator layout.  LayerNorm
+// reduces over channels = over the accumulator registers and the 4 lane-quads of the wave (two shuffles), never across
+// waves.  Only the depthwise conv (time neighbours) and attention (all 7..25 steps of a chunk) look across columns, so those
+// are the only phases that need workgroup barriers; after the attention a wave works on its own 16 columns alone.
+//   * GEMMs of the 32- and 64-channel layers (2-4): split-fp16 form (H3) -- three v_mfma_f32_16x16x32_f16 per k-block on
+//     host-split weights, activations in LDS as one pair of fp16 tiles [column][k] reused in place, fp32 accuracy.
+//   * GEMMs of the 16-channel first layer (and option "encoder" = 3): v_mfma_f32_16x16x4_f32 on fragment-major fp32 weights
+//     (one coalesced 256-byte load per MFMA), activations in LDS as [channel][column] fp32 (pitch 80).
+//   * conv block of layers 2-4: the input tile is staged once through LDS (16-byte loads); of the first layer (129 / 258
+//     input channels): the K = 1 form -- one lane per column, one input channel per v_mfma_f32_16x16x1_4b_f32, inputs straight
+//     from global along the frames (or, option "encoder" = 2, the LDS slab path).
+//   * attention: a lane pair per (head, column), Q / V rows padded per chunk for 16-byte reads, fp32 on the vector ALU.
 #include "common.h"
 #include <cstdio>
 
