@@ -41,8 +41,17 @@
 // over the four lane groups with two shuffles), a rotating wave adds the four shares in fixed order.  Per-frame bin sums: one
 // partial per wave; waves 2p and 2p+1 make up partial p of FM (common.h kBinSplit), added in that order.
 #include "common.h"
+#include <cstdio>
 
 namespace vadc {
+
+#ifdef VADC_PHASE_PROF
+__device__ unsigned long long g_gemm_phase[8];
+__device__ unsigned int g_gemm_groups;
+#define GPH(i) do { if (gph_on) { const unsigned long long t_ = __builtin_readcyclecounter(); g_gemm_phase[i] += t_ - gph_t; gph_t = t_; } } while (0)
+#else
+#define GPH(i) do { } while (0)
+#endif
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -157,8 +166,16 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
    };
 
    const int n_groups = (n_chunks + kGChunks - 1) / kGChunks;
+#ifdef VADC_PHASE_PROF
+   const bool gph_on = blockIdx.x == 3 && tid == 0;
+   unsigned long long gph_t = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+#ifdef VADC_PHASE_PROF
+      if (gph_on) g_gemm_groups += 1;
+#endif
+      GPH(0);
       __syncthreads();                                   // previous iteration's readers are done
       // ---- stage the group's chunks: reflect pad (no edge repeat), block pitch 68 ----
       for (int i = tid; i < kGChunks * (kChunk / 8); i += 512) {
@@ -181,12 +198,15 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       }
       static_assert(kPaddedG == kBlk * 64, "padded chunk must be whole blocks");
       __syncthreads();
+      GPH(1);
       prepare(0);
       __syncthreads();
+      GPH(2);
 
 #pragma unroll 1
       for (int ct = 0; ct < kTiles; ++ct) {
          if (ct + 1 < kTiles) prepare(ct + 1);           // into the other buffer; its last readers passed the barrier below
+         GPH(3);
          // column tile ct: positions 16 ct + f of the group; position -> (chunk c, frame fr)
          const int buf = ct & 1;
          const int pos = 16 * ct + f;
@@ -206,6 +226,10 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bh, acc[ti], 0, 0, 0);
             }
          }
+#ifdef VADC_PHASE_PROF
+         asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3]));
+#endif
+         GPH(4);
          // ---- epilogue: D rows = bins 16 w + 4 g + r, column = position f ----
          const int item = grp * kGChunks + c;
          const bool ok = pos_ok && item < n_chunks;
@@ -236,7 +260,9 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          part += __shfl_xor(part, 16);
          part += __shfl_xor(part, 32);
          if (g == 0) bsum[wave][pos] = part;               // one writer per (wave, position)
-         __syncthreads();                                  // fragment buffer ct & 1 and nyp[ct & 1] are free again; ct + 1 is ready
+         GPH(5);
+         __syncthreads();
+         GPH(6);                                  // fragment buffer ct & 1 and nyp[ct & 1] are free again; ct + 1 is ready
       }
       // FM partial p = the 32 bins of waves 2p, 2p+1 (+ Nyquist for p = 3); the consumer adds the 4 partials in fixed order
       for (int i = tid; i < 4 * kPos; i += 512) {
@@ -248,6 +274,21 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       }
    }
 }
+
+#ifdef VADC_PHASE_PROF
+extern "C" void vadc_gemm_phase_report(void)
+{
+   unsigned long long h[8]; unsigned int n;
+   (void)hipDeviceSynchronize();
+   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_phase), sizeof(h));
+   (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_gemm_groups), sizeof(n));
+   if (!n) return;
+   const char *names[7] = {"FM write-out / loop", "staging", "prepare(0)+barrier", "prepare(ct+1)", "B reads + MFMAs", "epilogue", "barrier"};
+   printf("k_frontend_gemm, %u groups of 4 chunks (cycles per group):", n);
+   for (int i = 0; i < 7; ++i) printf("  %s %.0f", names[i], (double)h[i] / n);
+   printf("\n");
+}
+#endif
 
 template <typename T>
 static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
