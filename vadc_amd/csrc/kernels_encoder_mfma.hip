@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // LDS: Yb (D rows) + Bb (3D rows).  The attention output ATT reuses Yb (y is dead once QKV is formed: the residual lives
    // in the accumulators) and relu(lin1) reuses the Q rows, so layer 4 (D = 64) needs 80 KB instead of 100 KB and TWO
    // workgroups fit a CU's 160 KB -- with one, its single wave per SIMD had nothing to hide MFMA/LDS latency behind.
-   constexpr int ROWS_B = (DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab;
+   // stages without a transformer block (v4) only keep the conv block's input tile (<= 35 rows) or the LSTM-native transpose (52 rows) here:
+   // 56 rows instead of 3 D (stage 4: 80 KB -> 38 KB of LDS, 2 -> 4 workgroups per CU)
+   constexpr int ROWS_B = (DIRECT && !HAS_TF) ? 56 : ((DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab);
    static_assert(!H3 || (DIRECT && HAS_TF && D % 32 == 0), "split-fp16 layer GEMMs: transformer layers with D = 32 / 64");
    constexpr int HP = D + 8, KB = H3 ? D / 32 : 1;       // H3: pitch (halves) of the split activation tiles, k-blocks per GEMM
    __shared__ __attribute__((aligned(16))) _Float16 SH[H3 ? 2 * kCol * HP : 8];   // H3: [hi | lo][column][k]: the B operand of every GEMM of the block, reused in place
