@@ -140,13 +140,15 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       const float *pd = row + (kb >> 1) * kGBlockPitch + 32 * (kb & 1) + 8 * g;
       const float4 d0 = *reinterpret_cast<const float4 *>(pd), d1 = *reinterpret_cast<const float4 *>(pd + 4);
       const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      // mirrored taps x[m0 - e], m0 = 256 - 32 kb - 8 g (a multiple of 8): x[m0 - 8 .. m0 - 1] is one aligned 8-float group inside a block
+      // (two 16-byte reads), x[m0] one more float that may sit in the next block
+      const int m0 = 256 - 32 * kb - 8 * g;
+      const float *pm = row + ((m0 - 8) >> 6) * kGBlockPitch + ((m0 - 8) & 63);
+      const float4 ma = *reinterpret_cast<const float4 *>(pm), mb = *reinterpret_cast<const float4 *>(pm + 4);
+      const float mv[8] = {row[(m0 >> 6) * kGBlockPitch + (m0 & 63)], mb.w, mb.z, mb.y, mb.x, ma.w, ma.z, ma.y};
       float xv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-         const int m = 256 - 32 * kb - 8 * g - e;                               // 1..256
-         const float mv = row[(m >> 6) * kGBlockPitch + (m & 63)];
-         xv[e] = sums ? dv[e] + mv : dv[e] - mv;
-      }
+      for (int e = 0; e < 8; ++e) xv[e] = sums ? dv[e] + mv[e] : dv[e] - mv[e];
       if (kb == 0 && g == 0) xv[0] = sums ? row[2 * kGBlockPitch] : 0.0f;       // tap 0 carries the unpaired centre tap 128
       h8v vh, vl;
       split8(xv, vh, vl);
