@@ -111,6 +111,8 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
    __shared__ float nyp[2][4][16];                                             // bin 128: share of k-block kb, per buffer and position
    __shared__ float bsum[8][kPosPad];
    __shared__ float nyv[kPosPad];                                              // log value of bin 128 per position
+   __shared__ int2 ptab[kPosPad];                                              // position -> {offset of its first block in X0, chunk | frame << 8 | valid << 16}
+   __shared__ int crow[kGChunks];                                              // this group's chunks -> row of the outputs (map), -1 past the end
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int f = lane & 15, g = lane >> 4;
 
@@ -127,16 +129,18 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       }
    }
    if (tid < 128) nyq_s[tid] = nyq[tid];
+   if (tid < kPosPad) {
+      const int pos = min(tid, kPos - 1), c = pos / kFr, fr = pos - c * kFr;
+      ptab[tid] = make_int2(c * kChunkPitch + fr * kGBlockPitch, c | (fr << 8) | (tid < kPos ? 1 << 16 : 0));
+   }
    if (tid < kGChunks) X0[tid * kChunkPitch + kBlk * kGBlockPitch] = 0.0f;       // the spare sample (index kPaddedG) that tap 0's mirror touches
 
    // fold + split k-block `wave & 3` of column tile ct into fragment buffer ct & 1: waves 0-3 the sums, waves 4-7 the differences
    auto prepare = [&](int ct) {
       const int kb = wave & 3;
       const bool sums = wave < 4;
-      const int pos = min(16 * ct + f, kPos - 1);
-      const int c = pos / kFr, fr = pos - c * kFr;
       // tap n = 32 kb + 8 g + e:  direct x[64 fr + n] = block fr + (kb >> 1), offset 32 (kb & 1) + 8 g + e;  mirrored x[64 fr + 256 - n]
-      const float *row = X0 + c * kChunkPitch + fr * kGBlockPitch;
+      const float *row = X0 + ptab[16 * ct + f].x;
       const float *pd = row + (kb >> 1) * kGBlockPitch + 32 * (kb & 1) + 8 * g;
       const float4 d0 = *reinterpret_cast<const float4 *>(pd), d1 = *reinterpret_cast<const float4 *>(pd + 4);
       const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -146,9 +150,10 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       const float *pm = row + ((m0 - 8) >> 6) * kGBlockPitch + ((m0 - 8) & 63);
       const float4 ma = *reinterpret_cast<const float4 *>(pm), mb = *reinterpret_cast<const float4 *>(pm + 4);
       const float mv[8] = {row[(m0 >> 6) * kGBlockPitch + (m0 & 63)], mb.w, mb.z, mb.y, mb.x, ma.w, ma.z, ma.y};
+      const float sgn = sums ? 1.0f : -1.0f;                                    // wave-uniform; mv * +-1 is exact, so the fma is the plain sum / difference
       float xv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[e] = sums ? dv[e] + mv[e] : dv[e] - mv[e];
+      for (int e = 0; e < 8; ++e) xv[e] = fmaf(mv[e], sgn, dv[e]);
       if (kb == 0 && g == 0) xv[0] = sums ? row[2 * kGBlockPitch] : 0.0f;       // tap 0 carries the unpaired centre tap 128
       h8v vh, vl;
       split8(xv, vh, vl);
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
          *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
+      if (tid < kGChunks) crow[tid] = grp * kGChunks + tid < n_chunks ? (int)map(grp * kGChunks + tid) : -1;
       for (int i = tid; i < kGChunks * 2 * kPadG; i += 512) {
          const int c = i / (2 * kPadG), j = i - c * (2 * kPadG);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
@@ -212,9 +218,6 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          // column tile ct: positions 16 ct + f of the group; position -> (chunk c, frame fr)
          const int buf = ct & 1;
          const int pos = 16 * ct + f;
-         const bool pos_ok = pos < kPos;
-         const int posc = pos_ok ? pos : kPos - 1;
-         const int c = posc / kFr, fr = posc - c * kFr;
          f4v acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};       // re, im
 #pragma unroll
          for (int kb = 0; kb < 4; ++kb) {
@@ -233,31 +236,36 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
 #endif
          GPH(4);
          // ---- epilogue: D rows = bins 16 w + 4 g + r, column = position f ----
-         const int item = grp * kGChunks + c;
-         const bool ok = pos_ok && item < n_chunks;
-         const size_t ybase = (size_t)map(item < n_chunks ? item : n_chunks - 1) * (kBins * kFr) + fr;
-         float part = 0.0f;
+         const int pcf = ptab[pos].y, orow = crow[pcf & 3];
+         const bool ok = (pcf >> 16) != 0 && orow >= 0;
+         const size_t ybase = (size_t)max(orow, 0) * (kBins * kFr) + ((pcf >> 8) & 31);
+         float mag[4], val[4];
 #pragma unroll
          for (int r = 0; r < 4; ++r) {
             const float re = acc[0][r], im = acc[1][r];
-            const float mag = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));    // v_sqrt_f32 (1 ulp): this front end is not the bit-exact one
-            const float val = log1p_hw_fast(mag * 1048576.0f);
-            const int bin = 16 * wave + 4 * g + r;
-            if (ok) {
-               Y[ybase + (size_t)bin * kFr] = val;
-               if (Geo::mag) MAG[ybase + (size_t)bin * kFr] = mag;
-            }
-            part += val;
+            mag[r] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));             // v_sqrt_f32 (1 ulp): this front end is not the bit-exact one
+            val[r] = log1p_hw_fast(mag[r] * 1048576.0f);
          }
+         if (ok) {                                                              // rows = bins 16 wave + 4 g + r: one address, constant offsets
+            float *yp = Y + ybase + (size_t)((16 * wave + 4 * g) * kFr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yp[r * kFr] = val[r];
+            if (Geo::mag) {
+               float *mp = MAG + ybase + (size_t)((16 * wave + 4 * g) * kFr);
+#pragma unroll
+               for (int r = 0; r < 4; ++r) mp[r * kFr] = mag[r];
+            }
+         }
+         float part = ((val[0] + val[1]) + val[2]) + val[3];
          if ((ct & 7) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
             const float ny = (nyp[buf][0][f] + nyp[buf][1][f]) + (nyp[buf][2][f] + nyp[buf][3][f]);
-            const float mag = fabsf(ny);
-            const float val = log1p_hw_fast(mag * 1048576.0f);
+            const float nmag = fabsf(ny);
+            const float nval = log1p_hw_fast(nmag * 1048576.0f);
             if (ok) {
-               Y[ybase + (size_t)128 * kFr] = val;
-               if (Geo::mag) MAG[ybase + (size_t)128 * kFr] = mag;
+               Y[ybase + (size_t)128 * kFr] = nval;
+               if (Geo::mag) MAG[ybase + (size_t)128 * kFr] = nmag;
             }
-            nyv[pos] = val;                                // added to partial 3 below: the sum must not depend on which wave took it
+            nyv[pos] = nval;                               // added to partial 3 below: the sum must not depend on which wave took it
          }
          part += __shfl_xor(part, 16);
          part += __shfl_xor(part, 32);
@@ -270,9 +278,9 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       for (int i = tid; i < 4 * kPos; i += 512) {
          const int wv = i / kPos, pos = i - wv * kPos;
          const int c = pos / kFr, fr = pos - c * kFr;
-         const int item = grp * kGChunks + c;
+         const int orow = crow[c];
          const float v = bsum[2 * wv][pos] + bsum[2 * wv + 1][pos];
-         if (item < n_chunks) FM[wv * fm_stride + (size_t)map(item) * kFr + fr] = (wv == 3) ? v + nyv[pos] : v;
+         if (orow >= 0) FM[wv * fm_stride + (size_t)orow * kFr + fr] = (wv == 3) ? v + nyv[pos] : v;
       }
    }
 }
