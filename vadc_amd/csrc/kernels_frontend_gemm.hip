@@ -154,7 +154,10 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       float xv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) xv[e] = fmaf(mv[e], sgn, dv[e]);
-      if (kb == 0 && g == 0) xv[0] = sums ? row[2 * kGBlockPitch] : 0.0f;       // tap 0 carries the unpaired centre tap 128
+      {                                                                         // tap 0 carries the unpaired centre tap 128 (branch-free)
+         const float ctr = row[2 * kGBlockPitch];
+         xv[0] = (kb == 0 && g == 0) ? (sums ? ctr : 0.0f) : xv[0];
+      }
       h8v vh, vl;
       split8(xv, vh, vl);
       const int buf = ct & 1;
@@ -213,7 +216,6 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
 
 #pragma unroll 1
       for (int ct = 0; ct < kTiles; ++ct) {
-         if (ct + 1 < kTiles) prepare(ct + 1);           // into the other buffer; its last readers passed the barrier below
          GPH(3);
          // column tile ct: positions 16 ct + f of the group; position -> (chunk c, frame fr)
          const int buf = ct & 1;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ti][kb], bh, acc[ti], 0, 0, 0);
             }
          }
+         if (ct + 1 < kTiles) prepare(ct + 1);           // into the other buffer (its last readers passed the previous barrier), while the matrix pipe works
 #ifdef VADC_PHASE_PROF
          asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3]));
 #endif
