@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
    __shared__ __attribute__((aligned(16))) float X0[kGChunks * kChunkPitch];
    __shared__ __attribute__((aligned(16))) _Float16 Bf[2][4][4][64][8];         // [buffer][kb][sh, sl, dh, dl][lane][8]: 32 KB
    __shared__ __attribute__((aligned(16))) float nyq_s[128];
-   __shared__ float nyp[2][4][16];                                             // bin 128: share of k-block kb, per buffer and position
+   __shared__ __attribute__((aligned(16))) float nyp[2][16][20];               // bin 128: [buffer][position][4 kb + lane group] shares (row pitch 20: conflict-free)
    __shared__ float bsum[8][kPosPad];
    __shared__ float nyv[kPosPad];                                              // log value of bin 128 per position
    __shared__ int2 ptab[kPosPad];                                              // position -> {offset of its first block in X0, chunk | frame << 8 | valid << 16}
@@ -169,9 +169,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
          float ny = w0.x * xv[0];
          ny = fmaf(w0.y, xv[1], ny); ny = fmaf(w0.z, xv[2], ny); ny = fmaf(w0.w, xv[3], ny);
          ny = fmaf(w1.x, xv[4], ny); ny = fmaf(w1.y, xv[5], ny); ny = fmaf(w1.z, xv[6], ny); ny = fmaf(w1.w, xv[7], ny);
-         ny += __shfl_xor(ny, 16);
-         ny += __shfl_xor(ny, 32);
-         if (g == 0) nyp[buf][kb][f] = ny;
+         nyp[buf][f][4 * kb + g] = ny;
       }
    };
 
@@ -260,8 +258,11 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
             }
          }
          float part = ((val[0] + val[1]) + val[2]) + val[3];
-         if ((ct & 7) == wave && g == 0) {                 // bin 128: re only (its im row is identically zero); shares added in fixed order
-            const float ny = (nyp[buf][0][f] + nyp[buf][1][f]) + (nyp[buf][2][f] + nyp[buf][3][f]);
+         if (4 + (ct & 3) == wave && g == 0) {             // bin 128: re only (its im row is identically zero); the 16 shares added in fixed order by one of the
+            const float4 *np = reinterpret_cast<const float4 *>(&nyp[buf][f][0]);   // waves that fold differences (they have no share to compute)
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            const float ny = (((n0.x + n0.y) + (n0.z + n0.w)) + ((n1.x + n1.y) + (n1.z + n1.w))) +
+                             (((n2.x + n2.y) + (n2.z + n2.w)) + ((n3.x + n3.y) + (n3.z + n3.w)));
             const float nmag = fabsf(ny);
             const float nval = log1p_hw_fast(nmag * 1048576.0f);
             if (ok) {
