@@ -26,7 +26,7 @@
 // ~2e-7 relative, the level of fp32 accumulation itself).  Operand layout: lane l holds A[l & 15][8 (l >> 4) + e],
 // B[8 (l >> 4) + e][l & 15].
 //
-// MAPPING.  Workgroup = 8 waves, persistent over groups of G = 4 chunks (4 x frames positions = 6 or 7 column tiles of 16).
+// MAPPING.  Workgroup = 8 waves, persistent over groups of G chunks (v4: 4 x 24 positions = 6 column tiles of 16; v3.1: 5 x 25 = 8 tiles).
 // Wave w keeps the split A fragments of bins [16w, 16w+16) -- one re and one im row tile, 64 VGPRs -- for the whole kernel
 // (4 waves with 32 bins each need 128 VGPRs and leave two waves per SIMD; measured the two layouts are within 4 % of each
 // other -- the kernel is bound by the vector-ALU epilogue, ~20 instructions per output with four transcendentals, not by
@@ -64,12 +64,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8v &hi, h8v &lo)
 }
 
 constexpr int kGBlockPitch = 68;
-constexpr int kGChunks = 4;                                                   // chunks per workgroup iteration
 
 // GEO 0: Silero v3.1 (reflect pad 128, 25 frames, 28 blocks; Y + FM);  GEO 1: Silero v4 (pad 96, 24 frames, 27 blocks; Y + MAG + FM)
 template <int GEO> struct GemmGeo;
-template <> struct GemmGeo<0> { static constexpr int pad = 128, frames = 25, blocks = 28; static constexpr bool mag = false; };
-template <> struct GemmGeo<1> { static constexpr int pad = 96, frames = 24, blocks = 27; static constexpr bool mag = true; };
+// chunks = chunks per workgroup iteration: 5 x 25 = 125 positions fill 8 column tiles of 16 to 98 % (4 x 25 = 100 fill 7 to 89 %), 4 x 24 = 96 fill 6
+template <> struct GemmGeo<0> { static constexpr int pad = 128, frames = 25, blocks = 28, chunks = 5; static constexpr bool mag = false; };
+template <> struct GemmGeo<1> { static constexpr int pad = 96, frames = 24, blocks = 27, chunks = 4; static constexpr bool mag = true; };
 
 __device__ __forceinline__ void g_stage8(const float *src, float (&v)[8])
 {
@@ -98,11 +98,11 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
                                                           int n_chunks, ItemMap map, size_t fm_stride)
 {
    typedef GemmGeo<GEO> Geo;
-   constexpr int kPadG = Geo::pad, kFr = Geo::frames, kBlk = Geo::blocks;
+   constexpr int kPadG = Geo::pad, kFr = Geo::frames, kBlk = Geo::blocks, kGChunks = Geo::chunks;
    constexpr int kPaddedG = kChunk + 2 * kPadG;
    constexpr int kChunkPitch = (kBlk + 1) * kGBlockPitch;                       // one spare block: the mirror of tap 0 is read (unused)
-   constexpr int kPos = kGChunks * kFr;                                         // positions per group (96 | 100)
-   constexpr int kTiles = (kPos + 15) / 16;                                     // 6 | 7 column tiles
+   constexpr int kPos = kGChunks * kFr;                                         // positions per group (96 | 125)
+   constexpr int kTiles = (kPos + 15) / 16;                                     // 6 | 8 column tiles
    constexpr int kPosPad = kTiles * 16;
 
    __shared__ __attribute__((aligned(16))) float X0[kGChunks * kChunkPitch];
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
 #endif
          GPH(4);
          // ---- epilogue: D rows = bins 16 w + 4 g + r, column = position f ----
-         const int pcf = ptab[pos].y, orow = crow[pcf & 3];
+         const int pcf = ptab[pos].y, orow = crow[pcf & 7];
          const bool ok = (pcf >> 16) != 0 && orow >= 0;
          const size_t ybase = (size_t)max(orow, 0) * (kBins * kFr) + ((pcf >> 8) & 31);
          float mag[4], val[4];
@@ -298,7 +298,7 @@ extern "C" void vadc_gemm_phase_report(void)
    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_gemm_groups), sizeof(n));
    if (!n) return;
    const char *names[7] = {"FM write-out / loop", "staging", "prepare(0)+barrier", "prepare(ct+1)", "B reads + MFMAs", "epilogue", "barrier"};
-   printf("k_frontend_gemm, %u groups of 4 chunks (cycles per group):", n);
+   printf("k_frontend_gemm, %u groups (cycles per group):", n);
    for (int i = 0; i < 7; ++i) printf("  %s %.0f", names[i], (double)h[i] / n);
    printf("\n");
 }
@@ -308,6 +308,7 @@ template <typename T>
 static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
                         int n_cus, hipStream_t st, int geo)
 {
+   const int kGChunks = geo == 1 ? GemmGeo<1>::chunks : GemmGeo<0>::chunks;
    const int groups = (n + kGChunks - 1) / kGChunks;
    const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
    if (geo == 1) hipLaunchKernelGGL((k_frontend_gemm<T, 1>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
