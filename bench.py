@@ -264,8 +264,8 @@ def main():
                                        "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm folds the "
                                        "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, as split-fp16 products on the fp16 matrix pipe "
                                        "(3 x v_mfma_f32_16x16x32_f16 per k-block).  When k_frontend is the dominant kernel its achieved / peak / frac are EXECUTED "
-                                       "split-fp16 MFMA FLOP against the fp16 dense peak (the kernel is bound by its vector-ALU epilogue -- sqrt, log1p, "
-                                       "fold + split -- not by the matrix pipe); path_frac stays algorithmic FLOP (dense basis) against the fp32 roof")
+                                       "split-fp16 MFMA FLOP against the fp16 dense peak (the kernel is not bound by the matrix pipe: HBM writes for the v4 geometry, "
+                                       "the per-tile barrier for v3.1's, DESIGN.md 4.5); path_frac stays algorithmic FLOP (dense basis) against the fp32 roof")
             out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * (24 if args.model == "v4" else 25)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)
