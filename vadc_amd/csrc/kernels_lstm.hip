@@ -616,21 +616,30 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
                   bh = *reinterpret_cast<const h8v *>(base + off);
                   bl = *reinterpret_cast<const h8v *>(base + kTileS * kHPitch + off);
                }
+#ifndef VADC_LSTM_ABL_NOMFMA
 #pragma unroll
                for (int g = 0; g < 4; ++g) {
                   acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kb], bh, acc[g], 0, 0, 0);
                   acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bl, acc[g], 0, 0, 0);
                   acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bh, acc[g], 0, 0, 0);
                }
+#else
+               acc[0][0] += (float)bh[0] + (float)bl[1];     // ablation (timing only): keep the fragment reads alive
+#endif
             }
          }
          h4v hi4, lo4;
 #pragma unroll
          for (int r = 0; r < 4; ++r) {
+#ifndef VADC_LSTM_ABL_NOGATES
             const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
             c[r] = fg * c[r] + ig * gg;
             const float hn = og * fast_tanh(c[r]);
+#else
+            c[r] = 0.5f * c[r] + 0.001f * (acc[0][r] + acc[1][r]);   // ablation (timing only)
+            const float hn = 0.001f * (acc[2][r] + acc[3][r]) + 0.01f * c[r];
+#endif
             hlast[r] = hn;
             hi4[r] = (_Float16)hn;
             lo4[r] = (_Float16)(hn - (float)hi4[r]);
