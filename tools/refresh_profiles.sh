@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --no-cpu-baseline > $O/prof_kt.log 2>&1
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- $B > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- $B > $O/prof_write.log 2>&1

@@ -11,7 +11,7 @@ rows = []
 for S, C in POINTS:
     for graph in ((False, True) if S <= 16 else (False,)):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--streams", str(S), "--chunks-per-step", str(C), "--no-cpu-baseline",
-               "--model", model, "--steps", "20", "--warmup", "3"] + (["--graph"] if graph else [])
+               "--model", model, "--steps", "300", "--warmup", "20"] + (["--graph"] if graph else [])
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
