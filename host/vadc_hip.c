@@ -104,6 +104,10 @@ static int parse_options(int argc, char **argv, Options *o)
       if (!strcmp(a, "--raw_probabilities")) { o->raw_probabilities = 1; continue; }
       if (!strcmp(a, "--output_centi_seconds")) { o->centiseconds = 1; continue; }
       if (!strcmp(a, "--stats")) { o->stats = 1; continue; }
+      if (strncmp(a, "--", 2) != 0) {                               /* vadc.c:1228-1232: a bare argument is an input file for ffmpeg (vadc.c:537) */
+         fprintf(stderr, "input file '%s': this build does not spawn ffmpeg; pipe 16 kHz mono s16le on stdin (ffmpeg -i FILE -f s16le -ac 1 -ar 16000 - | vadc_hip)\n", a);
+         return -1;
+      }
       if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a); return -1; }
       const char *v = argv[++i];
       if (!strcmp(a, "--model")) { o->model = v; continue; }
@@ -115,6 +119,10 @@ static int parse_options(int argc, char **argv, Options *o)
       else if (!strcmp(a, "--neg_threshold_relative")) o->neg_threshold_relative = f;
       else if (!strcmp(a, "--speech_pad")) o->speech_pad_ms = f;
       else if (!strcmp(a, "--batch")) o->batch = (int)f;
+      else if (!strcmp(a, "--sequence_count")) {                    /* vadc.c:743-752: clamped to the backend's [input_size_min, input_size_max] = 1536 */
+         if ((int)f != 1536) fprintf(stderr, "--sequence_count %d: the backend runs 1536-sample chunks (clamped, as vadc.c:743-752 does for the C backend)\n", (int)f);
+      }
+      else if (!strcmp(a, "--audio_source") || !strcmp(a, "--start_seconds")) { /* ffmpeg stream selection / seek (vadc.c:532-538): no effect on stdin input */ }
       else { fprintf(stderr, "unknown option %s\n", a); return -1; }
    }
    return 0;
