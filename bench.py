@@ -217,9 +217,12 @@ def main():
         achieved = FLOP_PER_CHUNK[dom] * chunks_per_launch / avg_s / 1e12
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")))
-            # the committed passes were collected with the default command (Silero v3.1, fp32 mode): only that workload gets their bytes
-            if args.model == "v31" and not split16 and prof.get("streams") == S and prof.get("chunks_per_step") == Cn and dom in prof.get("kernels", {}):
+            # a workload only gets the bytes of passes collected on exactly that workload (tools/rocprof_reduce.py names the files)
+            default_workload = args.model == "v31" and not split16 and S == 256 and Cn == 96
+            name = "latest_pmc_traffic.json" if default_workload else f"latest_pmc_traffic_{args.model}_{args.precision}_{S}x{Cn}.json"
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if (prof.get("streams") == S and prof.get("chunks_per_step") == Cn and prof.get("model", "v31") == args.model
+                    and prof.get("precision", "fp32") == args.precision and dom in prof.get("kernels", {})):
                 traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass

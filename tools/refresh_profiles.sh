@@ -12,6 +12,14 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- $B > $O/prof_
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB -- $B > $O/pmcB.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmcC -- $B > $O/pmcC.log 2>&1
+# HBM traffic of the two 4096-stream GEMM-front-end workloads (BASELINE configs 3 and 4)
+for w in "v4 fp32" "v31 split16"; do
+   set -- $w
+   W="--model $1 --precision $2 --streams 4096 --chunks-per-step 16"
+   rm -rf $O/prof_fetch_$1_$2 $O/prof_write_$1_$2
+   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_$1_$2 -- $B $W > $O/prof_fetch_$1_$2.log 2>&1
+   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_$1_$2 -- $B $W > $O/prof_write_$1_$2.log 2>&1
+done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_4096x16.json
 python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline --graph 2>/dev/null | tail -1 > $O/bench_4096x16_graph.json

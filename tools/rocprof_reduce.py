@@ -18,7 +18,7 @@ SHORT = [("k_frontend_mx2", "k_frontend"), ("k_frontend", "k_frontend"), ("k_lst
 def short_name(full):
     m = re.search(r"k_layer_mfma<(\d+), (\d+), (\d+)", full) or re.search(r"k_layer<(\d+), (\d+), (\d+)", full)
     if m:
-        return {("129", "16"): "k_layer1", ("16", "32"): "k_layer2", ("32", "32"): "k_layer3", ("32", "64"): "k_layer4"}[(m.group(1), m.group(2))]
+        return {("129", "16"): "k_layer1", ("258", "16"): "k_layer1", ("16", "32"): "k_layer2", ("32", "32"): "k_layer3", ("32", "64"): "k_layer4"}[(m.group(1), m.group(2))]
     for key, name in SHORT:
         if key in full:
             return name
@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--pmc", action="append", default=[], help="directory of an extra --pmc pass; all its counters are averaged per kernel")
     ap.add_argument("--out", required=True); ap.add_argument("--tag", required=True)
     ap.add_argument("--streams", type=int, default=256); ap.add_argument("--chunks-per-step", type=int, default=96)
+    ap.add_argument("--model", default="v31"); ap.add_argument("--precision", default="fp32")
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -64,13 +65,16 @@ def main():
         fe, wr = pmc_avg(a.fetch, "FETCH_SIZE"), pmc_avg(a.write, "WRITE_SIZE")
         out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {a.command}",
                "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 64 B per 128-B request; MI355X_MICROARCH.md section HBM)",
+               "model": a.model, "precision": a.precision,
                "streams": a.streams, "chunks_per_step": a.chunks_per_step, "kernels": {}}
         for k in sorted(set(fe) | set(wr)):
             out["kernels"][k] = {"FETCH_SIZE_KB": round(fe.get(k, 0.0), 1), "WRITE_SIZE_KB": round(wr.get(k, 0.0), 1),
                                  "hbm_bytes_per_launch": int((2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024)}
         p = os.path.join(a.out, a.tag + "_pmc_traffic.json")
         json.dump(out, open(p, "w"), indent=1)
-        shutil.copy(p, os.path.join(os.path.dirname(os.path.abspath(a.out)), "latest_pmc_traffic.json"))
+        default_workload = a.model == "v31" and a.precision == "fp32" and a.streams == 256 and a.chunks_per_step == 96
+        latest = "latest_pmc_traffic.json" if default_workload else f"latest_pmc_traffic_{a.model}_{a.precision}_{a.streams}x{a.chunks_per_step}.json"
+        shutil.copy(p, os.path.join(os.path.dirname(os.path.abspath(a.out)), latest))   # what bench.py reads for `roofline.traffic`
         print("wrote", p)
     if a.pmc:
         merged = defaultdict(dict)
