@@ -170,6 +170,7 @@ struct vadc_amd_engine {
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
+   int v4_mag = 0;                              // option "v4_mag": 0 = the v4 first stage recovers the magnitudes from Y (no MAG array on the hot path), 1 = it reads MAG
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
@@ -713,6 +714,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
+   if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && value >= 0 && value <= 2) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
@@ -729,6 +731,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
    else if (strcmp(key, "fe_overlap") == 0) *value = e->fe_overlap;
+   else if (strcmp(key, "v4_mag") == 0) *value = e->v4_mag;
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
    else if (strcmp(key, "lstm_kernel") == 0) *value = e->last_lstm_kernel;
@@ -749,13 +752,16 @@ static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const ch
    return VADC_AMD_OK;
 }
 
+// Silero v4: the first stage (K = 1 form) takes the magnitude half of its input from Y = log(1 + 2^20 m) instead of a second array
+static bool v4_mag_from_y(const vadc_amd_engine *e) { return e->model == VADC_AMD_MODEL_V4 && e->encoder_variant != 2 && e->v4_mag == 0; }
+
 // lstm_layout: the last layer writes the LSTM-native tile layout (hot path) instead of [n][64][7] (stage taps)
 static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st)
 {
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
       else if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
@@ -780,8 +786,9 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       const int fe_slots = 4 * ((st == e->sA || st == e->sF) && e->lstm_cus > 0 && !e->lstm_shared ? e->n_cus - e->lstm_cus : e->n_cus);
       if (e->use_gemm_frontend()) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
-         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
-         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
+         float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
+         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
+         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
       } else if (e->model == VADC_AMD_MODEL_V4) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);

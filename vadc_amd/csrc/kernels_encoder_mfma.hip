@@ -216,6 +216,8 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 
 // FIRST: 0 = plain input [n][CIN][T]; 1 = Silero v3.1 first layer (input = Y - mm, finishing the adaptive normalization);
 //        2 = Silero v4 first block: input = concat(magnitude `in2` [n][129][T], Y - mm) = 258 channels (silero_vad.py:212).
+//        3 = the same (K = 1 form only), but the magnitude half is RECOVERED from Y: m = (e^Y - 1) 2^-20 (Y = log(1 + 2^20 m)), so that the front end
+//            does not write, and this stage does not read, a second 0.8 GB array per 65,536 chunks; absolute error <= 2^-43 + 8e-7 m.
 // HAS_TF: false = Silero v4 encoder stage (ConvBlock -> strided 1x1 conv with folded BatchNorm -> ReLU, no transformer
 //        block; silero_vad.py:157-189 with is_v4).
 // LSTM_OUT: 0 = [n][D][TOUT] (next layer / stage taps); 1 = fp32 LSTM-native tiles (common.h lstm_x_index); 2 = split-fp16
@@ -285,14 +287,14 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
       const int item0 = blockIdx.x * NCH + cb0;
       const bool cv0 = (lane < NCOLV) && (item0 < n_chunks);
       const int chunk0 = map(cv0 ? item0 : min(blockIdx.x * NCH, n_chunks - 1));
-      xa = in + (size_t)chunk0 * (FIRST == 2 ? kBins : CIN) * T + t0;
-      xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;
+      xa = in + (size_t)chunk0 * ((FIRST >= 2) ? kBins : CIN) * T + t0;
+      xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;             // FIRST 3: the magnitude half is read from Y as well
       const int c0 = wave * CPW, c1 = min(c0 + CPW, CIN);
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
          const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
-         const bool first_half = FIRST == 2 && ch < kBins;  // magnitude half of the v4 input
-         xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)(FIRST == 2 ? ch - kBins : ch) * T];
+         const bool first_half = (FIRST >= 2) && ch < kBins;  // magnitude half of the v4 input
+         xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)((FIRST >= 2) ? ch - kBins : ch) * T];
       }
    }
    __shared__ float mm_s[FIRST ? NCH : 1];
@@ -506,14 +508,15 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
 #pragma unroll
    for (int i = 0; i < CPW; ++i) {
       const int ch = min(ch0 + i, ch1 - 1);                // wave-uniform
-      const bool first_half = FIRST == 2 && ch < kBins;    // magnitude half of the v4 input: no mean removed
+      const bool first_half = (FIRST >= 2) && ch < kBins;    // magnitude half of the v4 input: no mean removed
       const float xraw = xv[i % XR];
       if (i + XR < CPW) {                                  // the ring slot is free: request channel i + XR
          const int chn = min(ch0 + i + XR, ch1 - 1);
-         const bool fh = FIRST == 2 && chn < kBins;
-         xv[i % XR] = fh ? xb[(size_t)chn * T] : xa[(size_t)(FIRST == 2 ? chn - kBins : chn) * T];
+         const bool fh = (FIRST >= 2) && chn < kBins;
+         xv[i % XR] = fh ? xb[(size_t)chn * T] : xa[(size_t)((FIRST >= 2) ? chn - kBins : chn) * T];
       }
-      const float x = cvalid ? (first_half ? xraw : xraw - mm) : 0.0f;                                 // misc.c:84-96
+      const float xfh = FIRST == 3 ? fmaf(__builtin_amdgcn_exp2f(xraw * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f) : xraw;   // magnitude from log1p(2^20 m)
+      const float x = cvalid ? (first_half ? xfh : xraw - mm) : 0.0f;                                 // misc.c:84-96
       const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
       const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
       const float2 k01 = k01r[i % WR], k23 = k23r[i % WR], k45 = k45r[i % WR];
@@ -561,11 +564,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    const int chunk = map(cvalid ? item_raw : min(blockIdx.x * NCH, n_chunks - 1));
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
-   const float *x_in = in + (size_t)chunk * (FIRST == 2 ? kBins : CIN) * T + t;
-   const float *x_in2 = FIRST == 2 ? in2 + (size_t)chunk * kBins * T + t : nullptr;
+   const float *x_in = in + (size_t)chunk * ((FIRST >= 2) ? kBins : CIN) * T + t;
+   const float *x_in2 = (FIRST >= 2) ? in2 + (size_t)chunk * kBins * T + t : nullptr;
    auto load_x = [&](int ch) -> float {
       if (!(cvalid && ch < CIN)) return 0.0f;
-      if (FIRST == 2) return ch < kBins ? x_in2[(size_t)ch * T] : x_in[(size_t)(ch - kBins) * T];
+      if ((FIRST >= 2)) return ch < kBins ? x_in2[(size_t)ch * T] : x_in[(size_t)(ch - kBins) * T];
       return x_in[(size_t)ch * T];
    };
    // x slab: 8 rows per wave; rows >= CIN and invalid columns are zero.  The NEXT slab's rows are requested from
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
          const int r = wave * 8 + i, ch = c0 + r;
-         xc[i] = (cvalid && ch < CIN) ? xv[i] - ((FIRST == 2 && ch < kBins) ? 0.0f : mm) : 0.0f;  // misc.c:84-96
+         xc[i] = (cvalid && ch < CIN) ? xv[i] - (((FIRST >= 2) && ch < kBins) ? 0.0f : mm) : 0.0f;  // misc.c:84-96
          XS[r * kPitch + col] = xc[i];
       }
       if (s + 1 < NSLAB) {
@@ -906,7 +909,8 @@ void launch_layer_v4(int layer, const float *in, const float *in2, const float *
    switch (layer) {
    case 0:
       if (slab) hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else      hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else if (in2) hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else          hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 3, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
       break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 12, 2, true, 0, false, 5, true, false>), dim3((n + 4) / 5), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 6, 2, false, 0, false, 10, true, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;

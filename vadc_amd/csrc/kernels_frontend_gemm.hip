@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
             float *yp = Y + ybase + (size_t)((16 * wave + 4 * g) * kFr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) yp[r * kFr] = val[r];
-            if (Geo::mag) {
+            if (Geo::mag && MAG) {
                float *mp = MAG + ybase + (size_t)((16 * wave + 4 * g) * kFr);
 #pragma unroll
                for (int r = 0; r < 4; ++r) mp[r * kFr] = mag[r];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
             const float nval = log1p_hw_fast(nmag * 1048576.0f);
             if (ok) {
                Y[ybase + (size_t)128 * kFr] = nval;
-               if (Geo::mag) MAG[ybase + (size_t)128 * kFr] = nmag;
+               if (Geo::mag && MAG) MAG[ybase + (size_t)128 * kFr] = nmag;
             }
             nyv[pos] = nval;                               // added to partial 3 below: the sum must not depend on which wave took it
          }
