@@ -166,8 +166,11 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                             "graph"   1: capture the call's launch sequence into a hipGraph on first use and
  *                                      replay it afterwards (steady-state serving); 0 (default): eager launches
  *                             "fe_overlap" 1: the front end runs on its own internal stream, concurrently with the encoder
- *                                      layers of the previous call (buffers double buffered); 0: one stream.  Default: 1 for
- *                                      the v4 model, 0 for v3.1 (measured: it helps the GEMM front end, hurts the tree one)
+ *                                      layers of the previous call (buffers double buffered); 0 (default, both models): one stream
+ *                                      (measured: the front end's grid starves the layer kernels of workgroup slots)
+ *                             "v4_mag" 0 (default): the Silero v4 first stage recovers the magnitude half of its input from the
+ *                                      log-magnitudes, m = (e^Y - 1) 2^-20, and the front end writes no magnitude array on the hot
+ *                                      path; 1: magnitudes are written by the front end and read by the first stage
  *                             "cu_partition" 1 (default): when the LSTM needs few CUs it gets CUs of its own (CU masks): shared with
  *                                      the front end + encoder stream when every 16-stream tile has a CU to itself and the chain has
  *                                      slack, disjoint otherwise; 2: always shared; 0: never mask.

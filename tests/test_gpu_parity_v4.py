@@ -145,6 +145,19 @@ def test_first_stage_forms_agree(eng, gold):
     assert float(np.abs(a - b).max()) < 5e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
 
 
+def test_magnitude_recovered_from_log_magnitude_agrees_with_stored_magnitude(eng, gold):
+    """default: the first stage takes the magnitude half of its input as (e^Y - 1) 2^-20 from the log-magnitudes; option v4_mag=1: from the magnitude
+    array the front end then writes.  Same first-stage output to rounding noise, same probabilities to well inside the parity bar."""
+    x = f32(gold["pcm_speech1"])[:11 * 1536]
+    try:
+        eng.set_option("v4_mag", 0); a = eng.stage_from_samples(x, "layer1"); eng.reset_streams(); pa = eng.run(gold["pcm_speech0"][None, :])
+        eng.set_option("v4_mag", 1); b = eng.stage_from_samples(x, "layer1"); eng.reset_streams(); pb = eng.run(gold["pcm_speech0"][None, :])
+    finally:
+        eng.set_option("v4_mag", 0); eng.reset_streams()
+    assert float(np.abs(a - b).max()) < 2e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
+    assert float(np.abs(pa - pb).max()) < 2e-5, float(np.abs(pa - pb).max())
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_probabilities_both_frontends(eng, gold, variant):
     eng.set_option("frontend", variant)
