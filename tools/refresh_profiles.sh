@@ -19,6 +19,9 @@ for w in "v4 fp32" "v31 split16"; do
    rm -rf $O/prof_fetch_$1_$2 $O/prof_write_$1_$2
    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_$1_$2 -- $B $W > $O/prof_fetch_$1_$2.log 2>&1
    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_$1_$2 -- $B $W > $O/prof_write_$1_$2.log 2>&1
+   rm -rf $O/prof_kt_$1_$2 $O/pmcB_$1_$2
+   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_$1_$2 -- python3 bench.py --no-cpu-baseline $W > $O/prof_kt_$1_$2.log 2>&1
+   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB_$1_$2 -- $B $W > $O/pmcB_$1_$2.log 2>&1
 done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_4096x16.json
