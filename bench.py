@@ -33,14 +33,13 @@ CHUNK_SECONDS = 1536 / 16000.0
 FLOP_PER_CHUNK = {
     "k_frontend": 2 * 1_651_200,
     "k_layer1": 2 * 181_053, "k_layer2": 2 * 112_208, "k_layer3": 2 * 61_600, "k_layer4": 2 * 236_768,
-    "k_lstm": 2 * (458_752 + 896),                 # both layers incl. the input projection + decoder (fused, default)
-    "k_lstm_xproj": 2 * 114_688,                   # layer-0 input projection when hoisted ("lstm"=4/5; then k_lstm does that much less)
+    "k_lstm": 2 * (458_752 + 896),                 # both layers incl. the input projection + decoder
 }
 # Silero v4 (BASELINE config 4, `--model v4`): parity-test configuration, not the headline
 FLOP_PER_CHUNK_V4 = {
     "k_frontend": 2 * 1_585_152,
     "k_layer1": 2 * 232_176, "k_layer2": 2 * 19_392, "k_layer3": 2 * 10_176, "k_layer4": 2 * 25_056,
-    "k_lstm": 2 * (196_608 + 192), "k_lstm_xproj": 2 * 49_152,
+    "k_lstm": 2 * (196_608 + 192),
 }
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
@@ -200,8 +199,6 @@ def main():
         chunks_per_step = S * Cn * world
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
         kt = eng.kernel_times()
-        if kt.get("k_lstm_xproj", (0, 0.0))[0] > 0:                # hoisted variants: the projection is timed (and counted) separately
-            FLOP_PER_CHUNK["k_lstm"] -= FLOP_PER_CHUNK["k_lstm_xproj"]
         # The LSTM chain runs concurrently on its own small CU partition; weigh every kernel's
         # time by the share of the chip it occupies so that "dominant" means dominant in CU-time, not in wall time
         # of a kernel that leaves 240 CUs to the others.

@@ -182,7 +182,7 @@ int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
 enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,
-       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_LSTM_XPROJ, VADC_AMD_KERNEL_COUNT };
+       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_COUNT };
 /* When enabled every kernel launch of run_* is bracketed by hipEventRecord on its stream. */
 int  vadc_amd_set_profiling(vadc_amd_engine *e, int enabled);
 /* Synchronizes, then returns launch count and summed duration (ms) since the last reset. */

@@ -51,7 +51,7 @@ def test_model_kind_comes_from_the_container(eng):
     assert c["model_kind"] == MODEL_V4 and c["lstm_steps_per_chunk"] == 3
     assert (c["input_size_min"], c["input_size_max"], c["output_stride"], c["silero_probability_out_index"]) == (1536, 1536, 2, 1)
     with pytest.raises(VadcAmdError):
-        eng.set_option("lstm", 2)                    # v3.1 bring-up variants do not exist for v4
+        eng.set_option("encoder", 3)                 # split-fp16 / fp32 GEMM forms exist for the v3.1 transformer layers only
 
 
 @pytest.mark.parametrize("name", STREAMS)
@@ -100,6 +100,42 @@ def test_shapes_sweep_against_oracle(blob, orc, S, C, calls):
         assert float(np.abs(got[s] - want).max()) < PROB_TOL, (s, float(np.abs(got[s] - want).max()))
     for s in range(base.shape[0], S, max(1, S // 7)):
         assert np.array_equal(got[s], got[s % base.shape[0]])
+
+
+def test_config4_full_size_4096_streams(blob, orc):
+    """BASELINE config 4 at its stated size (Silero v4, 4096 streams x 16 chunks per call: the >= 2048-stream scheduling branch, no LSTM CU
+    partition): determinism, range, stream independence (the same audio in different slots gives the same bits), state carry over two calls =
+    one call of twice the length, hipGraph replay = eager, and every one of the 64 distinct streams against the oracle"""
+    import torch
+    S, Cn = 4096, 16
+    base = synth.make_streams(64, 2 * Cn, seed0=7400)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 64, 1)))
+    e = Engine(blob, max_streams=S, max_chunks_per_call=2 * Cn, device=0)
+    try:
+        a = np.concatenate([e.run(pcm[:, : Cn * 1536]), e.run(pcm[:, Cn * 1536:])], axis=1)
+        e.reset_streams()
+        b = e.run(pcm)                                       # one call of 32 chunks
+        assert np.array_equal(a, b)
+        assert np.isfinite(a).all() and (a >= 0).all() and (a <= 1).all()
+        assert np.array_equal(a[:64], a[64 * 17: 64 * 18]) and np.array_equal(a[:64], a[S - 64:])
+        want = orc.forward_streams(base)
+        assert float(np.abs(a[:64, :, 1] - want).max()) < PROB_TOL
+        # graph replay at this size, two caller streams / buffers as bench.py drives it
+        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(2)]
+        sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+        e.set_option("graph", 1)
+        for rep in range(2):
+            e.reset_streams()
+            outs = [torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+            for i in range(2):
+                with torch.cuda.stream(sts[i]):
+                    e.run_device(d_in[i].data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), sts[i].cuda_stream)
+            torch.cuda.synchronize()
+            g = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+            assert np.array_equal(g, a), rep
+        e.set_option("graph", 0)
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("ci", [0, 20])

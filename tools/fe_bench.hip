@@ -171,6 +171,64 @@ int main(int argc, char **argv)
       printf("concurrent chain kernel on CUs 0..7: %d iterations (~1.5 ms)\n", g_dummy_iters);
    }
    if (argc > 3 && !strcmp(argv[3], "cold")) { g_cold = true; CK(hipMalloc(&g_scratch, (size_t)256 << 20)); }
+   if (argc > 2 && !strcmp(argv[2], "sym")) {         // k_frontend_sym (33 base bins + symmetries) against k_frontend_fl (all 129 bins): bits and time
+      // a windowed-DFT basis with the reference's symmetries BY CONSTRUCTION: cos / sin from one quadrant table
+      double qc[65];
+      for (int k = 0; k <= 64; ++k) qc[k] = cos(2.0 * M_PI * k / 256.0);
+      auto cosi = [&](int m) { m &= 255; if (m > 128) m = 256 - m; return m <= 64 ? qc[m] : -qc[128 - m]; };
+      auto sini = [&](int m) { return cosi(m - 64); };
+      std::vector<float> nat((size_t)kFilters * 256);
+      for (int f = 0; f < kFilters; ++f)
+         for (int t = 0; t < 256; ++t) {
+            const int bin = f % kBins;
+            const double w = 0.5 - 0.5 * cosi(t);
+            nat[(size_t)f * 256 + t] = (float)(f < kBins ? w * cosi(bin * t) : -w * sini(bin * t));
+         }
+      for (int f = 0; f < kFilters; ++f)
+         for (int ii = 0; ii < 4; ++ii)
+            for (int lp = 0; lp < 4; ++lp)
+               for (int j = 0; j < 8; ++j)
+                  for (int b = 0; b < 2; ++b)
+                     h_basis[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = nat[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
+      CK(hipMemcpy(basis, h_basis.data(), h_basis.size() * 4, hipMemcpyHostToDevice));
+      float *FM1;
+      CK(hipMalloc(&FM1, (size_t)kBinSplit * n * kFrames * 4));
+      const size_t fm_stride = (size_t)n * kFrames;
+      const ItemMap map{n, 0, n};
+      const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+      auto time_it = [&](const char *name, auto launch) {
+         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+         launch(); CK(hipDeviceSynchronize());
+         CK(hipEventRecord(a, g_st));
+         for (int r = 0; r < reps; ++r) launch();
+         CK(hipEventRecord(b, g_st)); CK(hipEventSynchronize(b));
+         float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+         printf("%-44s %8.4f ms  %7.2f Mchunks/s\n", name, ms, n / ms / 1e3);
+      };
+      time_it("fl nb3 (all 129 bins), magnitude", [&] { hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y0, FM, n, map, fm_stride, nullptr); });
+      CK(hipMemcpy(ref.data(), Y0, ref.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb3 w4, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 3, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      check("sym nb3 w4", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 w4, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      check("sym nb2 w4", Y1);
+      time_it("fl nb3 (all 129 bins), log mode", [&] { hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y0, FM, n, map, fm_stride, nullptr); });
+      time_it("sym nb3 w4, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb2 w4, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb2 w5, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 5>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb3 w3, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      {  // log values: sym takes v_sqrt_f32 under the logarithm (<= 1 ulp of the magnitude): report the largest difference against fl
+         std::vector<float> a(ref.size()), b(ref.size());
+         CK(hipMemcpy(a.data(), Y0, a.size() * 4, hipMemcpyDeviceToHost));
+         hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride);
+         CK(hipDeviceSynchronize());
+         CK(hipMemcpy(b.data(), Y1, b.size() * 4, hipMemcpyDeviceToHost));
+         double mx = 0; for (size_t i = 0; i < a.size(); ++i) mx = fmax(mx, fabs((double)a[i] - b[i]));
+         printf("   max |Y_sym - Y_fl| (log mode) = %.3e\n", mx);
+      }
+      return 0;
+   }
    if (argc > 2 && !strcmp(argv[2], "fl")) {          // frame-lane kernel against the shipped k_frontend: magnitudes, log values and FM
       float *FM1;
       CK(hipMalloc(&FM1, (size_t)kBinSplit * n * kFrames * 4));

@@ -15,21 +15,17 @@
 #include <vector>
 
 namespace vadc {
-void launch_frontend_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int *, int);
-void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int *, int);
-void launch_frontend_mx2_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_mx2_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
-void launch_layer(int, const float *, const float *, const LayerWeights &, float *, int, ItemMap, int, size_t, hipStream_t);
-void launch_lstm(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
-void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, hipStream_t, int);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -127,14 +123,10 @@ struct vadc_amd_engine {
    hipStream_t stream = nullptr;
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
-   const float *d_basis_mx2 = nullptr;          // k_frontend_mx2: [17 tiles][l][i][j/4][16 filters][j%4]
-   int *d_fe_counter = nullptr;                 // k_frontend_fl persistent grid: work counter (zeroed on the launch's stream before every launch)
-   int fe_persist = 0;                          // option "fe_persist": 1 = persistent grid + work counter, 0 = one workgroup per unit (default: see kernels_frontend.hip)
-   int fe_nps = 1;                              // k_frontend_fl: position sets per workgroup (1 = 256 threads, 2 = 512 threads; see kernels_frontend.hip)
-   int frontend_variant = 0;                    // v3.1: 0 = k_frontend_fl (one lane per frame, default), 1 = k_frontend_mx2 (products issued as MFMA, experimental), 2 = k_frontend (one lane per block + wave shifts)
-   LayerWeights lw[4];
+   bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
+   int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
-   int encoder_variant = 0;                     // 0 = MFMA layers, 1 = VALU bring-up layers
+   int encoder_variant = 0;                     // 0 = MFMA layers (default), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4
    LstmWeights lstm;
    // workspace
    float *d_in_f32 = nullptr;
@@ -142,10 +134,10 @@ struct vadc_amd_engine {
    float *d_Y = nullptr, *d_FM = nullptr, *d_tap = nullptr;
    float *d_act[4] = {nullptr, nullptr, nullptr, nullptr};
    float *d_probs = nullptr;
-   float *d_gx = nullptr;                       // hoisted LSTM input projection (k_lstm_xproj)
-   // Encoder -> LSTM hand-off buffers are double buffered over forked calls: d_act[3] / d_gx alias pair [xpar], so that
+   // The encoder -> LSTM hand-off buffer is double buffered over forked calls: d_act[3] aliases pair [xpar], so that
    // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
-   float *d_xpair[2] = {nullptr, nullptr}, *d_gxpair[2] = {nullptr, nullptr};
+   float *d_xpair[2] = {nullptr, nullptr};
+   size_t x_tile_chunks = 0;                    // capacity of a hand-off buffer in (16-stream tile, chunk) blocks
    // ... and so are the front end -> encoder buffers (d_Y / d_FM / d_MAG alias pair [xpar]): with option "fe_overlap" the front
    // end of call k+1 runs on its own internal stream concurrently with the encoder layers of call k on the same CUs.
    float *d_ypair[2] = {nullptr, nullptr}, *d_fmpair[2] = {nullptr, nullptr}, *d_magpair[2] = {nullptr, nullptr};
@@ -167,6 +159,7 @@ struct vadc_amd_engine {
    int lstm_cus_forced = 0;                     // option "lstm_cus": CUs for the LSTM partition (0 = sized by lstm_partition_cus)
    int lstm_cus = -1;                           // CUs currently reserved for stream B (-1: streams not created)
    int last_lstm_kernel = -1;                   // what resolve_lstm chose for the last call
+   int last_frontend_kernel = -1;               // what the last call's front end was: 0 = k_frontend_sym, 1 = k_frontend_fl, 2 = k_frontend_gemm, 3 = k_frontend (v4 tree)
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
@@ -207,6 +200,33 @@ static std::vector<float> k1_pack(const std::vector<float> &pw, const std::vecto
    for (int c = 0; c < C; ++c)
       for (int o = 0; o < D; ++o) { r[((size_t)c * 2 + 0) * D + o] = pw[(size_t)o * C + c]; r[((size_t)c * 2 + 1) * D + o] = pj[(size_t)o * C + c]; }
    return r;
+}
+
+// k_frontend_sym (kernels_frontend.hip) evaluates the reference's tree for bins 0..32 only and derives the other 96 bins from
+//     re[128-b][n] = (-1)^n re[b][n]     im[128-b][n] = -(-1)^n im[b][n]
+//     re[64-b][n] = {re, -im, -re, im}[b][n] by n % 4     im[64-b][n] = {-im, -re, im, re}[b][n] by n % 4
+// which hold BIT FOR BIT for the reference's forward_basis_buffer (a zero may carry either sign).  Checked here on the loaded
+// tensor [258][256]; any other basis (a perturbed test tensor, a re-exported model) runs the full tree of k_frontend_fl instead.
+static bool basis_has_dft_symmetries(const std::vector<float> &basis)
+{
+   auto RE = [&](int k, int n) { return basis[(size_t)k * 256 + n]; };
+   auto IM = [&](int k, int n) { return basis[(size_t)(kBins + k) * 256 + n]; };
+   auto same = [](float a, float b) { return a == b; };               // +0 == -0: the sign of a zero tap never reaches a magnitude
+   for (int b = 0; b <= 64; ++b)
+      for (int n = 0; n < 256; ++n) {
+         const float sg = (n & 1) ? -1.0f : 1.0f;
+         if (!same(RE(128 - b, n), sg * RE(b, n)) || !same(IM(128 - b, n), -sg * IM(b, n))) return false;
+         float er, ei;
+         switch (n & 3) {
+         case 0:  er = RE(b, n);  ei = -IM(b, n); break;
+         case 1:  er = -IM(b, n); ei = -RE(b, n); break;
+         case 2:  er = -RE(b, n); ei = IM(b, n);  break;
+         default: er = IM(b, n);  ei = RE(b, n);  break;
+         }
+         if (!same(RE(64 - b, n), er) || !same(IM(64 - b, n), ei)) return false;
+      }
+   for (float v : basis) if (!(fabsf(v) < 3.0e38f)) return false;      // NaN / inf never compare equal to their mirror, but be explicit
+   return true;
 }
 
 // GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
@@ -259,26 +279,9 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                for (int b = 0; b < 2; ++b)
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
-   // k_frontend_mx2 B operand: tile ft = 8 bins x (re, im); column jj < 8 -> filter 8 ft + jj, jj >= 8 -> 129 + 8 ft + jj - 8;
-   // taps in the order the tree consumes them (l, i, j), tap-quads contiguous per filter so that one global_load_dwordx4
-   // fetches j..j+3
-   size_t off_basis_mx2;
-   {
-      std::vector<float> bt((size_t)17 * 256 * 16, 0.0f);
-      for (int ft = 0; ft < 17; ++ft)
-         for (int l = 0; l < 8; ++l)
-            for (int i = 0; i < 4; ++i)
-               for (int j = 0; j < 8; ++j)
-                  for (int jj = 0; jj < 16; ++jj) {
-                     const int bin = 8 * ft + (jj & 7);
-                     if (bin >= kBins) continue;
-                     const int filt = (jj < 8) ? bin : kBins + bin;
-                     bt[(size_t)ft * 4096 + (((l * 4 + i) * 2 + (j >> 2)) * 16 + jj) * 4 + (j & 3)] = tmp[(size_t)filt * 256 + 64 * i + 8 * j + l];
-                  }
-      off_basis_mx2 = pk.add(bt.data(), bt.size());
-   }
    size_t off_afrag = 0, off_nyq = 0;
    e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // SPLIT16 precision mode (BASELINE config 3)
+   e->sym_ok = basis_has_dft_symmetries(tmp);
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
@@ -379,10 +382,9 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
-      e->d_basis_mx2 = base + off_basis_mx2;
       if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
       for (int l = 0; l < 4; ++l) {
-         LayerWeights &w = e->lw[l];
+         LayerWeights w;
          w.dw_w = base + lo[l].dw_w; w.dw_b = base + lo[l].dw_b; w.pwT = base + lo[l].pwT; w.pw_b = base + lo[l].pw_b;
          w.pjT = kLayers[l].proj ? base + lo[l].pjT : nullptr; w.pj_b = kLayers[l].proj ? base + lo[l].pj_b : nullptr;
          w.qkv_w = base + lo[l].qkv_w; w.qkv_b = base + lo[l].qkv_b; w.out_w = base + lo[l].out_w; w.out_b = base + lo[l].out_b;
@@ -510,7 +512,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_ypair[0], e->d_ypair[1], e->d_magpair[0], e->d_magpair[1],
                    e->d_fmpair[0], e->d_fmpair[1], e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_gxpair[0], e->d_gxpair[1], e->d_fe_counter};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -578,15 +580,13 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElemsV31[2 + l] * sizeof(float));   // >= the v4 shapes
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
    const size_t padded_streams = (size_t)((max_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
+   e->x_tile_chunks = padded_streams / kLstmTile * max_chunks;
    for (int p = 0; p < 2; ++p) {
       if (he == hipSuccess) he = hipMalloc(&e->d_xpair[p], padded_streams * max_chunks * 448 * sizeof(float));
       if (he == hipSuccess) he = hipMemset(e->d_xpair[p], 0, padded_streams * max_chunks * 448 * sizeof(float));
-      if (he == hipSuccess) he = hipMalloc(&e->d_gxpair[p], padded_streams * max_chunks * 7 * 256 * sizeof(float));
    }
    e->d_act[3] = e->d_xpair[0];
-   e->d_gx = e->d_gxpair[0];
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
-   if (he == hipSuccess) he = hipMalloc(&e->d_fe_counter, 64);
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMemset(e->d_h, 0, (size_t)max_streams * 128 * sizeof(float));
@@ -687,30 +687,29 @@ extern "C" int vadc_amd_reset_kernel_times(vadc_amd_engine *e)
 
 extern "C" const char *vadc_amd_kernel_name(int kernel)
 {
-   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_xproj"};
+   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"};
    return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
-   if (e->model == VADC_AMD_MODEL_V4 && ((strcmp(key, "lstm") == 0 && value != 0 && value != 5 && value != 6) || (strcmp(key, "encoder") == 0 && (value == 1 || value == 3))))
-      return fail(VADC_AMD_EINVAL, "set_option: %s=%d is a Silero v3.1 bring-up variant; the v4 path has one implementation", key, value);
+   if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "encoder") == 0 && value == 3)
+      return fail(VADC_AMD_EINVAL, "set_option: %s=%d exists for Silero v3.1 only (the v4 stages carry no split-fp16 GEMMs)", key, value);
+   // every switch below changes the launch sequence a captured graph replays: drop the captured graphs (after their last replay has finished)
+   if (strcmp(key, "graph") != 0 && !e->graphs.empty()) {
+      if (e->ev_graph_valid) HIP_TRY(hipEventSynchronize(e->ev_graph), VADC_AMD_EHIP);
+      for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
+      e->graphs.clear();
+   }
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && value >= 0 && value <= 6) { e->lstm_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "frontend") == 0 && value >= 0 && value <= 2) {
-      if (value == 1 && e->max_items * (size_t)(kBins * kFrames) >= ((size_t)1 << 31))
-         return fail(VADC_AMD_EINVAL, "set_option: frontend=1 indexes Y with 32-bit offsets; workspace too large");
-      e->frontend_variant = value;
-      return VADC_AMD_OK;
-   }
-   if (strcmp(key, "fe_nps") == 0 && (value == 1 || value == 2)) { e->fe_nps = value; return VADC_AMD_OK; }
-   if (strcmp(key, "fe_persist") == 0 && (value == 0 || value == 1)) { e->fe_persist = value; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder") == 0 && value >= 0 && value <= 3) { e->encoder_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6)) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
@@ -725,8 +724,6 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (!e || !key || !value) return fail(VADC_AMD_EINVAL, "get_option: NULL argument");
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
-   else if (strcmp(key, "fe_nps") == 0) *value = e->fe_nps;
-   else if (strcmp(key, "fe_persist") == 0) *value = e->fe_persist;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
@@ -735,6 +732,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
    else if (strcmp(key, "lstm_kernel") == 0) *value = e->last_lstm_kernel;
+   else if (strcmp(key, "frontend_kernel") == 0) *value = e->last_frontend_kernel;
    else return fail(VADC_AMD_EINVAL, "get_option: unknown option %s", key);
    return VADC_AMD_OK;
 }
@@ -749,6 +747,11 @@ static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const ch
    if (n_streams > e->max_streams) return fail(VADC_AMD_EINVAL, "%s: n_streams=%d exceeds max_streams=%d", who, n_streams, e->max_streams);
    if ((size_t)n_streams * n_chunks > e->max_items)
       return fail(VADC_AMD_EINVAL, "%s: %d x %d chunks exceed the workspace (%zu)", who, n_streams, n_chunks, e->max_items);
+   // the encoder -> LSTM hand-off is stored in tiles of 16 streams: ceil(n_streams / 16) x n_chunks blocks must fit what
+   // ceil(max_streams / 16) x max_chunks_per_call allocated (few streams x very many chunks would otherwise overrun it)
+   if ((size_t)((n_streams + kLstmTile - 1) / kLstmTile) * n_chunks > e->x_tile_chunks)
+      return fail(VADC_AMD_EINVAL, "%s: %d streams x %d chunks need %zu (16-stream tile, chunk) blocks, the workspace holds %zu (max_streams=%d, max_chunks_per_call=%d)",
+                  who, n_streams, n_chunks, (size_t)((n_streams + kLstmTile - 1) / kLstmTile) * n_chunks, e->x_tile_chunks, e->max_streams, e->max_chunks);
    return VADC_AMD_OK;
 }
 
@@ -762,7 +765,6 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
       if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
-      else if (e->encoder_variant == 1) launch_layer(l, in, e->d_FM, e->lw[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
    }
@@ -782,25 +784,28 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    if (hold_first) (void)hipStreamWaitEvent(st, hold_first, 0);
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
-      // workgroups that fit the CUs this stream may use (4 per CU); the internal streams lose the LSTM partition's CUs
-      const int fe_slots = 4 * ((st == e->sA || st == e->sF) && e->lstm_cus > 0 && !e->lstm_shared ? e->n_cus - e->lstm_cus : e->n_cus);
+      const size_t fms = e->max_items * kFrames;
+      const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
       if (e->use_gemm_frontend()) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
          float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
-         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
-         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, geo);
+         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
+         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
+         e->last_frontend_kernel = 2;
       } else if (e->model == VADC_AMD_MODEL_V4) {
-         if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-         else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-      } else if (e->frontend_variant == 1) {
-         if (sizeof(T) == 2) launch_frontend_mx2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-         else                launch_frontend_mx2_f32(reinterpret_cast<const float *>(d_in), e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-      } else if (e->frontend_variant == 2) {
-         if (sizeof(T) == 2) launch_frontend_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
-         else                launch_frontend_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st);
+         if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
+         else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
+         e->last_frontend_kernel = 3;
+      } else if (e->sym_ok && e->frontend_variant == 0 && aligned) {
+         // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
+         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
+         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
+         e->last_frontend_kernel = 0;
       } else {
-         if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps, e->fe_persist ? e->d_fe_counter : nullptr, fe_slots);
-         else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, 0, st, e->fe_nps, e->fe_persist ? e->d_fe_counter : nullptr, fe_slots);
+         // any basis, any alignment: the full tree for all 129 bins
+         if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
+         else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
+         e->last_frontend_kernel = 1;
       }
    }
    if (st != st_enc) {
@@ -810,11 +815,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
    }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
    if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
-   run_encoder_layers(e, 3, 3, n, map, lstm_kernel == 6 ? 2 : 1, st);      // 2: split-fp16 tiles for the fused split-fp16 LSTM
-   if (lstm_kernel == 0 || lstm_kernel == 5) {
-      KernelTimer t(e, VADC_AMD_KERNEL_LSTM_XPROJ, st);
-      launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n / map.cg, map.C, map.c0, map.cg, st, e->model);
-   }
+   run_encoder_layers(e, 3, 3, n, map, lstm_kernel == 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3, 1: fp32 tiles for the fp32 kernel
 }
 
 // How many CUs the LSTM chain gets (0 = no partition).  Its workgroups (one per 16-stream tile) are latency-bound -- a slot
@@ -834,7 +835,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    if (lstm_wgs > e->n_cus / 2) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
    // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
-   const double slot_us = ((e->lstm_variant == 0 || e->lstm_variant == 5 || e->lstm_variant == 6) && e->lstm_h3_ok) ? 1.65 : 3.9;
+   const double slot_us = (e->lstm_variant != 3 && e->lstm_h3_ok) ? 1.65 : 3.9;
    const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : 0.100);
    // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
@@ -905,23 +906,12 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
    return VADC_AMD_OK;
 }
 
-// LSTM kernel for this call: option "lstm" 0 = auto (hoisted input projection + split-fp16 wavefront while the recurrence is
-// latency-bound or partitioned, i.e. few stream tiles; fused fp32 wavefront otherwise), 1 = simple, 2 = step-sequential MFMA,
-// 3 = fused fp32 wavefront, 4 = hoisted fp32 wavefront, 5 = hoisted split-fp16 wavefront
-static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
+// LSTM kernel for this call: option "lstm" 0 = auto: 6 = k_lstm_wavefront_h3 (split-fp16 operands on the fp16 matrix pipe, fp32 accuracy);
+// 3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when asked for
+static int resolve_lstm(const vadc_amd_engine *e, int)
 {
-   // split-fp16 needs every weight inside fp16's range; else the fp32 forms
-   if (e->lstm_variant == 5) return e->lstm_h3_ok ? 5 : 0;    // hoisted input projection + split-fp16 wavefront
-   if (e->lstm_variant == 6) return e->lstm_h3_ok ? 6 : 0;    // fused split-fp16 wavefront (x arrives as split-fp16 tiles, no GX)
-   if (e->model == VADC_AMD_MODEL_V4) return e->lstm_h3_ok ? 6 : 0;
-   if (e->lstm_variant == 0) {
-      if (e->lstm_h3_ok) return 6;
-      // fp32: hoisted while the chain is latency-bound or runs on its own CU partition; fused when it owns the chip
-      bool sh_ = false;
-      return ((n_streams + 15) / 16 <= e->n_cus / 2 || lstm_partition_cus(e, n_streams, &sh_) > 0) ? 0 : 3;
-   }
-   if (e->lstm_variant == 4) return 0;
-   return e->lstm_variant;
+   if (e->lstm_variant == 3 || !e->lstm_h3_ok) return 3;
+   return 6;
 }
 
 static int pick_groups(const vadc_amd_engine *e, int n_chunks)
@@ -951,7 +941,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
       {
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
       }
       if (!e->capturing) { (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true; }
    } else {
@@ -973,7 +963,6 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       e->xpar ^= 1;
       const int xp = e->xpar;
       e->d_act[3] = e->d_xpair[xp];
-      e->d_gx = e->d_gxpair[xp];
       e->d_Y = e->d_ypair[xp]; e->d_FM = e->d_fmpair[xp]; e->d_MAG = e->d_magpair[xp];
       hipEvent_t hold = (e->ev_b_valid[xp] && !e->capturing) ? e->ev_b[xp] : nullptr;
       hipEvent_t hold_first = (split_fe && e->ev_e_valid[xp] && !e->capturing) ? e->ev_e[xp] : nullptr;
@@ -998,7 +987,7 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-         launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
+         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
          c0 += cg;
       }
       // join
@@ -1065,7 +1054,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
    HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
    if (e->graphs.size() >= 8) {                            // evict the oldest signature; its last replay may still be in flight
-      (void)hipStreamSynchronize(e->graphs[0].st);
+      if (e->ev_graph_valid) (void)hipEventSynchronize(e->ev_graph);   // not the cached stream handle: the caller may have destroyed that stream
       (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin());
    }
    e->graphs.push_back(ge);
@@ -1138,6 +1127,12 @@ static int wait_last_lstm(vadc_amd_engine *e)
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
+// the stage taps overwrite the intermediates (Y, FM, layer outputs, hand-off tiles): wait for EVERYTHING enqueued before, on any stream
+static int wait_all_prior(vadc_amd_engine *e)
+{
+   if (e->ev_last_valid) HIP_TRY(hipEventSynchronize(e->ev_last_a), VADC_AMD_EHIP);
+   return wait_last_lstm(e);
+}
 
 extern "C" int vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *ids, int n)
 {
@@ -1195,16 +1190,15 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    if (!e || !samples || !out || stage < 0 || stage >= VADC_AMD_STAGE_COUNT) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: bad argument");
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: n=%d out of range", n);
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
    if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, e->model == VADC_AMD_MODEL_V4 ? 1 : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-   else if (e->frontend_variant == 1) launch_frontend_mx2_f32(e->d_in_f32, e->d_basis_mx2, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   else if (e->frontend_variant == 2) launch_frontend_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
-   else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_nps,
-                               e->fe_persist ? e->d_fe_counter : nullptr, 4 * e->n_cus);
+   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
@@ -1221,6 +1215,7 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    if (e->model == VADC_AMD_MODEL_V4 && from_stage < VADC_AMD_STAGE_LAYER1)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: the v4 first block takes magnitude AND normalized; feed LAYER1..3 or use from_samples");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
    const size_t in_bytes = (size_t)n * e->stage_elems[from_stage] * sizeof(float);
    int first_layer = 0;
@@ -1249,6 +1244,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
    if (rc) return rc;
    if (!x || !probs) return fail(VADC_AMD_EINVAL, "debug_lstm_decoder: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
    const size_t n = (size_t)n_streams * n_chunks;
    const int lk = resolve_lstm(e, n_streams);
@@ -1279,8 +1275,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
          HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       }
    }
-   if (lk == 0 || lk == 5) launch_lstm_xproj(e->d_act[3], e->d_gx, e->lstm, n_streams, n_chunks, 0, n_chunks, st, e->model);
-   launch_lstm(lk, e->d_act[3], e->d_gx, e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);

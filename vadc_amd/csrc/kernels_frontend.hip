@@ -584,6 +584,231 @@ __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__rest
    }
 }
 
+// =====================================================================================================
+// k_frontend_sym -- the bit-exact tree evaluated for 33 of the 129 bins; the other 96 follow from the basis' symmetries
+// =====================================================================================================
+// The reference's basis (row k < 129: w[n] cos(2 pi k n / 256), row 129 + k: -w[n] sin(2 pi k n / 256), w = periodic Hann) satisfies,
+// BIT FOR BIT (the engine verifies it on the loaded tensor at create time, engine.hip basis_has_dft_symmetries; otherwise
+// k_frontend_fl runs):
+//     re[128-b][n] = (-1)^n re[b][n]                      im[128-b][n] = -(-1)^n im[b][n]
+//     re[64-b][n]  = {re, -im, -re, im}[b][n]  by n % 4   im[64-b][n]  = {-im, -re, im, re}[b][n]  by n % 4
+// A tap is t = 64 i + 8 j + l, so n % 4 = l % 4: inside one tree lane l every tap of a derived row is +-(the same tap of row re[b] or
+// im[b]).  IEEE multiplication and addition commute with negation (round-to-nearest is symmetric), so the whole per-lane part of the
+// reference's tree -- products, the j tree, the group sums (stft.c:141-167) -- of a derived row equals +-v[l] of a base row EXACTLY:
+//     v'[l] = s(l) v_re[l]  or  s(l) v_im[l]
+// and only the last 7 additions over the tree lanes (stft.c:176-184) have to be redone per derived row, on sign-flipped operands:
+// with (x, y) = (v[2 LP], v[2 LP + 1]) of an l-pair LP, the pair sums of the 8 rows that base bin b yields are
+//     re b: rx + ry        im b: ix + iy        re 128-b: rx - ry     im 128-b: ix - iy     (same sign for every l-pair)
+//     re 64-b: rx - iy     im 64-b: ix + ry     re 64+b: rx + iy      im 64+b: ix - ry      (sign alternates with the l-pair)
+// (global signs dropped: only re^2 + im^2 is used; a zero may come out with the other sign, which squares away as well), and
+//     y = (e0 + e1) + (e2 + e3)  for the first four,   y = (e0 - e1) + (e2 - e3)  for the alternating ones.
+// Base bins 0..32 give all 129 bins: {b, 128-b, 64-b, 64+b}, with 64 -+ 0 and 64 -+ 32 coinciding with rows already there.  Work per
+// position: 33 x 2 trees of 511 operations + 56 additions per base bin instead of 258 trees -- 3.9x less of what bounds k_frontend_fl --
+// and magnitudes that are still the reference's bits (tests/test_gpu_parity.py::test_stft_magnitude_bit_exact_*; the derivation itself is
+// checked step by step in float32 numpy, tests/test_stft_symmetry.py).
+// Mapping as k_frontend_fl (one lane per (chunk, frame) position, samples from the workgroup's LDS tile, taps by scalar loads, NB base bins
+// per batch share the sample reads); the 4 waves of a workgroup split the base bins 9 / 9 / 9 / 6, and with them the partial bin sums.
+// MODE 0 takes v_sqrt_f32 (1 ulp) for the magnitude under the logarithm: Y moves by <= 6e-8, below log1p_hw's own error; the
+// magnitude tap (MODE 1) keeps the correctly rounded sqrtf of stft.c:209.
+constexpr int kSymBase = 33;                                     // base bins 0..32
+constexpr int kSymChunkPitch = 1956;                             // floats per staged chunk: == 25 * 68 (mod 64), so a lane's tile address is linear in
+                                                                 // its position across chunk boundaries and every ds_read_b128 phase stays conflict-free
+__host__ __device__ constexpr int sym_first_bin(int wave, int nb) { return nb == 3 ? 9 * wave : (wave == 0 ? 0 : 8 * wave + 1); }
+__host__ __device__ constexpr int sym_end_bin(int wave, int nb) { return wave == 3 ? kSymBase : sym_first_bin(wave + 1, nb); }
+
+template <int NB>
+struct SymState {
+   f2v ta[2 * NB], tb[2 * NB];      // g_0 (+ g_1), g_2 of the current l-pair; filter 2 B = re, 2 B + 1 = im of base bin B
+   float sa[8 * NB], sb[8 * NB];    // partial lane trees of the 8 rows of a base bin: e0 (+- e1), e2; sa ends up as the row's y
+};
+
+template <int LP, int NB>
+__device__ __forceinline__ void sym_rows(SymState<NB> &st, int B, f2v vr, f2v vi)
+{
+   float e[8];
+   e[0] = vr.x + vr.y; e[1] = vi.x + vi.y; e[2] = vr.x - vr.y; e[3] = vi.x - vi.y;
+   e[4] = vr.x - vi.y; e[5] = vi.x + vr.y; e[6] = vr.x + vi.y; e[7] = vi.x - vr.y;
+#pragma unroll
+   for (int k = 0; k < 8; ++k) {
+      float &sa = st.sa[8 * B + k], &sb = st.sb[8 * B + k];
+      if (LP == 0) sa = e[k];
+      else if (LP == 1) sa = (k < 4) ? sa + e[k] : sa - e[k];
+      else if (LP == 2) sb = e[k];
+      else { const float t = (k < 4) ? sb + e[k] : sb - e[k]; sa = sa + t; }
+   }
+}
+
+// Stage K of a batch = (step S = K / NB = 4 LP + I, base bin B = K % NB), pipelined exactly like FlStages
+template <int NB, int K>
+struct SymStages {
+   static __device__ __forceinline__ void run(SymState<NB> &st, const float *kf, unsigned xaddr, f16v &ca, f16v &cb, f16v &na, f16v &nb,
+                                              f4v (&xc)[4], f4v (&xn)[4])
+   {
+      constexpr int S = K / NB, B = K % NB, LP = S / 4, I = S % 4;
+      constexpr int Kn = K + 1;
+      constexpr int Sn = (Kn / NB) % 16, Bn = Kn % NB, LPn = Sn / 4, In = Sn % 4;
+      constexpr int noff = (Kn == 16 * NB ? NB * 1024 : 0) + fl_tap_off(Bn, In, LPn);
+      constexpr int kImOffB = kBins * kFilterLen * 4;
+      if constexpr (B == 0) {
+         constexpr int S1 = (S + 1) % 16;
+         VADC_FL_LDS16(xn, xaddr, ((S1 % 4) * kFlBlockPitch + (S1 / 4) * 16) * 4);
+      }
+      VADC_FL_SLOAD2(na, nb, kf, noff, noff + kImOffB);
+      const f2v gr = fl_tree8<0>(xc, ca), gi = fl_tree8<0>(xc, cb);
+      if constexpr (I == 0) { st.ta[2 * B] = gr; st.ta[2 * B + 1] = gi; }
+      else if constexpr (I == 1) { st.ta[2 * B] = st.ta[2 * B] + gr; st.ta[2 * B + 1] = st.ta[2 * B + 1] + gi; }       // g_0 + g_1   (stft.c:165)
+      else if constexpr (I == 2) { st.tb[2 * B] = gr; st.tb[2 * B + 1] = gi; }
+      else {
+         const f2v t23r = st.tb[2 * B] + gr, t23i = st.tb[2 * B + 1] + gi;                                                // g_2 + g_3   (stft.c:166)
+         sym_rows<LP, NB>(st, B, st.ta[2 * B] + t23r, st.ta[2 * B + 1] + t23i);                                            // stft.c:167, :176-184
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
+      if constexpr (B == NB - 1) {
+         asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
+         __builtin_amdgcn_sched_barrier(0);
+         SymStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
+      } else {
+         __builtin_amdgcn_sched_barrier(0);
+         SymStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
+      }
+   }
+};
+template <int NB>
+struct SymStages<NB, 16 * NB> {
+   static __device__ __forceinline__ void run(SymState<NB> &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
+};
+
+// one 8-sample octet of the reflect-padded chunk -> the tile (l-pair-major inside a block: sample 8 j + l at 16 (l / 2) + 2 j + l % 2)
+__device__ __forceinline__ void sym_store_octet(float *blk, int j, const float (&v)[8])
+{
+#pragma unroll
+   for (int lp = 0; lp < 4; ++lp) *reinterpret_cast<float2 *>(blk + lp * 16 + 2 * j) = make_float2(v[2 * lp], v[2 * lp + 1]);
+}
+__device__ __forceinline__ void sym_load_octet(const int16_t *p, float (&v)[8])
+{
+   const int4 q = *reinterpret_cast<const int4 *>(p);          // 16-byte aligned: chunk bases and octet offsets are multiples of 16 bytes
+   const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+   for (int k = 0; k < 4; ++k) {
+      v[2 * k] = (float)(int16_t)(w[k] & 0xffff) * (1.0f / 32768.0f);
+      v[2 * k + 1] = (float)(w[k] >> 16) * (1.0f / 32768.0f);
+   }
+}
+__device__ __forceinline__ void sym_load_octet(const float *p, float (&v)[8])
+{
+   const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <typename T, int MODE, int NB = 3, int MINW = 4>
+__global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict__ pcm,          // [n_chunks][1536], 16-byte aligned
+                                                           const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
+                                                           float *__restrict__ Y,              // [n_chunks][129][25]
+                                                           float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
+                                                           int n_chunks, ItemMap map, size_t fm_stride)
+{
+   static_assert(NB == 3 || NB == 2, "base-bin split tables exist for NB = 2, 3");
+   constexpr int kFlChunks = fl_chunks(1);
+   __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // base-bin split
+   const long total_pos = (long)n_chunks * kFrames;
+   const long p0 = (long)blockIdx.x * 64;
+   const int item0 = (int)(p0 / kFrames);
+
+   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954); interior octets with one 16-byte load
+   constexpr int kOctets = kPadded / 8;                                      // 224 per chunk
+   for (int o = tid; o < kFlChunks * kOctets; o += 256) {
+      const int c = o / kOctets, oc = o - c * kOctets;
+      const int it = min(item0 + c, n_chunks - 1);
+      const T *src = pcm + (size_t)map(it) * kChunk;
+      const int idx = oc * 8;                                                // padded index of the octet's first sample
+      float v[8];
+      if (idx >= kPad && idx < kPad + kChunk) sym_load_octet(src + (idx - kPad), v);
+      else {
+#pragma unroll
+         for (int k = 0; k < 8; ++k) {
+            int sidx = idx + k - kPad;
+            sidx = sidx < 0 ? -sidx : sidx;
+            sidx = sidx >= kChunk ? 2 * (kChunk - 1) - sidx : sidx;
+            v[k] = sample_to_f32(src[sidx]);
+         }
+      }
+      sym_store_octet(xs + c * kSymChunkPitch + (idx >> 6) * kFlBlockPitch, (idx >> 3) & 7, v);
+   }
+   __syncthreads();
+
+   const long pe = p0 + lane;
+   const bool writer = pe < total_pos;
+   const long pa_ = writer ? pe : total_pos - 1;
+   const int item = (int)(pa_ / kFrames), n = (int)(pa_ - (long)item * kFrames);
+   const int chunk = map(item);
+   typedef __attribute__((address_space(3))) float lds_f;
+   const unsigned xaddr = (unsigned)(uintptr_t)(lds_f *)(xs + (item - item0) * kSymChunkPitch + kFlBlockPitch * n);
+
+   const int f_start = sym_first_bin(wave, NB), f_end = sym_end_bin(wave, NB);
+   float *yout = Y + (size_t)chunk * (kBins * kFrames) + n;
+   float bin_sum = 0.0f;
+   constexpr int kImOffB = kBins * kFilterLen * 4;
+
+   f16v ca, cb, na, nb;
+   f4v xc[4], xn[4];
+   {
+      const float *k0 = basis + (size_t)f_start * kFilterLen;
+      VADC_FL_LDS16(xc, xaddr, 0);
+      VADC_FL_SLOAD2(ca, cb, k0, fl_tap_off(0, 0, 0), fl_tap_off(0, 0, 0) + kImOffB);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
+      asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
+      __builtin_amdgcn_sched_barrier(0);
+   }
+   // rows of base bin b: (b, 128 - b, 64 - b, 64 + b); 64 -+ 0 coincide, and 64 -+ 32 are rows 32 and 96 again
+   auto emit = [&](int b, const float *y8) {
+      const int bins[4] = {b, 128 - b, 64 - b, 64 + b};
+      const bool ok[4] = {true, true, b < 32, b > 0 && b < 32};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+         const float re = y8[2 * q], im = y8[2 * q + 1];
+         const float re2 = re * re, im2 = im * im;
+         const float p2 = re2 + im2;
+         float val;
+         if (MODE == 0) {
+            val = log1p_hw(__builtin_amdgcn_sqrtf(p2) * 1048576.0f);          // misc.c:42-45
+            if (ok[q]) bin_sum += val;                                         // misc.c:55-59
+         } else {
+            val = sqrtf(p2);                                                   // stft.c:209
+         }
+         if (writer && ok[q]) yout[bins[q] * kFrames] = val;
+      }
+   };
+#pragma unroll 1
+   for (int f = f_start; f + NB <= f_end; f += NB) {
+      const float *kf = basis + (size_t)f * kFilterLen;                        // wave-uniform
+      SymState<NB> st;
+      SymStages<NB, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
+#pragma unroll
+      for (int k = 0; k < 8 * NB; ++k) asm volatile("" : "+v"(st.sa[k]));     // pin the trees above the epilogue (see k_frontend_fl)
+#pragma unroll
+      for (int B = 0; B < NB; ++B) emit(f + B, &st.sa[8 * B]);
+   }
+   if constexpr (NB == 2) {                                                    // NB = 2: wave 0 owns 9 base bins, the odd one as a batch of its own
+      if (wave == 0) {
+         const int f = f_end - 1;
+         const float *kf = basis + (size_t)f * kFilterLen;
+         SymState<1> st;
+         VADC_FL_LDS16(xc, xaddr, 0);
+         VADC_FL_SLOAD2(ca, cb, kf, fl_tap_off(0, 0, 0), fl_tap_off(0, 0, 0) + kImOffB);
+         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
+         asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
+         __builtin_amdgcn_sched_barrier(0);
+         SymStages<1, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
+#pragma unroll
+         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st.sa[k]));
+         emit(f, &st.sa[0]);
+      }
+   }
+   if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
+}
+
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
 template <int kFrames>
@@ -641,61 +866,35 @@ __global__ void k_lognorm_from_magnitude(const float *__restrict__ mag, float *_
 }
 
 // n = number of items in this launch (= n_streams * map.cg)
-void launch_frontend_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+// k_frontend_fl: what runs when the loaded basis lacks the DFT symmetries k_frontend_sym needs, or the input is not 16-byte aligned
+void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
-   const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
-   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<float, 0, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<float, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
+   else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
 }
 
-void launch_frontend_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
-   const long waves = ((long)n * kBlocks + kLanesOut - 1) / kLanesOut;
-   const dim3 grid((unsigned)((waves + 3) / 4), kBinSplit);
-   if (mode == 0) hipLaunchKernelGGL((k_frontend<int16_t, 0, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend<int16_t, 1, 256, 4, 0, 0, 0, 0, 2>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
+   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
 }
 
-constexpr int kFlNps = 2;   // the alternative to nps == 1 (engine option "fe_nps"); 4 (1024 threads) measured 1.21 ms
-void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps,
-                            int *work_counter, int slots)
+// k_frontend_sym: the default v3.1 front end (basis symmetries verified by the engine, pcm 16-byte aligned)
+constexpr int kSymNB = 2;   // tools/fe_bench sym, 16,384 chunks: NB = 2 0.300 ms, NB = 3 0.329 ms (k_frontend_fl: 1.07 ms)
+void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
-   if (work_counter && mode == 0) {                     // persistent grid (option "fe_persist"): units of 64 positions drawn from a counter
-      const int units = (int)(((long)n * kFrames + 63) / 64);
-      (void)hipMemsetAsync(work_counter, 0, sizeof(int), st);
-      hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1, true>), dim3(units < slots ? units : slots), dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, work_counter);
-      return;
-   }
-   if (nps == 1) {
-      const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-      if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-      else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-      return;
-   }
-   const dim3 grid((unsigned)(((long)n * kFrames + 64 * kFlNps - 1) / (64 * kFlNps)));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<float, 0, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_fl<float, 1, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_sym<float, 0, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_sym<float, 1, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
-void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int nps,
-                            int *work_counter, int slots)
+void launch_frontend_sym_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
-   if (work_counter && mode == 0) {                     // persistent grid (option "fe_persist"): units of 64 positions drawn from a counter
-      const int units = (int)(((long)n * kFrames + 63) / 64);
-      (void)hipMemsetAsync(work_counter, 0, sizeof(int), st);
-      hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1, true>), dim3(units < slots ? units : slots), dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, work_counter);
-      return;
-   }
-   if (nps == 1) {
-      const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-      if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-      else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-      return;
-   }
-   const dim3 grid((unsigned)(((long)n * kFrames + 64 * kFlNps - 1) / (64 * kFlNps)));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, kFlNps>), grid, dim3(256 * kFlNps), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   if (mode == 0) hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   else           hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
@@ -724,147 +923,5 @@ void launch_lognorm_from_magnitude(const float *mag, float *Y, float *FM, size_t
    hipLaunchKernelGGL(k_lognorm_from_magnitude, dim3(n), dim3(64), 0, st, mag, Y, FM, n, fm_stride);
 }
 
-
-// =====================================================================================================
-// k_frontend_mx2 -- the same bit-exact STFT with the 256 PRODUCTS of every output issued as MFMA (experimental)
-// =====================================================================================================
-// v_mfma_f32_16x16x1_4b_f32 with a zero accumulator computes D[i][j] = fma(A[i], B[j], 0) = rnd(A[i]*B[j]): an outer
-// product of INDIVIDUALLY ROUNDED fp32 products (K = 1, nothing is accumulated inside the instruction), i.e. exactly
-// the p_t = x[t]*k[t] terms of the reference's tree (stft.c:141-155) -- checked bit for bit on the device
-// (tools/mfma_k1.hip).  For tap t the A operand is x[position][t] for 64 (chunk, frame) positions (one per lane), the
-// B operand k[filter][t] for the 16 filters of a tile (8 bins x (re, im)); all 256 products of one (position, filter)
-// output land in the SAME lane and register, one MFMA per tap, so the reference's tree of 255 separately rounded adds
-// (stft.c:143-184) is per-lane VALU work: no cross-lane shifts, no halo lanes, half the instructions of k_frontend.
-// hipcc cannot schedule this (it hoists the pure MFMAs and spills kilobytes), so the tile's 256 MFMAs and 255 x 16
-// v_add_f32 are emitted by a generator (tools/gen_mx_asm.py) that schedules and register-allocates them: MFMA k is followed by the add row whose operands completed one slot
-// earlier, operands are prefetched two 8-tap groups ahead (x: ds_read_b128 from the tile in LDS, basis: global_load_dwordx4
-// from the L2-resident repacked basis), 9 x 16 tree registers are live at most => 192 VGPRs for the block, 2 waves/SIMD, so
-// one wave's MFMA could overlap the other wave's adds.
-// STATUS / FINDING (tools/mx_tile_bench.hip, measured on MI355X): bit-identical to k_frontend, but NOT faster.  fp32 MFMA
-// executes on the same fp32 lanes as the vector ALU (which is why the fp32 matrix and vector peaks are both 157 TFLOP/s):
-// MFMA-only tile 48 cycles/tap, add-only 83, both 131 -- strictly additive, also with a 4-register-result MFMA, with one
-// or two waves per SIMD.  Products therefore cost the same ALU time wherever they are issued, and the exact tree is bound
-// by 511 fp32 lane-ops per output on either path.  In situ (16,384 chunks): 1.44 ms vs 1.41 ms for k_frontend, of which the
-// tiles are 1.19 ms and staging + sqrt/log1p + stores 0.26 ms.  Kept as option "frontend"=1 and as the record of that
-// measurement.
-//   x tile in LDS: per chunk 28 blocks of 64 samples, block pitch 68 floats, inside a block sample k = 8 j + l is stored at
-//   8 l + j so that the 8 taps j = 0..7 of one tree group (l, i) are two aligned 16-byte reads.
-//   basis tile ft: [l][i][j / 4][16 filters][j % 4]  (16 KB per tile; filter column jj < 8: re of bin 8 ft + jj, else im)
-#include "frontend_mx_tile.inc"
-constexpr int kMx2BlockPitch = 68;
-constexpr int kMx2ChunkPitch = kBlocks * kMx2BlockPitch;      // 1904 floats per chunk
-constexpr int kMxChunks = 4;                  // 64 consecutive positions span at most 4 chunks
-typedef float f16acc __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) float lds_float_t;
-
-__device__ __forceinline__ float dpp_row_ror8(float v)      // lane l of every 16-lane row reads lane (l + 8) % 16 of its row
-{
-   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-}
-
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, 2) void k_frontend_mx2(const T *__restrict__ pcm,          // [n_chunks][1536]
-                                                         const float *__restrict__ bt2,      // [17][l 8][i 4][jq 2][16][4]
-                                                         float *__restrict__ Y,              // [n_chunks][129][25]
-                                                         float *__restrict__ FM,             // [4][fm_stride] partial bin sums
-                                                         int n_chunks, ItemMap map, size_t fm_stride)
-{
-   __shared__ __attribute__((aligned(16))) float xs[kMxChunks * kMx2ChunkPitch];
-   __shared__ int posoff[64];                 // element offset of (chunk, frame) in Y, -1 = past the end
-   __shared__ float sy[4][8][65];             // per wave: one tile's 8 bins x 64 positions, transposed for coalesced stores
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int lc = lane & 15, quad = lane >> 4;
-   const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * 64;
-   const int item0 = (int)(p0 / kFrames);
-
-   // stage the (up to) 4 chunks these 64 positions touch: reflect pad (tensor.h:931-954), j-contiguous inside a block
-   for (int c = 0; c < kMxChunks; ++c) {
-      const int it = min(item0 + c, n_chunks - 1);
-      const T *src = pcm + (size_t)map(it) * kChunk;
-      for (int idx = tid; idx < kPadded; idx += 256) {
-         int s = idx - kPad;
-         s = s < 0 ? -s : s;
-         s = s >= kChunk ? 2 * (kChunk - 1) - s : s;
-         const int k = idx & 63;
-         xs[c * kMx2ChunkPitch + (idx >> 6) * kMx2BlockPitch + (k & 7) * 8 + (k >> 3)] = sample_to_f32(src[s]);
-      }
-   }
-   int fo = -1;                               // this lane's position as OUTPUT lane: offset in the frame-major FM buffer
-   {
-      const long pe = p0 + lane;
-      int yo = -1;
-      if (pe < total_pos) {
-         const int it = (int)(pe / kFrames), n = (int)(pe - (long)it * kFrames);
-         const int ch = map(it);
-         yo = ch * (kBins * kFrames) + n;       // < 2^31 (vadc_amd_create bounds max_streams * max_chunks)
-         fo = ch * kFrames + n;
-      }
-      if (wave == 0) posoff[lane] = yo;
-   }
-   __syncthreads();
-
-   // this lane's position (A operand): frame n of its chunk starts at block n
-   const long pa = min(p0 + lane, total_pos - 1);
-   const int item_a = (int)(pa / kFrames), n_a = (int)(pa - (long)item_a * kFrames);
-   const unsigned xaddr = (unsigned)(uintptr_t)(lds_float_t *)(xs + (item_a - item0) * kMx2ChunkPitch + kMx2BlockPitch * n_a);
-   const unsigned boff = lc * 16;
-   const int hi = lc >> 3;                    // epilogue: lanes 8..15 of a row take the second half of the accumulator
-   float bsum = 0.0f;                         // partial bin sum of position `lane` over this wave's tiles
-
-   // wave w owns tiles w, w+4, w+8, w+12; the 17th tile (bin 128 only) rotates over the waves with the workgroup index
-   const int extra = blockIdx.x & 3;
-#pragma unroll 1
-   for (int ti = 0; ti < 5; ++ti) {
-      if (ti == 4 && wave != extra) break;
-      const int ft = __builtin_amdgcn_readfirstlane(ti == 4 ? 16 : wave + 4 * ti);
-      const float *bbase = bt2 + (size_t)ft * (256 * 16);
-      f16acc y;
-      asm volatile(VADC_MX_TILE_ASM
-                   : VADC_MX_TILE_Y_CONSTRAINT(y)
-                   : [xaddr] "v"(xaddr), [boff] "v"(boff), [bbase] "s"(bbase)
-                   : VADC_MX_TILE_CLOBBERS);
-      // y[e]: position 16 (e/4) + 4 quad + e%4 of this workgroup, filter lc of tile ft (lc < 8: re of bin 8 ft + lc,
-      // lc >= 8: im of bin 8 ft + lc - 8).  re and im of one output sit 8 lanes apart in the same register; lanes 0..7 of a
-      // row finish outputs e = 0..7, lanes 8..15 outputs e = 8..15, so all 64 lanes do useful epilogue work.  The values
-      // go through a per-wave LDS tile [bin][position] so that the global stores run along the frames of a chunk.
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-         const float a = y[e], b = y[e + 8];
-         const float ra = dpp_row_ror8(a), rb = dpp_row_ror8(b);
-         const float re = hi ? rb : a, im = hi ? b : ra;
-         const float re2 = re * re, im2 = im * im;
-         const float mag = sqrtf(re2 + im2);                                  // stft.c:209
-         const float val = (MODE == 0) ? log1p_hw(mag * 1048576.0f) : mag;      // misc.c:42-45
-         sy[wave][lc & 7][16 * ((e >> 2) + 2 * hi) + 4 * quad + (e & 3)] = val;
-         if (e & 1) __builtin_amdgcn_sched_barrier(0);   // two elements at a time: bounds the live log1p temporaries
-      }
-      const int yo = posoff[lane];
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-         const float v = sy[wave][b][lane];                                    // same wave wrote it (LDS is in order per wave)
-         const int bin = 8 * ft + b;
-         if (yo >= 0 && bin < kBins) {
-            Y[(size_t)yo + bin * kFrames] = v;
-            bsum += v;
-         }
-      }
-   }
-   if (MODE == 0 && fo >= 0) FM[wave * fm_stride + fo] = bsum;
-}
-
-void launch_frontend_mx2_f32(const float *pcm, const float *bt2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
-{
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx2<float, 0>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_mx2<float, 1>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
-}
-
-void launch_frontend_mx2_s16(const int16_t *pcm, const float *bt2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
-{
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_mx2<int16_t, 0>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_mx2<int16_t, 1>), grid, dim3(256), 0, st, pcm, bt2, Y, FM, n, map, fm_stride);
-}
 
 }  // namespace vadc

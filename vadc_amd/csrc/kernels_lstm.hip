@@ -11,19 +11,17 @@
 // Here the unit of parallelism is the STREAM: state h,c is [n_streams][2][64] in HBM, loaded once per call,
 // kept on chip while the call's n_chunks chunks of the stream are consumed in order, stored once.
 //
-// The MFMA mapping (all MFMA variants): a workgroup = 16 streams.  Per (step, layer) the gate pre-activations are
-//   G[256 x 16] = W[256 x 128] . [x ; h][128 x 16]   on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).
+// The MFMA mapping: a workgroup = 16 streams.  Per (step, layer) the gate pre-activations are
+//   G[256 x 16] = W[256 x 128] . [x ; h][128 x 16]
 //   Wave w owns hidden units [16w,16w+16) for ALL four gates, so the i,f,g,o values of one (unit, stream) land in
-//   the same lane/register of its four accumulators and the cell update is register-local.  Both layers' weights
-//   live in registers as MFMA A-fragments (2 x 4 x 32 VGPRs) for the whole call; [x;h] is the B operand, read
-//   from a small LDS tile that double-buffers h: one barrier per (step, layer).
-// k_lstm_xproj + k_lstm_wavefront (default while the recurrence is latency-bound, variant 0/4): layer 0's input projection
-//   hoisted into a GEMM, the two layers of the recurrence run concurrently one step apart (see below);
-//   k_lstm_wavefront_fused (default for many stream tiles, variant 3): the same with the projection inside the recurrence;
-//   k_lstm_mfma (variant 2): the step-sequential version of the same MFMA mapping.  Template parameters TS / DEC select the
-//   steps per chunk and the decoder of Silero v3.1 (7, two-output mean-then-sigmoid) or v4 (3, one-output sigmoid-then-mean).
-// k_lstm_simple: bring-up/reference variant (one wave per stream, weights streamed from L2), selectable with
-//   vadc_amd_set_option(e, "lstm", 1); used by the tests to A/B the MFMA kernel on the device.
+//   the same lane/register of its four accumulators and the cell update is register-local.  The layer's weights
+//   live in registers as MFMA A-fragments for the whole call; [x;h] is the B operand.
+// Two kernels, one schedule (the two layers run concurrently one step apart, see k_lstm_wavefront_fused):
+//   k_lstm_wavefront_h3    (default, engine variant 6): gate GEMMs on the fp16 matrix pipe with split-fp16 operands, fp32 accuracy
+//   k_lstm_wavefront_fused (engine variant 3): fp32 MFMA; what runs when an LSTM weight does not fit fp16's range
+// Template parameters TS / DEC select the steps per chunk and the decoder of Silero v3.1 (7, two-output mean-then-sigmoid)
+// or v4 (3, one-output sigmoid-then-mean).  (Round 1 also carried a one-wave-per-stream bring-up kernel, a step-sequential MFMA
+// kernel and forms with layer 0's input projection hoisted into a GEMM of its own; all measured slower -- DESIGN.md 4.3 -- and removed.)
 #include "common.h"
 
 namespace vadc {
@@ -32,71 +30,11 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 
 // Hardware-transcendental forms for the recurrent inner loop (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute
 // error <= ~3e-7 on values in (0,1) / (-1,1), two decades below what the 1e-4 probability bar needs, and the
-// recurrence is contractive.  The bring-up kernel keeps the libm-grade forms for A/B tests.
+// recurrence is contractive.
 // (__frcp_rn is the correctly rounded reciprocal: a 10-instruction v_div_scale/fmas/fixup sequence; v_rcp_f32 is 1 ulp.)
 __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
-// ------------------------------------------------------------------------------------------------
-// simple variant
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lstm_simple(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
-                                                    LstmWeights w,
-                                                    float *__restrict__ hs,          // [S][2][64]
-                                                    float *__restrict__ cs,          // [S][2][64]
-                                                    float *__restrict__ probs,       // [S][C][2]
-                                                    int n_streams, int n_chunks, int ch0, int chn)
-{
-   __shared__ float xh[128];
-   const int s = blockIdx.x;
-   const int j = threadIdx.x;
-   if (s >= n_streams) return;
-   float h0 = hs[(size_t)s * 128 + j], h1 = hs[(size_t)s * 128 + 64 + j];
-   float c0 = cs[(size_t)s * 128 + j], c1 = cs[(size_t)s * 128 + 64 + j];
-   const float dw0 = w.dec_w[j], dw1 = w.dec_w[64 + j];
-
-   for (int ch = ch0; ch < ch0 + chn; ++ch) {
-      const float *x = enc + lstm_x_index(s, ch, n_chunks, 0, j);        // + t * 64 * 16
-      float d0 = 0.0f, d1 = 0.0f;                          // sum over t of (w . relu(h1_t))
-      for (int t = 0; t < 7; ++t) {
-#pragma unroll
-         for (int l = 0; l < 2; ++l) {
-            const float xin = (l == 0) ? x[(size_t)t * 64 * kLstmTile] : h0;
-            __syncthreads();
-            xh[j] = xin;
-            xh[64 + j] = (l == 0) ? h0 : h1;
-            __syncthreads();
-            const float *wT = w.wT + (size_t)l * 128 * 256;
-            float gi = w.b[l * 256 + j], gf = w.b[l * 256 + 64 + j], gg = w.b[l * 256 + 128 + j], go = w.b[l * 256 + 192 + j];
-            for (int k = 0; k < 128; ++k) {
-               const float v = xh[k];
-               gi = fmaf(wT[k * 256 + j], v, gi);
-               gf = fmaf(wT[k * 256 + 64 + j], v, gf);
-               gg = fmaf(wT[k * 256 + 128 + j], v, gg);
-               go = fmaf(wT[k * 256 + 192 + j], v, go);
-            }
-            const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), g = tanhf(gg), og = sigmoidf_(go);
-            if (l == 0) { c0 = fg * c0 + ig * g; h0 = og * tanhf(c0); }
-            else        { c1 = fg * c1 + ig * g; h1 = og * tanhf(c1); }
-         }
-         const float r = fmaxf(h1, 0.0f);
-         float p0 = dw0 * r, p1 = dw1 * r;
-#pragma unroll
-         for (int off = 32; off > 0; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); }
-         d0 += p0 + w.dec_b[0];
-         d1 += p1 + w.dec_b[1];
-      }
-      if (j == 0) {
-         probs[((size_t)s * n_chunks + ch) * 2 + 0] = sigmoidf_(d0 / 7.0f);
-         probs[((size_t)s * n_chunks + ch) * 2 + 1] = sigmoidf_(d1 / 7.0f);
-      }
-   }
-   hs[(size_t)s * 128 + j] = h0; hs[(size_t)s * 128 + 64 + j] = h1;
-   cs[(size_t)s * 128 + j] = c0; cs[(size_t)s * 128 + 64 + j] = c1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// MFMA variant
 // ------------------------------------------------------------------------------------------------
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -109,353 +47,7 @@ __device__ __forceinline__ void dma16(const float4 *src_lane, float *lds_wave_ba
 }
 
 constexpr int kTileS = kLstmTile;    // streams per workgroup (= MFMA N)
-constexpr int kXTile = 7 * 64 * kTileS;   // floats of one (tile, chunk) block of the encoder output
 
-// v_mfma_f32_16x16x4_f32 lane maps (cdna_hip_programming.md section 3):
-//   A: lane l holds A[row = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][col = l & 15]
-//   D: lane l, reg r holds D[row = 4 (l >> 4) + r][col = l & 15]
-__global__ __launch_bounds__(256, 1) void k_lstm_mfma(const float *__restrict__ enc,   // LSTM-native tiles (common.h)
-                                                      LstmWeights w,
-                                                      float *__restrict__ hs, float *__restrict__ cs,
-                                                      float *__restrict__ probs,
-                                                      int n_streams, int n_chunks, int c0, int cg)
-{
-   __shared__ __attribute__((aligned(16))) float xs[2][kXTile];   // [parity][t][unit][stream]  double buffered
-   __shared__ float hb[2][2][64 * kTileS];      // [layer][parity][unit][stream]  hidden state, double buffered
-   __shared__ float pd[4][2][kTileS];           // decoder partial dots per wave
-   __shared__ __attribute__((aligned(16))) float bl[2][256];                 // fused gate biases (accumulator init values)
-
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   const int wv = tid >> 6;                     // wave: owns hidden units [16 wv, 16 wv + 16)
-   const int col = lane & 15;                   // stream within the tile
-   const int quad = lane >> 4;
-   const int s0 = blockIdx.x * kTileS;
-   const int s_col = min(s0 + col, n_streams - 1);
-   const bool col_ok = (s0 + col) < n_streams;
-   const float4 *tile_base = reinterpret_cast<const float4 *>(enc + (size_t)blockIdx.x * n_chunks * kXTile);
-
-   // A fragments: a[l][g][kk] = W[l][g*64 + 16 wv + (lane & 15)][4 kk + (lane >> 4)]
-   float a[2][4][32];
-#pragma unroll
-   for (int l = 0; l < 2; ++l)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-         const float *row = w.w + ((size_t)l * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + quad;
-#pragma unroll
-         for (int kk = 0; kk < 32; ++kk) a[l][g][kk] = row[4 * kk];
-      }
-   // biases / cell state / decoder weights in the D layout: unit = 16 wv + 4 quad + r, stream = col
-   float c[2][4], dw[2][4];
-   for (int i = tid; i < 512; i += 256) bl[i >> 8][i & 255] = w.b[i];
-#pragma unroll
-   for (int r = 0; r < 4; ++r) {
-      const int u = 16 * wv + 4 * quad + r;
-      dw[0][r] = w.dec_w[u];
-      dw[1][r] = w.dec_w[64 + u];
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-         c[l][r] = cs[(size_t)s_col * 128 + l * 64 + u];
-         hb[l][0][u * kTileS + col] = hs[(size_t)s_col * 128 + l * 64 + u];
-      }
-   }
-   // stage the first chunk: 7168 contiguous floats, 7 coalesced float4 per thread
-   {
-      const float4 *src = tile_base + (size_t)c0 * (kXTile / 4);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) reinterpret_cast<float4 *>(xs[0])[tid + 256 * i] = src[tid + 256 * i];
-   }
-   int par = 0;                                 // parity of the buffers holding the CURRENT h of both layers
-   __syncthreads();
-
-   for (int ch = c0; ch < c0 + cg; ++ch) {
-      const int xb = (ch - c0) & 1;
-      // prefetch the next chunk's frames straight into the other xs buffer (LDS-DMA, no registers); its last
-      // readers finished before the previous chunk's closing barrier.
-      if ((ch + 1) < (c0 + cg)) {
-         const float4 *src = tile_base + (size_t)(ch + 1) * (kXTile / 4);
-#pragma unroll
-         for (int i = 0; i < 7; ++i) dma16(src + tid + 256 * i, xs[xb ^ 1] + (256 * i + 64 * wv) * 4);
-      }
-      float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-
-      for (int t = 0; t < 7; ++t) {
-#pragma unroll
-         for (int l = 0; l < 2; ++l) {
-            // layer 0 reads x_t and h0(par); layer 1 reads h0(par^1) (just written) and h1(par)
-            const float *xin = (l == 0) ? (xs[xb] + t * 64 * kTileS) : hb[0][par ^ 1];
-            const float *hin = hb[l][par];
-            f4v acc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-               const float4 b4 = *reinterpret_cast<const float4 *>(&bl[l][g * 64 + 16 * wv + 4 * quad]);
-               acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
-            }
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) {
-               const int k = 4 * kk + quad;
-               const float bv = (kk < 16) ? xin[k * kTileS + col] : hin[(k - 64) * kTileS + col];
-#pragma unroll
-               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[l][g][kk], bv, acc[g], 0, 0, 0);
-            }
-            float *hout = hb[l][par ^ 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-               const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
-               const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
-               c[l][r] = fg * c[l][r] + ig * gg;
-               const float hn = og * fast_tanh(c[l][r]);
-               hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
-               if (l == 1) rsum[r] += fmaxf(hn, 0.0f);
-            }
-            // one barrier per (step, layer): the buffer written here (par^1) was last READ two barriers ago
-            __syncthreads();
-         }
-         par ^= 1;
-      }
-      // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
-      // every lane owns 4 units of one stream: partial dot, reduce over the 4 quads of the wave, then over waves.
-      {
-         float d0 = 0.0f, d1 = 0.0f;
-#pragma unroll
-         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); }
-         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
-         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
-         if (quad == 0) { pd[wv][0][col] = d0; pd[wv][1][col] = d1; }
-      }
-      __syncthreads();                          // publishes pd and the prefetched xs buffer
-      if (tid < 2 * kTileS) {
-         const int sc = tid & 15, f = tid >> 4;
-         const float m = ((pd[0][f][sc] + pd[1][f][sc]) + (pd[2][f][sc] + pd[3][f][sc])) / 7.0f + w.dec_b[f];
-         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + ch) * 2 + f] = sigmoidf_(m);
-      }
-   }
-   __syncthreads();
-   if (col_ok) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l)
-#pragma unroll
-         for (int r = 0; r < 4; ++r) {
-            const int u = 16 * wv + 4 * quad + r;
-            cs[(size_t)s_col * 128 + l * 64 + u] = c[l][r];
-            hs[(size_t)s_col * 128 + l * 64 + u] = hb[l][par][u * kTileS + col];
-         }
-   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// input projection of layer 0, hoisted off the recurrent critical path
-// ------------------------------------------------------------------------------------------------
-// The x-part of layer 0's gates, W[0][:, 0:64] . x_t + b[0], does not depend on the recurrence: it is computed
-// for all 7 steps of every (stream tile, chunk) by the otherwise idle CUs in this small GEMM kernel and handed to
-// the recurrent kernel as the INITIAL VALUE of layer 0's accumulators (k-order x then h is unchanged, so the result
-// is bit-identical to doing both halves inside the recurrence).  Layout GX[tile][chunk][t][16 row tiles][64 lanes][4]:
-// the MFMA accumulator fragment itself (row 16 mt + 4 (lane >> 4) + r, stream lane & 15).
-// TS = LSTM steps per chunk: 7 (Silero v3.1) or 3 (Silero v4)
-template <int TS>
-__global__ __launch_bounds__(256) void k_lstm_xproj(const float *__restrict__ enc,   // LSTM-native tiles
-                                                    LstmWeights w, float *__restrict__ gx,
-                                                    int n_chunks, int c0, int cg)
-{
-   const int tile = blockIdx.x / cg, ch = c0 + blockIdx.x % cg;
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int quad = lane >> 4, lc = lane & 15;
-   constexpr int kGxTile = TS * 256 * kLstmTile;      // floats per (tile, chunk)
-   const float *X = enc + ((size_t)tile * n_chunks + ch) * (TS * 64 * kLstmTile);
-   float *G = gx + ((size_t)tile * n_chunks + ch) * kGxTile;
-#pragma unroll 1
-   for (int mi = 0; mi < 4; ++mi) {
-      const int mt = wave + 4 * mi;               // 16 gate rows [16 mt, 16 mt + 16)
-      float a[16];
-      const float *row = w.w + ((size_t)16 * mt + lc) * 128 + quad;      // layer 0, x half: k < 64
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) a[kk] = row[4 * kk];
-      const float4 b4 = *reinterpret_cast<const float4 *>(w.b + 16 * mt + 4 * quad);
-#pragma unroll 1
-      for (int t = 0; t < TS; ++t) {
-         f4v acc;
-         acc[0] = b4.x; acc[1] = b4.y; acc[2] = b4.z; acc[3] = b4.w;
-#pragma unroll
-         for (int kk = 0; kk < 16; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], X[(t * 64 + 4 * kk + quad) * kLstmTile + lc], acc, 0, 0, 0);
-         // GX in ACCUMULATOR-FRAGMENT order [t][mt = 4 gate + unit tile][lane][r]: one 16-byte store here, one 16-byte load per gate
-         // in the recurrent kernel (mt = 4 g + wv there), both fully coalesced
-         *reinterpret_cast<float4 *>(G + (((size_t)t * 16 + mt) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      }
-   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// layer-wavefront variant (default)
-// ------------------------------------------------------------------------------------------------
-// Layer 1 at step s and layer 0 at step s+1 both depend only on h0_s, so the two layers run CONCURRENTLY, one
-// step apart: a workgroup is 16 streams x 8 waves, waves 0-3 = layer 0, waves 4-7 = layer 1 (one of each per
-// SIMD).  In slot k layer 0 computes step k while layer 1 computes step k-1; both read h0_{k-1} from LDS.  A slot
-// costs one barrier instead of two, each wave keeps only ITS layer's weights in registers (128 VGPRs -> two waves
-// per SIMD fit), and on every SIMD the gate activations (VALU) of one layer overlap the MFMAs of the other.
-// TS = steps per chunk (7 / 3); DEC = decoder: 0 Silero v3.1 sigmoid(mean_t(W relu(h_t) + b)), two outputs (silero_v3.c:231-303);
-// 1 Silero v4 mean_t(sigmoid(w . relu(h_t) + b)), one output written to both probability slots (silero_vad.py:200-204,222)
-template <int TS, int DEC>
-__global__ __launch_bounds__(512, 2) void k_lstm_wavefront(const float *__restrict__ gx,    // GX tiles from k_lstm_xproj
-                                                           LstmWeights w,
-                                                           float *__restrict__ hs, float *__restrict__ cs,
-                                                           float *__restrict__ probs,
-                                                           int n_streams, int n_chunks, int c0, int cg)
-{
-   __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
-   __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
-   __shared__ float pd[2][4][2][kTileS];        // decoder partial dots per layer-1 wave, double buffered over slots (DEC 1)
-   constexpr int kGxTile = TS * 256 * kLstmTile;
-   __shared__ __attribute__((aligned(16))) float bl1[256];   // layer-1 fused biases (accumulator init)
-
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   const int wave = tid >> 6;
-   const int L = wave >> 2;                     // layer of this wave
-   const int wv = wave & 3;                     // owns hidden units [16 wv, 16 wv + 16) of its layer
-   const int col = lane & 15;
-   const int quad = lane >> 4;
-   const int s0 = blockIdx.x * kTileS;
-   const int s_col = min(s0 + col, n_streams - 1);
-   const bool col_ok = (s0 + col) < n_streams;
-   // this lane's accumulator-init values of step (chunk, t), gate g: float4 at gx_lane[((chunk*TS + t)*16 + 4 g) * 256]
-   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + ((size_t)wv * 64 + lane) * 4;
-
-   // A fragments: layer 0 keeps only the h half (k >= 64) -- its x half was applied by k_lstm_xproj
-   float a[4][32];
-#pragma unroll
-   for (int g = 0; g < 4; ++g) {
-      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + quad;
-#pragma unroll
-      for (int kk = 0; kk < 32; ++kk) a[g][kk] = (L == 0 && kk < 16) ? 0.0f : row[4 * kk];
-   }
-   float c[4], dw[2][4];
-   if (tid < 256) bl1[tid] = w.b[256 + tid];
-   float *hmine = L == 0 ? hb0[0] : hb1[0];
-#pragma unroll
-   for (int r = 0; r < 4; ++r) {
-      const int u = 16 * wv + 4 * quad + r;
-      dw[0][r] = w.dec_w[u];
-      dw[1][r] = w.dec_w[64 + u];
-      c[r] = cs[(size_t)s_col * 128 + L * 64 + u];
-      hmine[u * kTileS + col] = hs[(size_t)s_col * 128 + L * 64 + u];
-   }
-   int par0 = 0, par1 = 0;                      // buffers holding the CURRENT h0 / h1
-   float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-   // layer 0: accumulator init of the NEXT step, fetched one slot ahead
-   float gnext[4][4];
-   if (L == 0) {
-      const float *p = gx_lane + (size_t)c0 * kGxTile;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-         const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
-         gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
-      }
-   }
-   __syncthreads();
-
-   const int total = TS * cg;
-   float psum = 0.0f;                           // DEC 1: sum over the chunk's steps of sigmoid(decoder dot), lanes 0..15 of wave 4
-   for (int k = 0; k <= total; ++k) {
-      const bool active = (L == 0) ? (k < total) : (k >= 1);
-      const int step = (L == 0) ? k : k - 1;    // the step this wave computes in this slot
-      const int chi = step / TS, t = step - chi * TS;
-      if (active) {
-         f4v acc[4];
-         if (L == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
-            if (k + 1 < total) {                // prefetch the next step's init values (latency hidden by this slot)
-               const float *p = gx_lane + ((size_t)c0 * TS + (k + 1)) * (256 * kTileS);
-#pragma unroll
-               for (int g = 0; g < 4; ++g) {
-                  const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
-                  gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
-               }
-            }
-            const float *hin = hb0[par0];
-#pragma unroll
-            for (int kk = 16; kk < 32; ++kk) {
-               const float bv = hin[(4 * kk + quad - 64) * kTileS + col];
-#pragma unroll
-               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
-            }
-         } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-               const float4 b4 = *reinterpret_cast<const float4 *>(&bl1[g * 64 + 16 * wv + 4 * quad]);
-               acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
-            }
-            const float *xin = hb0[par0], *hin = hb1[par1];
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) {
-               const int kr = 4 * kk + quad;
-               const float bv = (kk < 16) ? xin[kr * kTileS + col] : hin[(kr - 64) * kTileS + col];
-#pragma unroll
-               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
-            }
-         }
-         float *hout = (L == 0) ? hb0[par0 ^ 1] : hb1[par1 ^ 1];
-#pragma unroll
-         for (int r = 0; r < 4; ++r) {
-            const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
-            const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
-            const float hn = og * fast_tanh(c[r]);
-            hout[(16 * wv + 4 * quad + r) * kTileS + col] = hn;
-            if (L == 1) rsum[r] = (DEC == 0 ? rsum[r] : 0.0f) + fmaxf(hn, 0.0f);
-         }
-      }
-      const bool chunk_done = (L == 1) && active && (t == TS - 1);
-      if (DEC == 1 && L == 1 && active) {
-         // per step: partial dot of this wave's 16 units, finished after the barrier by wave 4
-         float d0 = 0.0f;
-#pragma unroll
-         for (int r = 0; r < 4; ++r) d0 = fmaf(dw[0][r], rsum[r], d0);
-         d0 += __shfl_xor(d0, 16);
-         d0 += __shfl_xor(d0, 32);
-         if (quad == 0) pd[k & 1][wv][0][col] = d0;
-      }
-      if (DEC == 0 && chunk_done) {
-         // decoder, once per chunk: mean_t(w . relu(h_t) + b) = (w . sum_t relu(h_t)) / 7 + b   (silero_v3.c:231-303)
-         float d0 = 0.0f, d1 = 0.0f;
-#pragma unroll
-         for (int r = 0; r < 4; ++r) { d0 = fmaf(dw[0][r], rsum[r], d0); d1 = fmaf(dw[1][r], rsum[r], d1); rsum[r] = 0.0f; }
-         d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16);
-         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32);
-         if (quad == 0) { pd[0][wv][0][col] = d0; pd[0][wv][1][col] = d1; }
-      }
-      __syncthreads();                          // one barrier per slot
-      if (k < total) par0 ^= 1;                 // layer 0 wrote a new h0 in this slot
-      if (k >= 1) par1 ^= 1;                    // layer 1 wrote a new h1 in this slot
-      if (DEC == 0 && chunk_done && wv == 0 && lane < 2 * kTileS) {
-         const int sc = lane & 15, f = lane >> 4;
-         const float m = ((pd[0][0][f][sc] + pd[0][1][f][sc]) + (pd[0][2][f][sc] + pd[0][3][f][sc])) / (float)TS + w.dec_b[f];
-         if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
-      }
-      if (DEC == 1 && L == 1 && active && wv == 0 && lane < kTileS) {
-         const int q = k & 1;
-         psum += sigmoidf_(((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + w.dec_b[0]);
-         if (t == TS - 1) {
-            const float pr = psum / (float)TS;
-            if (s0 + lane < n_streams) {
-               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 0] = pr;
-               probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 1] = pr;
-            }
-            psum = 0.0f;
-         }
-      }
-   }
-   if (col_ok) {
-      const float *hfin = (L == 0) ? hb0[par0] : hb1[par1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const int u = 16 * wv + 4 * quad + r;
-         cs[(size_t)s_col * 128 + L * 64 + u] = c[r];
-         hs[(size_t)s_col * 128 + L * 64 + u] = hfin[u * kTileS + col];
-      }
-   }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_lstm_wavefront_h3: the same recurrence with the gate GEMMs on the fp16 matrix pipe, at fp32 accuracy
@@ -473,12 +65,11 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 constexpr int kHPitch = 72;                     // fp16 elements per stream row of an h tile (64 units + 8 pad)
 
-// FUSED = false: layer 0's input projection arrives as GX (k_lstm_xproj), its recurrent K is the h half (64).
-// FUSED = true : no GX -- `gx` points at the encoder output in split-fp16 LSTM-native tiles (common.h lstm_xh_index, written by
-//                the last encoder stage), layer 0 runs the full K = 128 = [x_t ; h0] like layer 1, its x fragments are fetched
-//                from global one slot ahead (four 16-byte loads per lane), the accumulators start at the bias.
-template <int TS, int DEC, bool FUSED>
-__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__restrict__ gx,    // GX tiles, or split-fp16 X tiles (FUSED)
+// `xh` is the encoder output in split-fp16 LSTM-native tiles (common.h lstm_xh_index, written by the last encoder stage): layer 0 runs
+// the full K = 128 = [x_t ; h0] like layer 1, its x fragments are fetched from global one slot ahead (four 16-byte loads per lane),
+// the accumulators start at the bias.
+template <int TS, int DEC>
+__global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__restrict__ xh,    // split-fp16 X tiles
                                                               LstmWeights w,
                                                               float *__restrict__ hs, float *__restrict__ cs,
                                                               float *__restrict__ probs,
@@ -487,9 +78,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    // [layer][parity][hi / lo][stream][unit]: the CURRENT h of each layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][2][kTileS * kHPitch];
    __shared__ float pd[2][4][2][kTileS];
-   constexpr int kGxTile = TS * 256 * kLstmTile;
    __shared__ __attribute__((aligned(16))) float bl1[256];
-   __shared__ __attribute__((aligned(16))) float bl0[256];   // FUSED: layer-0 fused biases
+   __shared__ __attribute__((aligned(16))) float bl0[256];   // fused gate biases of both layers (accumulator init)
 
    const int tid = threadIdx.x;
    const int lane = tid & 63;
@@ -501,20 +91,19 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    const int s0 = blockIdx.x * kTileS;
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = (s0 + col) < n_streams;
-   const float *gx_lane = gx + (size_t)blockIdx.x * n_chunks * kGxTile + ((size_t)wv * 64 + lane) * 4;
 
-   // A fragments, split: k-block kb covers k in [32 kb, 32 kb + 32) of this layer's K (layer 0: the h half only, K = 64;
-   // layer 1: [h0 ; h1], K = 128); lane holds row 16 wv + (lane & 15) of gate g, k = 32 kb + 8 quad + e
-   constexpr int KB1 = 4, KB0 = 2;
+   // A fragments, split: k-block kb covers k in [32 kb, 32 kb + 32) of this layer's K = 128 ([x_t ; h0] / [h0 ; h1]);
+   // lane holds row 16 wv + (lane & 15) of gate g, k = 32 kb + 8 quad + e
+   constexpr int KB1 = 4;
    h8v ah[4][KB1], al[4][KB1];
 #pragma unroll
    for (int g = 0; g < 4; ++g) {
-      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + ((L == 0 && !FUSED) ? 64 : 0) + 8 * quad;
+      const float *row = w.w + ((size_t)L * 256 + g * 64 + 16 * wv + (lane & 15)) * 128 + 8 * quad;
 #pragma unroll
       for (int kb = 0; kb < KB1; ++kb) {
 #pragma unroll
          for (int e = 0; e < 8; ++e) {
-            const float v = (L == 0 && !FUSED && kb >= KB0) ? 0.0f : row[32 * kb + e];
+            const float v = row[32 * kb + e];
             const _Float16 hi = (_Float16)v;
             ah[g][kb][e] = hi;
             al[g][kb][e] = (_Float16)(v - (float)hi);
@@ -540,19 +129,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
    }
    int par0 = 0, par1 = 0;
    float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-   float gnext[4][4];
-   // FUSED: this lane's x fragments of the NEXT step: k-blocks 0,1 (units 32 kb + 8 quad .. +7 of stream col), hi and lo
-   const _Float16 *xh_lane = reinterpret_cast<const _Float16 *>(gx) + (size_t)blockIdx.x * n_chunks * (TS * 2 * kTileS * 64) + col * 64 + 8 * quad;
+   // this lane's x fragments of the NEXT step: k-blocks 0,1 (units 32 kb + 8 quad .. +7 of stream col), hi and lo
+   const _Float16 *xh_lane = reinterpret_cast<const _Float16 *>(xh) + (size_t)blockIdx.x * n_chunks * (TS * 2 * kTileS * 64) + col * 64 + 8 * quad;
    h8v xnh[2], xnl[2];
-   if (L == 0 && !FUSED) {
-      const float *p = gx_lane + (size_t)c0 * kGxTile;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-         const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
-         gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
-      }
-   }
-   if (L == 0 && FUSED) {
+   if (L == 0) {
       const _Float16 *p = xh_lane + (size_t)c0 * TS * (2 * kTileS * 64);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -571,25 +151,14 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
       if (active) {
          f4v acc[4];
          h8v xch[2], xcl[2];
-         if (L == 0 && !FUSED) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { acc[g][0] = gnext[g][0]; acc[g][1] = gnext[g][1]; acc[g][2] = gnext[g][2]; acc[g][3] = gnext[g][3]; }
-            if (k + 1 < total) {
-               const float *p = gx_lane + ((size_t)c0 * TS + (k + 1)) * (256 * kTileS);
-#pragma unroll
-               for (int g = 0; g < 4; ++g) {
-                  const float4 v4 = *reinterpret_cast<const float4 *>(p + (size_t)g * 1024);
-                  gnext[g][0] = v4.x; gnext[g][1] = v4.y; gnext[g][2] = v4.z; gnext[g][3] = v4.w;
-               }
-            }
-         } else {
+         {
             const float *bias = (L == 0) ? bl0 : bl1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                const float4 b4 = *reinterpret_cast<const float4 *>(&bias[g * 64 + 16 * wv + 4 * quad]);
                acc[g][0] = b4.x; acc[g][1] = b4.y; acc[g][2] = b4.z; acc[g][3] = b4.w;
             }
-            if (L == 0) {                       // FUSED: take this step's x fragments, request the next step's
+            if (L == 0) {                       // take this step's x fragments, request the next step's
                xch[0] = xnh[0]; xch[1] = xnh[1]; xcl[0] = xnl[0]; xcl[1] = xnl[1];
                if (k + 1 < total) {
                   const _Float16 *p = xh_lane + ((size_t)c0 * TS + (k + 1)) * (2 * kTileS * 64);
@@ -601,14 +170,13 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
                }
             }
          }
-         // B fragments.  Layer 1: k-blocks 0,1 = h0, 2,3 = h1.  Layer 0: (hoisted) k-blocks 0,1 = h0; (FUSED) 0,1 = x_t from global,
-         // 2,3 = h0.  A lane reads units 32 kb' + 8 quad .. +7 of stream col.
-         const int nkb = (L == 0 && !FUSED) ? KB0 : KB1;
+         // B fragments.  Layer 1: k-blocks 0,1 = h0, 2,3 = h1.  Layer 0: 0,1 = x_t from global, 2,3 = h0.  A lane reads units
+         // 32 kb' + 8 quad .. +7 of stream col.
 #pragma unroll
          for (int kb = 0; kb < KB1; ++kb) {
-            if (kb < nkb) {
+            {
                h8v bh, bl;
-               if (L == 0 && FUSED && kb < 2) { bh = xch[kb]; bl = xcl[kb]; }
+               if (L == 0 && kb < 2) { bh = xch[kb]; bl = xcl[kb]; }
                else {
                   const bool from_h1 = (L == 1) && (kb >= 2);
                   const _Float16 *base = from_h1 ? hb[1][par1][0] : hb[0][par0][0];
@@ -707,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
                                                            float *__restrict__ probs,
                                                            int n_streams, int n_chunks, int c0, int cg)
 {
+   constexpr int kXTile = TS * 64 * kTileS;     // floats of one (tile, chunk) block of the encoder output
    __shared__ __attribute__((aligned(16))) float xs[2][kXTile];   // [parity][t][unit][stream]
    __shared__ float hb0[2][64 * kTileS];        // layer-0 hidden state, double buffered: [parity][unit][stream]
    __shared__ float hb1[2][64 * kTileS];        // layer-1 hidden state
@@ -760,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
          // finished before the previous slot's barrier
          const float4 *src = tile_base + (size_t)(c0 + chi + 1) * (kXTile / 4);
 #pragma unroll
-         for (int i = 0; i < 7; ++i) dma16(src + (tid & 255) + 256 * i, xs[(chi + 1) & 1] + (256 * i + 64 * wv) * 4);
+         for (int i = 0; i < TS; ++i) dma16(src + (tid & 255) + 256 * i, xs[(chi + 1) & 1] + (256 * i + 64 * wv) * 4);
       }
       if (active) {
          const float *xin = (L == 0) ? (xs[chi & 1] + t * 64 * kTileS) : hb0[par0];
@@ -841,38 +410,19 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 }
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
-// gx: scratch for the hoisted input projection, [ceil(S/16)][n_chunks][7][256][16] floats (variant 0 only)
-// model: 0 = Silero v3.1 (7 steps per chunk, all variants), 1 = Silero v4 (3 steps, hoisted wavefront only)
-void launch_lstm(int variant, const float *enc, float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
+// variant: 6 = k_lstm_wavefront_h3 (enc = split-fp16 tiles), 3 = k_lstm_wavefront_fused (enc = fp32 tiles)
+// model: 0 = Silero v3.1 (7 steps per chunk), 1 = Silero v4 (3 steps)
+void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
                  int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
-   if (model == 1 && variant == 6)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1, true>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 6)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0, true>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (model == 1 && variant == 5)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1, false>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (model == 1)
-      hipLaunchKernelGGL((k_lstm_wavefront<3, 1>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 5)
-      hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0, false>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 1)
-      hipLaunchKernelGGL(k_lstm_simple, dim3(n_streams), dim3(64), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 3)
-      hipLaunchKernelGGL((k_lstm_wavefront_fused<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else if (variant == 0)   // consumes GX written by launch_lstm_xproj for the same chunk range
-      hipLaunchKernelGGL((k_lstm_wavefront<7, 0>), dim3((n_streams + kTileS - 1) / kTileS), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else
-      hipLaunchKernelGGL(k_lstm_mfma, dim3((n_streams + kTileS - 1) / kTileS), dim3(256), 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-}
-
-// layer-0 input projection for chunks [c0, c0 + cg): a wide GEMM, launched with the encoder (all CUs), not with the
-// recurrent kernel
-void launch_lstm_xproj(const float *enc, float *gx, const LstmWeights &w, int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
-{
-   const int tiles = (n_streams + kTileS - 1) / kTileS;
-   if (model == 1) hipLaunchKernelGGL((k_lstm_xproj<3>), dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
-   else            hipLaunchKernelGGL((k_lstm_xproj<7>), dim3(tiles * cg), dim3(256), 0, st, enc, w, gx, n_chunks, c0, cg);
+   const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
+   if (variant == 6) {
+      if (model == 1) hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      else            hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   } else {
+      if (model == 1) hipLaunchKernelGGL((k_lstm_wavefront_fused<3, 1>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      else            hipLaunchKernelGGL((k_lstm_wavefront_fused<7, 0>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   }
 }
 
 }  // namespace vadc
