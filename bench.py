@@ -8,18 +8,28 @@ synthetic 16 kHz s16le audio: S independent streams x C consecutive 1536-sample 
 carried on the device from step to step.  Defaults: S = 256 (BASELINE config 2), C = 96 = the window vadc hands its backend per
 stream and call (`chunks_count = 96` vadc.c:799, `--batch` default 96 vadc.c:1116).  Inputs are resident in HBM before the timed region.
 value = streams x chunks x 0.096 s / wall_s  (audio-seconds per second == concurrent real-time streams),
-whole job over all ranks.  For N > 1 the driver launches one rank per GPU (torch.distributed, RCCL); streams
-are sharded across ranks with no data-path collective; the per-step speech probabilities are gathered to
-rank 0 with one RCCL gather (north star), inside the timed region.
+whole job over all ranks.
+
+Multi-GPU (`--gpus N`): one process per GPU.  Under a launcher (`python -m torch.distributed.run ... bench.py --gpus N`: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) this process IS one rank; started plainly (`python bench.py --gpus N`) it spawns the N ranks itself --
+before it imports torch or touches HIP -- waits for them and relays rank 0's JSON line.  Streams are sharded across ranks in contiguous
+blocks (vadc_amd/shard.py) with no data-path collective; the per-step speech probabilities are gathered to rank 0 with ONE RCCL gather
+(north star), inside the timed region.  `--dry-run` runs the same rank skeleton (spawn, rendezvous, sharding, gather, barrier, max-over-ranks
+timing) over gloo on the CPU with a stand-in for the engine: what tests/test_bench_spawn.py exercises where there is no GPU.
 
 The JSON line also carries
-  roofline     -- dominant kernel: algorithmic FLOP per launch / HIP-event duration vs the fp32 peak (events recorded inside the
-                  timed region, on the kernel's own stream, on every 4th step)
-  cpu_baseline -- the CPU oracle (kind "port") or oracle/_ref (kind "reference") timed on this box's host cores
+  roofline     -- dominant kernel (by CU-time): EXECUTED FLOP per launch / HIP-event duration against the peak of the pipe that executes them
+                  (events recorded inside the timed region, on the kernel's own stream, on every 4th step); the algorithmic (dense-basis,
+                  SURVEY.md 8(d)) figure rides along
+  cpu_baseline -- the reference C backend (oracle/_ref, kind "reference") or the CPU oracle (kind "port") on this box's host cores: all
+                  cores (one process per core, value = aggregate), one core at batch 96 and at batch 1 (BASELINE config 1)
+  host_fed     -- the same step through vadc_amd_run_s16 (pageable host buffers in and out: PCIe-inclusive); never `value`
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,95 +39,183 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CHUNK_SECONDS = 1536 / 16000.0
-# algorithmic work per chunk, FLOP = 2 x MAC
-FLOP_PER_CHUNK = {
-    "k_frontend": 2 * 1_651_200,
-    "k_layer1": 2 * 181_053, "k_layer2": 2 * 112_208, "k_layer3": 2 * 61_600, "k_layer4": 2 * 236_768,
-    "k_lstm": 2 * (458_752 + 896),                 # both layers incl. the input projection + decoder
-}
-# Silero v4 (BASELINE config 4, `--model v4`): parity-test configuration, not the headline
-FLOP_PER_CHUNK_V4 = {
-    "k_frontend": 2 * 1_585_152,
-    "k_layer1": 2 * 232_176, "k_layer2": 2 * 19_392, "k_layer3": 2 * 10_176, "k_layer4": 2 * 25_056,
-    "k_lstm": 2 * (196_608 + 192),
-}
+PEAKS = {"valu_nofma": 78.65,     # fp32 vector ALU with every product and every sum rounded separately (the reference's tree): half of the FMA peak
+         "fp32": 157.3,           # MI355X_MICROARCH.md: fp32 vector == fp32 matrix peak (FMA)
+         "fp16": 2500.0}          # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+# MAC per chunk by kernel: total, and the part that runs as split-fp16 MFMA (3 fp16 MFMAs per fp32 one)
+MAC_V31 = {"k_frontend": (1_651_200, 0), "k_layer1": (181_053, 0), "k_layer2": (112_208, 87_040), "k_layer3": (61_600, 57_344),
+           "k_layer4": (236_768, 229_376), "k_lstm": (458_752 + 896, 458_752)}
+MAC_V4 = {"k_frontend": (1_585_152, 0), "k_layer1": (232_176, 0), "k_layer2": (19_392, 0), "k_layer3": (10_176, 0), "k_layer4": (25_056, 0),
+          "k_lstm": (196_608 + 192, 196_608)}
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
-PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: vector == matrix fp32 peak
-PEAK_FP16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)"}
 
 
-def cpu_baseline(blob, weights_path, seconds_budget=12.0, model="v31"):
-    """Reported baseline, not the target: the oracle on ONE host core over a bounded sample."""
-    from oracle import oracle as O
+def kernel_cost(model, name, fe_kernel):
+    """-> (algorithmic FLOP per chunk, {pipe: executed FLOP per chunk}).  Executed = what the kernel issues: the symmetric front end
+    evaluates 33 of the 129 bins' trees, split-fp16 GEMMs issue three fp16 MFMAs per fp32 product, the folded GEMM front end half the taps."""
+    mac, mac16 = (MAC_V4 if model == "v4" else MAC_V31)[name]
+    alg = 2 * mac
+    if name == "k_frontend":
+        frames = 24 if model == "v4" else 25
+        if fe_kernel == 0:      # per position: 33 base bins x (2 x (256 mul + 248 add) + 56 lane-tree adds) + 129 x (re^2, im^2, +)
+            return alg, {"valu_nofma": frames * (33 * (2 * 504 + 56) + 129 * 3)}
+        if fe_kernel == 2:      # folded real-input DFT: 256 rows x K = 128, three split-fp16 MFMAs per k-block
+            return alg, {"fp16": 3 * 2 * 256 * 128 * frames}
+        return alg, {"valu_nofma": frames * (129 * 2 * 511 + 129 * 3)}
+    exe = {}
+    if mac16:
+        exe["fp16"] = 3 * 2 * mac16
+    if mac - mac16:
+        exe["fp32"] = 2 * (mac - mac16)
+    return alg, exe
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_runner(model, weights_path):
+    from oracle import oracle as O                      # the checker, timed here as the reported baseline -- never the product path
     from vadc_amd import synth
-    base = 2048                                  # chunks of one synthetic speech stream (3.3 min of audio), repeated
+    base = 2048                                         # chunks of one synthetic speech stream (3.3 min of audio), repeated
     pcm = synth.speech_like(base * 1536, seed=9)
-    kind, runner = "port", None
     try:
-        if model == "v4":                       # the reference has no C implementation of v4: only the restatement exists
+        if model == "v4":                               # the reference has no C implementation of v4: only the restatement exists
             raise FileNotFoundError
         ref = O.Reference(weights_path)
         x = pcm.astype(np.float32) / np.float32(32768)
-        kind, runner = "reference", (lambda n: ref.run(x[: n * 1536], batch=96))
+        return "reference", base, (lambda n, batch: ref.run(x[: n * 1536], batch=batch))
     except (FileNotFoundError, OSError, ValueError):
+        blob = open(weights_path, "rb").read()
         orc = O.OracleV4(blob) if model == "v4" else O.Oracle(blob)
-        runner = lambda n: orc.forward_stream(pcm[: n * 1536])
-    runner(8)
-    t0 = time.perf_counter(); runner(256); dt = time.perf_counter() - t0
-    reps = int(min(64, max(1, round(seconds_budget * 256 / max(dt, 1e-6) / base))))      # ~seconds_budget of CPU work
+        return "port", base, (lambda n, batch: orc.forward_stream(pcm[: n * 1536]))
+
+
+def cpu_worker(model, weights_path, seconds, batch):
+    """one core: chunks per second over ~`seconds` of work; prints one JSON line (run as a child process, one per core)"""
+    kind, base, run = _cpu_runner(model, weights_path)
+    run(8, batch)
+    n_unit = 256 if batch > 1 else 128
+    t0 = time.perf_counter(); run(n_unit, batch); dt = time.perf_counter() - t0
+    reps = max(1, int(round(seconds / max(dt, 1e-6))))
     t0 = time.perf_counter()
-    for _ in range(reps):
-        runner(base)
+    done = 0
+    for r in range(reps):
+        run(n_unit, batch); done += n_unit
     dt = time.perf_counter() - t0
-    return {"value": round(reps * base * CHUNK_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": 1, "kind": kind,
-            "sample": f"{reps} x {base} consecutive chunks of one synthetic speech stream ({dt:.1f} s of CPU work), single thread"}
+    print(json.dumps({"kind": kind, "chunks": done, "seconds": dt, "chunks_per_s": done / dt}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500,
-                    help="timed steps (default 500 = about 1 s: the fill and drain of the two-deep step pipeline -- one LSTM launch that nothing overlaps -- "
-                         "is 2.7 %% of a 20-step run and 0.1 %% of this one)")
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
-    ap.add_argument("--chunks-per-step", type=int, default=96, help="chunks per stream and step (default 96 = vadc's window, vadc.c:799)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["v31", "v4"], default="v31",
-                    help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
-    ap.add_argument("--precision", choices=["fp32", "split16"], default="fp32",
-                    help="fp32 = the parity mode (default, BASELINE config 2); split16 = BASELINE config 3: STFT as a split-fp16 GEMM on "
-                         "the matrix pipe instead of the reference's reduction tree (|dp| up to ~1e-4, see include/vadc_amd.h)")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
-                    help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="experiment: no per-kernel HIP events inside the timed region (kernel table then comes from a separate pass)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
-                         "through the two caller streams; 0 = engine default for single-stream callers)")
-    args = ap.parse_args()
+def cpu_baseline(model, weights_path, seconds=10.0):
+    """Reported baseline, not the target.  Children are plain `python bench.py --cpu-worker` processes started BEFORE this process touches the GPU."""
+    def spawn(batch, secs):
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--model", model, "--cpu-seconds", str(secs), "--cpu-batch", str(batch)],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    def collect(procs):
+        out = []
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            out.append(json.loads(o.strip().splitlines()[-1]))
+        return out
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    one1 = collect([spawn(1, 3.0)])[0]                  # BASELINE config 1: batch = 1, one core, the machine otherwise idle
+    one96 = collect([spawn(96, 3.0)])[0]
+    allc = collect([spawn(96, seconds) for _ in range(cores)])
+    agg = sum(r["chunks_per_s"] for r in allc)
+    return {"value": round(agg * CHUNK_SECONDS, 1), "unit": "audio-seconds/sec", "cores": cores, "kind": allc[0]["kind"],
+            "per_core": round(agg * CHUNK_SECONDS / cores, 2),
+            "single_core_batch96": round(one96["chunks_per_s"] * CHUNK_SECONDS, 2),
+            "single_core_batch1": round(one1["chunks_per_s"] * CHUNK_SECONDS, 2),
+            "sample": f"one process per core on {cores} cores, each {allc[0]['chunks']} consecutive chunks of one synthetic speech stream at batch 96 "
+                      f"({sum(r['seconds'] for r in allc):.0f} core-seconds); single-core points: {one96['chunks']} chunks at batch 96, {one1['chunks']} at batch 1 (BASELINE config 1)"}
+
+
+# ------------------------------------------------------------------------------------------------- rank spawning
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch and never touches HIP),
+    relay rank 0's stdout, exit with the worst return code."""
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------- dry run (CPU, gloo)
+def dry_run(args, world, rank):
+    """The rank skeleton without a GPU: gloo rendezvous, stream sharding, the per-step gather through the SAME helper the GPU path uses,
+    barrier + max-over-ranks timing, rank 0 prints the line.  The engine is replaced by values that encode (global stream, chunk, column, step)."""
+    import torch
+    import torch.distributed as dist
+    from vadc_amd import shard
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, Cn = args.streams, args.chunks_per_step
+    total = S * world
+    lo, hi = shard.stream_block(rank, world, total)
+    g = shard.ProbabilityGather(total, Cn, "cpu")
+    s = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
+    c = torch.arange(Cn, dtype=torch.float32).view(1, -1, 1)
+    k = torch.arange(2, dtype=torch.float32).view(1, 1, 2)
+    ok = True
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        g.gather(s * 1000 + c * 2 + k + i * 0.25)
+        if rank == 0 and i == args.steps - 1:
+            sa = torch.arange(total, dtype=torch.float32).view(-1, 1, 1)
+            ok = bool(torch.equal(g.result(), sa * 1000 + c * 2 + k + i * 0.25))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU): rank skeleton over gloo", "value": None, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "dry_run": True, "gather_verified": ok, "total_streams": total,
+                          "config": {"workload": f"stand-in engine, {S} streams/rank x {Cn} chunks/step", "parallelism": f"streams sharded over {world} rank(s), gloo gather"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------- one rank
+def run_rank(args, world, rank, local_rank):
+    weights_path = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor")
+    if args.model == "v4":
+        weights_path = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor")
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, weights_path)    # before this process initialises the GPU: its children are plain CPU processes
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path (--dry-run rehearses the rank skeleton over gloo)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from vadc_amd import synth
+    from vadc_amd import shard, synth
     from vadc_amd.engine import Engine
 
-    weights_path = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor")
-    if args.model == "v4":
-        weights_path = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor")
-        FLOP_PER_CHUNK.clear(); FLOP_PER_CHUNK.update(FLOP_PER_CHUNK_V4)
+    dev = f"cuda:{local_rank}"
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=1 if args.precision == "split16" else 0)
@@ -130,12 +228,10 @@ def main():
     # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
     base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
     pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(f"cuda:{local_rank}") for i in range(2)]
-    d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
-    gather_list = [torch.empty_like(d_probs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
-    from vadc_amd import shard
-    lo, hi = shard.stream_block(rank, world, S * world)     # weak scaling: S streams per GPU, contiguous blocks
-    assert hi - lo == S
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(2)]
+    d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    gather = shard.ProbabilityGather(S * world, Cn, dev)          # weak scaling: S streams per GPU, contiguous blocks
+    assert gather.hi - gather.lo == S
     # Two caller streams used alternately: each step is strictly ordered on its own stream, and the engine's
     # internal in-order streams overlap step k+1's front end + encoder with step k's LSTM.
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -145,7 +241,7 @@ def main():
         with torch.cuda.stream(st):
             eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs[i & 1].data_ptr(), st.cuda_stream)
             if world > 1:
-                dist.gather(d_probs[i & 1], gather_list, dst=0)   # the only collective: final probability gather
+                gather.gather(d_probs[i & 1])           # the only collective: final probability gather (RCCL)
 
     for i in range(2):                     # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
         step(i)
@@ -190,7 +286,7 @@ def main():
         torch.cuda.synchronize()
         eng.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -199,6 +295,7 @@ def main():
         chunks_per_step = S * Cn * world
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
         kt = eng.kernel_times()
+        fe_kernel = eng.get_option("frontend_kernel")
         # The LSTM chain runs concurrently on its own small CU partition; weigh every kernel's
         # time by the share of the chip it occupies so that "dominant" means dominant in CU-time, not in wall time
         # of a kernel that leaves 240 CUs to the others.
@@ -206,28 +303,34 @@ def main():
         cu_share = {k: 1.0 for k in kt}
         lstm_cus = eng.get_option("lstm_cus")                     # CUs the engine reserved for the LSTM chain (0: whole chip)
         cu_share["k_lstm"] = (lstm_cus / n_cus) if lstm_cus > 0 else 1.0
-        dom = max(kt, key=lambda k: kt[k][1] * cu_share[k])
-        launches, total_ms = kt[dom]
-        avg_s = total_ms / max(launches, 1) / 1e3
-        # chunks one launch of the dominant kernel processes (a step may be split into chunk groups)
-        chunks_per_launch = S * Cn * n_prof / max(launches, 1)
-        achieved = FLOP_PER_CHUNK[dom] * chunks_per_launch / avg_s / 1e12
+        per_kernel = {}
+        for k, (n_l, ms) in kt.items():
+            if not n_l:
+                continue
+            alg, exe = kernel_cost(args.model, k, fe_kernel)
+            per_launch = S * Cn * n_prof / n_l                    # chunks one launch processes (a step may be split into chunk groups)
+            sec = ms / n_l / 1e3
+            # binding pipe = the one whose executed FLOP take longest at its peak (the pipes can overlap: this is the LOWER bound on the kernel's time)
+            pipe = max(exe, key=lambda p: exe[p] / PEAKS[p])
+            per_kernel[k] = {"ms_per_launch": round(ms / n_l, 4), "cu_share": round(cu_share[k], 4), "chunks_per_launch": int(per_launch),
+                             "algorithmic_flop_per_chunk": alg, "algorithmic_tflops": round(alg * per_launch / sec / 1e12, 3),
+                             "executed_flop_per_chunk": exe, "pipe": pipe,
+                             "executed_tflops": round(exe[pipe] * per_launch / sec / 1e12, 3),
+                             "frac_of_pipe_peak": round(exe[pipe] * per_launch / sec / 1e12 / PEAKS[pipe], 4)}
+        dom = max(per_kernel, key=lambda k: kt[k][1] * cu_share[k])
+        d = per_kernel[dom]
         traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B)
-            # a workload only gets the bytes of passes collected on exactly that workload (tools/rocprof_reduce.py names the files)
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B): only a pass collected
+            # on exactly this workload AND this front-end kernel counts (tools/rocprof_reduce.py writes both into the file), else null
             default_workload = args.model == "v31" and not split16 and S == 256 and Cn == 96
             name = "latest_pmc_traffic.json" if default_workload else f"latest_pmc_traffic_{args.model}_{args.precision}_{S}x{Cn}.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             if (prof.get("streams") == S and prof.get("chunks_per_step") == Cn and prof.get("model", "v31") == args.model
-                    and prof.get("precision", "fp32") == args.precision and dom in prof.get("kernels", {})):
+                    and prof.get("precision", "fp32") == args.precision and prof.get("frontend_kernel") == FRONTEND_KERNELS.get(fe_kernel)
+                    and dom in prof.get("kernels", {})):
                 traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass
-        per_kernel = {}
-        for k, (n_l, ms) in kt.items():
-            if n_l:
-                per_kernel[k] = {"ms_per_launch": round(ms / n_l, 4), "cu_share": round(cu_share[k], 4),
-                                 "tflops": round(FLOP_PER_CHUNK[k] * (S * Cn * n_prof / n_l) / (ms / n_l / 1e3) / 1e12, 3)}
         out = {
             "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k" if args.model == "v31" else
                       "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
@@ -236,46 +339,88 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not split16 else "split-f16 (2 x fp16, fp32 accumulate) front end + f32", "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
                                    f"{'fp32' if not split16 else 'SPLIT16 precision mode (BASELINE config 3; not the parity mode)'}, s16le input resident in HBM",
-                       "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "avg_launch_ms": round(avg_s * 1e3, 4), "chunks_per_launch": int(chunks_per_launch),
-                         "algorithmic_flop_per_chunk": FLOP_PER_CHUNK[dom],
-                         # blended figure over the whole path: all kernels' algorithmic FLOP per chunk
-                         # x chunks/s of the job on one GPU, against the same fp32 peak
+                       "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
+                       "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
+            "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
+                         "unit": "TFLOP/s", "frac": d["frac_of_pipe_peak"], "traffic": traffic,
+                         "avg_launch_ms": d["ms_per_launch"], "chunks_per_launch": d["chunks_per_launch"], "pipe": d["pipe"],
+                         "executed_flop_per_chunk": d["executed_flop_per_chunk"][d["pipe"]],
+                         "algorithmic_flop_per_chunk": d["algorithmic_flop_per_chunk"], "algorithmic_tflops": d["algorithmic_tflops"],
+                         # the whole path in the dense formulation of SURVEY.md 8(d), as a rate only (no fraction: the kernels execute fewer FLOP than it counts)
                          "path_flop_per_chunk": PATH_FLOP_PER_CHUNK[args.model],
-                         "path_achieved": round(PATH_FLOP_PER_CHUNK[args.model] * S * Cn * args.steps / elapsed / 1e12, 3),
-                         "path_frac": round(PATH_FLOP_PER_CHUNK[args.model] * S * Cn * args.steps / elapsed / 1e12 / PEAK_FP32_TFLOPS, 4),
-                         "note": "dominant kernel by CU-time; fp32 peak (vector == matrix); the bit-exact STFT is unfused "
-                                 "mul+add (2 VALU instructions per MAC) => its ceiling is frac 0.5"},
+                         "path_algorithmic_tflops": round(PATH_FLOP_PER_CHUNK[args.model] * S * Cn * args.steps / elapsed / 1e12, 3),
+                         "note": "dominant kernel by CU-time.  achieved = EXECUTED FLOP of that kernel's binding pipe per launch / HIP-event launch duration; peak = that pipe: "
+                                 "valu_nofma 78.65 (fp32 vector ALU, products and sums rounded separately as the reference's STFT tree demands = half the FMA peak), "
+                                 "fp32 157.3 (vector == matrix), fp16 2500 (split-fp16 GEMMs: 3 MFMAs per fp32 product).  k_frontend_sym evaluates the tree for 33 of "
+                                 "the 129 bins (the rest follow from the basis' DFT symmetries, bit-exactly), so it EXECUTES 27 % of the dense-basis FLOP that "
+                                 "algorithmic_* counts (SURVEY.md 8(d))"},
             "kernels": per_kernel,
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
         }
-        gemm_fe = (args.model == "v4" and eng.get_option("frontend") == 0) or split16
-        if gemm_fe and dom == "k_frontend":
-            # the GEMM front end executes the FOLDED real-input DFT as split-fp16 products on the fp16 matrix pipe: 3 MFMAs per
-            # k-block, 256 rows (8 re + 8 im tiles) x K = 128 per position -- price it on what it executes against that pipe's peak
-            frames = 24 if args.model == "v4" else 25
-            executed = 3 * 2 * 256 * 128 * frames
-            ach = executed * chunks_per_launch / avg_s / 1e12
-            out["roofline"].update({"achieved": round(ach, 3), "peak": PEAK_FP16_TFLOPS, "frac": round(ach / PEAK_FP16_TFLOPS, 4),
-                                    "executed_mfma_flop_per_chunk": executed,
-                                    "algorithmic_tflops_dense_basis": round(achieved, 3)})
-        if args.model == "v4" or split16:
-            out["roofline"]["note"] = ("dominant kernel by CU-time; fp32 peak (vector == matrix).  FLOP are counted for the DENSE basis "
-                                       "(SURVEY.md 8(d): 2 x 258 x 256 x 24 per chunk for the front end); k_frontend_gemm folds the "
-                                       "real-input DFT (x[n] +- x[256-n]) and EXECUTES half of them, as split-fp16 products on the fp16 matrix pipe "
-                                       "(3 x v_mfma_f32_16x16x32_f16 per k-block).  When k_frontend is the dominant kernel its achieved / peak / frac are EXECUTED "
-                                       "split-fp16 MFMA FLOP against the fp16 dense peak (the kernel is not bound by the matrix pipe: HBM writes for the v4 geometry, "
-                                       "the per-tile barrier for v3.1's, DESIGN.md 4.5); path_frac stays algorithmic FLOP (dense basis) against the fp32 roof")
-            out["roofline"]["executed_flop_per_chunk_frontend"] = 2 * (129 * 128 + 128 * 128) * (24 if args.model == "v4" else 25)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(blob, weights_path, model=args.model)
+        if world == 1 and not args.no_host_fed:
+            # PCIe-inclusive rate of the synchronous host-buffer entry point (what a drop-in backend_run pays); reported, never `value`
+            host = np.ascontiguousarray(pcm[:, : Cn * 1536])
+            eng.run(host)
+            n_host = 5
+            t1 = time.perf_counter()
+            for _ in range(n_host):
+                eng.run(host)
+            dt = time.perf_counter() - t1
+            out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dt, 1), "unit": "audio-seconds/sec", "ms_per_step": round(dt / n_host * 1e3, 3),
+                               "note": "vadc_amd_run_s16: pageable host s16 in, probabilities out, synchronous (H2D 3 KB + D2H 8 B per chunk inside the timed call)"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500,
+                    help="timed steps (default 500: the fill and drain of the two-deep step pipeline -- one LSTM launch that nothing overlaps -- "
+                         "is a few %% of a 20-step run and 0.1 %% of this one)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=256, help="streams PER GPU (BASELINE config 2: 256)")
+    ap.add_argument("--chunks-per-step", type=int, default=96, help="chunks per stream and step (default 96 = vadc's window, vadc.c:799)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--model", choices=["v31", "v4"], default="v31",
+                    help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
+    ap.add_argument("--precision", choices=["fp32", "split16"], default="fp32",
+                    help="fp32 = the parity mode (default, BASELINE config 2); split16 = BASELINE config 3 (see include/vadc_amd.h)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="experiment: no per-kernel HIP events inside the timed region (kernel table then comes from a separate pass)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
+                         "through the two caller streams; 0 = engine default for single-stream callers)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse spawn / rendezvous / sharding / gather / timing over gloo on the CPU")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-batch", type=int, default=96, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.cpu_worker:
+        wp = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor" if args.model == "v4" else os.path.join("reference_fixtures", "silero_v31_16k.testtensor"))
+        cpu_worker(args.model, wp, args.cpu_seconds, args.cpu_batch)
+        return 0
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)                  # nothing above imported torch or touched HIP
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    return run_rank(args, world, rank, local_rank)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,11 +34,13 @@ def test_roofline_and_cpu_baseline_objects():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] > 0
-    # achieved = algorithmic FLOP per launch / average launch duration of the dominant kernel
-    want = r["algorithmic_flop_per_chunk"] * r["chunks_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
+    assert r["frac"] <= 1.0
+    # achieved = executed FLOP (binding pipe) per launch / average launch duration of the dominant kernel; the algorithmic figure rides along
+    flop = r.get("executed_flop_per_chunk", r["algorithmic_flop_per_chunk"])
+    want = flop * r["chunks_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
     assert abs(r["achieved"] - want) / want < 1e-2
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

@@ -1,0 +1,53 @@
+"""`python bench.py --gpus N` started WITHOUT a launcher must bring up N ranks itself (the driver's SCALE runs call it that way) and report the
+number of ranks the process group saw.  `--dry-run` runs exactly that skeleton -- spawn before any torch / HIP import, 127.0.0.1 rendezvous,
+contiguous stream blocks, the per-step gather through vadc_amd.shard.ProbabilityGather (the helper the GPU path uses), barrier,
+max-over-ranks timing, rank 0 prints ONE JSON line -- over gloo on the CPU with a stand-in for the engine."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, env=None):
+    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_bench_spawns_its_own_ranks(n):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--gpus", str(n), "--dry-run", "--steps", "4", "--warmup", "0", "--streams", "5", "--chunks-per-step", "3", env=env)
+    assert d["n_gpus"] == n and d["dry_run"] is True and d["gather_verified"] is True
+    assert d["total_streams"] == 5 * n and d["steps"] == 4 and d["scaling"] == "weak"
+
+
+def test_bench_runs_as_one_rank_under_a_launcher():
+    """with RANK / WORLD_SIZE in the environment (torch.distributed.run) the process is one rank and does not spawn: two such processes rendezvous"""
+    from test_multi_rank_gloo import _free_port
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--streams", "4", "--chunks-per-step", "2"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["gather_verified"] is True
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]           # only rank 0 prints
+
+
+def test_cpu_baseline_worker_reports_a_rate():
+    r = subprocess.run([sys.executable, BENCH, "--cpu-worker", "--cpu-seconds", "0.3", "--cpu-batch", "96"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["kind"] in ("reference", "port") and d["chunks_per_s"] > 100

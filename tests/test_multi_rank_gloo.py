@@ -43,7 +43,13 @@ def _worker(rank, world, port, total_streams, chunks, q):
     c = torch.arange(chunks, dtype=torch.float32).view(1, -1, 1)
     k = torch.arange(2, dtype=torch.float32).view(1, 1, 2)
     local = s * 1000 + c * 2 + k
-    out = shard.gather_probabilities(local, dst=0)
+    out = shard.gather_probabilities(local, total_streams, dst=0)
+    # the persistent form bench.py uses: preallocated buffers, one dist.gather per step, several steps
+    g = shard.ProbabilityGather(total_streams, chunks, "cpu")
+    for i in range(3):
+        g.gather(local + i)
+        if rank == 0:
+            assert torch.equal(g.result(), out + i)
     if rank == 0:
         q.put(out.numpy())
     else:

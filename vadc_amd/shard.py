@@ -1,7 +1,7 @@
 """Multi-GPU layout of the hot path: streams are independent units (per-stream LSTM state, read-only weights), so
 they are partitioned into contiguous blocks, one block per rank / GPU, with NO collective in the forward pass.  The
 only exchange is the final gather of the per-chunk speech probabilities to rank 0 (RCCL `gather` on GPUs; the same
-code runs over gloo on CPU in tests)."""
+code runs over gloo on CPU in tests and in `bench.py --dry-run`)."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -27,26 +27,48 @@ def owner_of(stream: int, world: int, total_streams: int) -> int:
     raise ValueError("stream out of range")
 
 
-def gather_probabilities(local: torch.Tensor, dst: int = 0, bufs: Optional[List[torch.Tensor]] = None):
-    """local: [streams_of_this_rank, chunks, 2].  Returns the [total_streams, chunks, 2] tensor on rank `dst`
-    (None elsewhere).  Equal block sizes use one `gather`; ragged blocks are padded to the largest block."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
-        return local
-    rank = dist.get_rank()
-    n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    send = local
-    if local.shape[0] != mx:
-        send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        send[: local.shape[0]] = local
-    if rank == dst:
-        if bufs is None:
-            bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send.contiguous(), bufs, dst=dst)
-        return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
-    dist.gather(send.contiguous(), None, dst=dst)
-    return None
+class ProbabilityGather:
+    """The path's one collective: per step, every rank's [streams_of_rank, chunks, 2] probabilities -> rank `dst`.
+
+    Block sizes follow from `stream_block`, so no size exchange is needed; equal blocks are ONE `dist.gather` into
+    preallocated buffers (what bench.py issues inside its timed region), ragged blocks are padded to the largest.
+    `gather()` only enqueues (on the current stream for RCCL); `result()` assembles [total_streams, chunks, 2] on `dst`."""
+
+    def __init__(self, total_streams: int, chunks: int, device, dtype=torch.float32, dst: int = 0):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.dst = dst
+        self.sizes = [hi - lo for lo, hi in (stream_block(r, self.world, total_streams) for r in range(self.world))]
+        self.lo, self.hi = stream_block(self.rank, self.world, total_streams)
+        self.mx = max(self.sizes) if self.sizes else 0
+        self.ragged = any(s != self.mx for s in self.sizes)
+        self.pad = torch.zeros((self.mx, chunks, 2), dtype=dtype, device=device) if self.ragged else None
+        self.bufs: Optional[List[torch.Tensor]] = None
+        if self.world > 1 and self.rank == dst:
+            self.bufs = [torch.empty((self.mx, chunks, 2), dtype=dtype, device=device) for _ in range(self.world)]
+
+    def gather(self, local: torch.Tensor) -> None:
+        if local.shape[0] != self.hi - self.lo:
+            raise ValueError("local block does not match this rank's stream block")
+        if self.world == 1:
+            self._single = local
+            return
+        send = local
+        if self.ragged:
+            self.pad[: local.shape[0]].copy_(local)
+            send = self.pad
+        dist.gather(send.contiguous(), self.bufs if self.rank == self.dst else None, dst=self.dst)
+
+    def result(self) -> Optional[torch.Tensor]:
+        if self.world == 1:
+            return self._single
+        if self.rank != self.dst:
+            return None
+        return torch.cat([b[:n] for b, n in zip(self.bufs, self.sizes)], dim=0)
+
+
+def gather_probabilities(local: torch.Tensor, total_streams: int, dst: int = 0):
+    """One-shot form: returns the [total_streams, chunks, 2] tensor on rank `dst` (None elsewhere)."""
+    g = ProbabilityGather(total_streams, local.shape[1], local.device, local.dtype, dst)
+    g.gather(local)
+    return g.result()
