@@ -218,8 +218,8 @@ def run_rank(args, world, rank, local_rank):
     dev = f"cuda:{local_rank}"
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
-    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=1 if args.precision == "split16" else 0)
-    split16 = args.precision == "split16" and eng.caps()["precision"] == 1
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision={"fp32": 0, "split16": 1, "fast_stft": 2}[args.precision])
+    mode = eng.caps()["precision"]
     eng.set_option("groups", args.groups)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -253,8 +253,8 @@ def run_rank(args, world, rank, local_rank):
         dist.barrier()
     torch.cuda.synchronize()
     eng.reset_kernel_times()
-    separate_pass = args.graph or args.no_kernel_timing
-    eng.set_profiling(not separate_pass)  # per-kernel HIP events need eager launches
+    separate_pass = args.no_kernel_timing
+    eng.set_profiling(False)
     if args.graph:
         eng.set_option("graph", 1)
         step(0); step(1)                  # capture both input buffers outside the timed region
@@ -322,7 +322,7 @@ def run_rank(args, world, rank, local_rank):
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B): only a pass collected
             # on exactly this workload AND this front-end kernel counts (tools/rocprof_reduce.py writes both into the file), else null
-            default_workload = args.model == "v31" and not split16 and S == 256 and Cn == 96
+            default_workload = args.model == "v31" and mode == 0 and S == 256 and Cn == 96
             name = "latest_pmc_traffic.json" if default_workload else f"latest_pmc_traffic_{args.model}_{args.precision}_{S}x{Cn}.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             if (prof.get("streams") == S and prof.get("chunks_per_step") == Cn and prof.get("model", "v31") == args.model
@@ -336,9 +336,9 @@ def run_rank(args, world, rank, local_rank):
                       "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not split16 else "split-f16 (2 x fp16, fp32 accumulate) front end + f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32", 1: "split-f16 (2 x fp16 operands, fp32 accumulate), exact f32 STFT, f32 LSTM state", 2: "split-f16 GEMM STFT + f32"}[mode], "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
-                                   f"{'fp32' if not split16 else 'SPLIT16 precision mode (BASELINE config 3; not the parity mode)'}, s16le input resident in HBM",
+                                   f"{ {0: 'fp32', 1: 'SPLIT16 precision mode (BASELINE config 3)', 2: 'FAST_STFT throughput mode (outside the 1e-4 bar)'}[mode]}, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
                        "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
@@ -390,13 +390,17 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--model", choices=["v31", "v4"], default="v31",
                     help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
-    ap.add_argument("--precision", choices=["fp32", "split16"], default="fp32",
-                    help="fp32 = the parity mode (default, BASELINE config 2); split16 = BASELINE config 3 (see include/vadc_amd.h)")
+    ap.add_argument("--precision", choices=["fp32", "split16", "fast_stft"], default="fp32",
+                    help="fp32 = the parity mode (default, BASELINE config 2); split16 = BASELINE config 3 (exact STFT + split-fp16 GEMMs, within 1e-4); "
+                         "fast_stft = throughput mode, STFT as a GEMM, NOT within 1e-4 (see include/vadc_amd.h)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine tuning switch (vadc_amd_set_option), e.g. --opt frontend=1; experiments only")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: no per-kernel HIP events inside the timed region (kernel table then comes from a separate pass)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (kernel timing then comes from a separate pass)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="eager launches only.  Default: hipGraph replay of the step's kernel sequences (north star: hipGraph-captured steady-state steps); "
+                         "every 4th step of the timed region is still issued eagerly so that its kernels carry HIP events")
+    ap.set_defaults(graph=True)
     ap.add_argument("--groups", type=int, default=1,
                     help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
                          "through the two caller streams; 0 = engine default for single-stream callers)")

@@ -57,15 +57,23 @@ enum {
                                 to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */
 };
 
-/* precision selector for vadc_amd_create */
+/* precision selector for vadc_amd_create.  In EVERY mode the LSTM state is fp32 and probabilities of modes 0 and 1 stay within 1e-4 of the C backend. */
 enum {
-   VADC_AMD_PRECISION_FP32 = 0,   /* fp32 everywhere, STFT with the reference's exact reduction tree: the parity mode (|dp| <= 1e-4 vs the C backend) */
-   VADC_AMD_PRECISION_SPLIT16 = 1 /* BASELINE config 3 ("reduced-precision compute + fp32 LSTM state"): the STFT runs as a folded GEMM on the
-                                     fp16 matrix pipe with 2-term split-fp16 operands (~22 significant bits, fp32 accumulation) instead of the
-                                     reference's reduction tree -- 3x faster front end; probabilities deviate from the C backend by up to
-                                     ~1e-4 on long streams (measured distribution: DESIGN.md).  Everything behind the front end is the
-                                     FP32 mode's code.  Silero v4 uses this front end in both modes.  If the loaded basis lacks the real-DFT
-                                     symmetries the folding needs, the engine keeps the tree and caps.precision reports FP32. */
+   VADC_AMD_PRECISION_FP32 = 0,   /* the parity mode (BASELINE config 2).  STFT with the reference's exact fp32 reduction tree (stft.c:115-184): bit-identical
+                                     magnitudes.  After the normalization every dense contraction runs at fp32 ACCURACY on whichever pipe is fastest:
+                                     split-fp16 operands (a = hi + lo, 22 significant bits, exact products, fp32 accumulation: 3 fp16 MFMAs per fp32 one) for
+                                     the LSTM gate GEMMs and the GEMMs of layers 2-4, fp32 MFMA for layer 1; options "encoder"=3 / "lstm"=3 force fp32 MFMA. */
+   VADC_AMD_PRECISION_SPLIT16 = 1,/* BASELINE config 3 ("reduced-precision compute + fp32 LSTM state"), as SURVEY.md section 0 prescribes it: the STFT keeps the
+                                     reference's exact tree -- any other summation order moves near-silent bins, log1p(2^20 x) amplifies that, and single chunks
+                                     leave the 1e-4 bar (measured: up to 7e-4 with the STFT as a GEMM) -- and everything behind the normalization is
+                                     split-precision 16-bit MFMA with fp32 accumulation.  Since k_frontend_sym made the exact tree as cheap as a GEMM this is
+                                     what mode 0 runs by default too; mode 1 additionally refuses the fp32-MFMA fallbacks (create fails with EWEIGHTS if a
+                                     weight does not fit fp16's range). */
+   VADC_AMD_PRECISION_FAST_STFT = 2 /* throughput mode, NOT within the 1e-4 bar: the STFT as a folded real-input GEMM on the fp16 matrix pipe (split-fp16
+                                     operands, any summation order): front end 2x faster than the exact tree; probabilities deviate from the C backend by up
+                                     to ~7e-4 on single chunks (p99.9 3e-4; distribution in DESIGN.md).  Silero v4 (whose parity target is a framework
+                                     convolution in any fp32 order) uses this front end in every mode.  If the loaded basis lacks the real-DFT symmetries
+                                     the folding needs, the engine keeps the tree and caps.precision reports SPLIT16. */
 };
 
 typedef struct vadc_amd_engine vadc_amd_engine;

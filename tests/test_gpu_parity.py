@@ -96,7 +96,7 @@ def test_frontend_sym_and_full_tree_bit_identical(eng, gold_py):
     eng.set_option("frontend", 0); eng.reset_streams(); pa = eng.run(pcm); assert eng.get_option("frontend_kernel") == 0
     eng.set_option("frontend", 1); eng.reset_streams(); pb = eng.run(pcm); assert eng.get_option("frontend_kernel") == 1
     eng.set_option("frontend", 0)
-    assert float(np.abs(pa - pb).max()) < 2e-6
+    assert float(np.abs(pa - pb).max()) < 1e-5
 
 
 def test_basis_without_dft_symmetries_runs_the_full_tree(weights_blob):
@@ -138,7 +138,7 @@ def test_unaligned_device_input_takes_the_full_tree(eng):
         eng.run_device(d_buf.data_ptr() + 2 * shift, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
         st.synchronize()
         assert eng.get_option("frontend_kernel") == kernel
-        assert float(np.abs(want - d_out.cpu().numpy()).max()) < 2e-6
+        assert float(np.abs(want - d_out.cpu().numpy()).max()) < 1e-5      # other order of the partial bin sums, v_sqrt under the log
     eng.reset_streams()
 
 
@@ -460,6 +460,8 @@ def test_create_rejects_bad_input(weights_blob):
     assert ei.value.code == _lib_code("ENODEVICE")
     with pytest.raises(VadcAmdError):
         Engine(weights_blob, max_streams=1, max_chunks_per_call=1, device=0, precision=7)
+    for mode in (1, 2):
+        Engine(weights_blob, max_streams=1, max_chunks_per_call=1, device=0, precision=mode).close()
 
 
 def _lib_code(name):
@@ -575,7 +577,7 @@ def test_config2_all_256_streams_vs_oracle(weights_blob, orc):
     assert float(d.max()) <= PROB_TOL, (float(d.max()), np.unravel_index(d.argmax(), d.shape))
 
 
-@pytest.mark.parametrize("precision,tol", [(0, PROB_TOL), (1, 1e-3)])
+@pytest.mark.parametrize("precision,tol", [(0, PROB_TOL), (1, PROB_TOL), (2, 1e-3)])
 def test_full_size_4096_streams_properties(weights_blob, orc, precision, tol):
     """BASELINE config 3 / 5 size (4096 streams x 16 chunks per GPU): determinism, range, stream independence (the same audio in two
     slots gives the same bits), state carry over two calls = one call of twice the length, and a spot check against the oracle"""
@@ -715,94 +717,117 @@ def test_long_stream_statistics(weights_blob, orc):
         assert np.array_equal(O.segments(got, **kw)[1], O.segments(want, **kw)[1]), int(near.sum())
 
 
-# ---------------------------------------------------------------------------------------------- SPLIT16 precision (BASELINE config 3)
-# Stated tolerance of this mode (include/vadc_amd.h): the front end leaves the reference's reduction tree, so near-silent bins carry
-# different fp32 noise than the reference's; almost every chunk stays within 1e-4 (p99.9 6.6e-5 over 64 x 16 chunks), a chunk on
-# a steep probability slope moved by 4.1e-4 (tools/split16_report.py).  Maximum 1e-3, 99 % within 1e-4.
-SPLIT16_TOL = 1e-3
-SPLIT16_P99 = 1e-4
+# ---------------------------------------------------------------------------------------------- precision modes 1 and 2
+# SPLIT16 (BASELINE config 3): exact STFT tree + split-fp16 GEMMs behind the normalization -> the parity bar, 1e-4, holds.
+# FAST_STFT (throughput mode): the STFT as a GEMM leaves the reference's reduction tree, near-silent bins carry different fp32 noise than the
+# reference's; almost every chunk stays within 1e-4, a chunk on a steep probability slope moved by 7e-4 (tools/split16_report.py):
+# stated tolerance maximum 1e-3, 99 % within 1e-4 (include/vadc_amd.h).
+MODES = {1: (PROB_TOL, PROB_TOL), 2: (1e-3, 1e-4)}
 
 
-@pytest.fixture(scope="module")
-def eng16(weights_blob):
-    e = Engine(weights_blob, max_streams=64, max_chunks_per_call=64, device=0, precision=1)
+@pytest.fixture(scope="module", params=[1, 2], ids=["split16", "fast_stft"])
+def engp(request, weights_blob):
+    e = Engine(weights_blob, max_streams=64, max_chunks_per_call=64, device=0, precision=request.param)
+    e.mode = request.param
     yield e
     e.close()
 
 
-def test_split16_is_reported_and_uses_the_gemm_front_end(eng16, eng, gold_py):
-    assert eng16.caps()["precision"] == 1 and eng.caps()["precision"] == 0
+def test_precision_modes_are_reported_and_pick_their_front_end(engp, eng, gold_py):
+    assert engp.caps()["precision"] == engp.mode and eng.caps()["precision"] == 0
     x = f32(gold_py["pcm_speech1"])[: 9 * 1536]
     a = eng.stage_from_samples(x, "normalized")
-    b = eng16.stage_from_samples(x, "normalized")
-    d = float(np.abs(a - b).max())
-    assert 0.0 < d < 0.05, d          # a different (GEMM-order) evaluation of the same STFT: near-silent bins move, the rest agrees
-    assert float(np.abs(a - b).mean()) < 1e-4
+    b = engp.stage_from_samples(x, "normalized")
+    engp.run(gold_py["pcm_speech1"][: 9 * 1536].reshape(1, -1))
+    if engp.mode == 1:
+        assert engp.get_option("frontend_kernel") == 0 and np.array_equal(bits(a), bits(b))     # the exact tree, like the parity mode
+        with pytest.raises(VadcAmdError):
+            engp.set_option("lstm", 3)                                                              # no fp32-MFMA fallbacks in this mode
+    else:
+        assert engp.get_option("frontend_kernel") == 2
+        d = float(np.abs(a - b).max())
+        assert 0.0 < d < 0.05, d      # a different (GEMM-order) evaluation of the same STFT: near-silent bins move, the rest agrees
+        assert float(np.abs(a - b).mean()) < 1e-4
+    engp.reset_streams()
 
 
 @pytest.mark.parametrize("name", STREAMS)
 @pytest.mark.parametrize("dtype", ["s16", "f32"])
-def test_split16_probabilities_vs_c_reference_golden(eng16, gold_c, gold_py, name, dtype):
+def test_precision_modes_probabilities_vs_c_reference_golden(engp, gold_c, gold_py, name, dtype):
+    tol, p99 = MODES[engp.mode]
     pcm = gold_py[f"pcm_{name}"]
-    eng16.reset_streams()
+    engp.reset_streams()
     x = pcm if dtype == "s16" else f32(pcm)
-    got = eng16.run(x.reshape(1, -1))[0]
+    got = engp.run(x.reshape(1, -1))[0]
     d = np.abs(got - gold_c[f"probs_{name}"])
-    assert float(d.max()) <= SPLIT16_TOL and float(np.quantile(d, 0.99)) <= SPLIT16_P99
+    assert float(d.max()) <= tol and float(np.quantile(d, 0.99)) <= p99
 
 
 @pytest.mark.parametrize("S,Cn", [(1, 1), (5, 3), (17, 2), (33, 7), (64, 16)])
-def test_split16_multi_stream_vs_oracle(eng16, orc, S, Cn):
+def test_precision_modes_multi_stream_vs_oracle(engp, orc, S, Cn):
     """ragged stream / chunk counts around the 4-chunk groups and 16-position column tiles of k_frontend_gemm<.., 0>"""
+    tol, p99 = MODES[engp.mode]
     pcm = synth.make_streams(S, Cn, seed0=500 + S)
-    eng16.reset_streams()
-    got = eng16.run(pcm)[:, :, 1]
+    engp.reset_streams()
+    got = engp.run(pcm)[:, :, 1]
     want = orc.forward_streams(pcm)
     d = np.abs(got - want)
-    assert float(d.max()) <= SPLIT16_TOL and float(np.quantile(d, 0.99)) <= SPLIT16_P99
+    assert float(d.max()) <= tol and float(np.quantile(d, 0.99)) <= p99
 
 
-def test_split16_long_stream_statistics_and_segments(weights_blob, orc):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_precision_modes_long_stream_statistics_and_segments(weights_blob, orc, mode):
+    tol, p99 = MODES[mode]
     n = 1000
     pcm = synth.speech_like(n * 1536, seed=777)
-    e = Engine(weights_blob, max_streams=1, max_chunks_per_call=100, device=0, precision=1)
+    e = Engine(weights_blob, max_streams=1, max_chunks_per_call=100, device=0, precision=mode)
     got = np.concatenate([e.run(pcm[i * 1536:(i + 100) * 1536].reshape(1, -1))[0] for i in range(0, n, 100)])[:, 1]
     e.close()
     want = orc.forward_stream(pcm)[:, 1]
     d = np.abs(got.astype(np.float64) - want)
-    assert d.max() <= SPLIT16_TOL, d.max()
-    assert np.quantile(d, 0.99) <= SPLIT16_P99 and d.mean() <= 2e-5
+    assert d.max() <= tol, d.max()
+    assert np.quantile(d, 0.99) <= p99 and d.mean() <= 2e-5
     # hysteresis decisions agree wherever no probability sits inside the mode's error band of a threshold
-    if not (np.abs(want - 0.5) < SPLIT16_TOL).any() and not (np.abs(want - 0.35) < SPLIT16_TOL).any():
+    if not (np.abs(want - 0.5) < tol).any() and not (np.abs(want - 0.35) < tol).any():
         assert np.array_equal(O.segments(got)[1], O.segments(want)[1])
 
 
-def test_split16_device_path_and_alignment_rule(eng16):
-    """device-resident buffers in the SPLIT16 mode: same bits as the host path; the GEMM front end stages the input with 16-byte loads, so a
+def test_fast_stft_device_path_and_alignment_rule(weights_blob):
+    """device-resident buffers in the FAST_STFT mode: same bits as the host path; the GEMM front end stages the input with 16-byte loads, so a
     misaligned device pointer is refused (EINVAL), not read"""
     import torch
-    pcm = synth.make_streams(8, 4, seed0=23)
-    eng16.reset_streams()
-    want = eng16.run(pcm)
-    eng16.reset_streams()
-    d_buf = torch.zeros(pcm.size + 8, dtype=torch.int16, device="cuda:0")
-    d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
-    st = torch.cuda.current_stream()
-    d_buf[:pcm.size].copy_(torch.from_numpy(pcm.reshape(-1)))
-    eng16.run_device(d_buf.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
-    st.synchronize()
-    assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
-    d_buf[1:pcm.size + 1].copy_(torch.from_numpy(pcm.reshape(-1)))
-    with pytest.raises(VadcAmdError) as ei:
-        eng16.run_device(d_buf.data_ptr() + 2, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
-    assert ei.value.code == _lib_code("EINVAL")
-    eng16.reset_streams()
+    eng16 = Engine(weights_blob, max_streams=8, max_chunks_per_call=4, device=0, precision=2)
+    try:
+        pcm = synth.make_streams(8, 4, seed0=23)
+        want = eng16.run(pcm)
+        eng16.reset_streams()
+        d_buf = torch.zeros(pcm.size + 8, dtype=torch.int16, device="cuda:0")
+        d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
+        st = torch.cuda.current_stream()
+        d_buf[:pcm.size].copy_(torch.from_numpy(pcm.reshape(-1)))
+        eng16.run_device(d_buf.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
+        d_buf[1:pcm.size + 1].copy_(torch.from_numpy(pcm.reshape(-1)))
+        with pytest.raises(VadcAmdError) as ei:
+            eng16.run_device(d_buf.data_ptr() + 2, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
+        assert ei.value.code == _lib_code("EINVAL")
+    finally:
+        eng16.close()
 
 
-def test_split16_state_carry_and_call_split_invariance(eng16, gold_py):
+def test_precision_modes_state_carry_and_call_split_invariance(engp, gold_py):
     pcm = gold_py["pcm_speech2"][: 24 * 1536].reshape(1, -1)
-    eng16.reset_streams()
-    whole = eng16.run(pcm)
-    eng16.reset_streams()
-    parts = np.concatenate([eng16.run(pcm[:, : 5 * 1536]), eng16.run(pcm[:, 5 * 1536: 6 * 1536]), eng16.run(pcm[:, 6 * 1536:])], axis=1)
+    engp.reset_streams()
+    whole = engp.run(pcm)
+    engp.reset_streams()
+    parts = np.concatenate([engp.run(pcm[:, : 5 * 1536]), engp.run(pcm[:, 5 * 1536: 6 * 1536]), engp.run(pcm[:, 6 * 1536:])], axis=1)
     assert np.array_equal(bits(whole), bits(parts))
+
+
+def test_split16_refuses_weights_outside_fp16_range(weights_blob):
+    ts = tt.loads(weights_blob)
+    w = ts[95][1].copy(); w[0, 0, 0] = 7.0e4
+    with pytest.raises(VadcAmdError) as ei:
+        Engine(_blob_with(weights_blob, {95: w}), max_streams=1, max_chunks_per_call=1, device=0, precision=1)
+    assert ei.value.code == _lib_code("EWEIGHTS")

@@ -18,7 +18,7 @@ def main():
     blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
     pcm = synth.make_streams(S, Cn, seed0=seed0)
     e32 = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
-    e16 = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0, precision=1)
+    e16 = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0, precision=2)
     p32 = e32.run(pcm)[:, :, 1].astype(np.float64)
     p16 = e16.run(pcm)[:, :, 1].astype(np.float64)
     d = np.abs(p32 - p16)

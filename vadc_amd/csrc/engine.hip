@@ -114,9 +114,9 @@ struct vadc_amd_engine {
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 / 3
    const int *stage_elems = nullptr;
-   const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in SPLIT16 precision): folded basis as MFMA A fragments, bin-128 weights
+   const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
-   bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_SPLIT16)); }
+   bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_FAST_STFT)); }
    float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
    int max_streams = 0, max_chunks = 0, precision = 0;
    size_t max_items = 0;
@@ -138,21 +138,14 @@ struct vadc_amd_engine {
    // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
    float *d_xpair[2] = {nullptr, nullptr};
    size_t x_tile_chunks = 0;                    // capacity of a hand-off buffer in (16-stream tile, chunk) blocks
-   // ... and so are the front end -> encoder buffers (d_Y / d_FM / d_MAG alias pair [xpar]): with option "fe_overlap" the front
-   // end of call k+1 runs on its own internal stream concurrently with the encoder layers of call k on the same CUs.
-   float *d_ypair[2] = {nullptr, nullptr}, *d_fmpair[2] = {nullptr, nullptr}, *d_magpair[2] = {nullptr, nullptr};
+   // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
-   int fe_overlap = 0;                          // option "fe_overlap": 1 = front end on its own internal stream, overlapping the previous
-                                                // call's encoder.  Off by default: the front end's grid starves the layer kernels of
-                                                // workgroup slots (v3.1 -10 %); for v4 it was worth +3 % until the shared LSTM partition,
-                                                // which needs the two-stream form, was worth more (256 streams: 2.66 M -> 2.81 M).
-   bool capturing = false;                      // inside hipStreamBeginCapture: no waits on events from outside the capture
    float *d_h = nullptr, *d_c = nullptr;
    int lstm_variant = 0;
    // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
    static constexpr int kMaxGroups = 16;
    int groups = 0;                              // 0 = auto
-   hipStream_t sA = nullptr, sB = nullptr, sF = nullptr;   // encoder (+ front end when fe_overlap = 0), LSTM, front end
+   hipStream_t sA = nullptr, sB = nullptr;      // front end + encoder, LSTM
    int n_cus = 0;
    bool enc_h3_ok = false;                      // every encoder GEMM weight fits fp16's range: layers 2-4 run their GEMMs in the split-fp16 form
    bool lstm_shared = false;                    // the LSTM partition's CUs are also in the other streams' mask
@@ -162,15 +155,13 @@ struct vadc_amd_engine {
    int last_frontend_kernel = -1;               // what the last call's front end was: 0 = k_frontend_sym, 1 = k_frontend_fl, 2 = k_frontend_gemm, 3 = k_frontend (v4 tree)
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
-   bool ev_e_valid[2] = {false, false};         // ev_e[p]: the encoder of the last forked call that used pair p is done with Y / FM
    int v4_mag = 0;                              // option "v4_mag": 0 = the v4 first stage recovers the magnitudes from Y (no MAG array on the hot path), 1 = it reads MAG
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
-   struct GraphEntry { const void *in; float *out; int S, C, elem, groups; hipStream_t st; hipGraph_t g; hipGraphExec_t x; };
+   struct GraphEntry { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
-   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_e[2] = {nullptr, nullptr}, ev_graph = nullptr,
-              ev_fe[kMaxGroups] = {nullptr}, ev_f[kMaxGroups] = {nullptr};
+   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr};
    bool ev_graph_valid = false;
    // Call-to-call ordering that does not depend on which stream the caller used: ev_last_a = the last work that touched the
    // front-end / encoder buffers, ev_last_b = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
@@ -280,7 +271,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    size_t off_afrag = 0, off_nyq = 0;
-   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // SPLIT16 precision mode (BASELINE config 3)
+   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // FAST_STFT precision mode
    e->sym_ok = basis_has_dft_symmetries(tmp);
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
@@ -510,18 +501,15 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_ypair[0], e->d_ypair[1], e->d_magpair[0], e->d_magpair[1],
-                   e->d_fmpair[0], e->d_fmpair[1], e->d_tap, e->d_act[0], e->d_act[1],
+   void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
-   if (e->sF) (void)hipStreamDestroy(e->sF);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_e[0], e->ev_e[1], e->ev_graph, e->ev_last_a, e->ev_last_b}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_graph, e->ev_last_a, e->ev_last_b}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
-   for (hipEvent_t ev : e->ev_f) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
 
@@ -533,7 +521,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (!blob || len < 8) return fail(VADC_AMD_EWEIGHTS, "create: empty weights blob");
    if (max_streams <= 0 || max_chunks <= 0 || (long)max_streams * max_chunks > (1L << 24))
       return fail(VADC_AMD_EINVAL, "create: max_streams=%d max_chunks_per_call=%d out of range", max_streams, max_chunks);
-   if (precision != VADC_AMD_PRECISION_FP32 && precision != VADC_AMD_PRECISION_SPLIT16) return fail(VADC_AMD_EINVAL, "create: unsupported precision %d", precision);
+   if (precision != VADC_AMD_PRECISION_FP32 && precision != VADC_AMD_PRECISION_SPLIT16 && precision != VADC_AMD_PRECISION_FAST_STFT)
+      return fail(VADC_AMD_EINVAL, "create: unsupported precision %d", precision);
 
    std::vector<HostTensor> ts;
    if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
@@ -559,23 +548,22 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
    e->stage_elems = e->model == VADC_AMD_MODEL_V4 ? kStageElemsV4 : kStageElemsV31;
-   e->fe_overlap = 0;
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
+   if (precision == VADC_AMD_PRECISION_SPLIT16 && (!e->lstm_h3_ok || (e->model != VADC_AMD_MODEL_V4 && !e->enc_h3_ok))) {
+      vadc_amd_destroy(e);
+      return fail(VADC_AMD_EWEIGHTS, "create: SPLIT16 precision runs every GEMM with split-fp16 operands, but a weight of this container does not fit fp16's range; use VADC_AMD_PRECISION_FP32");
+   }
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_e[0], &e->ev_e[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
-   for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_f[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
-   for (int p = 0; p < 2; ++p) {
-      if (he == hipSuccess) he = hipMalloc(&e->d_ypair[p], N * kBins * kFrames * sizeof(float));
-      if (he == hipSuccess) he = hipMalloc(&e->d_fmpair[p], kBinSplit * N * kFrames * sizeof(float));
-      if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_magpair[p], N * kBins * kFrames * sizeof(float));
-   }
-   e->d_Y = e->d_ypair[0]; e->d_FM = e->d_fmpair[0]; e->d_MAG = e->d_magpair[0];
+   if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_FM, kBinSplit * N * kFrames * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_MAG, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
    for (int l = 0; l < 3 && he == hipSuccess; ++l) he = hipMalloc(&e->d_act[l], N * kStageElemsV31[2 + l] * sizeof(float));   // >= the v4 shapes
    // encoder output: LSTM-native layout, streams padded to whole tiles of 16
@@ -615,7 +603,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    caps->max_streams = e->max_streams;
    caps->max_chunks_per_call = e->max_chunks;
    caps->device = e->device;
-   caps->precision = (e->precision == VADC_AMD_PRECISION_SPLIT16 && e->model != VADC_AMD_MODEL_V4 && !e->gemm_ok) ? VADC_AMD_PRECISION_FP32 : e->precision;
+   caps->precision = (e->precision == VADC_AMD_PRECISION_FAST_STFT && e->model != VADC_AMD_MODEL_V4 && !e->gemm_ok) ? VADC_AMD_PRECISION_SPLIT16 : e->precision;
    caps->model_kind = e->model;
    caps->lstm_steps_per_chunk = e->lstm_steps;
    return VADC_AMD_OK;
@@ -696,6 +684,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "encoder") == 0 && value == 3)
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d exists for Silero v3.1 only (the v4 stages carry no split-fp16 GEMMs)", key, value);
+   if (e->precision == VADC_AMD_PRECISION_SPLIT16 && value == 3 && (strcmp(key, "encoder") == 0 || strcmp(key, "lstm") == 0))
+      return fail(VADC_AMD_EINVAL, "set_option: %s=3 selects fp32 MFMA; the SPLIT16 precision mode runs split-fp16 GEMMs only", key);
    // every switch below changes the launch sequence a captured graph replays: drop the captured graphs (after their last replay has finished)
    if (strcmp(key, "graph") != 0 && !e->graphs.empty()) {
       if (e->ev_graph_valid) HIP_TRY(hipEventSynchronize(e->ev_graph), VADC_AMD_EHIP);
@@ -712,7 +702,6 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
-   if (strcmp(key, "fe_overlap") == 0 && (value == 0 || value == 1)) { e->fe_overlap = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && value >= 0 && value <= 2) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -727,7 +716,6 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
-   else if (strcmp(key, "fe_overlap") == 0) *value = e->fe_overlap;
    else if (strcmp(key, "v4_mag") == 0) *value = e->v4_mag;
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
@@ -770,51 +758,41 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    }
 }
 
-// hold_last: event the stream must wait for before the LAST layer + input projection overwrite this call's encoder-output /
-// GX pair (the LSTM of an earlier call that used the same pair may still be reading it on the other stream); nullptr = no wait
-// sf / ev_f: stream of the front end and the event that hands Y / FM over to the encoder stream `st` (sf == st: one stream);
-// hold_first: event the front end must wait for before it overwrites this call's Y / FM pair (an earlier call's encoder).
-template <typename T>
-static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, int lstm_kernel, hipStream_t st,
-                                  hipEvent_t hold_last = nullptr, hipStream_t sf = nullptr, hipEvent_t ev_f = nullptr,
-                                  hipEvent_t hold_first = nullptr)
+// which front-end kernel serves this input: 0 = k_frontend_sym, 1 = k_frontend_fl, 2 = k_frontend_gemm, 3 = k_frontend (v4 tree)
+static int pick_frontend(const vadc_amd_engine *e, const void *d_in)
 {
-   hipStream_t st_enc = st;
-   if (sf && sf != st) { st = sf; }
-   if (hold_first) (void)hipStreamWaitEvent(st, hold_first, 0);
+   if (e->use_gemm_frontend()) return 2;
+   if (e->model == VADC_AMD_MODEL_V4) return 3;
+   return (e->sym_ok && e->frontend_variant == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0) ? 0 : 1;
+}
+
+// The front end and the four encoder layers of one chunk group, enqueued on `st` (pure kernel launches: capturable).
+template <typename T>
+static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, ItemMap map, int lstm_kernel, hipStream_t st)
+{
    {
       KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, st);
       const size_t fms = e->max_items * kFrames;
-      const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
-      if (e->use_gemm_frontend()) {
+      const int fk = pick_frontend(e, d_in);
+      if (fk == 2) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
          float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
          if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
          else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
-         e->last_frontend_kernel = 2;
-      } else if (e->model == VADC_AMD_MODEL_V4) {
+      } else if (fk == 3) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
-         e->last_frontend_kernel = 3;
-      } else if (e->sym_ok && e->frontend_variant == 0 && aligned) {
+      } else if (fk == 0) {
          // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
          if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
          else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
-         e->last_frontend_kernel = 0;
       } else {
          // any basis, any alignment: the full tree for all 129 bins
          if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
          else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
-         e->last_frontend_kernel = 1;
       }
    }
-   if (st != st_enc) {
-      (void)hipEventRecord(ev_f, st);
-      (void)hipStreamWaitEvent(st_enc, ev_f, 0);
-      st = st_enc;
-   }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
-   if (hold_last) (void)hipStreamWaitEvent(st, hold_last, 0);
    run_encoder_layers(e, 3, 3, n, map, lstm_kernel == 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3, 1: fp32 tiles for the fp32 kernel
 }
 
@@ -834,16 +812,16 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 2) return 0;
    // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 SPLIT16 1.08 ms, v4 0.83 ms per 24,576 chunks)
+   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 FAST_STFT 1.08 ms, v4 0.83 ms per 24,576 chunks)
    const double slot_us = (e->lstm_variant != 3 && e->lstm_h3_ok) ? 1.65 : 3.9;
-   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : 0.100);
+   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : (e->sym_ok && e->frontend_variant == 0 ? 0.040 : 0.100));
    // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
    // resident LSTM workgroup leaves of those CUs, no shader engine is a CU short, and the chain is not slowed measurably
    // (256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
    // several tiles per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
-   // streams: 955 K -> 943 K), not with the front end on a third stream (option "fe_overlap": v4 2.63 M -> 2.22 M).
-   if (e->cu_partition == 1 && !e->fe_overlap) {
+   // streams: 955 K -> 943 K).
+   if (e->cu_partition == 1) {
       const int w1 = (lstm_wgs + 7) / 8 * 8;
       const double t_enc1 = 0.9 * n_streams * per_chunk_us;
       if (w1 <= e->n_cus / 2 && e->lstm_steps * slot_us <= 0.7 * t_enc1) { *shared = true; return w1; }   // 2048 streams on 128 shared CUs: 1.18 M -> 1.25 M
@@ -870,8 +848,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
 {
    bool shared = false;
    int want = lstm_partition_cus(e, n_streams, &shared);
-   if (e->lstm_cus == want && e->lstm_shared == shared && e->sA && e->sB && e->sF) return VADC_AMD_OK;
-   if (e->sF) { HIP_TRY(hipStreamSynchronize(e->sF), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
+   if (e->lstm_cus == want && e->lstm_shared == shared && e->sA && e->sB) return VADC_AMD_OK;
    if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
    if (e->sB) { HIP_TRY(hipStreamSynchronize(e->sB), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
    bool masked = false;
@@ -882,19 +859,16 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       if (shared) for (int cu = 0; cu < want; ++cu) ma[cu / 32] |= 1u << (cu % 32);   // the LSTM keeps its CUs, the other streams may use them too
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
       hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
-      hipError_t ef = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sF, (uint32_t)words, ma.data()) : eb;
-      masked = (ea == hipSuccess && eb == hipSuccess && ef == hipSuccess);
+      masked = (ea == hipSuccess && eb == hipSuccess);
       if (!masked) {
          (void)hipGetLastError();
          if (e->sA) { (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
          if (e->sB) { (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
-         if (e->sF) { (void)hipStreamDestroy(e->sF); e->sF = nullptr; }
       }
    }
    if (!masked) {
       want = 0;
       HIP_TRY(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking), VADC_AMD_EHIP);
-      HIP_TRY(hipStreamCreateWithFlags(&e->sF, hipStreamNonBlocking), VADC_AMD_EHIP);
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = highest priority
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
@@ -902,7 +876,6 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
    e->lstm_cus = want;
    e->lstm_shared = shared && want > 0;
    e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
-   e->ev_e_valid[0] = e->ev_e_valid[1] = false;
    return VADC_AMD_OK;
 }
 
@@ -922,50 +895,83 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
    return g < 1 ? 1 : g;
 }
 
-// The whole hot path for n_streams x n_chunks chunks; asynchronous on `st`.  No allocation, no host sync:
-// the sequence (including the fork/join over the two internal streams) can be captured into a hipGraph.
-template <typename T>
-static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+// hipGraph replay (option "graph"): a KERNEL SEQUENCE -- the whole small call, or the front end + encoder of one chunk group of a forked
+// call -- is captured the first time it is issued with a given signature and replayed as one hipGraphLaunch afterwards.  Only kernels are
+// inside a graph; the fork / join and the call-to-call ordering (events below) stay outside, exactly as for eager launches, so replays of
+// consecutive steps overlap the same way eager steps do (step k+1's front end + encoder under step k's LSTM chain) instead of serialising.
+// Profiling (per-kernel events) needs eager launches, so it bypasses the graphs.
+struct SeqKey { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; };
+template <typename F>
+static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, F &&enqueue)
 {
+   if (!e->use_graph || e->profiling) { enqueue(); return VADC_AMD_OK; }
+   for (auto &ge : e->graphs)
+      if (ge.in == k.in && ge.out == k.out && ge.S == k.S && ge.C == k.C && ge.elem == k.elem && ge.G == k.G && ge.gi == k.gi && ge.xp == k.xp &&
+          ge.lk == k.lk && ge.fe == k.fe) {
+         HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
+         HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
+         e->ev_graph_valid = true;
+         return VADC_AMD_OK;
+      }
+   vadc_amd_engine::GraphEntry ge{k.in, k.out, k.S, k.C, k.elem, k.G, k.gi, k.xp, k.lk, k.fe, nullptr, nullptr};
+   HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed), VADC_AMD_EHIP);
+   enqueue();
+   hipError_t he = hipStreamEndCapture(st, &ge.g);
+   if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
+   HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
+   if (e->graphs.size() >= 32) {                           // evict the oldest signature; its last replay may still be in flight
+      if (e->ev_graph_valid) (void)hipEventSynchronize(e->ev_graph);   // not a cached stream handle: the caller may have destroyed that stream
+      (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin());
+   }
+   e->graphs.push_back(ge);
+   HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
+   HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
+   e->ev_graph_valid = true;
+   return VADC_AMD_OK;
+}
+
+// The whole hot path for n_streams x n_chunks chunks; asynchronous on `st`.  No allocation, no host sync.
+template <typename T>
+static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
+{
+   if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
+      return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
    const int G = pick_groups(e, n_chunks);
    const int lk = resolve_lstm(e, n_streams);
    e->last_lstm_kernel = lk;
+   e->last_frontend_kernel = pick_frontend(e, d_in);
+   int rc = VADC_AMD_OK;
    // Small calls run straight on the caller's stream.  Larger ones always fork onto the two internal streams, even
    // with one group: the internal streams are in-order across calls, so a caller that alternates between two
    // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
    // while every call keeps strict stream semantics (its results are complete when its own stream reaches the join).
-   const bool order = e->ev_last_valid && !e->capturing;
+   const bool order = e->ev_last_valid;
    if (G == 1 && (long)n_streams * n_chunks < 2048) {
       const ItemMap map{n_chunks, 0, n_chunks};
       if (order) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); }
-      run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
-      {
+      rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
+         run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
          launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
-      }
-      if (!e->capturing) { (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true; }
+      });
+      if (rc) return rc;
+      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true;
    } else {
-      int rc = ensure_pipeline_streams(e, n_streams);
+      rc = ensure_pipeline_streams(e, n_streams);
       if (rc) return rc;
       // fork: stream A = front end + encoder of every chunk group in order, stream B = the LSTM chain
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
-      const bool split_fe = e->fe_overlap != 0;
-      if (split_fe) (void)hipStreamWaitEvent(e->sF, e->ev_in, 0);
       if (order) {
          (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
          (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
-         // the front end stream does NOT wait for the previous call's encoder (ev_last_a): it is in order with the previous front
-         // end, its Y / FM pair is guarded by hold_first below, and overlapping that encoder is the point of the third stream
       }
-      // this call's hand-off pair; its last reader was the LSTM of the forked call before the previous one
+      // this call's hand-off buffer; its last reader was the LSTM of the forked call before the previous one (long finished: the wait is free)
       e->xpar ^= 1;
       const int xp = e->xpar;
       e->d_act[3] = e->d_xpair[xp];
-      e->d_Y = e->d_ypair[xp]; e->d_FM = e->d_fmpair[xp]; e->d_MAG = e->d_magpair[xp];
-      hipEvent_t hold = (e->ev_b_valid[xp] && !e->capturing) ? e->ev_b[xp] : nullptr;
-      hipEvent_t hold_first = (split_fe && e->ev_e_valid[xp] && !e->capturing) ? e->ev_e[xp] : nullptr;
+      if (e->ev_b_valid[xp]) (void)hipStreamWaitEvent(e->sA, e->ev_b[xp], 0);
       // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
       int sizes[vadc_amd_engine::kMaxGroups];
       {
@@ -981,9 +987,10 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
          const int cg = sizes[gi];
          if (cg <= 0) continue;
          const ItemMap map{n_chunks, c0, cg};
-         run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA, hold, split_fe ? e->sF : nullptr, e->ev_f[gi], hold_first);
-         hold = nullptr;
-         hold_first = nullptr;
+         rc = launch_sequence(e, SeqKey{d_in, nullptr, n_streams, n_chunks, (int)sizeof(T), G, gi, xp, lk, e->last_frontend_kernel}, e->sA, [&] {
+            run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA);
+         });
+         if (rc) return rc;
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
@@ -992,73 +999,15 @@ static int run_device_eager(vadc_amd_engine *e, const T *d_in, int n_streams, in
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
-      if (!e->capturing) { (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); e->ev_last_valid = true; }
-      (void)hipEventRecord(e->ev_e[xp], e->sA);
-      e->ev_e_valid[xp] = !e->capturing;
+      (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); e->ev_last_valid = true;
       (void)hipEventRecord(e->ev_b[xp], e->sB);
-      e->ev_b_valid[xp] = !e->capturing;
+      e->ev_b_valid[xp] = true;
       (void)hipStreamWaitEvent(st, e->ev_a, 0);
       (void)hipStreamWaitEvent(st, e->ev_b[xp], 0);
    }
    hipError_t he = hipGetLastError();
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
    return VADC_AMD_OK;
-}
-
-// Steady-state replay: the first call with a given (buffers, shape, stream) signature captures the launch sequence
-// (including the fork/join over the internal streams) into a hipGraph; later calls are one hipGraphLaunch.
-// Profiling (per-kernel events) needs eager launches, so it bypasses the graph.  Kernel nodes do not inherit a
-// stream's CU mask, so the graph path always uses unmasked internal streams.
-// A captured step has no edges to the step before it (the eager path gets them from the in-order internal streams), and
-// all steps share the per-stream LSTM state and the intermediates: graph launches are chained through one event so that
-// they serialise even when the caller alternates streams.
-static int launch_graph_serialized(vadc_amd_engine *e, hipGraphExec_t x, hipStream_t st)
-{
-   if (e->ev_graph_valid) HIP_TRY(hipStreamWaitEvent(st, e->ev_graph, 0), VADC_AMD_EHIP);
-   if (e->ev_last_valid) {                                  // eager calls issued before this replay
-      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_a, 0), VADC_AMD_EHIP);
-      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_b, 0), VADC_AMD_EHIP);
-   }
-   HIP_TRY(hipGraphLaunch(x, st), VADC_AMD_EHIP);
-   HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
-   HIP_TRY(hipEventRecord(e->ev_last_a, st), VADC_AMD_EHIP);
-   HIP_TRY(hipEventRecord(e->ev_last_b, st), VADC_AMD_EHIP);
-   e->ev_last_valid = true;
-   e->ev_graph_valid = true;
-   return VADC_AMD_OK;
-}
-
-template <typename T>
-static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
-{
-   if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
-      return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
-   if (!e->use_graph || e->profiling) return run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
-   for (auto &ge : e->graphs)
-      if (ge.in == d_in && ge.out == d_probs && ge.S == n_streams && ge.C == n_chunks && ge.elem == (int)sizeof(T) &&
-          ge.groups == e->groups && ge.st == st) {
-         return launch_graph_serialized(e, ge.x, st);
-      }
-   const int saved_partition = e->cu_partition;
-   if (saved_partition) { e->cu_partition = 0; e->lstm_cus = -1; }
-   int rc = ensure_pipeline_streams(e, n_streams);              // create the (unmasked) streams BEFORE capturing
-   if (rc) { e->cu_partition = saved_partition; return rc; }
-   vadc_amd_engine::GraphEntry ge{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), e->groups, st, nullptr, nullptr};
-   HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed), VADC_AMD_EHIP);
-   e->capturing = true;
-   rc = run_device_eager<T>(e, d_in, n_streams, n_chunks, d_probs, st);
-   e->capturing = false;
-   hipError_t he = hipStreamEndCapture(st, &ge.g);
-   e->cu_partition = saved_partition;
-   if (rc) return rc;
-   if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
-   HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
-   if (e->graphs.size() >= 8) {                            // evict the oldest signature; its last replay may still be in flight
-      if (e->ev_graph_valid) (void)hipEventSynchronize(e->ev_graph);   // not the cached stream handle: the caller may have destroyed that stream
-      (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin());
-   }
-   e->graphs.push_back(ge);
-   return launch_graph_serialized(e, ge.x, st);
 }
 
 extern "C" int vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks, float *d_probs, void *hip_stream)

@@ -4,7 +4,7 @@
 // Used for (a) the Silero v4 model (default front end there; reference arithmetic: silero_vad.py:22-66, STFT_conv with is_v4 +
 // AdaptiveAudioNormalization; the reference itself runs it through onnxruntime, onnx_helpers.c:83-115): pad_reflect(96), conv1d
 // with the [258,1,256] basis at hop 64 (24 frames per 1536-sample chunk), sqrt(re^2 + im^2), log1p(2^20 m), bin sums; and
-// (b) Silero v3.1 in the engine's SPLIT16 precision mode (BASELINE config 3; replaces tensor.h:912-958, stft.c:15-224,
+// (b) Silero v3.1 in the engine's FAST_STFT precision mode (throughput mode; replaces tensor.h:912-958, stft.c:15-224,
 // misc.c:40-63 with pad 128 and 25 frames).
 //
 // Why a GEMM is the default for v4 but an opt-in precision mode for v3.1: v3.1 parity is defined against the reference C
