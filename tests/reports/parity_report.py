@@ -38,6 +38,14 @@ def main():
     ctrl = np.stack([synth.control_stream(k, 400 * 1536, seed=5) for k in ("zeros", "noise", "square")])
     rep["wide_sweep"] = compare(eng, orc, np.concatenate([wide, ctrl]), 100)
     eng.close()
+    # BASELINE config 3 (precision SPLIT16: exact STFT + split-fp16 GEMMs) and the throughput mode (FAST_STFT: GEMM STFT) over the same 33,600 chunks
+    for name, mode in (("split16", 1), ("fast_stft", 2)):
+        e = Engine(blob, max_streams=64, max_chunks_per_call=100, device=0, precision=mode)
+        rep[name] = compare(e, orc, np.concatenate([wide, ctrl]), 100)
+        rep[name]["rounded_long_streams"] = compare(e, orc, synth.make_streams(8, 1000, seed0=9000), 100)
+        if mode == 2:
+            rep[name]["tolerance"] = 1e-3
+        e.close()
     # Silero v4 against its own restatement (PyTorch-pinned)
     v4 = os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor")
     if os.path.exists(v4):

@@ -1,35 +1,28 @@
 #!/bin/bash
 # Re-create everything under profiles/rNN from one GPU box.  Run through gpurun from the repo root:
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'      (outputs land in gpurun_out/, then: python tools/rocprof_reduce.py ...)
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'      (outputs land in gpurun_out/, then: python tools/rocprof_reduce.py ...)
 # rocprofv3 rules on this pool: program directly after `--`, PMC passes separate from tracing, one counter group per pass.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py --no-cpu-baseline > $O/prof_kt.log 2>&1
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+NB="--no-cpu-baseline --no-host-fed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py $NB > $O/prof_kt.log 2>&1
+echo "kernel trace done"
+B="python3 bench.py --steps 3 --warmup 1 $NB"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- $B > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- $B > $O/prof_write.log 2>&1
+echo "traffic passes done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB -- $B > $O/pmcB.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmcC -- $B > $O/pmcC.log 2>&1
-# HBM traffic of the two 4096-stream GEMM-front-end workloads (BASELINE configs 3 and 4)
+echo "compute passes done"
+# HBM traffic of the 4096-stream workloads (BASELINE configs 3 and 4)
 for w in "v4 fp32" "v31 split16"; do
    set -- $w
    W="--model $1 --precision $2 --streams 4096 --chunks-per-step 16"
-   rm -rf $O/prof_fetch_$1_$2 $O/prof_write_$1_$2
+   rm -rf $O/prof_fetch_$1_$2 $O/prof_write_$1_$2 $O/prof_kt_$1_$2
    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch_$1_$2 -- $B $W > $O/prof_fetch_$1_$2.log 2>&1
    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write_$1_$2 -- $B $W > $O/prof_write_$1_$2.log 2>&1
-   rm -rf $O/prof_kt_$1_$2 $O/pmcB_$1_$2
-   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_$1_$2 -- python3 bench.py --no-cpu-baseline $W > $O/prof_kt_$1_$2.log 2>&1
-   rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB_$1_$2 -- $B $W > $O/pmcB_$1_$2.log 2>&1
+   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_$1_$2 -- python3 bench.py $NB $W > $O/prof_kt_$1_$2.log 2>&1
+   echo "$w done"
 done
-python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
-python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_4096x16.json
-python bench.py --streams 4096 --chunks-per-step 16 --no-cpu-baseline --graph 2>/dev/null | tail -1 > $O/bench_4096x16_graph.json
-python bench.py --precision split16 2>/dev/null | tail -1 > $O/bench_split16_256x96.json
-python bench.py --precision split16 --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_split16_4096x16.json
-python tools/split16_report.py 64 64 564 > $O/split16_report.json 2>$O/split16_report.err
-python bench.py --model v4 2>/dev/null | tail -1 > $O/bench_v4_256x96.json
-python bench.py --model v4 --streams 4096 --chunks-per-step 16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_v4_4096x16.json
-python tests/reports/parity_report.py > $O/parity_report.log 2>&1
-tail -1 $O/parity_report.log

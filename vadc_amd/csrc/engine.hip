@@ -25,7 +25,7 @@ void launch_frontend_gemm_f32(const float *, const float *, const float *, float
 void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
-void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, float *, unsigned *, unsigned *);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -138,6 +138,10 @@ struct vadc_amd_engine {
    // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
    float *d_xpair[2] = {nullptr, nullptr};
    size_t x_tile_chunks = 0;                    // capacity of a hand-off buffer in (16-stream tile, chunk) blocks
+   // k_lstm_pipe (two workgroups per stream tile): layer 0 -> layer 1 hand-off of h0 (same tile layout and size as a hand-off buffer), published-step
+   // flags per tile, and the word a consumer raises when its bounded spin expires (checked by the synchronous entry points)
+   float *d_h0seq = nullptr;
+   unsigned *d_pipe_flags = nullptr, *d_pipe_error = nullptr;
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
    float *d_h = nullptr, *d_c = nullptr;
@@ -502,7 +506,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -574,6 +578,10 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       if (he == hipSuccess) he = hipMemset(e->d_xpair[p], 0, padded_streams * max_chunks * 448 * sizeof(float));
    }
    e->d_act[3] = e->d_xpair[0];
+   if (he == hipSuccess) he = hipMalloc(&e->d_h0seq, padded_streams * max_chunks * 448 * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_pipe_flags, (padded_streams / kLstmTile + 1) * sizeof(unsigned));
+   if (he == hipSuccess) he = hipMalloc(&e->d_pipe_error, sizeof(unsigned));
+   if (he == hipSuccess) he = hipMemset(e->d_pipe_error, 0, sizeof(unsigned));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -697,7 +705,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6)) { e->lstm_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
@@ -793,50 +801,56 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       }
    }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
-   run_encoder_layers(e, 3, 3, n, map, lstm_kernel == 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3, 1: fp32 tiles for the fp32 kernel
+   run_encoder_layers(e, 3, 3, n, map, lstm_kernel >= 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3 / k_lstm_pipe, 1: fp32 tiles for the fp32 kernel
 }
 
-// How many CUs the LSTM chain gets (0 = no partition).  Its workgroups (one per 16-stream tile) are latency-bound -- a slot
-// costs the same whether a CU hosts one tile or takes several in turn -- while the front end + encoder scale with the CUs
-// they are given.  So the partition is the SMALLEST multiple of 8 CUs (one per XCD) on which the chain still finishes inside
-// the front-end/encoder time of the same call: tiles/want rounds x steps x ~3.9 us per slot versus ~0.12 us (v3.1) / 0.07 us
-// (v4) of whole-chip front-end + encoder time per chunk (both sides are per chunk of the call).
-// *shared = true: the chain's CUs stay in the other streams' mask too (see ensure_pipeline_streams)
+// Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
+// one stream tile, and whole-chip front-end + encoder time per chunk.
+static double lstm_slot_us(const vadc_amd_engine *e, int lk) { return lk == 7 ? 0.8 : (lk == 6 ? 1.6 : 3.9); }
+static double enc_us_per_chunk(const vadc_amd_engine *e)
+{
+   if (e->model == VADC_AMD_MODEL_V4) return 0.022;
+   return e->use_gemm_frontend() ? 0.027 : (e->sym_ok && e->frontend_variant == 0 ? 0.038 : 0.080);
+}
+
+// LSTM kernel for this call: option "lstm" 0 = auto.  3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when
+// asked for; otherwise split-fp16 operands on the fp16 matrix pipe at fp32 accuracy: 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile),
+// 7 = k_lstm_pipe (the two layers of a tile on two CUs) while the recurrence would otherwise be the longer of the two concurrent streams -- few
+// stream tiles: its time per call is steps x slot whatever the stream count, the front end + encoder's grows with it -- and 2 x tiles
+// workgroups still get a CU each.
+static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
+{
+   if (e->lstm_variant == 3 || !e->lstm_h3_ok) return 3;
+   if (e->lstm_variant == 6 || e->lstm_variant == 7) return e->lstm_variant;
+   const int tiles = (n_streams + kLstmTile - 1) / kLstmTile;
+   const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
+   return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
+}
+
+// How many CUs the LSTM chain gets (0 = no partition).  Its workgroups (one per 16-stream tile, two with k_lstm_pipe) are latency-bound -- a slot
+// costs the same whether a CU hosts one workgroup or takes several in turn -- while the front end + encoder scale with the CUs they are given:
+// the chain must never wait for a CU behind a front-end grid that fills the machine, so while it needs few CUs it gets CUs of its own.
+// *shared = true: the chain's CUs stay in the other stream's mask too (see ensure_pipeline_streams)
 static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *shared)
 {
    *shared = e->cu_partition == 2;
    if (!e->cu_partition) return 0;
    if (e->lstm_cus_forced > 0) return e->lstm_cus_forced;      // option "lstm_cus" (experiments)
-   const int lstm_wgs = (n_streams + 15) / 16;
+   const int lk = resolve_lstm(e, n_streams);
+   const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
-   // 4096: 806 K vs 895 K -- with more than n_cus/4 tiles the chain is throughput work and gets the whole chip
+   // 4096: 806 K vs 895 K -- with more than n_cus/2 tiles the chain is throughput work and gets the whole chip
    if (lstm_wgs > e->n_cus / 2) return 0;
-   // slot: k_lstm_wavefront_h3 1.6 us, the fp32 k_lstm_wavefront 3.9 us (options "lstm" = 0/5 vs 4)
-   // per_chunk_us: front end + encoder time per chunk on the whole chip (measured front end + encoder: v3.1 2.38 ms, v3.1 FAST_STFT 1.08 ms, v4 0.83 ms per 24,576 chunks)
-   const double slot_us = (e->lstm_variant != 3 && e->lstm_h3_ok) ? 1.65 : 3.9;
-   const double per_chunk_us = e->model == VADC_AMD_MODEL_V4 ? 0.034 : (e->use_gemm_frontend() ? 0.046 : (e->sym_ok && e->frontend_variant == 0 ? 0.040 : 0.100));
-   // SHARED partition: when every tile can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
+   const double slot_us = lstm_slot_us(e, lk), per_chunk_us = enc_us_per_chunk(e);
+   // SHARED partition: when every workgroup can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
    // resident LSTM workgroup leaves of those CUs, no shader engine is a CU short, and the chain is not slowed measurably
-   // (256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
-   // several tiles per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
-   // streams: 955 K -> 943 K).
-   if (e->cu_partition == 1) {
-      const int w1 = (lstm_wgs + 7) / 8 * 8;
-      const double t_enc1 = 0.9 * n_streams * per_chunk_us;
-      if (w1 <= e->n_cus / 2 && e->lstm_steps * slot_us <= 0.7 * t_enc1) { *shared = true; return w1; }   // 2048 streams on 128 shared CUs: 1.18 M -> 1.25 M
-   }
-   if (lstm_wgs > e->n_cus / 4) return 0;
-   for (int w = 8; w <= e->n_cus / 4; w += 8) {
-      const int rounds = (lstm_wgs + w - 1) / w;
-      const double t_lstm = rounds * e->lstm_steps * slot_us;
-      const double t_enc = 0.9 * n_streams * per_chunk_us * e->n_cus / (double)(e->n_cus - w);
-      // the chain must finish well inside the front end + encoder time, not just inside it: with the two equal (256 streams on 8 CUs:
-      // 2.20 vs 2.19 ms) every hiccup of the chain delays the next step -- 16 CUs: 0.995 M -> 1.040 M, 512 streams 16 -> 32 CUs: 1.070 -> 1.087 M;
-      // giving CUs away costs the front end little (power-limited clocks: 32 CUs fewer, same front-end time)
-      if (rounds == 1 || t_lstm <= 0.4 * t_enc) return w;
-   }
-   return 0;
+   // (round 1, 256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
+   // several workgroups per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
+   // streams: 955 K -> 943 K): then the masks are DISJOINT.
+   const int w1 = (lstm_wgs + 7) / 8 * 8;
+   if (e->cu_partition == 1 && e->lstm_steps * slot_us <= 0.7 * 0.9 * n_streams * per_chunk_us) *shared = true;
+   return w1;
 }
 
 // Streams A (front end + encoder) and B (LSTM) of the chunk-group pipeline.  The LSTM of a small batch is
@@ -877,14 +891,6 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
    e->lstm_shared = shared && want > 0;
    e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
    return VADC_AMD_OK;
-}
-
-// LSTM kernel for this call: option "lstm" 0 = auto: 6 = k_lstm_wavefront_h3 (split-fp16 operands on the fp16 matrix pipe, fp32 accuracy);
-// 3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when asked for
-static int resolve_lstm(const vadc_amd_engine *e, int)
-{
-   if (e->lstm_variant == 3 || !e->lstm_h3_ok) return 3;
-   return 6;
 }
 
 static int pick_groups(const vadc_amd_engine *e, int n_chunks)
@@ -952,7 +958,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
          run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
       });
       if (rc) return rc;
       (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true;
@@ -994,7 +1000,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
+         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
          c0 += cg;
       }
       // join
@@ -1201,7 +1207,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
       // pure data movement: reference layout [S][C][64][steps] -> LSTM-native tiles (common.h), fp32 or split fp16
       const size_t padded = (size_t)((n_streams + kLstmTile - 1) / kLstmTile) * kLstmTile;
       const int TS = e->lstm_steps;
-      if (lk == 6) {
+      if (lk >= 6) {
          std::vector<_Float16> tiles(padded * n_chunks * 64 * TS * 2, (_Float16)0.0f);
          for (int s = 0; s < n_streams; ++s)
             for (int c = 0; c < n_chunks; ++c)
@@ -1224,7 +1230,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
          HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       }
    }
-   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model);
+   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
