@@ -51,10 +51,14 @@ PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole p
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)"}
 
 
-def kernel_cost(model, name, fe_kernel):
+def kernel_cost(model, name, fe_kernel, layer_major=False):
     """-> (algorithmic FLOP per chunk, {pipe: executed FLOP per chunk}).  Executed = what the kernel issues: the symmetric front end
     evaluates 33 of the 129 bins' trees, split-fp16 GEMMs issue three fp16 MFMAs per fp32 product, the folded GEMM front end half the taps."""
-    mac, mac16 = (MAC_V4 if model == "v4" else MAC_V31)[name]
+    if name in ("k_lstm", "k_lstm_l1") and layer_major:      # k_lstm_layer: "k_lstm" is layer 0 alone, "k_lstm_l1" layer 1 + decoder
+        mac, mac16 = (MAC_V4 if model == "v4" else MAC_V31)["k_lstm"]
+        mac, mac16 = (mac16 // 2, mac16 // 2) if name == "k_lstm" else (mac - mac16 // 2, mac16 // 2)
+    else:
+        mac, mac16 = (MAC_V4 if model == "v4" else MAC_V31)[name]
     alg = 2 * mac
     if name == "k_frontend":
         frames = 24 if model == "v4" else 25
@@ -225,25 +229,39 @@ def run_rank(args, world, rank, local_rank):
         k, v = kv.split("=")
         eng.set_option(k, int(v))
 
-    # synthetic input: 16 distinct speech-like streams per rank tiled over S, two alternating step buffers
-    base = synth.make_streams(min(S, 16), 2 * Cn, seed0=1234 + 100 * rank)
+    # synthetic input: 16 distinct speech-like streams per rank tiled over S, NB step buffers used in turn
+    NB = args.caller_streams
+    base = synth.make_streams(min(S, 16), NB * Cn, seed0=1234 + 100 * rank)
     pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(2)]
-    d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
+    d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
     gather = shard.ProbabilityGather(S * world, Cn, dev)          # weak scaling: S streams per GPU, contiguous blocks
     assert gather.hi - gather.lo == S
-    # Two caller streams used alternately: each step is strictly ordered on its own stream, and the engine's
-    # internal in-order streams overlap step k+1's front end + encoder with step k's LSTM.
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # The engine's internal in-order streams overlap the stages of consecutive steps: front end + encoder of step k+2 beside LSTM layer 0 of step
+    # k+1 beside layer 1 of step k (layer-major LSTM, <= 512 streams), or front end + encoder beside the whole LSTM.  Default: all steps issued
+    # from streams[0], which a call does not block (defer_join); --strict-join: NB caller streams in turn, each strictly ordered.
+    streams = [torch.cuda.Stream() for _ in range(NB)]
+
+    if args.defer_join:
+        eng.set_option("defer_join", 1)
 
     def step(i):
-        st = streams[i & 1]
-        with torch.cuda.stream(st):
-            eng.run_device(d_in[i & 1].data_ptr(), np.int16, S, Cn, d_probs[i & 1].data_ptr(), st.cuda_stream)
+        b = i % NB
+        if args.defer_join:
+            # ONE issuing stream: the call does not block it; a side stream joins the call (device-side wait) and carries the gather
+            eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), streams[0].cuda_stream)
             if world > 1:
-                gather.gather(d_probs[i & 1])           # the only collective: final probability gather (RCCL)
+                eng.join(streams[1 + b % (NB - 1)].cuda_stream)
+                with torch.cuda.stream(streams[1 + b % (NB - 1)]):
+                    gather.gather(d_probs[b])
+            return
+        st = streams[b]
+        with torch.cuda.stream(st):
+            eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), st.cuda_stream)
+            if world > 1:
+                gather.gather(d_probs[b])               # the only collective: final probability gather (RCCL)
 
-    for i in range(2):                     # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
+    for i in range(2 * NB):                # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
         step(i)
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -257,7 +275,8 @@ def run_rank(args, world, rank, local_rank):
     eng.set_profiling(False)
     if args.graph:
         eng.set_option("graph", 1)
-        step(0); step(1)                  # capture both input buffers outside the timed region
+        for i in range(2 * NB):           # capture every (input buffer, hand-off buffer) pairing outside the timed region
+            step(i)
         torch.cuda.synchronize()
     # Per-kernel HIP events (two hipEventRecord per launch, on the launch's stream) cost ~2.5 % of the step when every launch
     # of the timed region carries them; they are recorded on every 4th step of the timed region instead (still "live", still
@@ -302,12 +321,14 @@ def run_rank(args, world, rank, local_rank):
         n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         cu_share = {k: 1.0 for k in kt}
         lstm_cus = eng.get_option("lstm_cus")                     # CUs the engine reserved for the LSTM chain (0: whole chip)
-        cu_share["k_lstm"] = (lstm_cus / n_cus) if lstm_cus > 0 else 1.0
+        layer_major = kt.get("k_lstm_l1", (0, 0.0))[0] > 0        # two layer launches, each on half of the LSTM's CU partition
+        cu_share["k_lstm"] = (lstm_cus / n_cus / (2 if layer_major else 1)) if lstm_cus > 0 else 1.0
+        cu_share["k_lstm_l1"] = cu_share["k_lstm"]
         per_kernel = {}
         for k, (n_l, ms) in kt.items():
             if not n_l:
                 continue
-            alg, exe = kernel_cost(args.model, k, fe_kernel)
+            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major)
             per_launch = S * Cn * n_prof / n_l                    # chunks one launch processes (a step may be split into chunk groups)
             sec = ms / n_l / 1e3
             # binding pipe = the one whose executed FLOP take longest at its peak (the pipes can overlap: this is the LOWER bound on the kernel's time)
@@ -404,6 +425,12 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
                          "through the two caller streams; 0 = engine default for single-stream callers)")
+    ap.add_argument("--strict-join", dest="defer_join", action="store_false",
+                    help="every call makes its own stream wait for its completion (strict stream semantics) and the steps rotate over --caller-streams streams.  "
+                         "Default: engine option defer_join = 1 -- all steps are issued from ONE stream, which a call does not block; the consumer of a step's "
+                         "probabilities (the RCCL gather, the final synchronize) joins it with vadc_amd_join")
+    ap.set_defaults(defer_join=True)
+    ap.add_argument("--caller-streams", type=int, default=3, help="step buffers used in turn (= caller streams with --strict-join)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse spawn / rendezvous / sharding / gather / timing over gloo on the CPU")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help=argparse.SUPPRESS)

@@ -125,7 +125,12 @@ int  vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_s
                              float *d_probs, void *hip_stream);
 int  vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks,
                              float *d_probs, void *hip_stream);
+/* Host-synchronous: returns when every call issued so far is complete. */
 int  vadc_amd_synchronize(vadc_amd_engine *e);
+/* Makes `hip_stream` wait (device-side, no host sync) for every call issued so far.  With option "defer_join" = 1 a vadc_amd_run_device_* call no longer
+ * makes its own stream wait for its completion -- consecutive calls issued from ONE stream then overlap inside the engine (front end + encoder of call k+2
+ * beside LSTM layer 0 of call k+1 beside layer 1 of call k) -- and this is how a consumer of the probabilities orders itself behind them. */
+int  vadc_amd_join(vadc_amd_engine *e, void *hip_stream);
 
 /* ---- per-stream state (the reference has one implicit stream; silero.h:36-37) ---------------- */
 /* Zero the state of the listed streams (stream_ids == NULL: all max_streams). */
@@ -190,7 +195,8 @@ int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
 enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,
-       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM, VADC_AMD_KERNEL_COUNT };
+       VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM /* both layers, or layer 0 of the layer-major form */, VADC_AMD_KERNEL_LSTM_L1 /* layer 1 + decoder of the layer-major form */,
+       VADC_AMD_KERNEL_COUNT };
 /* When enabled every kernel launch of run_* is bracketed by hipEventRecord on its stream. */
 int  vadc_amd_set_profiling(vadc_amd_engine *e, int enabled);
 /* Synchronizes, then returns launch count and summed duration (ms) since the last reset. */

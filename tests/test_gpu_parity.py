@@ -213,7 +213,7 @@ def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):     
     assert float(np.abs(got - ref).max()) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 3, 6])
+@pytest.mark.parametrize("variant", [0, 3, 6, 7])
 def test_reference_fixture_lstm(weights_blob, fixture_path, variant):                     # test.c:243
     x, h0, c0, w, b, ref = [a for _, a in tt.load(fixture_path("lstm_nito_reference_randn"))]
     e = Engine(_blob_with(weights_blob, {95: w, 96: b}), max_streams=1, max_chunks_per_call=4, device=0)
@@ -320,11 +320,38 @@ def test_first_stage_forms_agree(eng, gold_py):
 
 def test_lstm_variants_agree(eng):
     pcm = synth.make_streams(19, 6, seed0=5)
-    eng.set_option("lstm", 3); eng.reset_streams(); a = eng.run(pcm); ka = eng.get_option("lstm_kernel")   # fp32 MFMA wavefront
-    eng.set_option("lstm", 6); eng.reset_streams(); b = eng.run(pcm); kb = eng.get_option("lstm_kernel")   # split-fp16 operands on the fp16 matrix pipe (default)
-    eng.set_option("lstm", 0); eng.reset_streams(); c = eng.run(pcm)
-    assert (ka, kb) == (3, 6) and np.array_equal(bits(b), bits(c))
-    assert float(np.abs(a - b).max()) < 2e-5                             # fp32-grade: 22-bit operands, fp32 accumulation
+    out, state, kern = {}, {}, {}
+    for v in (3, 6, 7, 0):       # fp32 MFMA wavefront / split-fp16 on one CU / split-fp16, the two layers on two CUs (k_lstm_pipe) / auto
+        eng.set_option("lstm", v); eng.reset_streams()
+        out[v] = np.concatenate([eng.run(pcm[:, : 2 * 1536]), eng.run(pcm[:, 2 * 1536:])], axis=1)
+        kern[v] = eng.get_option("lstm_kernel")
+        state[v] = [eng.get_state(s_) for s_ in (0, 15, 16, 18)]
+    eng.set_option("lstm", 0)
+    assert (kern[3], kern[6], kern[7]) == (3, 6, 7) and kern[0] in (6, 7)   # auto: 6 on the caller's stream, 7 (layer-major) for forked calls
+    assert np.array_equal(bits(out[7]), bits(out[0]))
+    assert float(np.abs(out[3] - out[6]).max()) < 2e-5                    # fp32-grade: 22-bit operands, fp32 accumulation
+    # 6 and 7 issue the same MFMAs in the same k order per gate row, pin the same contraction in the cell update (one copy of the slot body: no
+    # unrolling) and sum the decoder dots in the same tree: state and probabilities are BIT-identical, so a stream's bits do not depend on
+    # which of the two the engine picks for a call shape
+    for a, b in zip(state[6], state[7]):
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    assert np.array_equal(bits(out[6]), bits(out[7]))
+
+
+def test_lstm_pipeline_long_calls_and_ragged_tiles(weights_blob, orc):
+    """k_lstm_pipe: many steps per call (the consumer follows the producer through thousands of hand-offs), stream counts that leave a ragged
+    last tile, several calls with carried state; every stream against the oracle"""
+    for S, Cn, calls in ((1, 200, 2), (33, 40, 2), (100, 12, 3)):
+        e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+        e.set_option("lstm", 7)
+        base = synth.make_streams(min(S, 6), Cn * calls, seed0=8800 + S)
+        pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+        got = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)[:, :, 1]
+        assert e.get_option("lstm_kernel") == 7
+        e.close()
+        want = orc.forward_streams(base)
+        for s_ in range(S):
+            assert float(np.abs(got[s_] - want[s_ % base.shape[0]]).max()) <= PROB_TOL, (S, s_)
 
 
 @pytest.mark.parametrize("groups", [1, 2, 3, 4, 8])
@@ -393,6 +420,38 @@ def test_hipgraph_replay_at_bench_sizes(weights_blob, S, Cn):
         e.close()
     assert np.array_equal(bits(want), bits(got))
     assert np.array_equal(bits(want[:16]), bits(want[S - 16:]))
+
+
+def test_deferred_join_overlaps_calls_issued_from_one_stream(weights_blob):
+    """option defer_join = 1: a forked call does not make its own stream wait; consecutive calls issued from ONE stream overlap inside the engine
+    and `vadc_amd_join` orders a consumer stream behind them -- same bits as strictly ordered calls, also when the outputs are read on another stream"""
+    import torch
+    S, Cn, steps = 128, 24, 6
+    pcm = synth.make_streams(16, steps * Cn, seed0=7100)
+    pcm = np.ascontiguousarray(np.tile(pcm, (S // 16, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        want = np.concatenate([e.run(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(steps)], axis=1)
+        e.reset_streams()
+        e.set_option("defer_join", 1)
+        d_in = torch.from_numpy(pcm).to("cuda:0")
+        outs = [torch.zeros((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(steps)]
+        issue, reader = torch.cuda.Stream(), torch.cuda.Stream()
+        row = pcm.shape[1]
+        for i in range(steps):                                   # strided input view: copy each step's block to its own contiguous buffer first
+            blk = d_in[:, i * Cn * 1536:(i + 1) * Cn * 1536].contiguous()
+            issue.wait_stream(torch.cuda.current_stream())
+            e.run_device(blk.data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), issue.cuda_stream)
+            blk.record_stream(issue)
+            outs[i].record_stream(issue)
+        e.join(reader.cuda_stream)
+        with torch.cuda.stream(reader):
+            got = torch.cat(outs, dim=1).cpu().numpy()
+        reader.synchronize()
+        e.set_option("defer_join", 0)
+    finally:
+        e.close()
+    assert np.array_equal(bits(want), bits(got))
 
 
 def test_limits_are_enforced(eng):
@@ -474,8 +533,8 @@ def test_auto_lstm_choice_and_partition_are_reported(weights_blob):
     e = Engine(weights_blob, max_streams=256, max_chunks_per_call=16, device=0)
     assert e.get_option("lstm") == 0 and e.get_option("cu_partition") == 1
     e.run(np.zeros((256, 16 * 1536), np.int16))                 # 4096 chunks: forked path
-    assert e.get_option("lstm_kernel") == 6
-    assert e.get_option("lstm_cus") in (8, 16, 24, 32)
+    assert e.get_option("lstm_kernel") == 7                     # 16 stream tiles: the chain would be the longer stream -> two CUs per tile
+    assert e.get_option("lstm_cus") == 32
     e.set_option("lstm", 3)
     e.run(np.zeros((256, 16 * 1536), np.int16))
     assert e.get_option("lstm_kernel") == 3 and e.get_option("lstm_cus") >= 16

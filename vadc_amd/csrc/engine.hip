@@ -25,7 +25,8 @@ void launch_frontend_gemm_f32(const float *, const float *, const float *, float
 void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
-void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, float *, unsigned *, unsigned *);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
+void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -138,10 +139,9 @@ struct vadc_amd_engine {
    // the encoder of call k+1 never waits for the LSTM of call k (it only waits for call k-1's, long finished).
    float *d_xpair[2] = {nullptr, nullptr};
    size_t x_tile_chunks = 0;                    // capacity of a hand-off buffer in (16-stream tile, chunk) blocks
-   // k_lstm_pipe (two workgroups per stream tile): layer 0 -> layer 1 hand-off of h0 (same tile layout and size as a hand-off buffer), published-step
-   // flags per tile, and the word a consumer raises when its bounded spin expires (checked by the synchronous entry points)
-   float *d_h0seq = nullptr;
-   unsigned *d_pipe_flags = nullptr, *d_pipe_error = nullptr;
+   // layer-major LSTM (k_lstm_layer, variant 7): layer 0 -> layer 1 hand-off of the h0 sequence (same tile layout and size as an encoder hand-off
+   // buffer), double buffered over forked calls like it: layer 1 of call k reads pair [xpar] while layer 0 of call k+1 writes the other one
+   float *d_h0pair[2] = {nullptr, nullptr};
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
    float *d_h = nullptr, *d_c = nullptr;
@@ -149,7 +149,8 @@ struct vadc_amd_engine {
    // chunk-group pipeline: front end + encoder of group g+1 (stream A) overlap the LSTM of group g (stream B)
    static constexpr int kMaxGroups = 16;
    int groups = 0;                              // 0 = auto
-   hipStream_t sA = nullptr, sB = nullptr;      // front end + encoder, LSTM
+   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;   // front end + encoder; LSTM (layer 0 in the layer-major form); layer 1 of the layer-major form
+   bool streams_split = false;                  // sB / sC were created for the layer-major form (each half of the LSTM's CU partition)
    int n_cus = 0;
    bool enc_h3_ok = false;                      // every encoder GEMM weight fits fp16's range: layers 2-4 run their GEMMs in the split-fp16 form
    bool lstm_shared = false;                    // the LSTM partition's CUs are also in the other streams' mask
@@ -159,18 +160,21 @@ struct vadc_amd_engine {
    int last_frontend_kernel = -1;               // what the last call's front end was: 0 = k_frontend_sym, 1 = k_frontend_fl, 2 = k_frontend_gemm, 3 = k_frontend (v4 tree)
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
+   bool ev_c_valid[2] = {false, false};         // ev_c[p]: layer 1 of the last layer-major call that used pair p has read its h0 sequence
    int v4_mag = 0;                              // option "v4_mag": 0 = the v4 first stage recovers the magnitudes from Y (no MAG array on the hot path), 1 = it reads MAG
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
+   int defer_join = 0;                          // option "defer_join": forked calls do not make the caller's stream wait for their completion; vadc_amd_join does
    struct GraphEntry { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
-   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr};
+   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr},
+              ev_l0[kMaxGroups] = {nullptr};
    bool ev_graph_valid = false;
    // Call-to-call ordering that does not depend on which stream the caller used: ev_last_a = the last work that touched the
    // front-end / encoder buffers, ev_last_b = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
    // stream(s) that touch these wait for them first (free when it is the same stream) and re-records them.
-   hipEvent_t ev_last_a = nullptr, ev_last_b = nullptr;
+   hipEvent_t ev_last_a = nullptr, ev_last_b = nullptr, ev_last_c = nullptr;   // ev_last_b: last work on layer-0 state, ev_last_c: on layer-1 state (and probabilities)
    bool ev_last_valid = false;
    // profiling
    bool profiling = false;
@@ -506,13 +510,15 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1]};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_graph, e->ev_last_a, e->ev_last_b}) if (ev) (void)hipEventDestroy(ev);
+   if (e->sC) (void)hipStreamDestroy(e->sC);
+   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_c[0], e->ev_c[1], e->ev_graph, e->ev_last_a, e->ev_last_b, e->ev_last_c}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : e->ev_l0) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
@@ -561,7 +567,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b, &e->ev_last_c}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
@@ -578,10 +585,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       if (he == hipSuccess) he = hipMemset(e->d_xpair[p], 0, padded_streams * max_chunks * 448 * sizeof(float));
    }
    e->d_act[3] = e->d_xpair[0];
-   if (he == hipSuccess) he = hipMalloc(&e->d_h0seq, padded_streams * max_chunks * 448 * sizeof(float));
-   if (he == hipSuccess) he = hipMalloc(&e->d_pipe_flags, (padded_streams / kLstmTile + 1) * sizeof(unsigned));
-   if (he == hipSuccess) he = hipMalloc(&e->d_pipe_error, sizeof(unsigned));
-   if (he == hipSuccess) he = hipMemset(e->d_pipe_error, 0, sizeof(unsigned));
+   for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -683,7 +687,7 @@ extern "C" int vadc_amd_reset_kernel_times(vadc_amd_engine *e)
 
 extern "C" const char *vadc_amd_kernel_name(int kernel)
 {
-   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"};
+   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1"};
    return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
@@ -710,6 +714,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
+   if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && value >= 0 && value <= 2) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -724,6 +729,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
+   else if (strcmp(key, "defer_join") == 0) *value = e->defer_join;
    else if (strcmp(key, "v4_mag") == 0) *value = e->v4_mag;
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
@@ -801,12 +807,12 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       }
    }
    run_encoder_layers(e, 0, 2, n, map, 0, st);
-   run_encoder_layers(e, 3, 3, n, map, lstm_kernel >= 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3 / k_lstm_pipe, 1: fp32 tiles for the fp32 kernel
+   run_encoder_layers(e, 3, 3, n, map, lstm_kernel >= 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3 / k_lstm_layer, 1: fp32 tiles for the fp32 kernel
 }
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
 // one stream tile, and whole-chip front-end + encoder time per chunk.
-static double lstm_slot_us(const vadc_amd_engine *e, int lk) { return lk == 7 ? 0.8 : (lk == 6 ? 1.6 : 3.9); }
+static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 1.0 : (lk == 6 ? 1.6 : 3.9); }
 static double enc_us_per_chunk(const vadc_amd_engine *e)
 {
    if (e->model == VADC_AMD_MODEL_V4) return 0.022;
@@ -815,13 +821,17 @@ static double enc_us_per_chunk(const vadc_amd_engine *e)
 
 // LSTM kernel for this call: option "lstm" 0 = auto.  3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when
 // asked for; otherwise split-fp16 operands on the fp16 matrix pipe at fp32 accuracy: 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile),
-// 7 = k_lstm_pipe (the two layers of a tile on two CUs) while the recurrence would otherwise be the longer of the two concurrent streams -- few
-// stream tiles: its time per call is steps x slot whatever the stream count, the front end + encoder's grows with it -- and 2 x tiles
-// workgroups still get a CU each.
-static int resolve_lstm(const vadc_amd_engine *e, int n_streams)
+// 7 = the layer-major form (k_lstm_layer: layer 0 and layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) while the
+// recurrence would otherwise be the longer of the concurrent streams -- few stream tiles: its time per call is steps x slot whatever the stream
+// count, the front end + encoder's grows with it -- and 2 x tiles workgroups still get a CU each.
+// 6 and 7 are BIT-identical (same MFMAs in the same k order per gate row, pinned contraction in the cell update, the same decoder summation tree:
+// tests/test_gpu_parity.py::test_lstm_variants_agree), so the choice may depend on the call's shape without a stream's bits depending on how its
+// chunks are cut into calls.  A small call that stays on the caller's stream takes 6: there the two layer launches would run one after the other.
+static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = true)
 {
    if (e->lstm_variant == 3 || !e->lstm_h3_ok) return 3;
-   if (e->lstm_variant == 6 || e->lstm_variant == 7) return e->lstm_variant;
+   if (e->lstm_variant >= 6) return e->lstm_variant;
+   if (!forked) return 6;
    const int tiles = (n_streams + kLstmTile - 1) / kLstmTile;
    const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
    return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
@@ -858,26 +868,29 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
 // front-end grid that already fills the machine would keep the LSTM workgroups waiting for a free CU.  So
 // when the LSTM needs few CUs the two streams get DISJOINT CU masks (hipExtStreamCreateWithCUMask): the
 // LSTM chain owns `want` CUs outright and runs truly concurrently with the next group's front end.
-static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
+static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
 {
    bool shared = false;
    int want = lstm_partition_cus(e, n_streams, &shared);
-   if (e->lstm_cus == want && e->lstm_shared == shared && e->sA && e->sB) return VADC_AMD_OK;
-   if (e->sA) { HIP_TRY(hipStreamSynchronize(e->sA), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
-   if (e->sB) { HIP_TRY(hipStreamSynchronize(e->sB), VADC_AMD_EHIP); (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
+   const bool split = lk == 7;                                  // layer-major LSTM: stream B = layer 0 on one half of the partition, stream C = layer 1 on the other
+   if (e->lstm_cus == want && e->lstm_shared == shared && e->streams_split == split && e->sA && e->sB && e->sC) return VADC_AMD_OK;
+   for (hipStream_t *ps : {&e->sA, &e->sB, &e->sC})
+      if (*ps) { HIP_TRY(hipStreamSynchronize(*ps), VADC_AMD_EHIP); (void)hipStreamDestroy(*ps); *ps = nullptr; }
    bool masked = false;
    if (want > 0) {
       const int words = (e->n_cus + 31) / 32;
-      std::vector<uint32_t> mb(words, 0u), ma(words, 0u);
-      for (int cu = 0; cu < e->n_cus; ++cu) (cu < want ? mb : ma)[cu / 32] |= 1u << (cu % 32);
-      if (shared) for (int cu = 0; cu < want; ++cu) ma[cu / 32] |= 1u << (cu % 32);   // the LSTM keeps its CUs, the other streams may use them too
+      const int wb = split ? want / 2 : want;
+      std::vector<uint32_t> mb(words, 0u), mc(words, 0u), ma(words, 0u);
+      for (int cu = 0; cu < e->n_cus; ++cu) (cu < wb ? mb : (cu < want ? mc : ma))[cu / 32] |= 1u << (cu % 32);
+      if (!split) mc = mb;
+      if (shared) for (int cu = 0; cu < want; ++cu) ma[cu / 32] |= 1u << (cu % 32);   // the LSTM keeps its CUs, the other stream may use them too
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
       hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
-      masked = (ea == hipSuccess && eb == hipSuccess);
+      hipError_t ec = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sC, (uint32_t)words, mc.data()) : eb;
+      masked = (ea == hipSuccess && eb == hipSuccess && ec == hipSuccess);
       if (!masked) {
          (void)hipGetLastError();
-         if (e->sA) { (void)hipStreamDestroy(e->sA); e->sA = nullptr; }
-         if (e->sB) { (void)hipStreamDestroy(e->sB); e->sB = nullptr; }
+         for (hipStream_t *ps : {&e->sA, &e->sB, &e->sC}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
       }
    }
    if (!masked) {
@@ -886,10 +899,13 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams)
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = highest priority
       HIP_TRY(hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamCreateWithPriority(&e->sC, hipStreamNonBlocking, hi), VADC_AMD_EHIP);
    }
    e->lstm_cus = want;
    e->lstm_shared = shared && want > 0;
+   e->streams_split = split;
    e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
+   e->ev_c_valid[0] = e->ev_c_valid[1] = false;
    return VADC_AMD_OK;
 }
 
@@ -906,6 +922,19 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 // inside a graph; the fork / join and the call-to-call ordering (events below) stay outside, exactly as for eager launches, so replays of
 // consecutive steps overlap the same way eager steps do (step k+1's front end + encoder under step k's LSTM chain) instead of serialising.
 // Profiling (per-kernel events) needs eager launches, so it bypasses the graphs.
+// the LSTM + decoder of chunks [c0, c0 + cg) on ONE stream: one kernel for both layers, or (lk == 7 asked for on a single stream) the two layer launches in turn
+static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+{
+   if (lk == 7) {
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model); }
+      KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
+      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model);
+      return;
+   }
+   KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
+   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model);
+}
+
 struct SeqKey { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; };
 template <typename F>
 static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, F &&enqueue)
@@ -943,7 +972,8 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
       return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
    const int G = pick_groups(e, n_chunks);
-   const int lk = resolve_lstm(e, n_streams);
+   const bool forked = !(G == 1 && (long)n_streams * n_chunks < 2048);
+   const int lk = resolve_lstm(e, n_streams, forked);
    e->last_lstm_kernel = lk;
    e->last_frontend_kernel = pick_frontend(e, d_in);
    int rc = VADC_AMD_OK;
@@ -952,32 +982,39 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
    // while every call keeps strict stream semantics (its results are complete when its own stream reaches the join).
    const bool order = e->ev_last_valid;
-   if (G == 1 && (long)n_streams * n_chunks < 2048) {
+   if (!forked) {
       const ItemMap map{n_chunks, 0, n_chunks};
-      if (order) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); }
+      if (order) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); (void)hipStreamWaitEvent(st, e->ev_last_c, 0); }
       rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
          run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
-         KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
+         launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, 0, n_chunks, st);
       });
       if (rc) return rc;
-      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); e->ev_last_valid = true;
+      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); (void)hipEventRecord(e->ev_last_c, st); e->ev_last_valid = true;
    } else {
-      rc = ensure_pipeline_streams(e, n_streams);
+      rc = ensure_pipeline_streams(e, n_streams, lk);
       if (rc) return rc;
-      // fork: stream A = front end + encoder of every chunk group in order, stream B = the LSTM chain
+      // fork: stream A = front end + encoder of every chunk group in order, stream B = the LSTM chain (layer-major form: B = layer 0, C = layer 1)
+      const bool split = lk == 7;
       (void)hipEventRecord(e->ev_in, st);
       (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
       (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+      if (split) (void)hipStreamWaitEvent(e->sC, e->ev_in, 0);
       if (order) {
+         // ev_last_b / ev_last_c: the last work on the layer-0 / layer-1 halves of the per-stream state, whichever stream it ran on.  One kernel for
+         // both layers waits for both; in the layer-major form each layer waits for its own half only (that is what lets layer 0 of this
+         // call run beside layer 1 of the previous one)
          (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
          (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
+         if (split) (void)hipStreamWaitEvent(e->sC, e->ev_last_c, 0);
+         else       (void)hipStreamWaitEvent(e->sB, e->ev_last_c, 0);
       }
       // this call's hand-off buffer; its last reader was the LSTM of the forked call before the previous one (long finished: the wait is free)
       e->xpar ^= 1;
       const int xp = e->xpar;
       e->d_act[3] = e->d_xpair[xp];
       if (e->ev_b_valid[xp]) (void)hipStreamWaitEvent(e->sA, e->ev_b[xp], 0);
+      if (split && e->ev_c_valid[xp]) (void)hipStreamWaitEvent(e->sB, e->ev_c[xp], 0);     // this call's h0 pair: last read by layer 1 two calls ago
       // group sizes: a SHORT first group (the LSTM chain starts early), the rest split evenly
       int sizes[vadc_amd_engine::kMaxGroups];
       {
@@ -999,17 +1036,34 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          if (rc) return rc;
          (void)hipEventRecord(e->ev_fe[gi], e->sA);
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
-         KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
+         if (!split) launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, c0, cg, e->sB);
+         else {
+            {
+               KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
+            }
+            (void)hipEventRecord(e->ev_l0[gi], e->sB);
+            (void)hipStreamWaitEvent(e->sC, e->ev_l0[gi], 0);
+            KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
+            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model);
+         }
          c0 += cg;
       }
       // join
       (void)hipEventRecord(e->ev_a, e->sA);
-      (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); e->ev_last_valid = true;
+      (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); (void)hipEventRecord(e->ev_last_c, split ? e->sC : e->sB);
+      e->ev_last_valid = true;
       (void)hipEventRecord(e->ev_b[xp], e->sB);
       e->ev_b_valid[xp] = true;
-      (void)hipStreamWaitEvent(st, e->ev_a, 0);
-      (void)hipStreamWaitEvent(st, e->ev_b[xp], 0);
+      if (split) {
+         (void)hipEventRecord(e->ev_c[xp], e->sC);
+         e->ev_c_valid[xp] = true;
+      }
+      if (!e->defer_join) {                                    // strict stream semantics: the caller's stream continues when the call is complete
+         (void)hipStreamWaitEvent(st, e->ev_a, 0);
+         (void)hipStreamWaitEvent(st, e->ev_b[xp], 0);
+         if (split) (void)hipStreamWaitEvent(st, e->ev_c[xp], 0);
+      }
    }
    hipError_t he = hipGetLastError();
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he));
@@ -1038,7 +1092,25 @@ extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "synchronize: NULL engine");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   if (e->ev_last_valid) {
+      HIP_TRY(hipEventSynchronize(e->ev_last_a), VADC_AMD_EHIP);
+      HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP);
+      HIP_TRY(hipEventSynchronize(e->ev_last_c), VADC_AMD_EHIP);
+   }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_join(vadc_amd_engine *e, void *hip_stream)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "join: NULL engine");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   if (e->ev_last_valid) {
+      hipStream_t st = (hipStream_t)hip_stream;
+      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_a, 0), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_b, 0), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_c, 0), VADC_AMD_EHIP);
+   }
    return VADC_AMD_OK;
 }
 
@@ -1078,7 +1150,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
 // state accessors are synchronous; they first wait for the last LSTM enqueued through ANY stream
 static int wait_last_lstm(vadc_amd_engine *e)
 {
-   if (e->ev_last_valid) HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP);
+   if (e->ev_last_valid) { HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP); HIP_TRY(hipEventSynchronize(e->ev_last_c), VADC_AMD_EHIP); }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -1230,7 +1302,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
          HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       }
    }
-   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, e->d_probs, n_streams, n_chunks, 0, n_chunks, st, e->model, e->d_h0seq, e->d_pipe_flags, e->d_pipe_error);
+   launch_lstm_on(e, lk, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);

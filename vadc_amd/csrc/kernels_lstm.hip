@@ -144,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
 
    const int total = TS * cg;
    float psum = 0.0f;
+#pragma unroll 1      // one copy of the slot body (see k_lstm_layer): a step's bits must not depend on its position in the call
    for (int k = 0; k <= total; ++k) {
       const bool active = (L == 0) ? (k < total) : (k >= 1);
       const int step = (L == 0) ? k : k - 1;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_h3(const float *__res
 #ifndef VADC_LSTM_ABL_NOGATES
             const float ig = fast_sigmoid(acc[0][r]), fg = fast_sigmoid(acc[1][r]);
             const float gg = fast_tanh(acc[2][r]), og = fast_sigmoid(acc[3][r]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = fmaf(fg, c[r], ig * gg);                    // pinned contraction: k_lstm_layer rounds the same way (bit-identical state)
             const float hn = og * fast_tanh(c[r]);
 #else
             c[r] = 0.5f * c[r] + 0.001f * (acc[0][r] + acc[1][r]);   // ablation (timing only)
@@ -410,59 +411,36 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_lstm_pipe: the two layers of a 16-stream tile on TWO CUs, layer 1 trailing layer 0 through a step-by-step hand-off in global memory
+// k_lstm_layer: ONE layer of the recurrence over all steps of the call; the two layers are two launches on two CU sets, pipelined over calls
 // ------------------------------------------------------------------------------------------------
 // With few stream tiles the recurrence is a latency chain (TS x chunks dependent slots per call) and k_lstm_wavefront_h3's slot is bound by what
 // ONE CU's four matrix pipes have to issue: 8 waves x 48 split-fp16 MFMAs = 1536 pipe cycles per slot, before the gates.  Layer 1 at
-// step s needs only h0_s, never anything newer, so the layers are a producer / consumer PIPELINE, not a loop: here a tile is served by two
-// workgroups on two CUs.  Workgroup L = 0 runs layer 0 over all steps of the call and publishes every h0_s (as the split-fp16 tile the next GEMM
-// wants as its B operand: 4 KB per step, the layout of the encoder hand-off) to global memory; workgroup L = 1 runs layer 1 + decoder over the
-// same steps, reading h0_s as ITS input sequence.  Both are the same code: "one LSTM layer over an input sequence of split-fp16 tiles".  All 8
-// waves of a workgroup work on one layer: a wave owns 8 hidden units x 4 gates = 2 MFMA row tiles (rows ordered [unit][gate], so that i, f, g, o
-// of a unit are the 4 accumulator registers of one lane), 24 MFMAs and 2 cells per lane and slot -- half of the single-CU kernel's -- and the
-// recurrent h stays in the workgroup's LDS exactly as before (one barrier per slot).
-// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): the producer copies the h tile of slot k from LDS to global with 16-byte `sc1`
-// (write-through) stores during slot k+1, every storing wave drains them (s_waitcnt vmcnt(0)) and bumps a counter in LDS, the wave whose bump is
-// the last publishes `flag[tile] = k + 1` with an agent-scope store.  The consumer reads the flag with agent-scope (sc1) loads, one slot ahead of
-// need and off its critical path (the value is consumed at the end of the slot), and every load of handed-off bytes is an `sc1` load.  It only
-// spins when it has caught up with the producer; the spin is bounded (kPipeSpinLimit polls ~ seconds): on expiry it raises `*error` and runs on
-// with whatever it reads, so a lost producer can never hang the GPU.  The host zeroes the flags on the launch's stream before every launch.
-// The engine uses this kernel while 2 x tiles workgroups fit the LSTM's CU partition one per CU (<= 1024 streams); beyond that the chain is
-// throughput work and k_lstm_wavefront_h3 keeps both layers on one CU.
-constexpr unsigned kPipeSpinLimit = 1u << 22;
-
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_sc1(void *gptr, u4v v)
+// step s needs only h0_s, never anything newer: the layers are a producer / consumer pipeline, not a loop.  The recurrence is therefore also run
+// LAYER-MAJOR (mathematically the reference's step-major order, lstm.c:128-144): launch L = 0 runs layer 0 over all steps of the call and writes
+// every h0_s -- as the split-fp16 tile the next GEMM wants as its B operand, 4 KB per step, the layout of the encoder hand-off -- to global
+// memory; launch L = 1 runs layer 1 + decoder over the same steps with that sequence as ITS input.  Both are the same code: "one LSTM layer over
+// an input sequence of split-fp16 tiles".  The engine puts the two launches on two streams with CU sets of their own: layer 1 of call k runs
+// beside layer 0 of call k+1 (and beside the front end + encoder of call k+2), so in steady state a call costs max(layer time), not their sum,
+// and the hand-off needs nothing but the kernel boundary.
+// All 8 waves of a workgroup work on one layer: a wave owns 8 hidden units x 4 gates = 2 MFMA row tiles (rows ordered [unit][gate], so that
+// i, f, g, o of a unit are the 4 accumulator registers of one lane), 24 MFMAs and 2 cells per lane and slot -- half of the two-layer kernel's.
+// Measured slot: 1.0 us against 1.54 us (tools: bench.py --opt lstm=6 / 7).
+template <int TS, int DEC, int L>
+__global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
+                                                       _Float16 *__restrict__ h0seq,            // L = 0: the h0 sequence, same layout
+                                                       LstmWeights w,
+                                                       float *__restrict__ hs, float *__restrict__ cs,
+                                                       float *__restrict__ probs,               // L = 1
+                                                       int n_streams, int n_chunks, int c0, int cg)
 {
-   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(gptr), "v"(v) : "memory");
-}
-__device__ __forceinline__ u4v load16_sc1(const void *gptr)
-{
-   u4v v;
-   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(gptr) : "memory");
-   return v;
-}
-
-template <int TS, int DEC>
-__global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ xh,    // split-fp16 X tiles (encoder output)
-                                                      _Float16 *__restrict__ h0seq,    // [tile][n_chunks][TS][hi|lo][16][64] halves: layer 0 -> layer 1
-                                                      unsigned *__restrict__ flags,    // [tiles]: steps of h0seq published (zeroed by the host before the launch)
-                                                      unsigned *__restrict__ error,    // raised when a consumer's bounded spin expires
-                                                      LstmWeights w,
-                                                      float *__restrict__ hs, float *__restrict__ cs,
-                                                      float *__restrict__ probs,
-                                                      int n_streams, int n_chunks, int c0, int cg, int tiles)
-{
-   // [parity][hi / lo][stream][unit]: the CURRENT h of this workgroup's layer as split fp16
+   // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
    __shared__ float pd[2][8][2][kTileS];
-   __shared__ unsigned drained_s, known_s;
 
    const int tid = threadIdx.x;
    const int lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int L = blockIdx.x >= tiles ? 1 : 0;            // layer-0 workgroups first: dispatched first
-   const int tile = blockIdx.x - L * tiles;
+   const int tile = blockIdx.x;
    const int col = lane & 15;
    const int quad = lane >> 4;
    const int s0 = tile * kTileS;
@@ -488,7 +466,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
             }
       }
    }
-   if (tid == 0) { drained_s = 0; known_s = 0; }
+   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
    float c[2], hlast[2], dw[2][2], bias_r[2][4];
 #pragma unroll
    for (int m = 0; m < 2; ++m)
@@ -505,72 +483,30 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
          hi2[m] = (_Float16)hlast[m];
          lo2[m] = (_Float16)(hlast[m] - (float)hi2[m]);
       }
-      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
       *reinterpret_cast<h2v *>(&hb[0][0][col * kHPitch + u0]) = (h2v){hi2[0], hi2[1]};
       *reinterpret_cast<h2v *>(&hb[0][1][col * kHPitch + u0]) = (h2v){lo2[0], lo2[1]};
    }
-   // input sequence of this layer: split-fp16 tiles, 4 KB per step; a lane's B fragments of k-block kb: 16 bytes at (row col) + 32 kb + 8 quad
+   // input sequence: 4 KB per step; a lane's B fragments of k-block kb: 16 bytes at (row col) + 32 kb + 8 quad of the hi and of the lo tile
    constexpr int kStepHalves = 2 * kTileS * 64;
-   const _Float16 *in_seq = (L == 0 ? reinterpret_cast<const _Float16 *>(xh) : h0seq) + ((size_t)tile * n_chunks + c0) * TS * kStepHalves;
-   const _Float16 *in_lane = in_seq + col * 64 + 8 * quad;
+   const _Float16 *in_lane = in_tiles + ((size_t)tile * n_chunks + c0) * TS * kStepHalves + col * 64 + 8 * quad;
    _Float16 *out_seq = h0seq + ((size_t)tile * n_chunks + c0) * TS * kStepHalves;
    const int total = TS * cg;
-   __syncthreads();
-
-   // consumer: steps known to be published.  `need` steps must be visible before the fragments of step need - 1 are requested.
-   unsigned known = (L == 0) ? 0xffffffffu : 0u;
-   unsigned spins = 0;
-   auto wait_for = [&](unsigned need) {
-      while (known < need) {                                 // uniform over the workgroup: `known` comes from LDS behind a barrier
-         if (tid == 0) {
-            unsigned v = __hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v < need) {
-               __builtin_amdgcn_s_sleep(2);
-               if (++spins > kPipeSpinLimit) { atomicOr(error, 1u); v = 0xffffffffu; }        // give up loudly, never hang
-            }
-            known_s = v;
-         }
-         __syncthreads();
-         known = known_s;
-         __syncthreads();
-      }
-   };
-   auto load_frags = [&](int step, h8v (&fh)[2], h8v (&fl)[2]) {
-      const _Float16 *p = in_lane + (size_t)step * kStepHalves;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-         if (L == 0) {
-            fh[kb] = *reinterpret_cast<const h8v *>(p + 32 * kb);
-            fl[kb] = *reinterpret_cast<const h8v *>(p + kTileS * 64 + 32 * kb);
-         } else {                                             // handed-off bytes: sc1 loads only
-            const u4v a = load16_sc1(p + 32 * kb), b = load16_sc1(p + kTileS * 64 + 32 * kb);
-            fh[kb] = __builtin_bit_cast(h8v, a);
-            fl[kb] = __builtin_bit_cast(h8v, b);
-         }
-      }
-   };
    h8v xnh[2], xnl[2];
-   // the consumer's fragment loads are inline asm (sc1): hipcc does not count them, so the wait is explicit and TIED to the registers
-   // ("+v"), which keeps every use of them behind it
-#define VADC_PIPE_WAIT_FRAGS() asm volatile("s_waitcnt vmcnt(0)" : "+v"(xnh[0]), "+v"(xnh[1]), "+v"(xnl[0]), "+v"(xnl[1])::"memory")
-   wait_for(1);
-   load_frags(0, xnh, xnl);
-   if (L == 1) VADC_PIPE_WAIT_FRAGS();
+#pragma unroll
+   for (int kb = 0; kb < 2; ++kb) {
+      xnh[kb] = *reinterpret_cast<const h8v *>(in_lane + 32 * kb);
+      xnl[kb] = *reinterpret_cast<const h8v *>(in_lane + kTileS * 64 + 32 * kb);
+   }
+   __syncthreads();
 
    int par = 0;
    float rsum[2] = {0.0f, 0.0f};
    float psum = 0.0f;
+   // one copy of the slot body: an unrolled loop may round its copies differently (fma contraction is decided per copy), and then a step's
+   // bits would depend on its position in the call
+#pragma unroll 1
    for (int k = 0; k < total; ++k) {
       const int chi = k / TS, t = k - chi * TS;
-      // consumer: look at the flag early, use the value at the end of the slot (off the critical path)
-      unsigned flag_seen = 0;
-      if (L == 1 && tid == 0) flag_seen = __hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // producer: publish the h tile of slot k - 1 (LDS parity `par`, complete since the last barrier) while this slot computes
-      if (L == 0 && k >= 1 && tid < 256) {
-         const int rowi = tid >> 3, seg = tid & 7;           // 32 rows (16 hi + 16 lo) of 64 halves = 8 x 16 bytes
-         const u4v v = *reinterpret_cast<const u4v *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
-         store16_sc1(out_seq + (size_t)(k - 1) * kStepHalves + rowi * 64 + seg * 8, v);
-      }
       f4v acc[2];
       h8v xch[2], xcl[2];
 #pragma unroll
@@ -578,12 +514,28 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
 #pragma unroll
          for (int r = 0; r < 4; ++r) acc[m][r] = bias_r[m][r];
       xch[0] = xnh[0]; xch[1] = xnh[1]; xcl[0] = xnl[0]; xcl[1] = xnl[1];
-      if (k + 1 < total && known >= (unsigned)(k + 2)) load_frags(k + 1, xnh, xnl);       // next step's input, one slot ahead (if already published)
-      const bool prefetched = (k + 1 < total) && known >= (unsigned)(k + 2);
+      if (k + 1 < total) {                                    // next step's input, one slot ahead
+         const _Float16 *p = in_lane + (size_t)(k + 1) * kStepHalves;
+#pragma unroll
+         for (int kb = 0; kb < 2; ++kb) {
+            xnh[kb] = *reinterpret_cast<const h8v *>(p + 32 * kb);
+            xnl[kb] = *reinterpret_cast<const h8v *>(p + kTileS * 64 + 32 * kb);
+         }
+      }
+      // layer 0: write the h tile of slot k - 1 (LDS parity `par`, complete since the last barrier) to the h0 sequence while this slot computes.
+      // Issued AFTER the input loads: vector-memory operations retire in order, so a store in front of them would put its completion on the
+      // path of the next slot's input (measured: 0.96 instead of 0.70 ms per 672 slots)
+      if (L == 0 && k >= 1 && tid < 256) {
+         __builtin_amdgcn_sched_barrier(0);
+         const int rowi = tid >> 3, seg = tid & 7;           // 32 rows (16 hi + 16 lo) of 64 halves = 8 x 16 bytes
+         *reinterpret_cast<uint4 *>(out_seq + (size_t)(k - 1) * kStepHalves + rowi * 64 + seg * 8) =
+            *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
+         __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
          h8v bh, bl;
-         if (kb < 2) { bh = xch[kb]; bl = xcl[kb]; }
+         if (kb < 2) { bh = xch[kb]; bl = xcl[kb]; }          // k-blocks 0, 1: the layer's input; 2, 3: its own h
          else {
             const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
             bh = *reinterpret_cast<const h8v *>(&hb[par][0][off]);
@@ -601,61 +553,50 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
       for (int m = 0; m < 2; ++m) {
          const float ig = fast_sigmoid(acc[m][0]), fg = fast_sigmoid(acc[m][1]);
          const float gg = fast_tanh(acc[m][2]), og = fast_sigmoid(acc[m][3]);
-         c[m] = fg * c[m] + ig * gg;
+         c[m] = fmaf(fg, c[m], ig * gg);                       // as k_lstm_wavefront_h3
          const float hn = og * fast_tanh(c[m]);
          hlast[m] = hn;
          hi2[m] = (_Float16)hn;
          lo2[m] = (_Float16)(hn - (float)hi2[m]);
          if (L == 1) rsum[m] = (DEC == 0 ? rsum[m] : 0.0f) + fmaxf(hn, 0.0f);
       }
-      {
-         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-         *reinterpret_cast<h2v *>(&hb[par ^ 1][0][col * kHPitch + u0]) = (h2v){hi2[0], hi2[1]};
-         *reinterpret_cast<h2v *>(&hb[par ^ 1][1][col * kHPitch + u0]) = (h2v){lo2[0], lo2[1]};
-      }
+      *reinterpret_cast<h2v *>(&hb[par ^ 1][0][col * kHPitch + u0]) = (h2v){hi2[0], hi2[1]};
+      *reinterpret_cast<h2v *>(&hb[par ^ 1][1][col * kHPitch + u0]) = (h2v){lo2[0], lo2[1]};
       const bool chunk_done = (L == 1) && (t == TS - 1);
       if (L == 1 && (DEC == 1 || chunk_done)) {
-         // decoder partial dots of this wave's 8 units: DEC 0 once per chunk (mean_t then sigmoid, two outputs), DEC 1 every step (one output)
-         float d0 = fmaf(dw[0][1], rsum[1], dw[0][0] * rsum[0]), d1 = 0.0f;
-         if (DEC == 0) { d1 = fmaf(dw[1][1], rsum[1], dw[1][0] * rsum[0]); rsum[0] = rsum[1] = 0.0f; }
-         d0 += __shfl_xor(d0, 16); d0 += __shfl_xor(d0, 32);
-         if (DEC == 0) { d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32); }
-         if (quad == 0) { pd[k & 1][wave][0][col] = d0; if (DEC == 0) pd[k & 1][wave][1][col] = d1; }
+         // decoder partial dots of this wave's 8 units: DEC 0 once per chunk (mean_t then sigmoid, two outputs: silero_v3.c:231-303),
+         // DEC 1 every step (one output, sigmoid then mean_t: silero_vad.py:200-204,222)
+         // The summation tree is k_lstm_wavefront_h3's, so that the probabilities do not depend on which of the two kernels served a call: there a
+         // lane chains 4 consecutive units with fma, the 4 quads of a wave add as (q0 + q1) + (q2 + q3), the 4 waves as (w0 + w1) + (w2 + w3).
+         // Here those 4 units are this lane's 2 (even quad) followed by the 2 of the lane 16 above (odd quad): the odd quad continues the chain.
+         float d0, d1 = 0.0f;
+         {
+            const float pe0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], 0.0f));
+            const float up0 = __shfl_up(pe0, 16);
+            d0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], up0));         // odd quads: the 4-unit chain of h3's lane
+            d0 += __shfl_xor(d0, 32);                                           // quads 1 + 3 = h3's (q0 + q1) in even waves, (q2 + q3) in odd waves
+            if (DEC == 0) {
+               const float pe1 = fmaf(dw[1][1], rsum[1], fmaf(dw[1][0], rsum[0], 0.0f));
+               const float up1 = __shfl_up(pe1, 16);
+               d1 = fmaf(dw[1][1], rsum[1], fmaf(dw[1][0], rsum[0], up1));
+               d1 += __shfl_xor(d1, 32);
+               rsum[0] = rsum[1] = 0.0f;
+            }
+         }
+         if (quad == 1) { pd[k & 1][wave][0][col] = d0; if (DEC == 0) pd[k & 1][wave][1][col] = d1; }
       }
-      // producer: the copy of slot k - 1's tile is drained -> count; the last of the 4 storing waves publishes step k - 1
-      if (L == 0 && k >= 1 && tid < 256) {
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-         unsigned old = 0;
-         if (lane == 0) old = atomicAdd(&drained_s, 1u);
-         old = __builtin_amdgcn_readfirstlane(old);
-         if (lane == 0 && old == 4u * (unsigned)(k - 1) + 3u) __hip_atomic_store(flags + tile, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (L == 1) {
-         if (prefetched) VADC_PIPE_WAIT_FRAGS();
-         if (tid == 0) known_s = flag_seen;
-      }
-      __syncthreads();
+      __syncthreads();                                        // one barrier per slot
       par ^= 1;
       if (L == 1) {
-         known = max(known, known_s);
-         if (k + 1 < total && !prefetched) {                 // caught up with the producer: wait (bounded), then fetch the next step's input now
-            wait_for((unsigned)(k + 2));
-            load_frags(k + 1, xnh, xnl);
-            VADC_PIPE_WAIT_FRAGS();
-         }
          if (DEC == 0 && chunk_done && wave == 0 && lane < 2 * kTileS) {
             const int sc = lane & 15, f = lane >> 4, q = k & 1;
-            float m = 0.0f;
-#pragma unroll
-            for (int wv = 0; wv < 8; wv += 2) m += pd[q][wv][f][sc] + pd[q][wv + 1][f][sc];
+            float m = ((pd[q][0][f][sc] + pd[q][1][f][sc]) + (pd[q][2][f][sc] + pd[q][3][f][sc])) + ((pd[q][4][f][sc] + pd[q][5][f][sc]) + (pd[q][6][f][sc] + pd[q][7][f][sc]));
             m = m / (float)TS + w.dec_b[f];
             if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
          }
          if (DEC == 1 && wave == 0 && lane < kTileS) {
             const int q = k & 1;
-            float m = 0.0f;
-#pragma unroll
-            for (int wv = 0; wv < 8; wv += 2) m += pd[q][wv][0][lane] + pd[q][wv + 1][0][lane];
+            const float m = ((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + ((pd[q][4][0][lane] + pd[q][5][0][lane]) + (pd[q][6][0][lane] + pd[q][7][0][lane]));
             psum += sigmoidf_(m + w.dec_b[0]);
             if (t == TS - 1) {
                const float pr = psum / (float)TS;
@@ -668,19 +609,11 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
          }
       }
    }
-   if (L == 0) {                                              // the last step's tile
-      if (tid < 256) {
-         const int rowi = tid >> 3, seg = tid & 7;
-         const u4v v = *reinterpret_cast<const u4v *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
-         store16_sc1(out_seq + (size_t)(total - 1) * kStepHalves + rowi * 64 + seg * 8, v);
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-         unsigned old = 0;
-         if (lane == 0) old = atomicAdd(&drained_s, 1u);
-         old = __builtin_amdgcn_readfirstlane(old);
-         if (lane == 0 && old == 4u * (unsigned)(total - 1) + 3u) __hip_atomic_store(flags + tile, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+   if (L == 0 && tid < 256) {                                 // the last step's tile
+      const int rowi = tid >> 3, seg = tid & 7;
+      *reinterpret_cast<uint4 *>(out_seq + (size_t)(total - 1) * kStepHalves + rowi * 64 + seg * 8) =
+         *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
    }
-#undef VADC_PIPE_WAIT_FRAGS
    if (col_ok) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -690,20 +623,30 @@ __global__ __launch_bounds__(512, 1) void k_lstm_pipe(const float *__restrict__ 
    }
 }
 
-// processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
-// variant: 6 = k_lstm_wavefront_h3 (enc = split-fp16 tiles), 7 = k_lstm_pipe (the same tiles; two workgroups per stream tile, h0seq / flags /
-// error are its hand-off buffers), 3 = k_lstm_wavefront_fused (enc = fp32 tiles)
-// model: 0 = Silero v3.1 (7 steps per chunk), 1 = Silero v4 (3 steps)
-void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
-                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, float *h0seq, unsigned *flags, unsigned *error)
+// one layer of the layer-major form (engine variant 7): layer 0 reads the encoder's split-fp16 tiles and writes h0seq, layer 1 reads h0seq
+void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
+                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
 {
    const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
-   if (variant == 7) {
-      const int tiles = (int)grid.x;
-      (void)hipMemsetAsync(flags, 0, sizeof(unsigned) * tiles, st);
-      if (model == 1) hipLaunchKernelGGL((k_lstm_pipe<3, 1>), dim3(2 * tiles), block, 0, st, enc, reinterpret_cast<_Float16 *>(h0seq), flags, error, w, hs, cs, probs, n_streams, n_chunks, c0, cg, tiles);
-      else            hipLaunchKernelGGL((k_lstm_pipe<7, 0>), dim3(2 * tiles), block, 0, st, enc, reinterpret_cast<_Float16 *>(h0seq), flags, error, w, hs, cs, probs, n_streams, n_chunks, c0, cg, tiles);
-   } else if (variant == 6) {
+   const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
+   _Float16 *h = reinterpret_cast<_Float16 *>(h0seq);
+   if (layer == 0) {
+      if (model == 1) hipLaunchKernelGGL((k_lstm_layer<3, 1, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      else            hipLaunchKernelGGL((k_lstm_layer<7, 0, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   } else {
+      if (model == 1) hipLaunchKernelGGL((k_lstm_layer<3, 1, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+      else            hipLaunchKernelGGL((k_lstm_layer<7, 0, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   }
+}
+
+// processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
+// variant: 6 = k_lstm_wavefront_h3 (enc = split-fp16 tiles), 3 = k_lstm_wavefront_fused (enc = fp32 tiles); 7 is two launch_lstm_layer calls
+// model: 0 = Silero v3.1 (7 steps per chunk), 1 = Silero v4 (3 steps)
+void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
+                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
+{
+   const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
+   if (variant == 6) {
       if (model == 1) hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
       else            hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
    } else {

@@ -24,7 +24,7 @@ STAGES = {"magnitude": 0, "normalized": 1, "layer1": 2, "layer2": 3, "layer3": 4
 STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}          # Silero v3.1
 STAGE_SHAPES_V4 = {0: (129, 24), 1: (129, 24), 2: (16, 12), 3: (32, 6), 4: (32, 3), 5: (64, 3)}       # Silero v4
 MODEL_V31, MODEL_V4 = 0, 1
-KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm"]
+KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1"]
 
 
 class VadcAmdError(RuntimeError):
@@ -109,6 +109,10 @@ class Engine:
 
     def synchronize(self):
         self._check(self._L.vadc_amd_synchronize(self._h))
+
+    def join(self, hip_stream: int = 0):
+        """make `hip_stream` wait for every call issued so far (see option "defer_join")"""
+        self._check(self._L.vadc_amd_join(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     # ---- state ----
     def reset_streams(self, ids: Optional[np.ndarray] = None):
