@@ -113,7 +113,10 @@ int  vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps);
 /* ---- the hot path: replaces backend_run (silero.h:53-74) ------------------------------------ */
 
 /* Host buffers, synchronous (copies in, runs, copies out).  samples: f32 in [-1,1) exactly as
- * process_chunks hands them over (vadc.c:74-75); probs: [n_streams][n_chunks][2]. */
+ * process_chunks hands them over (vadc.c:74-75); probs: [n_streams][n_chunks][2].
+ * Limits of a call (else VADC_AMD_EINVAL): n_streams <= max_streams; n_streams * n_chunks <= max_streams * max_chunks_per_call; and, because the encoder ->
+ * LSTM hand-off is stored in tiles of 16 streams, ceil(n_streams / 16) * n_chunks <= ceil(max_streams / 16) * max_chunks_per_call (so ONE stream may bring
+ * up to ceil(max_streams / 16) * max_chunks_per_call chunks, not max_streams * max_chunks_per_call). */
 int  vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, int n_chunks, float *probs);
 /* Same from s16le PCM; the /32768.0f of vadc.c:883,898 happens on the device (exact in fp32). */
 int  vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs);
@@ -156,41 +159,30 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* Tuning / bring-up switches:  "lstm"   0 = auto (default): layer-wavefront kernel with all gate GEMMs on the fp16 matrix pipe
- *                                      with split-fp16 operands (fp32 accuracy; variant 6); the fp32 kernels (0/3) if an LSTM
- *                                      weight does not fit fp16's range;
- *                                      1 = simple reference kernel, 2 = step-sequential fp32 MFMA, 3 = fp32 wavefront with
- *                                      fused input projection, 4 = fp32 wavefront with hoisted input projection,
- *                                      5 = split-fp16 wavefront with hoisted input projection, 6 = split-fp16 wavefront with the
- *                                      projection inside (the last encoder stage hands over split-fp16 tiles; what auto picks)
- *                             "frontend" v3.1: 0 = k_frontend_fl (bit-exact VALU tree, one lane per frame, default), 1 = k_frontend_mx2
- *                                      (products issued as MFMA K=1; experimental, bit-identical, not faster: fp32 MFMA shares the
- *                                      vector ALU lanes), 2 = k_frontend (the same tree with one lane per 64-sample block and wave shifts);
- *                                      v4: 0 = k_frontend_gemm_v4 (folded STFT GEMM on the fp16 matrix pipe, default),
- *                                      1 = the tree kernel with the v4 geometry
- *                             "fe_nps" k_frontend_fl workgroup size: 1 = 64 positions / 256 threads (default), 2 = 128 positions / 512 threads
- *                             "fe_persist" k_frontend_fl grid: 0 = one workgroup per 64 positions (default), 1 = persistent workgroups drawing
- *                                      their units from a work counter (faster alone on the chip, not inside the engine)
- *                             "encoder" 0 = MFMA layer kernels (default), 1 = VALU bring-up layer kernels (v3.1), 2 = MFMA layer kernels with
- *                                      the first stage as the LDS slab path instead of the K = 1 MFMA form, 3 = MFMA layer kernels with fp32
- *                                      MFMA for the GEMMs of layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16)
- *                             "groups" number of chunk groups the call is pipelined in (0 = auto): the LSTM of
- *                                      group g overlaps the front end + encoder of group g+1.
- *                             "graph"   1: capture the call's launch sequence into a hipGraph on first use and
- *                                      replay it afterwards (steady-state serving); 0 (default): eager launches
- *                             "fe_overlap" 1: the front end runs on its own internal stream, concurrently with the encoder
- *                                      layers of the previous call (buffers double buffered); 0 (default, both models): one stream
- *                                      (measured: the front end's grid starves the layer kernels of workgroup slots)
- *                             "v4_mag" 0 (default): the Silero v4 first stage recovers the magnitude half of its input from the
- *                                      log-magnitudes, m = (e^Y - 1) 2^-20, and the front end writes no magnitude array on the hot
- *                                      path; 1: magnitudes are written by the front end and read by the first stage
- *                             "cu_partition" 1 (default): when the LSTM needs few CUs it gets CUs of its own (CU masks): shared with
- *                                      the front end + encoder stream when every 16-stream tile has a CU to itself and the chain has
- *                                      slack, disjoint otherwise; 2: always shared; 0: never mask.
- *                             "lstm_cus" size of that partition in CUs (multiple of 8; 0 = sized by the engine) */
+/* Switches (all int-valued; an unknown key or value is VADC_AMD_EINVAL):
+ *   "graph"       1: kernel sequences (a whole small call; the front end + encoder of one chunk group of a forked call) are captured into hipGraphs on
+ *                 first use and replayed afterwards -- the fork / join and the call-to-call ordering stay outside the graphs, so replays of consecutive
+ *                 steps overlap like eager steps; 0 (default): eager launches
+ *   "defer_join"  1: a forked vadc_amd_run_device_* call does not make its own stream wait for its completion (see vadc_amd_join); 0 (default): strict
+ *                 stream semantics
+ *   "groups"      number of chunk groups a call is pipelined in (0 = auto): the LSTM of group g overlaps the front end + encoder of group g+1
+ *   "lstm"        0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy -- 7 = layer-major (k_lstm_layer: layer 0 and
+ *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls while the recurrence would otherwise be
+ *                 the longer of the concurrent streams, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both layers); 6 and 7 produce
+ *                 the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
+ *   "frontend"    Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins 0..32, the other 96 bins from the basis'
+ *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
+ *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = k_frontend_gemm (default), 1 = the tree kernel with the v4 geometry
+ *   "encoder"     0 = MFMA layer kernels (default); 2 = first stage as the LDS slab path instead of the K = 1 MFMA form; 3 = fp32 MFMA for the GEMMs of
+ *                 layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16)
+ *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
+ *                 1: magnitudes are written by the front end and read by the first stage
+ *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream
+ *                 when the chain has slack, disjoint otherwise; 2: always shared; 0: never mask.  "lstm_cus": size of that partition (multiple of 8; 0 =
+ *                 sized by the engine) */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
-/* Reads a switch back, plus two read-only facts about the last forked call: "lstm_cus" = CUs reserved for the LSTM chain
- * (0 = no partition) and "lstm_kernel" = the LSTM variant "lstm"=0 resolved to. */
+/* Reads a switch back, plus read-only facts about the last call: "lstm_cus" = CUs reserved for the LSTM (0 = no partition), "lstm_kernel" = the
+ * LSTM variant it ran (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 k_frontend_gemm, 3 k_frontend v4 tree). */
 int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */

@@ -74,3 +74,16 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), os.path.join(dirpath, f)
     out = subprocess.check_output(["ldd", _lib.LIB_PATH], text=True)
     assert "oracle" not in out and "libvadc_ref" not in out
+
+
+def test_adapter_header_compiles_against_the_reference_vadc_h():
+    """include/vadc_backend_hip.h (the literal backend_init / backend_create_tensors / backend_run trio) inside a translation unit that includes the
+    REFERENCE's own vadc.h: the types it touches (MemoryArena, String8, Silero_Config, VADC_Context, Tensor_Buffers) are the reference's.  Build
+    container only: /root/reference does not travel."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "vadc.h")):
+        pytest.skip("reference tree not present")
+    src = os.path.join(ROOT, "tests", "c", "adapter_check.c")
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-fsyntax-only", "-include", "stddef.h", "-DONNX_INFERENCE_ENABLED=0",
+                        "-I", ref, "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

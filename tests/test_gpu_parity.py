@@ -437,13 +437,10 @@ def test_deferred_join_overlaps_calls_issued_from_one_stream(weights_blob):
         d_in = torch.from_numpy(pcm).to("cuda:0")
         outs = [torch.zeros((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(steps)]
         issue, reader = torch.cuda.Stream(), torch.cuda.Stream()
-        row = pcm.shape[1]
-        for i in range(steps):                                   # strided input view: copy each step's block to its own contiguous buffer first
-            blk = d_in[:, i * Cn * 1536:(i + 1) * Cn * 1536].contiguous()
-            issue.wait_stream(torch.cuda.current_stream())
-            e.run_device(blk.data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), issue.cuda_stream)
-            blk.record_stream(issue)
-            outs[i].record_stream(issue)
+        blks = [d_in[:, i * Cn * 1536:(i + 1) * Cn * 1536].contiguous() for i in range(steps)]      # every step's block in a buffer of its own, alive until the end
+        torch.cuda.synchronize()
+        for i in range(steps):
+            e.run_device(blks[i].data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), issue.cuda_stream)
         e.join(reader.cuda_stream)
         with torch.cuda.stream(reader):
             got = torch.cat(outs, dim=1).cpu().numpy()
