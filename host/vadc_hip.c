@@ -37,6 +37,7 @@ typedef struct {
    float min_silence_ms, min_speech_ms, threshold, neg_threshold_relative, speech_pad_ms;
    int batch, raw_probabilities, centiseconds, stats;
    const char *model;
+   int sequence_count;          /* --sequence_count (vadc.c:1117, default 1536) */
 } Options;
 
 static double g_total_speech = 0.0;
@@ -119,9 +120,7 @@ static int parse_options(int argc, char **argv, Options *o)
       else if (!strcmp(a, "--neg_threshold_relative")) o->neg_threshold_relative = f;
       else if (!strcmp(a, "--speech_pad")) o->speech_pad_ms = f;
       else if (!strcmp(a, "--batch")) o->batch = (int)f;
-      else if (!strcmp(a, "--sequence_count")) {                    /* vadc.c:743-752: clamped to the backend's [input_size_min, input_size_max] = 1536 */
-         if ((int)f != 1536) fprintf(stderr, "--sequence_count %d: the backend runs 1536-sample chunks (clamped, as vadc.c:743-752 does for the C backend)\n", (int)f);
-      }
+      else if (!strcmp(a, "--sequence_count")) o->sequence_count = (int)f;     /* clamped to the backend's range after backend_init (vadc.c:743-752) */
       else if (!strcmp(a, "--audio_source") || !strcmp(a, "--start_seconds")) { /* ffmpeg stream selection / seek (vadc.c:532-538): no effect on stdin input */ }
       else { fprintf(stderr, "unknown option %s\n", a); return -1; }
    }
@@ -150,7 +149,7 @@ int main(int argc, char **argv)
 #else
    const char *default_model = "silero_v31_16k.testtensor";
 #endif
-   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model};  /* vadc.c:1110-1124 */
+   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model, CHUNK};  /* vadc.c:1110-1124 */
    if (parse_options(argc, argv, &o)) return 2;
    if (o.batch > WINDOW_CHUNKS) o.batch = WINDOW_CHUNKS;
 
@@ -180,12 +179,24 @@ int main(int argc, char **argv)
    }
    free(blob);
    fprintf(stderr, "Running with batch size %d\n", o.batch);       /* vadc.c:716 */
-   fprintf(stderr, "Running with sequence count %d\n", CHUNK);     /* vadc.c:753 */
+   /* vadc.c:743-752: the desired sequence count is clamped to what backend_init reported.  The C backend's range is 1536..1536 (silero.h:41-42); a
+    * Silero v4 container reports 512..1536 like the reference's onnxruntime path (onnx_helpers.c:164-170), of which this backend runs 512 / 1024 /
+    * 1536: other requests are rounded DOWN to the next of those. */
+   vadc_amd_caps caps;
+   if (vadc_amd_get_caps(eng, &caps) != VADC_AMD_OK) { fprintf(stderr, "get_caps failed: %s\n", vadc_amd_last_error()); return -1; }
+   int seq = o.sequence_count;
+   if (seq < caps.input_size_min) seq = caps.input_size_min;
+   if (seq > caps.input_size_max) seq = caps.input_size_max;
+   if (caps.input_size_min != caps.input_size_max) seq = seq >= 1536 ? 1536 : (seq >= 1024 ? 1024 : 512);
+   if (seq != o.sequence_count) fprintf(stderr, "--sequence_count %d: the backend runs %d-sample chunks\n", o.sequence_count, seq);
+   if (seq != CHUNK && vadc_amd_set_option(eng, "window", seq) != VADC_AMD_OK) { fprintf(stderr, "cannot set the window: %s\n", vadc_amd_last_error()); return -1; }
+   const int chunk = seq;
+   fprintf(stderr, "Running with sequence count %d\n", chunk);     /* vadc.c:753 */
 
-   const float chunk_ms = CHUNK / (float)SAMPLE_RATE * 1000.0f;    /* vadc.c:756 */
+   const float chunk_ms = chunk / (float)SAMPLE_RATE * 1000.0f;    /* vadc.c:756 */
    int min_speech = (int)(o.min_speech_ms / chunk_ms + 0.5f);   if (min_speech < 1) min_speech = 1;
    int min_silence = (int)(o.min_silence_ms / chunk_ms + 0.5f); if (min_silence < 1) min_silence = 1;
-   const float spc = (float)CHUNK / SAMPLE_RATE;                   /* vadc.c:846 */
+   const float spc = (float)chunk / SAMPLE_RATE;                   /* vadc.c:846 */
    const float neg_thr = o.threshold - o.neg_threshold_relative;   /* vadc.c:1243 */
 
    static int16_t pcm[WINDOW_CHUNKS * CHUNK];
@@ -197,15 +208,16 @@ int main(int argc, char **argv)
    struct timespec t0, t1;
    clock_gettime(CLOCK_MONOTONIC, &t0);
 
+   const size_t window_bytes = (size_t)WINDOW_CHUNKS * chunk * sizeof(int16_t);      /* vadc.c:799-805: chunks_count = 96 chunks of input_count samples */
    for (;;) {
-      size_t bytes = read_full(0, pcm, sizeof(pcm));
+      size_t bytes = read_full(0, pcm, window_bytes);
       size_t values = bytes / sizeof(int16_t);
       if (values == 0) break;
       total_samples += (int64_t)values;
-      int n_chunks = (int)(values / CHUNK);                        /* vadc.c:964: a partial tail chunk is dropped */
+      int n_chunks = (int)(values / chunk);                        /* vadc.c:964: a partial tail chunk is dropped */
       for (int c0 = 0; c0 < n_chunks; c0 += o.batch) {
          int n = n_chunks - c0 < o.batch ? n_chunks - c0 : o.batch;
-         if (vadc_amd_run_s16(eng, pcm + (size_t)c0 * CHUNK, 1, n, probs + 2 * c0) != VADC_AMD_OK) {
+         if (vadc_amd_run_s16(eng, pcm + (size_t)c0 * chunk, 1, n, probs + 2 * c0) != VADC_AMD_OK) {
             fprintf(stderr, "backend_run failed: %s\n", vadc_amd_last_error());
             return 1;
          }
@@ -220,13 +232,13 @@ int main(int argc, char **argv)
          }
          ++global_idx;
       }
-      if (bytes < sizeof(pcm)) break;
+      if (bytes < window_bytes) break;
    }
    if (!o.raw_probabilities) {                                     /* vadc.c:1005-1027 */
       if (st.triggered) {
-         int audio_len = (global_idx - 1) * CHUNK;
-         if (audio_len - (st.current_start * CHUNK) > (min_speech * CHUNK)) {
-            Segment fin = {st.current_start, audio_len / CHUNK, 1};
+         int audio_len = (global_idx - 1) * chunk;
+         if (audio_len - (st.current_start * chunk) > (min_speech * chunk)) {
+            Segment fin = {st.current_start, audio_len / chunk, 1};
             buffered = combine_or_emit(buffered, fin, &o, spc);
          }
       }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VADC_AMD_CHUNK_SAMPLES 1536
+#define VADC_AMD_CHUNK_SAMPLES 1536    /* the reference's chunk; every buffer below is [stream][chunk][window], window = 1536 unless option "window" says otherwise */
 #define VADC_AMD_HIDDEN        64
 #define VADC_AMD_LSTM_LAYERS   2
 
@@ -82,7 +82,7 @@ typedef struct vadc_amd_engine vadc_amd_engine;
 typedef struct vadc_amd_caps {
    int32_t batch_size_restriction;        /* -1: any                                   */
    int32_t is_silero_v5;                  /* 0                                         */
-   int32_t input_size_min;                /* 1536                                      */
+   int32_t input_size_min;                /* 1536; Silero v4: 512 (onnx_helpers.c:164-170) */
    int32_t input_size_max;                /* 1536                                      */
    int32_t output_dims;                   /* 3  => output [B,2,1]                      */
    int32_t output_stride;                 /* 2                                         */
@@ -93,7 +93,8 @@ typedef struct vadc_amd_caps {
    int32_t device;
    int32_t precision;
    int32_t model_kind;                    /* VADC_AMD_MODEL_*                          */
-   int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3 (v4)                         */
+   int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3, 2, 1 (v4: window / 512)    */
+   int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1024 / 512 (option "window") */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -165,6 +166,9 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                 steps overlap like eager steps; 0 (default): eager launches
  *   "defer_join"  1: a forked vadc_amd_run_device_* call does not make its own stream wait for its completion (see vadc_amd_join); 0 (default): strict
  *                 stream semantics
+ *   "window"      samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4 also 1024 and 512 -- the v4
+ *                 graph takes 512 ... 1536 samples (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): samples / 64 STFT frames, samples / 512 LSTM
+ *                 steps.  Changes the stride of every samples / probability buffer; waits for the calls issued before
  *   "groups"      number of chunk groups a call is pipelined in (0 = auto): the LSTM of group g overlaps the front end + encoder of group g+1
  *   "lstm"        0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy -- 7 = layer-major (k_lstm_layer: layer 0 and
  *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls while the recurrence would otherwise be

@@ -84,6 +84,7 @@ def lib():
         L.so4_forward_chunk.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.POINTER(_TapsV4)]
         L.so4_forward_stream_f32.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p]
         L.so4_forward_stream_s16.argtypes = [C.c_void_p, _i16p, C.c_int, _f32p, _f32p, _f32p]
+        L.so4_forward_stream_f32_w.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p]
         _lib = L
     return _lib
 
@@ -186,21 +187,24 @@ class OracleV4:
         p = self._L.so4_forward_chunk(self._m, samples, h, c, C.byref(tp) if tp is not None else None)
         return (p, tapd) if taps else p
 
-    def forward_stream(self, pcm_or_f32, h=None, c=None):
+    def forward_stream(self, pcm_or_f32, h=None, c=None, window=1536):
         x = np.ascontiguousarray(pcm_or_f32).reshape(-1)
-        n = x.size // 1536
+        n = x.size // window
         if h is None:
             h, c = self.new_state()
         probs = np.zeros(n, np.float32)
-        if x.dtype == np.int16:
+        if window != 1536:                       # 512 ... 1536-sample windows (onnx_helpers.c:164-170)
+            xf = x.astype(np.float32) / np.float32(32768) if x.dtype == np.int16 else _c(x)      # vadc.c:883,898
+            self._L.so4_forward_stream_f32_w(self._m, _c(xf), n, window, h, c, probs)
+        elif x.dtype == np.int16:
             self._L.so4_forward_stream_s16(self._m, x, n, h, c, probs)
         else:
             self._L.so4_forward_stream_f32(self._m, _c(x), n, h, c, probs)
         return probs
 
-    def forward_streams(self, pcm):
+    def forward_streams(self, pcm, window=1536):
         pcm = np.ascontiguousarray(pcm)
-        return np.stack([self.forward_stream(pcm[s]) for s in range(pcm.shape[0])])
+        return np.stack([self.forward_stream(pcm[s], window=window) for s in range(pcm.shape[0])])
 
 
 def segments(probs, threshold=0.5, neg_threshold_relative=0.15, min_silence_ms=200.0, min_speech_ms=250.0,

@@ -85,9 +85,9 @@ void so4_model_free(so4_model *m)
 
 /* ConvBlock (silero_vad.py:68-93) for any T >= 1: the v3.1 restatement so_dw_conv_k5 spells out the reference C edge
  * handling and needs T >= 5; v4's last block runs at T = 3. */
-static void so4_conv_block(const float *in, const so4_block *B, float *out)
+static void so4_conv_block(const float *in, const so4_block *B, int t, float *out)
 {
-   const int cin = B->cin, t = B->t_in, cout = B->cout;
+   const int cin = B->cin, cout = B->cout;
    float *dw = a4((size_t)cin * t);
    for (int c = 0; c < cin; ++c)
       for (int i = 0; i < t; ++i) {
@@ -112,48 +112,66 @@ static void so4_conv_block(const float *in, const so4_block *B, float *out)
    free(dw);
 }
 
-/* silero_vad.py:191-236 */
-float so4_forward_chunk(const so4_model *m, const float *samples, float *h, float *c, const so4_taps *taps)
+/* silero_vad.py:191-236 for a window of n_samples (the class takes any length; the reference's onnxruntime path feeds 512 ... 1536 samples,
+ * onnx_helpers.c:164-170).  frames = (n_samples + 2 * 96 - 256) / 64 + 1 (conv1d, stride 64, no padding: trailing samples that do not fill a
+ * frame are ignored, as F.conv1d does); stage lengths 1 + (t - 1) / stride. */
+float so4_forward_chunk_w(const so4_model *m, const float *samples, int n_samples, float *h, float *c, const so4_taps *taps)
 {
-   float *padded = a4(SO4_PADDED), *conv = a4((size_t)258 * SO4_FRAMES), *x0 = a4((size_t)258 * SO4_FRAMES);
-   so_reflect_pad(samples, 1536, SO4_PAD, SO4_PAD, padded);                 /* :32,40 (to_pad = 96) */
-   so_stft_conv(padded, SO4_PADDED, m->basis, conv);                        /* :45 */
-   so_magnitude(conv, SO4_FRAMES, x0);                                      /* :47-50, rows 0..128 */
-   float *norm = x0 + (size_t)129 * SO4_FRAMES;                             /* rows 129..257: torch.cat([spect, normalized], 1) :212 */
-   memcpy(norm, x0, sizeof(float) * 129 * SO4_FRAMES);
-   so_adaptive_norm(norm, 129, SO4_FRAMES);                                 /* :57-66 */
-   if (taps && taps->magnitude)  memcpy(taps->magnitude, x0, sizeof(float) * 129 * SO4_FRAMES);
-   if (taps && taps->normalized) memcpy(taps->normalized, norm, sizeof(float) * 129 * SO4_FRAMES);
+   const int padded_len = n_samples + 2 * SO4_PAD, frames = (padded_len - 256) / 64 + 1;
+   float *padded = a4((size_t)padded_len), *conv = a4((size_t)258 * frames), *x0 = a4((size_t)258 * frames);
+   so_reflect_pad(samples, n_samples, SO4_PAD, SO4_PAD, padded);            /* :32,40 (to_pad = 96) */
+   so_stft_conv(padded, padded_len, m->basis, conv);                        /* :45 */
+   so_magnitude(conv, frames, x0);                                          /* :47-50, rows 0..128 */
+   float *norm = x0 + (size_t)129 * frames;                                 /* rows 129..257: torch.cat([spect, normalized], 1) :212 */
+   memcpy(norm, x0, sizeof(float) * 129 * frames);
+   so_adaptive_norm(norm, 129, frames);                                     /* :57-66 */
+   if (taps && taps->magnitude)  memcpy(taps->magnitude, x0, sizeof(float) * 129 * frames);
+   if (taps && taps->normalized) memcpy(taps->normalized, norm, sizeof(float) * 129 * frames);
    float *cur = x0, *louts[4];
+   int t_in = frames, t_outs[4];
    for (int l = 0; l < 4; ++l) {
       const so4_block *B = &m->block[l];
-      float *cb = a4((size_t)B->cout * B->t_in);
-      so4_conv_block(cur, B, cb);                                             /* :68-93 */
-      louts[l] = a4((size_t)B->cout * B->t_out);
-      so_conv_k1(cb, B->cout, B->t_in, B->conv_w, B->conv_b, B->cout, B->stride, louts[l]); /* :160-186, BN folded */
-      for (int i = 0; i < B->cout * B->t_out; ++i) louts[l][i] = louts[l][i] > 0.0f ? louts[l][i] : 0.0f;
+      const int t_out = 1 + (t_in - 1) / B->stride;
+      float *cb = a4((size_t)B->cout * t_in);
+      so4_conv_block(cur, B, t_in, cb);                                       /* :68-93 */
+      louts[l] = a4((size_t)B->cout * t_out);
+      so_conv_k1(cb, B->cout, t_in, B->conv_w, B->conv_b, B->cout, B->stride, louts[l]); /* :160-186, BN folded */
+      for (int i = 0; i < B->cout * t_out; ++i) louts[l][i] = louts[l][i] > 0.0f ? louts[l][i] : 0.0f;
       free(cb);
       cur = louts[l];
+      t_in = t_out; t_outs[l] = t_out;
    }
-   if (taps && taps->l1) memcpy(taps->l1, louts[0], sizeof(float) * 16 * 12);
-   if (taps && taps->l2) memcpy(taps->l2, louts[1], sizeof(float) * 32 * 6);
-   if (taps && taps->l3) memcpy(taps->l3, louts[2], sizeof(float) * 32 * 3);
-   if (taps && taps->l4) memcpy(taps->l4, louts[3], sizeof(float) * 64 * 3);
-   float seq[SO4_LSTM_STEPS * 64], lout[SO4_LSTM_STEPS * 64];
-   for (int t = 0; t < SO4_LSTM_STEPS; ++t)
-      for (int u = 0; u < 64; ++u) seq[t * 64 + u] = louts[3][u * SO4_LSTM_STEPS + t];   /* permute [0,2,1] :215 */
-   so_lstm_seq(seq, SO4_LSTM_STEPS, m->lstm_w, m->lstm_b, 2, h, c, lout);     /* :217, :229-234 */
-   if (taps && taps->lstm_out) memcpy(taps->lstm_out, lout, sizeof(lout));
+   const int steps = t_outs[3];
+   if (taps && taps->l1) memcpy(taps->l1, louts[0], sizeof(float) * 16 * t_outs[0]);
+   if (taps && taps->l2) memcpy(taps->l2, louts[1], sizeof(float) * 32 * t_outs[1]);
+   if (taps && taps->l3) memcpy(taps->l3, louts[2], sizeof(float) * 32 * t_outs[2]);
+   if (taps && taps->l4) memcpy(taps->l4, louts[3], sizeof(float) * 64 * t_outs[3]);
+   float *seq = a4((size_t)steps * 64), *lout = a4((size_t)steps * 64);
+   for (int t = 0; t < steps; ++t)
+      for (int u = 0; u < 64; ++u) seq[t * 64 + u] = louts[3][u * steps + t];   /* permute [0,2,1] :215 */
+   so_lstm_seq(seq, steps, m->lstm_w, m->lstm_b, 2, h, c, lout);             /* :217, :229-234 */
+   if (taps && taps->lstm_out) memcpy(taps->lstm_out, lout, sizeof(float) * steps * 64);
    float acc = 0.0f;
-   for (int t = 0; t < SO4_LSTM_STEPS; ++t) {                                 /* ReLU -> conv 64->1 -> sigmoid :200-204, mean :222 */
+   for (int t = 0; t < steps; ++t) {                                          /* ReLU -> conv 64->1 -> sigmoid :200-204, mean :222 */
       float d = 0.0f;
       for (int u = 0; u < 64; ++u) d += m->dec_w[u] * (lout[t * 64 + u] > 0.0f ? lout[t * 64 + u] : 0.0f);
       d += m->dec_b[0];
       acc += 1.0f / (1.0f + expf(-d));
    }
    for (int l = 0; l < 4; ++l) free(louts[l]);
+   free(seq); free(lout);
    free(padded); free(conv); free(x0);
-   return acc / (float)SO4_LSTM_STEPS;
+   return acc / (float)steps;
+}
+
+float so4_forward_chunk(const so4_model *m, const float *samples, float *h, float *c, const so4_taps *taps)
+{
+   return so4_forward_chunk_w(m, samples, 1536, h, c, taps);
+}
+
+void so4_forward_stream_f32_w(const so4_model *m, const float *x, int n_chunks, int window, float *h, float *c, float *probs)
+{
+   for (int i = 0; i < n_chunks; ++i) probs[i] = so4_forward_chunk_w(m, x + (size_t)i * window, window, h, c, NULL);
 }
 
 void so4_forward_stream_f32(const so4_model *m, const float *x, int n_chunks, float *h, float *c, float *probs)

@@ -69,8 +69,8 @@ def build_model(weights_path):
 
 
 @torch.no_grad()
-def run_stream(m, pcm_i16, dtype):
-    x = torch.from_numpy(pcm_i16.astype(np.float32) / np.float32(32768)).to(dtype).reshape(-1, 1536)
+def run_stream(m, pcm_i16, dtype, window=1536):
+    x = torch.from_numpy(pcm_i16.astype(np.float32) / np.float32(32768)).to(dtype).reshape(-1, window)
     h = torch.zeros(2, 1, 64, dtype=dtype); c = torch.zeros(2, 1, 64, dtype=dtype)
     probs = []
     for i in range(x.shape[0]):
@@ -124,6 +124,18 @@ def main():
     path = os.path.join(HERE, "python_reference_v4.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # 512- and 1024-sample windows (the v4 graph takes 512 ... 1536 samples: onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): the same
+    # streams cut into shorter chunks, float64 probabilities and final state
+    outw = {}
+    for window in (512, 1024):
+        for name in ("speech0", "speech1", "noise", "square"):
+            x = pcm[name][: (pcm[name].size // window) * window]
+            p64, h64, c64 = run_stream(m64, x, torch.float64, window)
+            outw[f"probs64_w{window}_{name}"] = p64; outw[f"h64_w{window}_{name}"] = h64; outw[f"c64_w{window}_{name}"] = c64
+            print(f"window {window} {name}: {p64.size} chunks, p[min,max]=({p64.min():.4f},{p64.max():.4f})")
+    pathw = os.path.join(HERE, "python_reference_v4_windows.npz")
+    np.savez_compressed(pathw, **outw)
+    print("wrote", pathw, os.path.getsize(pathw), "bytes  (pcm: the streams of python_reference_v4.npz)")
 
 
 if __name__ == "__main__":

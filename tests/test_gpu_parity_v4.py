@@ -49,7 +49,7 @@ def f32(pcm):
 def test_model_kind_comes_from_the_container(eng):
     c = eng.caps()
     assert c["model_kind"] == MODEL_V4 and c["lstm_steps_per_chunk"] == 3
-    assert (c["input_size_min"], c["input_size_max"], c["output_stride"], c["silero_probability_out_index"]) == (1536, 1536, 2, 1)
+    assert (c["input_size_min"], c["input_size_max"], c["output_stride"], c["silero_probability_out_index"]) == (512, 1536, 2, 1)
     with pytest.raises(VadcAmdError):
         eng.set_option("encoder", 3)                 # split-fp16 / fp32 GEMM forms exist for the v3.1 transformer layers only
 
@@ -259,3 +259,74 @@ def test_cli_with_v4_weights(gold):
     r = subprocess.run([exe, "--model", V4_WEIGHTS], input=pcm.tobytes(), capture_output=True, timeout=300)
     sec, _ = O.segments(gold["probs64_speech0"].astype(np.float32))
     assert r.stdout.decode().splitlines() == ["%.2f,%.2f" % (a, b) for a, b in sec]
+
+
+# ---------------------------------------------------------------------------------------------- window sizes (vadc --sequence_count)
+@pytest.mark.parametrize("window", [512, 1024])
+def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
+    """Silero v4 with 512- and 1024-sample windows (option "window": the v4 graph takes 512 ... 1536 samples, onnx_helpers.c:164-170): caps report the
+    range, probabilities against the float64 PyTorch goldens and the oracle, many ragged streams, state carried over calls, forked calls"""
+    gw = np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz"))
+    e = Engine(blob, max_streams=40, max_chunks_per_call=150, device=0)
+    try:
+        c = e.caps()
+        assert (c["input_size_min"], c["input_size_max"], c["window_samples"]) == (512, 1536, 1536)
+        e.set_window(window)
+        c = e.caps()
+        assert c["window_samples"] == window and c["lstm_steps_per_chunk"] == window // 512 and e.get_option("window") == window
+        for name in ("speech0", "speech1", "noise", "square"):
+            pcm = gold[f"pcm_{name}"]
+            pcm = pcm[: (pcm.size // window) * window]
+            e.reset_streams()
+            p = e.run(pcm.reshape(1, -1))[0]
+            assert np.array_equal(p[:, 0], p[:, 1])
+            assert float(np.abs(p[:, 1] - gw[f"probs64_w{window}_{name}"]).max()) < PROB_TOL, name
+        # ragged stream count, two calls with carried state, enough chunks to fork (37 x 60 = 2220 chunks per call)
+        S, n = 37, 120
+        pcm = synth.make_streams(S, (n * window + 1535) // 1536, seed0=6100 + window)[:, : n * window]
+        e.reset_streams()
+        got = np.concatenate([e.run(pcm[:, : 60 * window]), e.run(pcm[:, 60 * window:])], axis=1)[:, :, 1]
+        want = orc.forward_streams(pcm, window=window)
+        assert float(np.abs(got - want).max()) < PROB_TOL
+        # stage taps have the window's shapes
+        x = f32(gold["pcm_speech0"])[: 5 * window]
+        assert e.stage_from_samples(x, "magnitude").shape == (5, 129, window // 64)
+        assert e.stage_from_samples(x, "layer4").shape == (5, 64, window // 512)
+        with pytest.raises(VadcAmdError):
+            e.set_option("window", 768)
+        e.set_window(1536)
+        e.reset_streams()
+        p = e.run(gold["pcm_speech0"].reshape(1, -1))[0]
+        assert float(np.abs(p[:, 1] - gold["probs64_speech0"]).max()) < PROB_TOL
+    finally:
+        e.close()
+
+
+def test_window_option_is_v4_only():
+    from conftest import WEIGHTS
+    e = Engine(open(WEIGHTS, "rb").read(), max_streams=1, max_chunks_per_call=1, device=0)
+    try:
+        c = e.caps()
+        assert (c["input_size_min"], c["input_size_max"]) == (1536, 1536)      # the C backend's contract (silero.h:41-42)
+        with pytest.raises(VadcAmdError):
+            e.set_option("window", 512)
+        e.set_option("window", 1536)
+    finally:
+        e.close()
+
+
+def test_cli_sequence_count_selects_the_v4_window(gold):
+    """`--sequence_count` (vadc.c:743-752, 1117): clamped to the backend's range; with a Silero v4 container 512 / 1024 / 1536 are run (other
+    values rounded down), one %f line per FULL chunk of that size"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "host", "vadc_hip")
+    gw = np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz"))
+    pcm = gold["pcm_speech0"]
+    for arg, window in (("512", 512), ("1024", 1024), ("1100", 1024), ("100", 512), ("9999", 1536)):
+        r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities", "--sequence_count", arg], input=pcm.tobytes(), capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        assert f"Running with sequence count {window}" in r.stderr.decode()
+        got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
+        want = gw[f"probs64_w{window}_speech0"] if window != 1536 else gold["probs64_speech0"]
+        assert got.shape == want.shape and float(np.abs(got - want).max()) < PROB_TOL + 5e-7

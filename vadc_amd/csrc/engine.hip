@@ -25,8 +25,8 @@ void launch_frontend_gemm_f32(const float *, const float *, const float *, float
 void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
-void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
-void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int);
+void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
+void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -34,7 +34,7 @@ struct LayerWeightsM {
    const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
-void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool);
+void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int);
 }  // namespace vadc
 
 using namespace vadc;
@@ -95,7 +95,11 @@ static const LayerShape kLayers[4] = {{129, 16, 25, 2, 1}, {16, 32, 13, 2, 1}, {
 static const int kStageElemsV31[VADC_AMD_STAGE_COUNT] = {129 * 25, 129 * 25, 16 * 13, 32 * 7, 32 * 7, 64 * 7};
 // Silero v4 (silero_vad.py:157-236): 24 frames, encoder [16,12] [32,6] [32,3] [64,3]
 static const LayerShape kLayersV4[4] = {{258, 16, 24, 2, 1}, {16, 32, 12, 2, 1}, {32, 32, 6, 2, 0}, {32, 64, 3, 1, 1}};
-static const int kStageElemsV4[VADC_AMD_STAGE_COUNT] = {129 * 24, 129 * 24, 16 * 12, 32 * 6, 32 * 3, 64 * 3};
+// elements per chunk of every stage tap for a Silero v4 window of 64 * frames samples (frames = 24 / 16 / 8: T -> T/2 -> T/4 -> T/8 -> T/8)
+static void stage_elems_v4(int frames, int (&out)[VADC_AMD_STAGE_COUNT])
+{
+   out[0] = out[1] = 129 * frames; out[2] = 16 * (frames / 2); out[3] = 32 * (frames / 4); out[4] = 32 * (frames / 8); out[5] = 64 * (frames / 8);
+}
 
 struct Packer {
    std::vector<float> buf;
@@ -113,8 +117,9 @@ struct vadc_amd_engine {
    int device = 0;
    int model = VADC_AMD_MODEL_V31;              // decided by the weights container: 99 tensors = v3.1, 36 = v4
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
-   int lstm_steps = 7;                          // LSTM steps per chunk: 7 / 3
-   const int *stage_elems = nullptr;
+   int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 2, 1 (v4 with 1536-, 1024-, 512-sample windows)
+   int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170)
+   int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
    bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_FAST_STFT)); }
@@ -557,7 +562,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->model = ts.size() == 36 ? VADC_AMD_MODEL_V4 : VADC_AMD_MODEL_V31;
    e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
-   e->stage_elems = e->model == VADC_AMD_MODEL_V4 ? kStageElemsV4 : kStageElemsV31;
+   if (e->model == VADC_AMD_MODEL_V4) stage_elems_v4(24, e->stage_elems);
+   else memcpy(e->stage_elems, kStageElemsV31, sizeof(kStageElemsV31));
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    if (precision == VADC_AMD_PRECISION_SPLIT16 && (!e->lstm_h3_ok || (e->model != VADC_AMD_MODEL_V4 && !e->enc_h3_ok))) {
@@ -606,8 +612,10 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    if (!e || !caps) return fail(VADC_AMD_EINVAL, "get_caps: NULL argument");
    caps->batch_size_restriction = -1;          // silero.h:39
    caps->is_silero_v5 = 0;                     // silero.h:40
-   caps->input_size_min = kChunk;              // silero.h:41
-   caps->input_size_max = kChunk;              // silero.h:42
+   // silero.h:41-42 (the C backend: 1536 only); onnx_helpers.c:164-170 for the v4 graph: 512 ... 1536, of which this engine runs 512 / 1024 / 1536
+   caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? 512 : kChunk;
+   caps->input_size_max = kChunk;
+   caps->window_samples = e->window;
    caps->output_dims = 3;                      // silero.h:43
    caps->output_stride = 2;                    // vadc.c:704-708
    caps->silero_probability_out_index = 1;
@@ -691,6 +699,7 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
    return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
+static int wait_all_prior_fwd(vadc_amd_engine *e);
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
@@ -704,6 +713,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
       e->graphs.clear();
    }
+   if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value == 1 && e->window != kChunk)
+      return fail(VADC_AMD_EINVAL, "set_option: the v4 tree front end exists for 1536-sample windows only");
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
       e->frontend_variant = value;
@@ -713,6 +724,17 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
+   if (strcmp(key, "window") == 0) {
+      // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
+      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which 512 / 1024 / 1536 (8 / 16 / 24 STFT frames) are built here
+      if (value == kChunk && e->window == kChunk) return VADC_AMD_OK;
+      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || (value != 512 && value != 1024 && value != kChunk))
+         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 1024 or 1536", value);
+      { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
+      e->window = value; e->frames = value / 64; e->lstm_steps = e->frames / 8;
+      stage_elems_v4(e->frames, e->stage_elems);
+      return VADC_AMD_OK;
+   }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
@@ -729,6 +751,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
+   else if (strcmp(key, "window") == 0) *value = e->window;
    else if (strcmp(key, "defer_join") == 0) *value = e->defer_join;
    else if (strcmp(key, "v4_mag") == 0) *value = e->v4_mag;
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
@@ -766,7 +789,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
    }
@@ -789,7 +812,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       const size_t fms = e->max_items * kFrames;
       const int fk = pick_frontend(e, d_in);
       if (fk == 2) {
-         const int geo = e->model == VADC_AMD_MODEL_V4 ? 1 : 0;
+         const int geo = e->model == VADC_AMD_MODEL_V4 ? (e->window == 1024 ? 2 : (e->window == 512 ? 3 : 1)) : 0;
          float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
          if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
          else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
@@ -926,13 +949,13 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (lk == 7) {
-      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model); }
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps); }
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model);
+      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model);
+   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
 }
 
 struct SeqKey { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; };
@@ -1040,12 +1063,12 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          else {
             {
                KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps);
             }
             (void)hipEventRecord(e->ev_l0[gi], e->sB);
             (void)hipStreamWaitEvent(e->sC, e->ev_l0[gi], 0);
             KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
-            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model);
+            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps);
          }
          c0 += cg;
       }
@@ -1121,7 +1144,7 @@ extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_
    if (!samples || !probs) return fail(VADC_AMD_EINVAL, "run_f32: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    const size_t n = (size_t)n_streams * n_chunks;
-   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, n * kChunk * sizeof(float), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, n * e->window * sizeof(float), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
    rc = run_device<float>(e, e->d_in_f32, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
@@ -1136,7 +1159,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    if (!pcm || !probs) return fail(VADC_AMD_EINVAL, "run_s16: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    const size_t n = (size_t)n_streams * n_chunks;
-   HIP_TRY(hipMemcpyAsync(e->d_in_s16, pcm, n * kChunk * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(e->d_in_s16, pcm, n * e->window * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
    rc = run_device<int16_t>(e, e->d_in_s16, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
@@ -1154,6 +1177,8 @@ static int wait_last_lstm(vadc_amd_engine *e)
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
+static int wait_all_prior(vadc_amd_engine *e);
+static int wait_all_prior_fwd(vadc_amd_engine *e) { HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP); return wait_all_prior(e); }
 // the stage taps overwrite the intermediates (Y, FM, layer outputs, hand-off tiles): wait for EVERYTHING enqueued before, on any stream
 static int wait_all_prior(vadc_amd_engine *e)
 {
@@ -1219,10 +1244,11 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
-   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * kChunk * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * e->window * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
    if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
-      launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st, e->model == VADC_AMD_MODEL_V4 ? 1 : 0);
+      launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
+                               e->model == VADC_AMD_MODEL_V4 ? (e->window == 1024 ? 2 : (e->window == 512 ? 3 : 1)) : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);

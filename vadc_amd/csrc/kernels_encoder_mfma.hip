@@ -901,25 +901,43 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
    }
 }
 
-// Silero v4 encoder stages (silero_vad.py:157-189, is_v4): T = 24 -> 12 -> 6 -> 3 -> 3
-// chunks per workgroup: 2 (48 of 64 columns), 5 (60), 10 (60), 21 (63)
-void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
+// Silero v4 encoder stages (silero_vad.py:157-189, is_v4, strides 2, 2, 2, 1).  T0 = frames of the window = samples / 64 (onnx_helpers.c:164-170
+// lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 16 -> 8 -> 4 -> 2 -> 2 (1024), 8 -> 4 -> 2 -> 1 -> 1 (512).
+// chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.
+template <int T0, int NCH, bool SLAB, int FIRSTK>
+static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st)
 {
+   hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, NCH, false, false, !SLAB>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+}
+template <int T0>
+static void launch_v4_t(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                        int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
+{
+   constexpr int T1 = T0 / 2, T2 = T0 / 4, T3 = T0 / 8;
+   constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
    switch (layer) {
    case 0:
-      if (slab) hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else if (in2) hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 2, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else          hipLaunchKernelGGL((k_layer_mfma<258, 16, 24, 2, true, 3, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      if (slab)     launch_v4_first<T0, N0, true, 2>(in, in2, fm, w, out, n, map, fm_stride, st);
+      else if (in2) launch_v4_first<T0, N0, false, 2>(in, in2, fm, w, out, n, map, fm_stride, st);
+      else          launch_v4_first<T0, N0, false, 3>(in, in2, fm, w, out, n, map, fm_stride, st);
       break;
-   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 12, 2, true, 0, false, 5, true, false>), dim3((n + 4) / 5), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
-   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 6, 2, false, 0, false, 10, true, false>), dim3((n + 9) / 10), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, 2, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
-      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 2, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 1, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 3, 1, true, 0, 0, 21, true, false>), dim3((n + 20) / 21), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 2, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 1, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 0, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
       break;
    }
+}
+
+// frames = STFT frames per chunk: 24 (1536-sample windows), 16 (1024), 8 (512)
+void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames)
+{
+   if (frames == 16)     launch_v4_t<16>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   else if (frames == 8) launch_v4_t<8>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   else                  launch_v4_t<24>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
 }
 
 }  // namespace vadc

@@ -68,8 +68,11 @@ constexpr int kGBlockPitch = 68;
 // GEO 0: Silero v3.1 (reflect pad 128, 25 frames, 28 blocks; Y + FM);  GEO 1: Silero v4 (pad 96, 24 frames, 27 blocks; Y + MAG + FM)
 template <int GEO> struct GemmGeo;
 // chunks = chunks per workgroup iteration: 5 x 25 = 125 positions fill 8 column tiles of 16 to 98 % (4 x 25 = 100 fill 7 to 89 %), 4 x 24 = 96 fill 6
-template <> struct GemmGeo<0> { static constexpr int pad = 128, frames = 25, blocks = 28, chunks = 5; static constexpr bool mag = false; };
-template <> struct GemmGeo<1> { static constexpr int pad = 96, frames = 24, blocks = 27, chunks = 4; static constexpr bool mag = true; };
+template <> struct GemmGeo<0> { static constexpr int samples = 1536, pad = 128, frames = 25, blocks = 28, chunks = 5; static constexpr bool mag = false; };
+template <> struct GemmGeo<1> { static constexpr int samples = 1536, pad = 96, frames = 24, blocks = 27, chunks = 4; static constexpr bool mag = true; };
+// Silero v4 with 1024- and 512-sample windows (onnx_helpers.c:164-170: the v4 graph takes 512 ... 1536 samples; frames = samples / 64)
+template <> struct GemmGeo<2> { static constexpr int samples = 1024, pad = 96, frames = 16, blocks = 19, chunks = 6; static constexpr bool mag = true; };
+template <> struct GemmGeo<3> { static constexpr int samples = 512, pad = 96, frames = 8, blocks = 11, chunks = 12; static constexpr bool mag = true; };
 
 __device__ __forceinline__ void g_stage8(const float *src, float (&v)[8])
 {
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
 {
    typedef GemmGeo<GEO> Geo;
    constexpr int kPadG = Geo::pad, kFr = Geo::frames, kBlk = Geo::blocks, kGChunks = Geo::chunks;
+   constexpr int kChunk = Geo::samples;                                         // samples per chunk (shadows the v3.1 constant of common.h)
    constexpr int kPaddedG = kChunk + 2 * kPadG;
    constexpr int kChunkPitch = (kBlk + 1) * kGBlockPitch;                       // one spare block: the mirror of tap 0 is read (unused)
    constexpr int kPos = kGChunks * kFr;                                         // positions per group (96 | 125)
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
 #endif
          GPH(4);
          // ---- epilogue: D rows = bins 16 w + 4 g + r, column = position f ----
-         const int pcf = ptab[pos].y, orow = crow[pcf & 7];
+         const int pcf = ptab[pos].y, orow = crow[pcf & 255];
          const bool ok = (pcf >> 16) != 0 && orow >= 0;
          const size_t ybase = (size_t)max(orow, 0) * (kBins * kFr) + ((pcf >> 8) & 31);
          float mag[4], val[4];
@@ -304,18 +308,27 @@ extern "C" void vadc_gemm_phase_report(void)
 }
 #endif
 
+template <typename T, int GEO>
+static void launch_gemm_geo(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
+                            int n_cus, hipStream_t st)
+{
+   const int groups = (n + GemmGeo<GEO>::chunks - 1) / GemmGeo<GEO>::chunks;
+   const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
+   hipLaunchKernelGGL((k_frontend_gemm<T, GEO>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+}
 template <typename T>
 static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
                         int n_cus, hipStream_t st, int geo)
 {
-   const int kGChunks = geo == 1 ? GemmGeo<1>::chunks : GemmGeo<0>::chunks;
-   const int groups = (n + kGChunks - 1) / kGChunks;
-   const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
-   if (geo == 1) hipLaunchKernelGGL((k_frontend_gemm<T, 1>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
-   else          hipLaunchKernelGGL((k_frontend_gemm<T, 0>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   switch (geo) {
+   case 1:  launch_gemm_geo<T, 1>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 2:  launch_gemm_geo<T, 2>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 3:  launch_gemm_geo<T, 3>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   default: launch_gemm_geo<T, 0>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   }
 }
 
-// geo: 0 = Silero v3.1 geometry (MAG unused), 1 = Silero v4
+// geo: 0 = Silero v3.1 geometry (MAG unused), 1 / 2 / 3 = Silero v4 with 1536- / 1024- / 512-sample windows
 void launch_frontend_gemm_f32(const float *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
                               int n, ItemMap map, int n_cus, hipStream_t st, int geo)
 {

@@ -624,35 +624,44 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
 }
 
 // one layer of the layer-major form (engine variant 7): layer 0 reads the encoder's split-fp16 tiles and writes h0seq, layer 1 reads h0seq
-void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
-                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
+// steps = LSTM steps per chunk: 7 (Silero v3.1); 3 / 2 / 1 (Silero v4 with 1536- / 1024- / 512-sample windows)
+template <int TS, int DEC>
+static void launch_layer_ts(int layer, const _Float16 *x, _Float16 *h, const LstmWeights &w, float *hs, float *cs, float *probs,
+                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
+   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+}
+void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
+                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps)
+{
    const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
    _Float16 *h = reinterpret_cast<_Float16 *>(h0seq);
-   if (layer == 0) {
-      if (model == 1) hipLaunchKernelGGL((k_lstm_layer<3, 1, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-      else            hipLaunchKernelGGL((k_lstm_layer<7, 0, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   } else {
-      if (model == 1) hipLaunchKernelGGL((k_lstm_layer<3, 1, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-      else            hipLaunchKernelGGL((k_lstm_layer<7, 0, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   }
+   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
 }
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
 // variant: 6 = k_lstm_wavefront_h3 (enc = split-fp16 tiles), 3 = k_lstm_wavefront_fused (enc = fp32 tiles); 7 is two launch_lstm_layer calls
-// model: 0 = Silero v3.1 (7 steps per chunk), 1 = Silero v4 (3 steps)
-void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
-                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model)
+// model: 0 = Silero v3.1 (7 steps per chunk), 1 = Silero v4 (`steps` = 3 / 2 / 1)
+template <int TS, int DEC>
+static void launch_lstm_ts(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
+                           int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
-   if (variant == 6) {
-      if (model == 1) hipLaunchKernelGGL((k_lstm_wavefront_h3<3, 1>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-      else            hipLaunchKernelGGL((k_lstm_wavefront_h3<7, 0>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   } else {
-      if (model == 1) hipLaunchKernelGGL((k_lstm_wavefront_fused<3, 1>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-      else            hipLaunchKernelGGL((k_lstm_wavefront_fused<7, 0>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   }
+   if (variant == 6) hipLaunchKernelGGL((k_lstm_wavefront_h3<TS, DEC>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   else              hipLaunchKernelGGL((k_lstm_wavefront_fused<TS, DEC>), grid, block, 0, st, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+}
+void launch_lstm(int variant, const float *enc, const LstmWeights &w, float *hs, float *cs, float *probs,
+                 int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps)
+{
+   if (model == 0)      launch_lstm_ts<7, 0>(variant, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else if (steps == 3) launch_lstm_ts<3, 1>(variant, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else if (steps == 2) launch_lstm_ts<2, 1>(variant, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   else                 launch_lstm_ts<1, 1>(variant, enc, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
 }
 
 }  // namespace vadc

@@ -51,6 +51,15 @@ class Engine:
         self.max_chunks_per_call = max_chunks_per_call
         self.model = self.caps()["model_kind"]          # decided by the weights container (99 tensors v3.1 / 36 v4)
         self.stage_shapes = STAGE_SHAPES_V4 if self.model == MODEL_V4 else STAGE_SHAPES
+        self.window = CHUNK
+
+    def set_window(self, samples: int):
+        """samples per chunk: 1536 (default); Silero v4 also 1024 / 512 (option "window": --sequence_count of the reference's onnxruntime path)"""
+        self.set_option("window", samples)
+        self.window = samples
+        if self.model == MODEL_V4:
+            t = samples // 64
+            self.stage_shapes = {0: (129, t), 1: (129, t), 2: (16, t // 2), 3: (32, t // 4), 4: (32, t // 8), 5: (64, t // 8)}
 
     @classmethod
     def from_file(cls, path: str, **kw) -> "Engine":
@@ -80,13 +89,13 @@ class Engine:
 
     # ---- hot path ----
     def run(self, samples: np.ndarray) -> np.ndarray:
-        """samples: int16 or float32 [S, C*1536] (or [S, C, 1536]); returns probs float32 [S, C, 2]."""
+        """samples: int16 or float32 [S, C*window] (or [S, C, window]; window = 1536 unless set_window); returns probs float32 [S, C, 2]."""
         a = np.ascontiguousarray(samples)
         if a.ndim == 3:
             a = a.reshape(a.shape[0], -1)
-        if a.ndim != 2 or a.shape[1] % CHUNK != 0 or a.shape[1] == 0:
-            raise ValueError("samples must be [streams, chunks*1536]")
-        S, Cn = a.shape[0], a.shape[1] // CHUNK
+        if a.ndim != 2 or a.shape[1] % self.window != 0 or a.shape[1] == 0:
+            raise ValueError("samples must be [streams, chunks*window]")
+        S, Cn = a.shape[0], a.shape[1] // self.window
         out = np.empty((S, Cn, 2), np.float32)
         if a.dtype == np.int16:
             self._check(self._L.vadc_amd_run_s16(self._h, _ptr(a), S, Cn, _ptr(out)))
@@ -99,7 +108,7 @@ class Engine:
     def backend_run(self, input_samples: np.ndarray, batch_size: int) -> np.ndarray:
         """Literal backend_run (silero.h:53-74): `batch_size` consecutive 1536-sample windows of ONE stream
         (f32 in [-1,1)), output [batch_size, 2] with the speech probability at index 1."""
-        x = np.ascontiguousarray(input_samples, dtype=np.float32).reshape(1, batch_size * CHUNK)
+        x = np.ascontiguousarray(input_samples, dtype=np.float32).reshape(1, batch_size * self.window)
         return self.run(x)[0]
 
     def run_device(self, d_in_ptr: int, dtype, n_streams: int, n_chunks: int, d_probs_ptr: int, hip_stream: int = 0):
@@ -135,7 +144,7 @@ class Engine:
 
     # ---- stage taps ----
     def stage_from_samples(self, samples_f32: np.ndarray, stage: str) -> np.ndarray:
-        x = np.ascontiguousarray(samples_f32, dtype=np.float32).reshape(-1, CHUNK)
+        x = np.ascontiguousarray(samples_f32, dtype=np.float32).reshape(-1, self.window)
         s = STAGES[stage]
         out = np.empty((x.shape[0],) + self.stage_shapes[s], np.float32)
         self._check(self._L.vadc_amd_debug_stage_from_samples(self._h, _ptr(x), x.shape[0], s, _ptr(out)))
