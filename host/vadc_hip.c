@@ -28,7 +28,7 @@
 
 #define WINDOW_CHUNKS 96
 #define CHUNK VADC_AMD_CHUNK_SAMPLES
-#define SAMPLE_RATE 16000
+
 
 typedef struct { int start, end, valid; } Segment;
 typedef struct { int temp_end, current_start, triggered; } FeedState;
@@ -187,16 +187,20 @@ int main(int argc, char **argv)
    int seq = o.sequence_count;
    if (seq < caps.input_size_min) seq = caps.input_size_min;
    if (seq > caps.input_size_max) seq = caps.input_size_max;
-   if (caps.input_size_min != caps.input_size_max) seq = seq >= 1536 ? 1536 : (seq >= 1024 ? 1024 : 512);
+   if (caps.input_size_min != caps.input_size_max) {               /* a third, two thirds or all of the maximum: 512 / 1024 / 1536 (8 kHz: 256 / 512 / 768) */
+      const int third = caps.input_size_max / 3;
+      seq = seq >= 3 * third ? 3 * third : (seq >= 2 * third ? 2 * third : third);
+   }
    if (seq != o.sequence_count) fprintf(stderr, "--sequence_count %d: the backend runs %d-sample chunks\n", o.sequence_count, seq);
-   if (seq != CHUNK && vadc_amd_set_option(eng, "window", seq) != VADC_AMD_OK) { fprintf(stderr, "cannot set the window: %s\n", vadc_amd_last_error()); return -1; }
+   if (seq != caps.window_samples && vadc_amd_set_option(eng, "window", seq) != VADC_AMD_OK) { fprintf(stderr, "cannot set the window: %s\n", vadc_amd_last_error()); return -1; }
    const int chunk = seq;
    fprintf(stderr, "Running with sequence count %d\n", chunk);     /* vadc.c:753 */
 
-   const float chunk_ms = chunk / (float)SAMPLE_RATE * 1000.0f;    /* vadc.c:756 */
+   const int sample_rate = caps.sample_rate;                       /* vadc.h:97 hard-codes 16000; the container of the v4 graph's 8 kHz branch says 8000 */
+   const float chunk_ms = chunk / (float)sample_rate * 1000.0f;    /* vadc.c:756 */
    int min_speech = (int)(o.min_speech_ms / chunk_ms + 0.5f);   if (min_speech < 1) min_speech = 1;
    int min_silence = (int)(o.min_silence_ms / chunk_ms + 0.5f); if (min_silence < 1) min_silence = 1;
-   const float spc = (float)chunk / SAMPLE_RATE;                   /* vadc.c:846 */
+   const float spc = (float)chunk / sample_rate;                   /* vadc.c:846 */
    const float neg_thr = o.threshold - o.neg_threshold_relative;   /* vadc.c:1243 */
 
    static int16_t pcm[WINDOW_CHUNKS * CHUNK];
@@ -248,7 +252,7 @@ int main(int argc, char **argv)
    if (o.stats) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       double wall = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-      double dur = (double)total_samples / SAMPLE_RATE;
+      double dur = (double)total_samples / sample_rate;
       fprintf(stderr, "time=%.2fs speech=%.2fs (%.1f%%), duration=%.2fs (%.1fx)\n", wall, g_total_speech,
               dur > 0 ? 100.0 * g_total_speech / dur : 0.0, dur, wall > 0 ? dur / wall : 0.0);
    }

@@ -42,7 +42,7 @@ extern "C" {
 enum {
    VADC_AMD_OK        =  0,
    VADC_AMD_EINVAL    = -1,   /* bad argument (NULL, out-of-range stream/chunk count, ...)        */
-   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 / 36-tensor v4 container */
+   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 / 36- or 37-tensor v4 container */
    VADC_AMD_ENODEVICE = -3,   /* no usable gfx950 device / HIP runtime failure at creation         */
    VADC_AMD_EHIP      = -4,   /* HIP runtime error during a call                                    */
    VADC_AMD_ENOMEM    = -5
@@ -51,8 +51,9 @@ enum {
 /* model kind, decided by the weights container handed to vadc_amd_create and reported by vadc_amd_get_caps */
 enum {
    VADC_AMD_MODEL_V31 = 0,   /* Silero v3.1 / 16 kHz: the 99-tensor .testtensor the reference's C backend loads (tensor.h:114-191) */
-   VADC_AMD_MODEL_V4  = 1    /* Silero v4 / 16 kHz: 36-tensor container written from the reference's silero_vad_v4.onnx by
-                                vadc_amd/onnx_weights.py.  The reference runs v4 only through onnxruntime (silero.h:59,
+   VADC_AMD_MODEL_V4  = 1    /* Silero v4: 36-tensor container (16 kHz branch) or 37-tensor container (8 kHz branch `model_8k.*`: own weights, third strided
+                                conv with stride 1, silero_vad.py:178-181; caps.sample_rate = 8000, windows 768 / 512 / 256) written from the reference's
+                                silero_vad_v4.onnx by vadc_amd/onnx_weights.py.  The reference runs v4 only through onnxruntime (silero.h:59,
                                 onnx_helpers.c:83-115); arithmetic per silero_vad.py:191-236.  One probability per chunk, written
                                 to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */
 };
@@ -94,7 +95,8 @@ typedef struct vadc_amd_caps {
    int32_t precision;
    int32_t model_kind;                    /* VADC_AMD_MODEL_*                          */
    int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3, 2, 1 (v4: window / 512)    */
-   int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1024 / 512 (option "window") */
+   int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1024 / 512 (option "window"); v4 8 kHz: 768 / 512 / 256 */
+   int32_t sample_rate;                   /* 16000; 8000 for the container of the v4 graph's 8 kHz branch               */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -22,7 +22,7 @@ so4_model *so4_model_from_bytes(const void *blob, size_t len)
 {
    rd4 r = { (const unsigned char *)blob, len, 0, 1 };
    int32_t version = rd4_i32(&r), count = rd4_i32(&r);
-   if (!r.ok || version != 1 || count != SO4_TENSORS) return NULL;
+   if (!r.ok || version != 1 || (count != SO4_TENSORS && count != SO4_TENSORS + 1)) return NULL;   /* + 1: the 8 kHz container's sample-rate marker */
    for (int i = 0; i < count; ++i) {
       int32_t n = rd4_i32(&r);
       if (!r.ok || n <= 0 || r.off + (size_t)n > len) return NULL;
@@ -42,8 +42,8 @@ so4_model *so4_model_from_bytes(const void *blob, size_t len)
    if (r2.off != len) return NULL;
    so4_model *m = (so4_model *)calloc(1, sizeof(so4_model));
    m->storage = a4(total);
-   const float *t[SO4_TENSORS];
-   int sizes[SO4_TENSORS];
+   const float *t[SO4_TENSORS + 1];
+   int sizes[SO4_TENSORS + 1];
    size_t used = 0;
    for (int i = 0; i < count; ++i) {
       int32_t ndim = rd4_i32(&r);
@@ -53,7 +53,10 @@ so4_model *so4_model_from_bytes(const void *blob, size_t len)
       r.off += (size_t)nbytes;
       t[i] = m->storage + used; sizes[i] = size; used += (size_t)size;
    }
-   static const int cin[4] = {258, 16, 32, 32}, cout[4] = {16, 32, 32, 64}, stride[4] = {2, 2, 2, 1}, proj[4] = {1, 1, 0, 1};
+   /* 8 kHz branch (silero_vad.py:178-181, `sr == 16000` else): the third strided conv has stride 1 */
+   m->sample_rate = (count == SO4_TENSORS + 1) ? 8000 : 16000;
+   static const int cin[4] = {258, 16, 32, 32}, cout[4] = {16, 32, 32, 64}, proj[4] = {1, 1, 0, 1};
+   const int stride[4] = {2, 2, m->sample_rate == 8000 ? 1 : 2, 1};
    int idx = 0, ok = 1, t_in = SO4_FRAMES;
    m->basis = t[idx]; ok &= sizes[idx] == 258 * 256; idx++;
    for (int l = 0; l < 4; ++l) {
@@ -72,7 +75,8 @@ so4_model *so4_model_from_bytes(const void *blob, size_t len)
    m->dec_w = t[idx]; ok &= sizes[idx] == 64; idx++;
    m->dec_b = t[idx]; ok &= sizes[idx] == 1; idx++;
    ok &= sizes[idx] == 7; idx++;                       /* adaptive-normalization filter: so_adaptive_norm carries the constants */
-   if (!ok || idx != SO4_TENSORS) { so4_model_free(m); return NULL; }
+   if (count == SO4_TENSORS + 1) { ok &= sizes[idx] == 1 && t[idx][0] == 8000.0f; idx++; }
+   if (!ok || idx != count) { so4_model_free(m); return NULL; }
    return m;
 }
 

@@ -27,7 +27,7 @@ import silero_vad  # noqa: E402  (reference, build container only)
 from vadc_amd import synth, testtensor  # noqa: E402
 
 
-def build_model(weights_path):
+def build_model(weights_path, sr=16000):
     ts = [a for _, a in testtensor.load(weights_path)]
     sd = {}
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a).copy())
@@ -58,7 +58,7 @@ def build_model(weights_path):
         sd[f"decoder.rnn.weight_ih_l{l}"] = T(W[l][:, :64]); sd[f"decoder.rnn.weight_hh_l{l}"] = T(W[l][:, 64:])
         sd[f"decoder.rnn.bias_ih_l{l}"] = T(B[l]); sd[f"decoder.rnn.bias_hh_l{l}"] = torch.zeros(256)
     sd["decoder.decoder.1.weight"] = T(ts[33]); sd["decoder.decoder.1.bias"] = T(ts[34])
-    m = silero_vad.Silero_V4(16000)
+    m = silero_vad.Silero_V4(sr)
     own = m.state_dict()
     for k in own:
         if k.endswith("num_batches_tracked"):
@@ -136,6 +136,20 @@ def main():
     pathw = os.path.join(HERE, "python_reference_v4_windows.npz")
     np.savez_compressed(pathw, **outw)
     print("wrote", pathw, os.path.getsize(pathw), "bytes  (pcm: the streams of python_reference_v4.npz)")
+    # the 8 kHz branch of the v4 graph (silero_vad.py::Silero_V4(8000): third strided conv with stride 1; weights `model_8k.*` of the reference's
+    # silero_vad_v4.onnx -> tests/golden/silero_v4_8k.testtensor): windows of 768 / 512 / 256 samples = 12 / 8 / 4 STFT frames.  The streams
+    # are the same sample sequences, now read as 8 kHz audio.
+    m64_8k = build_model(os.path.join(HERE, "silero_v4_8k.testtensor"), 8000).double()
+    out8 = {}
+    for window in (768, 512, 256):
+        for name in ("speech0", "speech1", "noise", "square"):
+            x = pcm[name][: (pcm[name].size // window) * window]
+            p64, h64, c64 = run_stream(m64_8k, x, torch.float64, window)
+            out8[f"probs64_w{window}_{name}"] = p64; out8[f"h64_w{window}_{name}"] = h64; out8[f"c64_w{window}_{name}"] = c64
+            print(f"8 kHz window {window} {name}: {p64.size} chunks, p[min,max]=({p64.min():.4f},{p64.max():.4f})")
+    path8 = os.path.join(HERE, "python_reference_v4_8k.npz")
+    np.savez_compressed(path8, **out8)
+    print("wrote", path8, os.path.getsize(path8), "bytes  (pcm: the streams of python_reference_v4.npz)")
 
 
 if __name__ == "__main__":

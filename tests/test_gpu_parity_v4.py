@@ -330,3 +330,53 @@ def test_cli_sequence_count_selects_the_v4_window(gold):
         got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
         want = gw[f"probs64_w{window}_speech0"] if window != 1536 else gold["probs64_speech0"]
         assert got.shape == want.shape and float(np.abs(got - want).max()) < PROB_TOL + 5e-7
+
+
+# ---------------------------------------------------------------------------------------------- the 8 kHz branch of the v4 graph
+V4_8K_WEIGHTS = os.path.join(GOLDEN, "silero_v4_8k.testtensor")
+
+
+@pytest.mark.parametrize("window", [768, 512, 256])
+def test_8khz_branch_vs_python_reference_and_oracle(gold, window):
+    """the 37-tensor container (the graph's `model_8k.*` weights; third strided conv with stride 1, silero_vad.py:178-181): caps say 8000 Hz and
+    256 ... 768-sample windows; probabilities against the float64 PyTorch goldens (Silero_V4(8000)) and the oracle; ragged streams, forked calls"""
+    g8 = np.load(os.path.join(GOLDEN, "python_reference_v4_8k.npz"))
+    blob8 = open(V4_8K_WEIGHTS, "rb").read()
+    orc8 = O.OracleV4(blob8)
+    e = Engine(blob8, max_streams=40, max_chunks_per_call=300, device=0)
+    try:
+        c = e.caps()
+        assert (c["model_kind"], c["sample_rate"], c["input_size_min"], c["input_size_max"], c["window_samples"]) == (MODEL_V4, 8000, 256, 768, 768)
+        if window != 768:
+            e.set_window(window)
+        assert e.caps()["window_samples"] == window and e.caps()["lstm_steps_per_chunk"] == window // 256
+        for name in ("speech0", "speech1", "noise", "square"):
+            pcm = gold[f"pcm_{name}"]
+            pcm = pcm[: (pcm.size // window) * window]
+            e.reset_streams()
+            p = e.run(pcm.reshape(1, -1))[0]
+            assert float(np.abs(p[:, 1] - g8[f"probs64_w{window}_{name}"]).max()) < PROB_TOL, name
+        S, n = 37, 120
+        pcm = synth.make_streams(S, (n * window + 1535) // 1536, seed0=6900 + window)[:, : n * window]
+        e.reset_streams()
+        got = np.concatenate([e.run(pcm[:, : 60 * window]), e.run(pcm[:, 60 * window:])], axis=1)[:, :, 1]
+        want = orc8.forward_streams(pcm, window=window)
+        assert float(np.abs(got - want).max()) < PROB_TOL
+        x = f32(gold["pcm_speech0"])[: 5 * window]
+        assert e.stage_from_samples(x, "layer3").shape == (5, 32, window // 256) and e.stage_from_samples(x, "layer4").shape == (5, 64, window // 256)
+        with pytest.raises(VadcAmdError):
+            e.set_option("window", 1536)
+    finally:
+        e.close()
+
+
+def test_cli_with_the_8khz_container(gold):
+    import subprocess
+    from conftest import ROOT
+    g8 = np.load(os.path.join(GOLDEN, "python_reference_v4_8k.npz"))
+    r = subprocess.run([os.path.join(ROOT, "host", "vadc_hip"), "--model", V4_8K_WEIGHTS, "--raw_probabilities"], input=gold["pcm_speech0"].tobytes(),
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert "Running with sequence count 768" in r.stderr.decode()            # the default 1536 clamped to the branch's maximum (vadc.c:743-752)
+    got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
+    assert float(np.abs(got - g8["probs64_w768_speech0"]).max()) < PROB_TOL + 5e-7

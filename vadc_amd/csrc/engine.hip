@@ -34,7 +34,7 @@ struct LayerWeightsM {
    const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
-void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int);
+void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int);
 }  // namespace vadc
 
 using namespace vadc;
@@ -95,10 +95,12 @@ static const LayerShape kLayers[4] = {{129, 16, 25, 2, 1}, {16, 32, 13, 2, 1}, {
 static const int kStageElemsV31[VADC_AMD_STAGE_COUNT] = {129 * 25, 129 * 25, 16 * 13, 32 * 7, 32 * 7, 64 * 7};
 // Silero v4 (silero_vad.py:157-236): 24 frames, encoder [16,12] [32,6] [32,3] [64,3]
 static const LayerShape kLayersV4[4] = {{258, 16, 24, 2, 1}, {16, 32, 12, 2, 1}, {32, 32, 6, 2, 0}, {32, 64, 3, 1, 1}};
-// elements per chunk of every stage tap for a Silero v4 window of 64 * frames samples (frames = 24 / 16 / 8: T -> T/2 -> T/4 -> T/8 -> T/8)
-static void stage_elems_v4(int frames, int (&out)[VADC_AMD_STAGE_COUNT])
+// elements per chunk of every stage tap for a Silero v4 window of 64 * frames samples: T -> T/2 -> T/4 -> T/8 -> T/8 in the 16 kHz branch
+// (frames 24 / 16 / 8), T -> T/2 -> T/4 -> T/4 -> T/4 in the 8 kHz branch (third strided conv with stride 1; frames 12 / 8 / 4)
+static void stage_elems_v4(int frames, int stride3, int (&out)[VADC_AMD_STAGE_COUNT])
 {
-   out[0] = out[1] = 129 * frames; out[2] = 16 * (frames / 2); out[3] = 32 * (frames / 4); out[4] = 32 * (frames / 8); out[5] = 64 * (frames / 8);
+   const int t3 = stride3 == 2 ? frames / 8 : frames / 4;
+   out[0] = out[1] = 129 * frames; out[2] = 16 * (frames / 2); out[3] = 32 * (frames / 4); out[4] = 32 * t3; out[5] = 64 * t3;
 }
 
 struct Packer {
@@ -118,7 +120,14 @@ struct vadc_amd_engine {
    int model = VADC_AMD_MODEL_V31;              // decided by the weights container: 99 tensors = v3.1, 36 = v4
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 2, 1 (v4 with 1536-, 1024-, 512-sample windows)
-   int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170)
+   int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
+   int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
+   int stride3() const { return sample_rate == 8000 ? 1 : 2; }
+   int v4_geo() const                           // k_frontend_gemm geometry of the window in effect
+   {
+      if (sample_rate == 8000) return window == 768 ? 4 : (window == 512 ? 3 : 5);
+      return window == 1024 ? 2 : (window == 512 ? 3 : 1);
+   }
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
@@ -542,8 +551,13 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    std::vector<HostTensor> ts;
    if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
       return fail(VADC_AMD_EWEIGHTS, "create: weights blob is not a valid .testtensor container");
-   if (ts.size() != 99 && ts.size() != 36)
-      return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors (Silero v3.1) or 36 (Silero v4), found %zu", ts.size());
+   if (ts.size() != 99 && ts.size() != 36 && ts.size() != 37)
+      return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors (Silero v3.1), 36 (Silero v4, 16 kHz) or 37 (Silero v4, 8 kHz branch), found %zu", ts.size());
+   if (ts.size() == 37) {
+      float sr = 0.0f;
+      if (ts[36].size == 1) memcpy(&sr, ts[36].data, 4);
+      if (sr != 8000.0f) return fail(VADC_AMD_EWEIGHTS, "create: the 37th tensor of a Silero v4 container must be the sample-rate marker [8000]");
+   }
 
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -559,10 +573,12 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    vadc_amd_engine *e = new vadc_amd_engine();
    e->device = device; e->max_streams = max_streams; e->max_chunks = max_chunks; e->precision = precision;
    e->max_items = (size_t)max_streams * max_chunks;
-   e->model = ts.size() == 36 ? VADC_AMD_MODEL_V4 : VADC_AMD_MODEL_V31;
-   e->frames = e->model == VADC_AMD_MODEL_V4 ? 24 : kFrames;
+   e->model = ts.size() != 99 ? VADC_AMD_MODEL_V4 : VADC_AMD_MODEL_V31;
+   e->sample_rate = ts.size() == 37 ? 8000 : 16000;
+   e->window = e->sample_rate == 8000 ? 768 : kChunk;           // 96 ms either way
+   e->frames = e->model == VADC_AMD_MODEL_V4 ? e->window / 64 : kFrames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
-   if (e->model == VADC_AMD_MODEL_V4) stage_elems_v4(24, e->stage_elems);
+   if (e->model == VADC_AMD_MODEL_V4) stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
    else memcpy(e->stage_elems, kStageElemsV31, sizeof(kStageElemsV31));
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
@@ -613,9 +629,11 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    caps->batch_size_restriction = -1;          // silero.h:39
    caps->is_silero_v5 = 0;                     // silero.h:40
    // silero.h:41-42 (the C backend: 1536 only); onnx_helpers.c:164-170 for the v4 graph: 512 ... 1536, of which this engine runs 512 / 1024 / 1536
-   caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? 512 : kChunk;
-   caps->input_size_max = kChunk;
+   const int wmax = e->sample_rate == 8000 ? 768 : kChunk;
+   caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
+   caps->input_size_max = wmax;
    caps->window_samples = e->window;
+   caps->sample_rate = e->sample_rate;
    caps->output_dims = 3;                      // silero.h:43
    caps->output_stride = 2;                    // vadc.c:704-708
    caps->silero_probability_out_index = 1;
@@ -713,8 +731,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
       e->graphs.clear();
    }
-   if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value == 1 && e->window != kChunk)
-      return fail(VADC_AMD_EINVAL, "set_option: the v4 tree front end exists for 1536-sample windows only");
+   if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value == 1 && (e->window != kChunk || e->sample_rate != 16000))
+      return fail(VADC_AMD_EINVAL, "set_option: the v4 tree front end exists for 1536-sample windows of the 16 kHz branch only");
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value >= 0 && value <= 1) {
       // v4: 0 = GEMM front end on the matrix cores (default; needs the symmetric basis), 1 = the tree kernel with the v4 geometry
       e->frontend_variant = value;
@@ -727,12 +745,14 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "window") == 0) {
       // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
       // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which 512 / 1024 / 1536 (8 / 16 / 24 STFT frames) are built here
-      if (value == kChunk && e->window == kChunk) return VADC_AMD_OK;
-      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || (value != 512 && value != 1024 && value != kChunk))
-         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 1024 or 1536", value);
+      if (value == e->window) return VADC_AMD_OK;
+      const int wmax = e->sample_rate == 8000 ? 768 : kChunk;     // 8 kHz branch: 256 / 512 / 768 samples = the same 32 / 64 / 96 ms
+      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || (value != wmax / 3 && value != 2 * wmax / 3 && value != wmax))
+         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 1024 or 1536 "
+                                      "(its 8 kHz branch 256, 512 or 768)", value);
       { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
-      e->window = value; e->frames = value / 64; e->lstm_steps = e->frames / 8;
-      stage_elems_v4(e->frames, e->stage_elems);
+      e->window = value; e->frames = value / 64; e->lstm_steps = e->stride3() == 2 ? e->frames / 8 : e->frames / 4;
+      stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
       return VADC_AMD_OK;
    }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
@@ -789,7 +809,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
    for (int l = first; l <= last; ++l) {
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
       const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames, e->stride3());
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
    }
@@ -812,7 +832,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       const size_t fms = e->max_items * kFrames;
       const int fk = pick_frontend(e, d_in);
       if (fk == 2) {
-         const int geo = e->model == VADC_AMD_MODEL_V4 ? (e->window == 1024 ? 2 : (e->window == 512 ? 3 : 1)) : 0;
+         const int geo = e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0;
          float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
          if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
          else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
@@ -1248,7 +1268,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    const ItemMap map{n, 0, n};
    if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
-                               e->model == VADC_AMD_MODEL_V4 ? (e->window == 1024 ? 2 : (e->window == 512 ? 3 : 1)) : 0);
+                               e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);

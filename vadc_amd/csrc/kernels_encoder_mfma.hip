@@ -903,17 +903,17 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
 
 // Silero v4 encoder stages (silero_vad.py:157-189, is_v4, strides 2, 2, 2, 1).  T0 = frames of the window = samples / 64 (onnx_helpers.c:164-170
 // lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 16 -> 8 -> 4 -> 2 -> 2 (1024), 8 -> 4 -> 2 -> 1 -> 1 (512).
-// chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.
+// chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.  S3 = stride of the third strided conv.
 template <int T0, int NCH, bool SLAB, int FIRSTK>
 static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st)
 {
    hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, NCH, false, false, !SLAB>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
 }
-template <int T0>
+template <int T0, int S3>
 static void launch_v4_t(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
                         int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
 {
-   constexpr int T1 = T0 / 2, T2 = T0 / 4, T3 = T0 / 8;
+   constexpr int T1 = T0 / 2, T2 = T0 / 4, T3 = S3 == 2 ? T0 / 8 : T2;
    constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
    switch (layer) {
    case 0:
@@ -922,7 +922,7 @@ static void launch_v4_t(int layer, const float *in, const float *in2, const floa
       else          launch_v4_first<T0, N0, false, 3>(in, in2, fm, w, out, n, map, fm_stride, st);
       break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
-   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, 2, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
       if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 2, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
       else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 1, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
@@ -931,13 +931,20 @@ static void launch_v4_t(int layer, const float *in, const float *in2, const floa
    }
 }
 
-// frames = STFT frames per chunk: 24 (1536-sample windows), 16 (1024), 8 (512)
+// frames = STFT frames per chunk; stride3 = stride of the third strided conv: 2 in the 16 kHz branch (frames 24 / 16 / 8 = 1536- / 1024- / 512-sample
+// windows), 1 in the 8 kHz branch (silero_vad.py:178-181; frames 12 / 8 / 4 = 768- / 512- / 256-sample windows: 12 -> 6 -> 3 -> 3 -> 3, ...)
 void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames)
+                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames, int stride3)
 {
-   if (frames == 16)     launch_v4_t<16>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-   else if (frames == 8) launch_v4_t<8>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-   else                  launch_v4_t<24>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   if (stride3 == 1) {
+      if (frames == 8)      launch_v4_t<8, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+      else if (frames == 4) launch_v4_t<4, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+      else                  launch_v4_t<12, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+      return;
+   }
+   if (frames == 16)     launch_v4_t<16, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   else if (frames == 8) launch_v4_t<8, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   else                  launch_v4_t<24, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
 }
 
 }  // namespace vadc

@@ -73,6 +73,9 @@ template <> struct GemmGeo<1> { static constexpr int samples = 1536, pad = 96, f
 // Silero v4 with 1024- and 512-sample windows (onnx_helpers.c:164-170: the v4 graph takes 512 ... 1536 samples; frames = samples / 64)
 template <> struct GemmGeo<2> { static constexpr int samples = 1024, pad = 96, frames = 16, blocks = 19, chunks = 6; static constexpr bool mag = true; };
 template <> struct GemmGeo<3> { static constexpr int samples = 512, pad = 96, frames = 8, blocks = 11, chunks = 12; static constexpr bool mag = true; };
+// the 8 kHz branch of the v4 graph (same basis, same hop): 768- and 256-sample windows (512 is GEO 3)
+template <> struct GemmGeo<4> { static constexpr int samples = 768, pad = 96, frames = 12, blocks = 15, chunks = 8; static constexpr bool mag = true; };
+template <> struct GemmGeo<5> { static constexpr int samples = 256, pad = 96, frames = 4, blocks = 7, chunks = 16; static constexpr bool mag = true; };
 
 __device__ __forceinline__ void g_stage8(const float *src, float (&v)[8])
 {
@@ -324,11 +327,13 @@ static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, floa
    case 1:  launch_gemm_geo<T, 1>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    case 2:  launch_gemm_geo<T, 2>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    case 3:  launch_gemm_geo<T, 3>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 4:  launch_gemm_geo<T, 4>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 5:  launch_gemm_geo<T, 5>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    default: launch_gemm_geo<T, 0>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    }
 }
 
-// geo: 0 = Silero v3.1 geometry (MAG unused), 1 / 2 / 3 = Silero v4 with 1536- / 1024- / 512-sample windows
+// geo: 0 = Silero v3.1 geometry (MAG unused), 1 / 2 / 3 / 4 / 5 = Silero v4 with 1536- / 1024- / 512- / 768- / 256-sample windows
 void launch_frontend_gemm_f32(const float *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
                               int n, ItemMap map, int n_cus, hipStream_t st, int geo)
 {

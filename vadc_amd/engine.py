@@ -52,14 +52,21 @@ class Engine:
         self.model = self.caps()["model_kind"]          # decided by the weights container (99 tensors v3.1 / 36 v4)
         self.stage_shapes = STAGE_SHAPES_V4 if self.model == MODEL_V4 else STAGE_SHAPES
         self.window = CHUNK
+        self.sample_rate = self.caps()["sample_rate"]
+        if self.sample_rate == 8000:                    # the v4 graph's 8 kHz branch: 768-sample chunks by default (the same 96 ms)
+            self._set_v4_shapes(768)
 
     def set_window(self, samples: int):
         """samples per chunk: 1536 (default); Silero v4 also 1024 / 512 (option "window": --sequence_count of the reference's onnxruntime path)"""
         self.set_option("window", samples)
+        self._set_v4_shapes(samples)
+
+    def _set_v4_shapes(self, samples: int):
         self.window = samples
         if self.model == MODEL_V4:
             t = samples // 64
-            self.stage_shapes = {0: (129, t), 1: (129, t), 2: (16, t // 2), 3: (32, t // 4), 4: (32, t // 8), 5: (64, t // 8)}
+            t3 = t // 4 if self.sample_rate == 8000 else t // 8
+            self.stage_shapes = {0: (129, t), 1: (129, t), 2: (16, t // 2), 3: (32, t // 4), 4: (32, t3), 5: (64, t3)}
 
     @classmethod
     def from_file(cls, path: str, **kw) -> "Engine":

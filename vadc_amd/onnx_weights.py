@@ -128,8 +128,12 @@ def load_onnx_tensors(path: str) -> Tuple[Dict[str, np.ndarray], List[dict]]:
 #          (the reference C layout, lstm.c:31-110; ONNX stores W/R/B separately in gate order i,o,f,c)
 #   33,34  decoder conv 64->1: weight [1,64,1], bias [1]
 #   35     adaptive-normalization filter [1,1,7] (the constants of misc.c:5-13)
+#   36     (8 kHz container only) sample_rate [1] = 8000: marks the 8 kHz branch of the graph (`model_8k.*`), whose third strided conv has stride 1
+#          (silero_vad.py:178-181) -- 37 tensors select it in libvadc_amd.so
 V4_LSTM_16K = (("343", "345", "347"), ("415", "417", "419"))
 V4_FOLDED_16K = (("1110", "1111"), ("1113", "1114"), ("1116", "1117"), ("1119", "1120"))
+V4_LSTM_8K = (("833", "835", "837"), ("905", "907", "909"))
+V4_FOLDED_8K = (("1122", "1123"), ("1125", "1126"), ("1128", "1129"), ("1131", "1132"))
 
 
 def _lstm_onnx_to_c(W, R, B):
@@ -141,15 +145,18 @@ def _lstm_onnx_to_c(W, R, B):
     return w.astype(np.float32), b.astype(np.float32)
 
 
-def silero_v4_16k_tensors(onnx_path: str):
-    """-> [(name, array)] in the positional order above"""
+def silero_v4_16k_tensors(onnx_path: str, sr: int = 16000):
+    """-> [(name, array)] in the positional order above; sr = 8000 takes the graph's 8 kHz branch and appends the sample-rate marker"""
     t, _ = load_onnx_tensors(onnx_path)
-    out = [("forward_basis_buffer", t["model.feature_extractor.forward_basis_buffer"])]
+    if sr not in (16000, 8000):
+        raise ValueError("sr must be 16000 or 8000")
+    model = "model" if sr == 16000 else "model_8k"
+    out = [("forward_basis_buffer", t[f"{model}.feature_extractor.forward_basis_buffer"])]
     def block(prefix, proj=True):
         names = ["dw_conv.0.weight", "dw_conv.0.bias", "pw_conv.0.weight", "pw_conv.0.bias"] + (["proj.weight", "proj.bias"] if proj else [])
-        return [(f"{prefix}.{n}", t[f"model.{prefix}.{n}"]) for n in names]
+        return [(f"{prefix}.{n}", t[f"{model}.{prefix}.{n}"]) for n in names]
     out += block("first_layer.0")
-    convs = V4_FOLDED_16K
+    convs = V4_FOLDED_16K if sr == 16000 else V4_FOLDED_8K
     out += [("encoder.0.folded.weight", t[convs[0][0]]), ("encoder.0.folded.bias", t[convs[0][1]])]
     out += block("encoder.3.0")
     out += [("encoder.4.folded.weight", t[convs[1][0]]), ("encoder.4.folded.bias", t[convs[1][1]])]
@@ -157,18 +164,20 @@ def silero_v4_16k_tensors(onnx_path: str):
     out += [("encoder.8.folded.weight", t[convs[2][0]]), ("encoder.8.folded.bias", t[convs[2][1]])]
     out += block("encoder.11.0")
     out += [("encoder.12.folded.weight", t[convs[3][0]]), ("encoder.12.folded.bias", t[convs[3][1]])]
-    ws, bs = zip(*[_lstm_onnx_to_c(t[a], t[b], t[c]) for a, b, c in V4_LSTM_16K])
+    ws, bs = zip(*[_lstm_onnx_to_c(t[a], t[b], t[c]) for a, b, c in (V4_LSTM_16K if sr == 16000 else V4_LSTM_8K)])
     out += [("lstm_weights", np.stack(ws)), ("lstm_biases", np.stack(bs))]
-    out += [("decoder_weights", t["model.decoder.decoder.1.weight"]), ("decoder_biases", t["model.decoder.decoder.1.bias"])]
-    out += [("adaptive_normalization_filter", t["model.adaptive_normalization.filter_"])]
+    out += [("decoder_weights", t[f"{model}.decoder.decoder.1.weight"]), ("decoder_biases", t[f"{model}.decoder.decoder.1.bias"])]
+    out += [("adaptive_normalization_filter", t[f"{model}.adaptive_normalization.filter_"])]
+    if sr == 8000:
+        out += [("sample_rate", np.asarray([8000.0], np.float32))]
     return [(n, np.ascontiguousarray(a, dtype=np.float32)) for n, a in out]
 
 
 if __name__ == "__main__":
     import sys
     from . import testtensor
-    if len(sys.argv) != 3:
-        sys.exit("usage: python -m vadc_amd.onnx_weights silero_vad_v4.onnx out.testtensor")
-    ts = silero_v4_16k_tensors(sys.argv[1])
+    if len(sys.argv) not in (3, 4):
+        sys.exit("usage: python -m vadc_amd.onnx_weights silero_vad_v4.onnx out.testtensor [8000]")
+    ts = silero_v4_16k_tensors(sys.argv[1], int(sys.argv[3]) if len(sys.argv) == 4 else 16000)
     testtensor.dump(sys.argv[2], ts)
     print(f"wrote {sys.argv[2]}: {len(ts)} tensors, {sum(a.size for _, a in ts)} floats")
