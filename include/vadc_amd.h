@@ -42,7 +42,7 @@ extern "C" {
 enum {
    VADC_AMD_OK        =  0,
    VADC_AMD_EINVAL    = -1,   /* bad argument (NULL, out-of-range stream/chunk count, ...)        */
-   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 / 36- or 37-tensor v4 container */
+   VADC_AMD_EWEIGHTS  = -2,   /* weights blob is not a valid 99-tensor v3.1 / 36- or 37-tensor v4 / 13-tensor v5 container */
    VADC_AMD_ENODEVICE = -3,   /* no usable gfx950 device / HIP runtime failure at creation         */
    VADC_AMD_EHIP      = -4,   /* HIP runtime error during a call                                    */
    VADC_AMD_ENOMEM    = -5
@@ -55,7 +55,11 @@ enum {
                                 conv with stride 1, silero_vad.py:178-181; caps.sample_rate = 8000, windows 768 / 512 / 256) written from the reference's
                                 silero_vad_v4.onnx by vadc_amd/onnx_weights.py.  The reference runs v4 only through onnxruntime (silero.h:59,
                                 onnx_helpers.c:83-115); arithmetic per silero_vad.py:191-236.  One probability per chunk, written
-                                to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */
+                                to BOTH slots of probs[stream][chunk][2] so that hosts index it like v3.1. */,
+   VADC_AMD_MODEL_V5  = 2    /* Silero v5 SHAPES (13-tensor container in the order of the reference's C test, test.c:2045-2068): per chunk the previous 64
+                                samples + a 512-sample window, STFT hop 128, four k = 3 convs, LSTM(128), one probability (vadc.c:105-162,
+                                silero_vad.py:290-434).  The reference ships no v5 weights; parity is pinned on seeded weights.  The
+                                context is per-stream device state like h and c: samples[stream][chunk][512], state h, c [128] each. */
 };
 
 /* precision selector for vadc_amd_create.  In EVERY mode the LSTM state is fp32 and probabilities of modes 0 and 1 stay within 1e-4 of the C backend. */
@@ -97,6 +101,7 @@ typedef struct vadc_amd_caps {
    int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3, 2, 1 (v4: window / 512)    */
    int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1024 / 512 (option "window"); v4 8 kHz: 768 / 512 / 256 */
    int32_t sample_rate;                   /* 16000; 8000 for the container of the v4 graph's 8 kHz branch               */
+   int32_t context_size;                  /* 0; 64 for Silero v5 (vadc.c:697-701): kept per stream on the device, callers pass windows only */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -85,6 +85,10 @@ def lib():
         L.so4_forward_stream_f32.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p]
         L.so4_forward_stream_s16.argtypes = [C.c_void_p, _i16p, C.c_int, _f32p, _f32p, _f32p]
         L.so4_forward_stream_f32_w.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p]
+        L.so5_model_from_bytes.restype = C.c_void_p
+        L.so5_model_from_bytes.argtypes = [C.c_char_p, C.c_size_t]
+        L.so5_model_free.argtypes = [C.c_void_p]
+        L.so5_forward_stream_f32.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p]
         _lib = L
     return _lib
 
@@ -205,6 +209,40 @@ class OracleV4:
     def forward_streams(self, pcm, window=1536):
         pcm = np.ascontiguousarray(pcm)
         return np.stack([self.forward_stream(pcm[s], window=window) for s in range(pcm.shape[0])])
+
+
+class OracleV5:
+    """Whole-path oracle for Silero v5 shapes (oracle/silero_v5_oracle.c; 13-tensor container, see its header).  One probability per
+    512-sample chunk; the 64-sample context, h and c [128] are carried per stream."""
+
+    def __init__(self, weights_blob: bytes):
+        self._L = lib()
+        self._m = self._L.so5_model_from_bytes(weights_blob, len(weights_blob))
+        if not self._m:
+            raise ValueError("oracle: malformed v5 weights blob")
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            self._L.so5_model_free(self._m)
+            self._m = None
+
+    @staticmethod
+    def new_state():
+        return np.zeros(64, np.float32), np.zeros(128, np.float32), np.zeros(128, np.float32)
+
+    def forward_stream(self, pcm_or_f32, state=None):
+        x = np.ascontiguousarray(pcm_or_f32).reshape(-1)
+        if x.dtype == np.int16:
+            x = x.astype(np.float32) / np.float32(32768)            # vadc.c:883,898
+        n = x.size // 512
+        ctx, h, c = state if state is not None else self.new_state()
+        probs = np.zeros(n, np.float32)
+        self._L.so5_forward_stream_f32(self._m, _c(x), n, ctx, h, c, probs)
+        return probs
+
+    def forward_streams(self, pcm):
+        pcm = np.ascontiguousarray(pcm)
+        return np.stack([self.forward_stream(pcm[s]) for s in range(pcm.shape[0])])
 
 
 def segments(probs, threshold=0.5, neg_threshold_relative=0.15, min_silence_ms=200.0, min_speech_ms=250.0,

@@ -1,0 +1,140 @@
+"""Silero v5 shapes on the HIP path (through the C-ABI) against the v5 CPU oracle and the goldens generated from the reference's
+PyTorch class silero_vad.py::Silero_Vad_5 with seeded weights (tests/golden/gen_golden_v5_from_python_reference.py).
+Needs an MI355X: `-m gpu`.  Bar: per-chunk probability within 1e-4 (north star)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from vadc_amd import synth
+from vadc_amd.engine import Engine, VadcAmdError, MODEL_V5
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4
+V5_WEIGHTS = os.path.join(GOLDEN, "silero_v5_seeded.testtensor")
+STREAMS = ["speech0", "speech1", "speech2", "zeros", "noise", "square"]
+
+
+@pytest.fixture(scope="module")
+def blob():
+    return open(V5_WEIGHTS, "rb").read()
+
+
+@pytest.fixture(scope="module")
+def eng(blob):
+    e = Engine(blob, max_streams=64, max_chunks_per_call=192, device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(blob):
+    return O.OracleV5(blob)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "python_reference_v5.npz"))
+
+
+def streams512(S, n, seed0):
+    """S streams x n 512-sample windows of the synthetic speech-like signal"""
+    c = -(-n * 512 // 1536)
+    return np.ascontiguousarray(synth.make_streams(S, c, seed0=seed0)[:, :n * 512])
+
+
+def test_model_kind_comes_from_the_container(eng):
+    c = eng.caps()
+    assert c["model_kind"] == MODEL_V5 and c["is_silero_v5"] == 1 and c["lstm_steps_per_chunk"] == 1
+    assert (c["input_size_min"], c["input_size_max"], c["context_size"], c["lstm_hidden_size"]) == (512, 512, 64, 128)
+    assert eng.window == 512
+    with pytest.raises(VadcAmdError):
+        eng.stage_from_samples(np.zeros(512, np.float32), "magnitude")
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_probabilities_and_state_match_python_reference(eng, gold, name):
+    pcm = gold[f"pcm_{name}"]
+    eng.reset_streams()
+    p = eng.run(pcm.reshape(1, -1))[0]
+    assert np.array_equal(p[:, 0], p[:, 1])
+    assert float(np.abs(p[:, 1] - gold[f"probs64_{name}"]).max()) < PROB_TOL
+    h, c = eng.get_state(0)
+    assert float(np.abs(h.reshape(-1) - gold[f"h64_{name}"]).max()) < PROB_TOL
+    assert float(np.abs(c.reshape(-1) - gold[f"c64_{name}"]).max()) < 5 * PROB_TOL
+
+
+def test_f32_and_s16_inputs_agree(eng, gold):
+    pcm = gold["pcm_speech2"].reshape(1, -1)
+    eng.reset_streams(); a = eng.run(pcm)
+    eng.reset_streams(); b = eng.run(pcm.astype(np.float32) / np.float32(32768))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("S,n", [(1, 1), (3, 7), (16, 33), (24, 40), (64, 96)])
+def test_probabilities_match_oracle_many_streams(eng, orc, S, n):
+    pcm = streams512(S, n, seed0=5151 + S)
+    eng.reset_streams()
+    got = eng.run(pcm)[:, :, 1]
+    ref = orc.forward_streams(pcm)
+    assert float(np.abs(got - ref).max()) < PROB_TOL
+
+
+def test_context_and_state_carry_across_calls(eng, orc):
+    S, n = 5, 60
+    pcm = streams512(S, n, seed0=99)
+    eng.reset_streams()
+    whole = eng.run(pcm)
+    eng.reset_streams()
+    parts = [eng.run(pcm[:, a * 512:b * 512]) for a, b in ((0, 1), (1, 2), (2, 31), (31, 60))]
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)      # bit-identical: the context reaches the next call
+    # without the context the second call differs (the first 64 padded samples are the previous window's tail)
+    eng.reset_streams()
+    cold = eng.run(pcm[:, 512:1024])
+    assert not np.array_equal(cold, whole[:, 1:2])
+
+
+def test_reset_of_selected_streams_clears_context_and_state(eng):
+    S, n = 4, 12
+    pcm = streams512(S, n, seed0=7)
+    eng.reset_streams()
+    first = eng.run(pcm)
+    eng.reset_streams(np.array([1, 3], np.int32))
+    again = eng.run(pcm)
+    assert np.array_equal(again[1], first[1]) and np.array_equal(again[3], first[3])
+    assert not np.array_equal(again[0], first[0])
+
+
+def test_device_buffers_and_caller_stream(eng, orc):
+    torch = pytest.importorskip("torch")
+    S, n = 20, 24
+    pcm = streams512(S, n, seed0=31)
+    d_in = torch.from_numpy(pcm).cuda()
+    d_out = torch.empty(S, n, 2, device="cuda")
+    st = torch.cuda.Stream()
+    eng.reset_streams(); eng.synchronize()
+    with torch.cuda.stream(st):
+        eng.run_device(d_in.data_ptr(), np.int16, S, n, d_out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    ref = orc.forward_streams(pcm)
+    assert float(np.abs(d_out.cpu().numpy()[:, :, 1] - ref).max()) < PROB_TOL
+
+
+def test_cli_with_v5_weights(gold):
+    """the POSIX CLI (host/vadc_hip.c) takes the model kind and the 512-sample window from the container's caps (vadc.c:743-752 clamps the
+    default 1536 to the backend's range; onnx_helpers.c:158-160 for v5)"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "host", "vadc_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
+    pcm = gold["pcm_speech0"]
+    r = subprocess.run([exe, "--model", V5_WEIGHTS, "--raw_probabilities"], input=pcm.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert "Running with sequence count 512" in r.stderr.decode()
+    got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
+    assert got.size == gold["probs64_speech0"].size
+    assert float(np.abs(got - gold["probs64_speech0"]).max()) <= PROB_TOL + 5e-7        # %f quantises to 5e-7

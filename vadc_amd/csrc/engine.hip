@@ -34,6 +34,11 @@ struct LayerWeightsM {
    const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
+struct V5Weights {
+   const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const float *dec_w; const float *dec_b;
+};
+void launch_v5_f32(const float *, float *, const V5Weights &, float *, float *, float *, float *, int, int, hipStream_t);
+void launch_v5_s16(const int16_t *, float *, const V5Weights &, float *, float *, float *, float *, int, int, hipStream_t);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int);
 }  // namespace vadc
 
@@ -121,6 +126,8 @@ struct vadc_amd_engine {
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 2, 1 (v4 with 1536-, 1024-, 512-sample windows)
    int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
+   V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
+   float *d_gx5 = nullptr, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512]; per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
    int stride3() const { return sample_rate == 8000 ? 1 : 2; }
    int v4_geo() const                           // k_frontend_gemm geometry of the window in effect
@@ -510,6 +517,62 @@ bad:
    return fail(VADC_AMD_EWEIGHTS, "weights (v4): tensor %d has an unexpected size", idx);
 }
 
+// Silero v5 shapes: 13-tensor container in the order of the reference's C test (test.c:2045-2068 without its input / expected-output tensors):
+// basis [258,1,256]; reparam_conv_{0..3} weight [Co,Ci,3] + bias; lstm weights [1,512,256] = [i,f,g,o][x(128) | h(128)] (utils.py:93-97), lstm biases
+// [1,512]; decoder weight [1,128,1], bias [1]
+static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
+{
+   static const int co[4] = {128, 64, 64, 128}, ci[4] = {129, 128, 64, 64};
+   static const int expect[13] = {258 * 256, 128 * 129 * 3, 128, 64 * 128 * 3, 64, 64 * 64 * 3, 64, 128 * 64 * 3, 128, 512 * 256, 512, 128, 1};
+   for (int i = 0; i < 13; ++i) if (ts[i].size != expect[i]) return fail(VADC_AMD_EWEIGHTS, "weights (v5): tensor %d has an unexpected size", i);
+   Packer pk;
+   std::vector<float> v;
+   // MFMA A-fragment order for v_mfma_f32_16x16x4_f32: [m-tile][k-step][lane], lane l holds A[16 mt + (l & 15)][4 kk + (l >> 4)]
+   copy_unaligned(v, ts[0]);
+   std::vector<float> sf((size_t)17 * 64 * 64, 0.0f);
+   for (int mt = 0; mt < 17; ++mt)
+      for (int kk = 0; kk < 64; ++kk)
+         for (int l = 0; l < 64; ++l) {
+            const int row = 16 * mt + (l & 15), k = 4 * kk + (l >> 4);
+            if (row < 258) sf[((size_t)mt * 64 + kk) * 64 + l] = v[(size_t)row * 256 + k];
+         }
+   const size_t o_stft = pk.add(sf.data(), sf.size());
+   size_t o_cf[4], o_cb[4];
+   for (int c = 0; c < 4; ++c) {
+      copy_unaligned(v, ts[1 + 2 * c]);
+      const int CI = ci[c], CO = co[c], KT = (CI + 3) / 4, KKW = 3 * KT;
+      std::vector<float> f((size_t)(CO / 16) * KKW * 64, 0.0f);         // K order (tap, input channel padded to a multiple of 4)
+      for (int mt = 0; mt < CO / 16; ++mt)
+         for (int tap = 0; tap < 3; ++tap)
+            for (int kk = 0; kk < KT; ++kk)
+               for (int l = 0; l < 64; ++l) {
+                  const int o = 16 * mt + (l & 15), i = 4 * kk + (l >> 4);
+                  if (i < CI) f[((size_t)mt * KKW + tap * KT + kk) * 64 + l] = v[((size_t)o * CI + i) * 3 + tap];
+               }
+      o_cf[c] = pk.add(f.data(), f.size());
+      copy_unaligned(v, ts[2 + 2 * c]);
+      o_cb[c] = pk.add(v.data(), v.size());
+   }
+   std::vector<float> W;
+   copy_unaligned(W, ts[9]);
+   std::vector<float> wih((size_t)32 * 32 * 64), whh((size_t)512 * 128);
+   for (int mt = 0; mt < 32; ++mt)
+      for (int kk = 0; kk < 32; ++kk)
+         for (int l = 0; l < 64; ++l) wih[((size_t)mt * 32 + kk) * 64 + l] = W[(size_t)(16 * mt + (l & 15)) * 256 + 4 * kk + (l >> 4)];
+   for (int r = 0; r < 512; ++r) memcpy(&whh[(size_t)r * 128], &W[(size_t)r * 256 + 128], 128 * sizeof(float));
+   const size_t o_wih = pk.add(wih.data(), wih.size()), o_whh = pk.add(whh.data(), whh.size());
+   copy_unaligned(v, ts[10]); const size_t o_lb = pk.add(v.data(), v.size());
+   copy_unaligned(v, ts[11]); const size_t o_dw = pk.add(v.data(), v.size());
+   copy_unaligned(v, ts[12]); const size_t o_db = pk.add(v.data(), v.size());
+   HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
+   HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   const float *base = e->d_weights;
+   e->v5.stft_f = base + o_stft;
+   for (int c = 0; c < 4; ++c) { e->v5.conv_f[c] = base + o_cf[c]; e->v5.conv_b[c] = base + o_cb[c]; }
+   e->v5.wih_f = base + o_wih; e->v5.whh = base + o_whh; e->v5.lstm_b = base + o_lb; e->v5.dec_w = base + o_dw; e->v5.dec_b = base + o_db;
+   return VADC_AMD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // lifetime
 // ---------------------------------------------------------------------------------------------------
@@ -524,7 +587,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1]};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5, e->d_ctx5};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -551,8 +614,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    std::vector<HostTensor> ts;
    if (!parse_testtensor(static_cast<const unsigned char *>(blob), len, ts))
       return fail(VADC_AMD_EWEIGHTS, "create: weights blob is not a valid .testtensor container");
-   if (ts.size() != 99 && ts.size() != 36 && ts.size() != 37)
-      return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors (Silero v3.1), 36 (Silero v4, 16 kHz) or 37 (Silero v4, 8 kHz branch), found %zu", ts.size());
+   if (ts.size() != 99 && ts.size() != 36 && ts.size() != 37 && ts.size() != 13)
+      return fail(VADC_AMD_EWEIGHTS, "create: expected 99 tensors (Silero v3.1), 36 (Silero v4, 16 kHz), 37 (Silero v4, 8 kHz branch) or 13 (Silero v5 shapes), found %zu", ts.size());
    if (ts.size() == 37) {
       float sr = 0.0f;
       if (ts[36].size == 1) memcpy(&sr, ts[36].data, 4);
@@ -573,14 +636,14 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    vadc_amd_engine *e = new vadc_amd_engine();
    e->device = device; e->max_streams = max_streams; e->max_chunks = max_chunks; e->precision = precision;
    e->max_items = (size_t)max_streams * max_chunks;
-   e->model = ts.size() != 99 ? VADC_AMD_MODEL_V4 : VADC_AMD_MODEL_V31;
+   e->model = ts.size() == 99 ? VADC_AMD_MODEL_V31 : (ts.size() == 13 ? VADC_AMD_MODEL_V5 : VADC_AMD_MODEL_V4);
    e->sample_rate = ts.size() == 37 ? 8000 : 16000;
-   e->window = e->sample_rate == 8000 ? 768 : kChunk;           // 96 ms either way
+   e->window = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);   // v5: 512 + 64 of context (vadc.c:105-162); v4 8 kHz: the same 96 ms
    e->frames = e->model == VADC_AMD_MODEL_V4 ? e->window / 64 : kFrames;
-   e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : 7;
+   e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : (e->model == VADC_AMD_MODEL_V5 ? 1 : 7);
    if (e->model == VADC_AMD_MODEL_V4) stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
    else memcpy(e->stage_elems, kStageElemsV31, sizeof(kStageElemsV31));
-   int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : build_weights(e, ts);
+   int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : (e->model == VADC_AMD_MODEL_V5 ? build_weights_v5(e, ts) : build_weights(e, ts));
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
    if (precision == VADC_AMD_PRECISION_SPLIT16 && (!e->lstm_h3_ok || (e->model != VADC_AMD_MODEL_V4 && !e->enc_h3_ok))) {
       vadc_amd_destroy(e);
@@ -608,6 +671,9 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    }
    e->d_act[3] = e->d_xpair[0];
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5, N * 512 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMemset(e->d_ctx5, 0, (size_t)max_streams * 64 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_h, (size_t)max_streams * 128 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_c, (size_t)max_streams * 128 * sizeof(float));
@@ -627,17 +693,18 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
 {
    if (!e || !caps) return fail(VADC_AMD_EINVAL, "get_caps: NULL argument");
    caps->batch_size_restriction = -1;          // silero.h:39
-   caps->is_silero_v5 = 0;                     // silero.h:40
+   caps->is_silero_v5 = e->model == VADC_AMD_MODEL_V5;   // silero.h:40 / onnx_helpers.c:154-156
    // silero.h:41-42 (the C backend: 1536 only); onnx_helpers.c:164-170 for the v4 graph: 512 ... 1536, of which this engine runs 512 / 1024 / 1536
-   const int wmax = e->sample_rate == 8000 ? 768 : kChunk;
+   const int wmax = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);     // v5: onnx_helpers.c:158-160
    caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
    caps->input_size_max = wmax;
+   caps->context_size = e->model == VADC_AMD_MODEL_V5 ? 64 : 0;
    caps->window_samples = e->window;
    caps->sample_rate = e->sample_rate;
    caps->output_dims = 3;                      // silero.h:43
    caps->output_stride = 2;                    // vadc.c:704-708
    caps->silero_probability_out_index = 1;
-   caps->lstm_hidden_size = kHidden;
+   caps->lstm_hidden_size = e->model == VADC_AMD_MODEL_V5 ? 128 : kHidden;
    caps->max_streams = e->max_streams;
    caps->max_chunks_per_call = e->max_chunks;
    caps->device = e->device;
@@ -1014,6 +1081,17 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
 {
    if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
       return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
+   if (e->model == VADC_AMD_MODEL_V5) {
+      // Silero v5 shapes: encoder (+ LSTM input projection), LSTM(128) + decoder, context update -- three launches on the caller's stream, ordered
+      // behind whatever touched the state last
+      if (e->ev_last_valid) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); (void)hipStreamWaitEvent(st, e->ev_last_c, 0); }
+      if (sizeof(T) == 2) launch_v5_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
+      else                launch_v5_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
+      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); (void)hipEventRecord(e->ev_last_c, st); e->ev_last_valid = true;
+      hipError_t he5 = hipGetLastError();
+      if (he5 != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he5));
+      return VADC_AMD_OK;
+   }
    const int G = pick_groups(e, n_chunks);
    const bool forked = !(G == 1 && (long)n_streams * n_chunks < 2048);
    const int lk = resolve_lstm(e, n_streams, forked);
@@ -1212,11 +1290,13 @@ extern "C" int vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *ids, in
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    if (!ids) {
+      if (e->d_ctx5) HIP_TRY(hipMemsetAsync(e->d_ctx5, 0, (size_t)e->max_streams * 64 * sizeof(float), e->stream), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_h, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_c, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
    } else {
       for (int i = 0; i < n; ++i) {
          if (ids[i] < 0 || ids[i] >= e->max_streams) return fail(VADC_AMD_EINVAL, "reset_streams: stream %d out of range", ids[i]);
+         if (e->d_ctx5) HIP_TRY(hipMemsetAsync(e->d_ctx5 + (size_t)ids[i] * 64, 0, 64 * sizeof(float), e->stream), VADC_AMD_EHIP);
          HIP_TRY(hipMemsetAsync(e->d_h + (size_t)ids[i] * 128, 0, 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
          HIP_TRY(hipMemsetAsync(e->d_c + (size_t)ids[i] * 128, 0, 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
       }
@@ -1260,6 +1340,7 @@ static float *stage_buffer(vadc_amd_engine *e, int stage)
 extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples, int n, int stage, float *out)
 {
    if (!e || !samples || !out || stage < 0 || stage >= VADC_AMD_STAGE_COUNT) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: bad argument");
+   if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: no stage taps for the Silero v5 path");
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: n=%d out of range", n);
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
@@ -1284,6 +1365,7 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
 {
    if (!e || !in || !out || from_stage < 0 || to_stage >= VADC_AMD_STAGE_COUNT || to_stage <= from_stage)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: bad argument");
+   if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: no stage taps for the Silero v5 path");
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: n=%d out of range", n);
    if (e->model == VADC_AMD_MODEL_V4 && from_stage < VADC_AMD_STAGE_LAYER1)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: the v4 first block takes magnitude AND normalized; feed LAYER1..3 or use from_samples");
@@ -1316,6 +1398,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
    int rc = check_shape(e, n_streams, n_chunks, "debug_lstm_decoder");
    if (rc) return rc;
    if (!x || !probs) return fail(VADC_AMD_EINVAL, "debug_lstm_decoder: NULL buffer");
+   if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_lstm_decoder: no stage taps for the Silero v5 path");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;

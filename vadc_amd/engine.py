@@ -23,7 +23,7 @@ CHUNK = 1536
 STAGES = {"magnitude": 0, "normalized": 1, "layer1": 2, "layer2": 3, "layer3": 4, "layer4": 5}
 STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}          # Silero v3.1
 STAGE_SHAPES_V4 = {0: (129, 24), 1: (129, 24), 2: (16, 12), 3: (32, 6), 4: (32, 3), 5: (64, 3)}       # Silero v4
-MODEL_V31, MODEL_V4 = 0, 1
+MODEL_V31, MODEL_V4, MODEL_V5 = 0, 1, 2
 KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1"]
 
 
@@ -55,6 +55,7 @@ class Engine:
         self.sample_rate = self.caps()["sample_rate"]
         if self.sample_rate == 8000:                    # the v4 graph's 8 kHz branch: 768-sample chunks by default (the same 96 ms)
             self._set_v4_shapes(768)
+        self.window = self.caps()["window_samples"]     # 512 for the v5 shapes (plus 64 samples of context the engine keeps per stream)
 
     def set_window(self, samples: int):
         """samples per chunk: 1536 (default); Silero v4 also 1024 / 512 (option "window": --sequence_count of the reference's onnxruntime path)"""
@@ -139,6 +140,7 @@ class Engine:
             self._check(self._L.vadc_amd_reset_streams(self._h, _ptr(ids), ids.size))
 
     def get_state(self, stream: int):
+        """h, c as [2, 64] (two layers of 64; Silero v5: the same 128 floats are ONE layer of 128)"""
         h = np.empty((2, 64), np.float32)
         c = np.empty((2, 64), np.float32)
         self._check(self._L.vadc_amd_get_state(self._h, stream, _ptr(h), _ptr(c)))
