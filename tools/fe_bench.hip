@@ -218,6 +218,12 @@ int main(int argc, char **argv)
       time_it("sym nb2 w4, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
       time_it("sym nb2 w5, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 5>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
       time_it("sym nb3 w3, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      // occupancy probes: unused dynamic LDS caps the workgroups per CU (31 KB static + pad): 3, 2 and 1 workgroups = 3, 2, 1 waves per SIMD
+      time_it("sym nb2 w4, log mode, 3 waves/SIMD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 16 << 10, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb2 w4, log mode, 2 waves/SIMD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 40 << 10, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb3 w3, log mode, 2 waves/SIMD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 3>), grid, dim3(256), 40 << 10, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb3 w2, log mode, 2 waves/SIMD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 2>), grid, dim3(256), 40 << 10, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
+      time_it("sym nb2 w4, log mode, 1 wave/SIMD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 60 << 10, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
       {  // log values: sym takes v_sqrt_f32 under the logarithm (<= 1 ulp of the magnitude): report the largest difference against fl
          std::vector<float> a(ref.size()), b(ref.size());
          CK(hipMemcpy(a.data(), Y0, a.size() * 4, hipMemcpyDeviceToHost));

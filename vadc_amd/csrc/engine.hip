@@ -1126,6 +1126,10 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          // both layers waits for both; in the layer-major form each layer waits for its own half only (that is what lets layer 0 of this
          // call run beside layer 1 of the previous one)
          (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
+         // With more stream tiles than half the CUs the LSTM is throughput work that fills the chip by itself: the next call's front end beside it
+         // only loses (the persistent GEMM front end cannot place its two workgroups per CU: 0.57 -> 0.80 ms per 65,536 chunks, v4 4.02 M -> 3.65 M
+         // audio-s/s at 4096 x 16), so the calls run back to back
+         if ((n_streams + kLstmTile - 1) / kLstmTile > e->n_cus / 2) { (void)hipStreamWaitEvent(e->sA, e->ev_last_b, 0); (void)hipStreamWaitEvent(e->sA, e->ev_last_c, 0); }
          (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
          if (split) (void)hipStreamWaitEvent(e->sC, e->ev_last_c, 0);
          else       (void)hipStreamWaitEvent(e->sB, e->ev_last_c, 0);
