@@ -887,3 +887,4 @@ def test_split16_refuses_weights_outside_fp16_range(weights_blob):
     with pytest.raises(VadcAmdError) as ei:
         Engine(_blob_with(weights_blob, {95: w}), max_streams=1, max_chunks_per_call=1, device=0, precision=1)
     assert ei.value.code == _lib_code("EWEIGHTS")
+

@@ -189,13 +189,19 @@ struct vadc_amd_engine {
    int defer_join = 0;                          // option "defer_join": forked calls do not make the caller's stream wait for their completion; vadc_amd_join does
    struct GraphEntry { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
-   hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, ev_graph = nullptr, ev_fe[kMaxGroups] = {nullptr},
+   hipEvent_t ev_in = nullptr, ev_b[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, ev_fe[kMaxGroups] = {nullptr},
               ev_l0[kMaxGroups] = {nullptr};
-   bool ev_graph_valid = false;
-   // Call-to-call ordering that does not depend on which stream the caller used: ev_last_a = the last work that touched the
-   // front-end / encoder buffers, ev_last_b = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
-   // stream(s) that touch these wait for them first (free when it is the same stream) and re-records them.
-   hipEvent_t ev_last_a = nullptr, ev_last_b = nullptr, ev_last_c = nullptr;   // ev_last_b: last work on layer-0 state, ev_last_c: on layer-1 state (and probabilities)
+   // Call-to-call ordering that does not depend on which stream the caller used: last_a = the last work that touched the
+   // front-end / encoder buffers, last_b / last_c = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
+   // stream(s) that touch these wait for them first and re-points them.
+   // They are ALIASES of whichever event object was recorded at that point (one record per stream and call, not one per purpose), together with
+   // the stream it was recorded on: a stream never waits for its own earlier work (it is in-order) -- every cross-queue wait and every record
+   // is a barrier packet the command processor handles between kernels, and seven of them per call left 40 us between one call's last encoder
+   // kernel and the next call's front end (4 % of the 256 x 96 step).
+   hipEvent_t ev_last = nullptr;                                               // recorded by the calls that run on the caller's stream
+   hipEvent_t last_a = nullptr, last_b = nullptr, last_c = nullptr;            // last_b: last work on layer-0 state, last_c: on layer-1 state (and probabilities)
+   hipStream_t last_a_on = nullptr, last_b_on = nullptr, last_c_on = nullptr;
+   bool last_on_valid = false;                                                 // false: the *_on handles may be stale (streams re-created): wait regardless
    bool ev_last_valid = false;
    // profiling
    bool profiling = false;
@@ -594,7 +600,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    if (e->sA) (void)hipStreamDestroy(e->sA);
    if (e->sB) (void)hipStreamDestroy(e->sB);
    if (e->sC) (void)hipStreamDestroy(e->sC);
-   for (hipEvent_t ev : {e->ev_in, e->ev_a, e->ev_b[0], e->ev_b[1], e->ev_c[0], e->ev_c[1], e->ev_graph, e->ev_last_a, e->ev_last_b, e->ev_last_c}) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : {e->ev_in, e->ev_b[0], e->ev_b[1], e->ev_c[0], e->ev_c[1], e->ev_last}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_l0) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
@@ -652,7 +658,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   for (hipEvent_t *ev : {&e->ev_in, &e->ev_a, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_graph, &e->ev_last_a, &e->ev_last_b, &e->ev_last_c}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+   for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
@@ -794,7 +800,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return fail(VADC_AMD_EINVAL, "set_option: %s=3 selects fp32 MFMA; the SPLIT16 precision mode runs split-fp16 GEMMs only", key);
    // every switch below changes the launch sequence a captured graph replays: drop the captured graphs (after their last replay has finished)
    if (strcmp(key, "graph") != 0 && !e->graphs.empty()) {
-      if (e->ev_graph_valid) HIP_TRY(hipEventSynchronize(e->ev_graph), VADC_AMD_EHIP);
+      if (e->ev_last_valid && e->last_a) HIP_TRY(hipEventSynchronize(e->last_a), VADC_AMD_EHIP);   // every replay is followed by the record last_a points at
       for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
       e->graphs.clear();
    }
@@ -1016,6 +1022,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
    e->streams_split = split;
    e->ev_b_valid[0] = e->ev_b_valid[1] = false; // the old streams were drained above
    e->ev_c_valid[0] = e->ev_c_valid[1] = false;
+   e->last_on_valid = false;                    // a new stream may get a destroyed one's handle
    return VADC_AMD_OK;
 }
 
@@ -1045,6 +1052,29 @@ static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_str
    launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
 }
 
+// call-to-call ordering (see the engine's last_a / last_b / last_c): `st` continues after the last work of that kind, wherever it ran
+static void wait_last(vadc_amd_engine *e, hipStream_t st, hipEvent_t ev, hipStream_t on)
+{
+   if (!e->ev_last_valid || !ev) return;
+   // the same in-order stream -- for the engine's own streams only: a caller may have destroyed its stream and been handed the same handle again
+   if (e->last_on_valid && on == st && (st == e->sA || st == e->sB || st == e->sC)) return;
+   (void)hipStreamWaitEvent(st, ev, 0);
+}
+static void wait_last_all(vadc_amd_engine *e, hipStream_t st)
+{
+   wait_last(e, st, e->last_a, e->last_a_on);
+   if (e->last_b != e->last_a) wait_last(e, st, e->last_b, e->last_b_on);
+   if (e->last_c != e->last_a && e->last_c != e->last_b) wait_last(e, st, e->last_c, e->last_c_on);
+}
+// a call that ran entirely on `st`: one record marks all three
+static void record_last_on(vadc_amd_engine *e, hipStream_t st)
+{
+   (void)hipEventRecord(e->ev_last, st);
+   e->last_a = e->last_b = e->last_c = e->ev_last;
+   e->last_a_on = e->last_b_on = e->last_c_on = st;
+   e->ev_last_valid = true; e->last_on_valid = true;
+}
+
 struct SeqKey { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; };
 template <typename F>
 static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, F &&enqueue)
@@ -1054,8 +1084,6 @@ static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, 
       if (ge.in == k.in && ge.out == k.out && ge.S == k.S && ge.C == k.C && ge.elem == k.elem && ge.G == k.G && ge.gi == k.gi && ge.xp == k.xp &&
           ge.lk == k.lk && ge.fe == k.fe) {
          HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
-         HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
-         e->ev_graph_valid = true;
          return VADC_AMD_OK;
       }
    vadc_amd_engine::GraphEntry ge{k.in, k.out, k.S, k.C, k.elem, k.G, k.gi, k.xp, k.lk, k.fe, nullptr, nullptr};
@@ -1065,13 +1093,11 @@ static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, 
    if (he != hipSuccess) return fail(VADC_AMD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(he));
    HIP_TRY(hipGraphInstantiate(&ge.x, ge.g, nullptr, nullptr, 0), VADC_AMD_EHIP);
    if (e->graphs.size() >= 32) {                           // evict the oldest signature; its last replay may still be in flight
-      if (e->ev_graph_valid) (void)hipEventSynchronize(e->ev_graph);   // not a cached stream handle: the caller may have destroyed that stream
+      if (e->ev_last_valid && e->last_a) (void)hipEventSynchronize(e->last_a);   // every replay is followed by the record last_a points at (not a cached stream handle: the caller may have destroyed that stream)
       (void)hipGraphExecDestroy(e->graphs[0].x); (void)hipGraphDestroy(e->graphs[0].g); e->graphs.erase(e->graphs.begin());
    }
    e->graphs.push_back(ge);
    HIP_TRY(hipGraphLaunch(ge.x, st), VADC_AMD_EHIP);
-   HIP_TRY(hipEventRecord(e->ev_graph, st), VADC_AMD_EHIP);
-   e->ev_graph_valid = true;
    return VADC_AMD_OK;
 }
 
@@ -1084,10 +1110,10 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (e->model == VADC_AMD_MODEL_V5) {
       // Silero v5 shapes: encoder (+ LSTM input projection), LSTM(128) + decoder, context update -- three launches on the caller's stream, ordered
       // behind whatever touched the state last
-      if (e->ev_last_valid) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); (void)hipStreamWaitEvent(st, e->ev_last_c, 0); }
+      wait_last_all(e, st);
       if (sizeof(T) == 2) launch_v5_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
       else                launch_v5_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
-      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); (void)hipEventRecord(e->ev_last_c, st); e->ev_last_valid = true;
+      record_last_on(e, st);
       hipError_t he5 = hipGetLastError();
       if (he5 != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he5));
       return VADC_AMD_OK;
@@ -1102,37 +1128,40 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    // with one group: the internal streams are in-order across calls, so a caller that alternates between two
    // streams gets the NEXT call's front end + encoder overlapped with THIS call's LSTM (cross-call pipelining)
    // while every call keeps strict stream semantics (its results are complete when its own stream reaches the join).
-   const bool order = e->ev_last_valid;
    if (!forked) {
       const ItemMap map{n_chunks, 0, n_chunks};
-      if (order) { (void)hipStreamWaitEvent(st, e->ev_last_a, 0); (void)hipStreamWaitEvent(st, e->ev_last_b, 0); (void)hipStreamWaitEvent(st, e->ev_last_c, 0); }
+      wait_last_all(e, st);
       rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
          run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
          launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, 0, n_chunks, st);
       });
       if (rc) return rc;
-      (void)hipEventRecord(e->ev_last_a, st); (void)hipEventRecord(e->ev_last_b, st); (void)hipEventRecord(e->ev_last_c, st); e->ev_last_valid = true;
+      record_last_on(e, st);
    } else {
       rc = ensure_pipeline_streams(e, n_streams, lk);
       if (rc) return rc;
       // fork: stream A = front end + encoder of every chunk group in order, stream B = the LSTM chain (layer-major form: B = layer 0, C = layer 1)
       const bool split = lk == 7;
-      (void)hipEventRecord(e->ev_in, st);
-      (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
-      (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
-      if (split) (void)hipStreamWaitEvent(e->sC, e->ev_in, 0);
-      if (order) {
-         // ev_last_b / ev_last_c: the last work on the layer-0 / layer-1 halves of the per-stream state, whichever stream it ran on.  One kernel for
+      // everything the caller enqueued on `st` before this call comes first -- unless `st` has drained already (a caller that issues call after
+      // call with defer_join never puts anything on it): then there is nothing to order against, and three cross-queue waits are saved
+      if (hipStreamQuery(st) != hipSuccess) {
+         (void)hipGetLastError();                              // hipErrorNotReady is not an error
+         (void)hipEventRecord(e->ev_in, st);
+         (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
+         (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+         if (split) (void)hipStreamWaitEvent(e->sC, e->ev_in, 0);
+      }
+      {
+         // last_b / last_c: the last work on the layer-0 / layer-1 halves of the per-stream state, whichever stream it ran on.  One kernel for
          // both layers waits for both; in the layer-major form each layer waits for its own half only (that is what lets layer 0 of this
          // call run beside layer 1 of the previous one)
-         (void)hipStreamWaitEvent(e->sA, e->ev_last_a, 0);
+         wait_last(e, e->sA, e->last_a, e->last_a_on);
          // With more stream tiles than half the CUs the LSTM is throughput work that fills the chip by itself: the next call's front end beside it
          // only loses (the persistent GEMM front end cannot place its two workgroups per CU: 0.57 -> 0.80 ms per 65,536 chunks, v4 4.02 M -> 3.65 M
          // audio-s/s at 4096 x 16), so the calls run back to back
-         if ((n_streams + kLstmTile - 1) / kLstmTile > e->n_cus / 2) { (void)hipStreamWaitEvent(e->sA, e->ev_last_b, 0); (void)hipStreamWaitEvent(e->sA, e->ev_last_c, 0); }
-         (void)hipStreamWaitEvent(e->sB, e->ev_last_b, 0);
-         if (split) (void)hipStreamWaitEvent(e->sC, e->ev_last_c, 0);
-         else       (void)hipStreamWaitEvent(e->sB, e->ev_last_c, 0);
+         if ((n_streams + kLstmTile - 1) / kLstmTile > e->n_cus / 2) { wait_last(e, e->sA, e->last_b, e->last_b_on); wait_last(e, e->sA, e->last_c, e->last_c_on); }
+         wait_last(e, e->sB, e->last_b, e->last_b_on);
+         wait_last(e, split ? e->sC : e->sB, e->last_c, e->last_c_on);
       }
       // this call's hand-off buffer; its last reader was the LSTM of the forked call before the previous one (long finished: the wait is free)
       e->xpar ^= 1;
@@ -1159,33 +1188,38 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA);
          });
          if (rc) return rc;
-         (void)hipEventRecord(e->ev_fe[gi], e->sA);
+         const bool last_group = c0 + cg >= n_chunks;
+         (void)hipEventRecord(e->ev_fe[gi], e->sA);           // one record per group: the LSTM's go-ahead, and for the last group also "encoder buffers free" (last_a) and the join
+         e->last_a = e->ev_fe[gi]; e->last_a_on = e->sA; e->ev_last_valid = true; e->last_on_valid = true;
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[gi], 0);
          if (!split) launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, c0, cg, e->sB);
          else {
+            // (Cutting a group's recurrence into several launches per layer, layer 1 of a part beside layer 0 of the next, was measured: the
+            // call's last probability is ready earlier, but 256 x 96 loses 1.5 % in steady state -- 2.49 M -> 2.45 M -- to the extra launches,
+            // records and cross-queue waits, and a 20-step run gains nothing measurable.)
             {
                KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
                launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps);
             }
-            (void)hipEventRecord(e->ev_l0[gi], e->sB);
-            (void)hipStreamWaitEvent(e->sC, e->ev_l0[gi], 0);
+            hipEvent_t l0_done = last_group ? e->ev_b[xp] : e->ev_l0[gi];   // the call's last record on this stream is also this hand-off pair's "layer 0 done"
+            (void)hipEventRecord(l0_done, e->sB);
+            (void)hipStreamWaitEvent(e->sC, l0_done, 0);
             KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
             launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps);
          }
          c0 += cg;
       }
-      // join
-      (void)hipEventRecord(e->ev_a, e->sA);
-      (void)hipEventRecord(e->ev_last_a, e->sA); (void)hipEventRecord(e->ev_last_b, e->sB); (void)hipEventRecord(e->ev_last_c, split ? e->sC : e->sB);
-      e->ev_last_valid = true;
-      (void)hipEventRecord(e->ev_b[xp], e->sB);
+      // one record per stream marks the end of the call there
+      if (!split) (void)hipEventRecord(e->ev_b[xp], e->sB);
       e->ev_b_valid[xp] = true;
+      e->last_b = e->ev_b[xp]; e->last_b_on = e->sB;
       if (split) {
          (void)hipEventRecord(e->ev_c[xp], e->sC);
          e->ev_c_valid[xp] = true;
-      }
+         e->last_c = e->ev_c[xp]; e->last_c_on = e->sC;
+      } else { e->last_c = e->ev_b[xp]; e->last_c_on = e->sB; }
       if (!e->defer_join) {                                    // strict stream semantics: the caller's stream continues when the call is complete
-         (void)hipStreamWaitEvent(st, e->ev_a, 0);
+         (void)hipStreamWaitEvent(st, e->last_a, 0);
          (void)hipStreamWaitEvent(st, e->ev_b[xp], 0);
          if (split) (void)hipStreamWaitEvent(st, e->ev_c[xp], 0);
       }
@@ -1218,9 +1252,9 @@ extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
    if (!e) return fail(VADC_AMD_EINVAL, "synchronize: NULL engine");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    if (e->ev_last_valid) {
-      HIP_TRY(hipEventSynchronize(e->ev_last_a), VADC_AMD_EHIP);
-      HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP);
-      HIP_TRY(hipEventSynchronize(e->ev_last_c), VADC_AMD_EHIP);
+      HIP_TRY(hipEventSynchronize(e->last_a), VADC_AMD_EHIP);
+      HIP_TRY(hipEventSynchronize(e->last_b), VADC_AMD_EHIP);
+      HIP_TRY(hipEventSynchronize(e->last_c), VADC_AMD_EHIP);
    }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
@@ -1231,10 +1265,9 @@ extern "C" int vadc_amd_join(vadc_amd_engine *e, void *hip_stream)
    if (!e) return fail(VADC_AMD_EINVAL, "join: NULL engine");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    if (e->ev_last_valid) {
-      hipStream_t st = (hipStream_t)hip_stream;
-      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_a, 0), VADC_AMD_EHIP);
-      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_b, 0), VADC_AMD_EHIP);
-      HIP_TRY(hipStreamWaitEvent(st, e->ev_last_c, 0), VADC_AMD_EHIP);
+      wait_last_all(e, (hipStream_t)hip_stream);
+      hipError_t he = hipGetLastError();
+      if (he != hipSuccess) return fail(VADC_AMD_EHIP, "join: %s", hipGetErrorString(he));
    }
    return VADC_AMD_OK;
 }
@@ -1275,7 +1308,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
 // state accessors are synchronous; they first wait for the last LSTM enqueued through ANY stream
 static int wait_last_lstm(vadc_amd_engine *e)
 {
-   if (e->ev_last_valid) { HIP_TRY(hipEventSynchronize(e->ev_last_b), VADC_AMD_EHIP); HIP_TRY(hipEventSynchronize(e->ev_last_c), VADC_AMD_EHIP); }
+   if (e->ev_last_valid) { HIP_TRY(hipEventSynchronize(e->last_b), VADC_AMD_EHIP); HIP_TRY(hipEventSynchronize(e->last_c), VADC_AMD_EHIP); }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -1284,7 +1317,7 @@ static int wait_all_prior_fwd(vadc_amd_engine *e) { HIP_TRY(hipSetDevice(e->devi
 // the stage taps overwrite the intermediates (Y, FM, layer outputs, hand-off tiles): wait for EVERYTHING enqueued before, on any stream
 static int wait_all_prior(vadc_amd_engine *e)
 {
-   if (e->ev_last_valid) HIP_TRY(hipEventSynchronize(e->ev_last_a), VADC_AMD_EHIP);
+   if (e->ev_last_valid) HIP_TRY(hipEventSynchronize(e->last_a), VADC_AMD_EHIP);
    return wait_last_lstm(e);
 }
 
