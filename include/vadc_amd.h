@@ -176,7 +176,8 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *   "window"      samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4 also 1024 and 512 -- the v4
  *                 graph takes 512 ... 1536 samples (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): samples / 64 STFT frames, samples / 512 LSTM
  *                 steps.  Changes the stride of every samples / probability buffer; waits for the calls issued before
- *   "groups"      number of chunk groups a call is pipelined in (0 = auto): the LSTM of group g overlaps the front end + encoder of group g+1
+ *   "groups"      number of chunk groups a call is pipelined in: the LSTM of group g overlaps the front end + encoder of group g+1.  0 = auto (default): up
+ *                 to 4 for calls the caller waits for, 1 with "defer_join" (consecutive calls overlap instead)
  *   "lstm"        0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy -- 7 = layer-major (k_lstm_layer: layer 0 and
  *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls while the recurrence would otherwise be
  *                 the longer of the concurrent streams, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both layers); 6 and 7 produce

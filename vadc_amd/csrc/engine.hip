@@ -1029,7 +1029,9 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
 static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 {
    int g = e->groups;
-   if (g <= 0) g = n_chunks >= 16 ? 4 : (n_chunks >= 4 ? 2 : 1);
+   // auto: a call whose caller waits for it (strict join, the synchronous host entry points) overlaps its own LSTM with its later groups' front end +
+   // encoder; with deferred joins consecutive CALLS overlap instead, and whole-call launches fill the chip better (256 x 96: 2.12 M with 4 groups, 2.47 M with 1)
+   if (g <= 0) g = e->defer_join ? 1 : (n_chunks >= 16 ? 4 : (n_chunks >= 4 ? 2 : 1));
    if (g > n_chunks) g = n_chunks;
    return g < 1 ? 1 : g;
 }
