@@ -131,7 +131,11 @@ int  vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int
 
 /* Device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's default stream, as in
  * hipLaunchKernelGGL).  d_* are device pointers valid on the engine's device.  The call enqueues work only
- * (no allocation, no host synchronisation), so it may be captured into a hipGraph for steady-state replay. */
+ * (no allocation, no host synchronisation).  Larger calls fork onto the engine's own streams; for steady-state
+ * replay use the engine's option "graph" (it captures the kernel sequences itself) -- the call queries its
+ * stream and must not be issued while that stream is being captured.  Pass a stream of your own for overlap
+ * between consecutive calls: HIP's NULL stream synchronises with the engine's CU-masked streams, which
+ * serialises them (results are the same). */
 int  vadc_amd_run_device_f32(vadc_amd_engine *e, const float *d_samples, int n_streams, int n_chunks,
                              float *d_probs, void *hip_stream);
 int  vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm, int n_streams, int n_chunks,

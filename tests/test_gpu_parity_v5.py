@@ -97,6 +97,39 @@ def test_context_and_state_carry_across_calls(eng, orc):
     assert not np.array_equal(cold, whole[:, 1:2])
 
 
+def test_forked_calls_and_fp32_recurrence(blob, orc):
+    """calls of >= 2048 windows fork onto the engine's streams (encoder of call k+1 beside the recurrence of call k, deferred joins): context, state
+    and the hand-off buffers carry over exactly as on one stream; the split-fp16 recurrence (default) and the fp32-MFMA one (option lstm=3) both
+    hold the 1e-4 bar"""
+    S, n = 64, 120
+    pcm = streams512(S, n, seed0=2024)
+    ref = orc.forward_streams(pcm)
+    out = {}
+    for lstm in (0, 3):
+        e = Engine(blob, max_streams=S, max_chunks_per_call=n, device=0)
+        try:
+            e.set_option("lstm", lstm)
+            whole = e.run(pcm)
+            assert e.get_option("lstm_kernel") == (3 if lstm == 3 else 6)
+            e.reset_streams()
+            e.set_option("defer_join", 1)
+            torch = pytest.importorskip("torch")
+            d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, a * 512:b * 512])).cuda() for a, b in ((0, 40), (40, 41), (41, 80), (80, 120))]
+            d_out = [torch.empty(S, x.shape[1] // 512, 2, device="cuda") for x in d_in]
+            st = torch.cuda.Stream()
+            for x, y in zip(d_in, d_out):                        # forked, small (on the caller's stream), forked, forked
+                e.run_device(x.data_ptr(), np.int16, S, y.shape[1], y.data_ptr(), st.cuda_stream)
+            e.join(st.cuda_stream)
+            st.synchronize()
+            parts = np.concatenate([y.cpu().numpy() for y in d_out], axis=1)
+            assert np.array_equal(parts, whole)
+            assert float(np.abs(whole[:, :, 1] - ref).max()) < PROB_TOL
+            out[lstm] = whole
+        finally:
+            e.close()
+    assert float(np.abs(out[0] - out[3]).max()) < PROB_TOL
+
+
 def test_reset_of_selected_streams_clears_context_and_state(eng):
     S, n = 4, 12
     pcm = streams512(S, n, seed0=7)

@@ -19,17 +19,19 @@ def main():
     from vadc_amd import synth
     blob = open(os.path.join(ROOT, "tests", "golden", "silero_v5_seeded.testtensor"), "rb").read()
     eng = Engine(blob, max_streams=a.streams, max_chunks_per_call=a.chunks, device=0)
+    eng.set_option("defer_join", 1)                 # calls overlap: encoder of call k+1 beside the recurrence of call k
     base = synth.make_streams(16, -(-a.chunks * 512 // 1536), seed0=11)[:, :a.chunks * 512]
     pcm = np.ascontiguousarray(np.tile(base, (-(-a.streams // 16), 1))[:a.streams])
     d_in = torch.from_numpy(pcm).cuda()
     d_out = torch.empty(a.streams, a.chunks, 2, device="cuda")
-    st = torch.cuda.current_stream()
+    st = torch.cuda.Stream()                        # not the null stream: that one synchronises with the engine's CU-masked (blocking) streams
     for _ in range(a.warmup):
         eng.run_device(d_in.data_ptr(), np.int16, a.streams, a.chunks, d_out.data_ptr(), st.cuda_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng.run_device(d_in.data_ptr(), np.int16, a.streams, a.chunks, d_out.data_ptr(), st.cuda_stream)
+    eng.join(st.cuda_stream)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     audio_s = a.streams * a.chunks * 512 / 16000.0 * a.steps

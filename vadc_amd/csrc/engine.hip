@@ -35,10 +35,12 @@ struct LayerWeightsM {
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 struct V5Weights {
-   const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const float *dec_w; const float *dec_b;
+   const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
+   const float *dec_w; const float *dec_b;
 };
-void launch_v5_f32(const float *, float *, const V5Weights &, float *, float *, float *, float *, int, int, hipStream_t);
-void launch_v5_s16(const int16_t *, float *, const V5Weights &, float *, float *, float *, float *, int, int, hipStream_t);
+void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, int, int, hipStream_t);
+void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, int, int, hipStream_t);
+void launch_v5_lstm(const V5Weights &, const float *, float *, float *, float *, int, int, bool, hipStream_t);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int);
 }  // namespace vadc
 
@@ -127,7 +129,7 @@ struct vadc_amd_engine {
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 2, 1 (v4 with 1536-, 1024-, 512-sample windows)
    int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
    V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
-   float *d_gx5 = nullptr, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512]; per-stream 64-sample context [max_streams][64]
+   float *d_gx5[2] = {nullptr, nullptr}, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512] (one per hand-off parity); per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
    int stride3() const { return sample_rate == 8000 ? 1 : 2; }
    int v4_geo() const                           // k_frontend_gemm geometry of the window in effect
@@ -567,6 +569,23 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
          for (int l = 0; l < 64; ++l) wih[((size_t)mt * 32 + kk) * 64 + l] = W[(size_t)(16 * mt + (l & 15)) * 256 + 4 * kk + (l >> 4)];
    for (int r = 0; r < 512; ++r) memcpy(&whh[(size_t)r * 128], &W[(size_t)r * 256 + 128], 128 * sizeof(float));
    const size_t o_wih = pk.add(wih.data(), wih.size()), o_whh = pk.add(whh.data(), whh.size());
+   // split-fp16 A fragments of W_hh for v_mfma_f32_16x16x32_f16: [m-tile][k-block][lane][hi 8 | lo 8], lane l holds W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + e]
+   bool h3_ok = true;
+   std::vector<_Float16> wh((size_t)32 * 4 * 64 * 16);
+   for (int mt = 0; mt < 32; ++mt)
+      for (int kb = 0; kb < 4; ++kb)
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el) {
+               const float x = whh[(size_t)(16 * mt + (l & 15)) * 128 + 32 * kb + 8 * (l >> 4) + el];
+               if (!(fabsf(x) < 60000.0f)) h3_ok = false;
+               const _Float16 hi = (_Float16)x;
+               wh[(((size_t)mt * 4 + kb) * 64 + l) * 16 + el] = hi;
+               wh[(((size_t)mt * 4 + kb) * 64 + l) * 16 + 8 + el] = (_Float16)(x - (float)hi);
+            }
+   std::vector<float> whf(wh.size() / 2);
+   memcpy(whf.data(), wh.data(), wh.size() * sizeof(_Float16));
+   const size_t o_whh_h = pk.add(whf.data(), whf.size());
+   e->lstm_h3_ok = h3_ok;
    copy_unaligned(v, ts[10]); const size_t o_lb = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[11]); const size_t o_dw = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[12]); const size_t o_db = pk.add(v.data(), v.size());
@@ -575,6 +594,7 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
    const float *base = e->d_weights;
    e->v5.stft_f = base + o_stft;
    for (int c = 0; c < 4; ++c) { e->v5.conv_f[c] = base + o_cf[c]; e->v5.conv_b[c] = base + o_cb[c]; }
+   e->v5.whh_h = h3_ok ? reinterpret_cast<const _Float16 *>(base + o_whh_h) : nullptr;
    e->v5.wih_f = base + o_wih; e->v5.whh = base + o_whh; e->v5.lstm_b = base + o_lb; e->v5.dec_w = base + o_dw; e->v5.dec_b = base + o_db;
    return VADC_AMD_OK;
 }
@@ -593,7 +613,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5, e->d_ctx5};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -677,7 +697,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    }
    e->d_act[3] = e->d_xpair[0];
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
-   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5, N * 512 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMemset(e->d_ctx5, 0, (size_t)max_streams * 64 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
@@ -976,6 +997,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    // streams: 955 K -> 943 K): then the masks are DISJOINT.
    const int w1 = (lstm_wgs + 7) / 8 * 8;
    if (e->cu_partition == 1 && e->lstm_steps * slot_us <= 0.7 * 0.9 * n_streams * per_chunk_us) *shared = true;
+   // Silero v5: the recurrence's workgroup (8 waves x 205 VGPRs) needs a CU to itself; on a shared CU the encoder grid's workgroups keep taking each
+   // other's place and it only starts when that grid has drained (measured: encoder 1.58 + recurrence 0.58 ms back to back)
+   if (e->model == VADC_AMD_MODEL_V5 && e->cu_partition != 2) *shared = false;
    return w1;
 }
 
@@ -1110,12 +1134,44 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
       return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
    if (e->model == VADC_AMD_MODEL_V5) {
-      // Silero v5 shapes: encoder (+ LSTM input projection), LSTM(128) + decoder, context update -- three launches on the caller's stream, ordered
-      // behind whatever touched the state last
-      wait_last_all(e, st);
-      if (sizeof(T) == 2) launch_v5_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
-      else                launch_v5_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, e->d_gx5, e->d_h, e->d_c, d_probs, n_streams, n_chunks, st);
-      record_last_on(e, st);
+      // Silero v5 shapes: encoder + LSTM input projection (+ the streams' new context), then LSTM(128) + decoder.  Small calls run on the caller's
+      // stream; larger ones fork like the other models: stream A = encoder, stream B = the recurrence, so that the next call's encoder runs beside it
+      const bool fp32 = e->lstm_variant == 3;
+      auto enc = [&](float *gx, hipStream_t s_) {
+         if (sizeof(T) == 2) launch_v5_encoder_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, s_);
+         else                launch_v5_encoder_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, s_);
+      };
+      e->last_lstm_kernel = (fp32 || !e->v5.whh_h) ? 3 : 6;
+      if ((long)n_streams * n_chunks < 2048) {
+         wait_last_all(e, st);
+         enc(e->d_gx5[0], st);
+         launch_v5_lstm(e->v5, e->d_gx5[0], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, st);
+         record_last_on(e, st);
+      } else {
+         int rc5 = ensure_pipeline_streams(e, n_streams, 6);
+         if (rc5) return rc5;
+         if (hipStreamQuery(st) != hipSuccess) {                 // see the fork of the other models below
+            (void)hipGetLastError();
+            (void)hipEventRecord(e->ev_in, st);
+            (void)hipStreamWaitEvent(e->sA, e->ev_in, 0);
+            (void)hipStreamWaitEvent(e->sB, e->ev_in, 0);
+         }
+         wait_last(e, e->sA, e->last_a, e->last_a_on);
+         wait_last(e, e->sB, e->last_b, e->last_b_on);
+         if (e->last_c != e->last_b) wait_last(e, e->sB, e->last_c, e->last_c_on);
+         e->xpar ^= 1;
+         const int xp = e->xpar;
+         if (e->ev_b_valid[xp]) (void)hipStreamWaitEvent(e->sA, e->ev_b[xp], 0);     // gx of this parity: last read by the recurrence two forked calls ago
+         enc(e->d_gx5[xp], e->sA);
+         (void)hipEventRecord(e->ev_fe[0], e->sA);
+         e->last_a = e->ev_fe[0]; e->last_a_on = e->sA; e->ev_last_valid = true; e->last_on_valid = true;
+         (void)hipStreamWaitEvent(e->sB, e->ev_fe[0], 0);
+         launch_v5_lstm(e->v5, e->d_gx5[xp], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, e->sB);
+         (void)hipEventRecord(e->ev_b[xp], e->sB);
+         e->ev_b_valid[xp] = true;
+         e->last_b = e->last_c = e->ev_b[xp]; e->last_b_on = e->last_c_on = e->sB;
+         if (!e->defer_join) { (void)hipStreamWaitEvent(st, e->last_a, 0); (void)hipStreamWaitEvent(st, e->ev_b[xp], 0); }
+      }
       hipError_t he5 = hipGetLastError();
       if (he5 != hipSuccess) return fail(VADC_AMD_EHIP, "kernel launch failed: %s", hipGetErrorString(he5));
       return VADC_AMD_OK;

@@ -28,6 +28,8 @@ struct V5Weights {
    const float *wih_f;         // [32][32][64]                        A fragments of W_ih (rows i, f, g, o x 128)
    const float *lstm_b;        // [512]  b_ih + b_hh
    const float *whh;           // [512][128] recurrent weights, row-major
+   const _Float16 *whh_h;      // [32 m-tiles][4 k-blocks][64 lanes][hi 8 | lo 8]  split-fp16 A fragments of W_hh for v_mfma_f32_16x16x32_f16 (null: a weight
+                               // does not fit fp16's range; k_v5_lstm runs)
    const float *dec_w;         // [128]
    const float *dec_b;         // [1]
 };
@@ -292,6 +294,116 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx
    }
 }
 
+// The same recurrence with W_hh h as split-fp16 MFMAs (W h ~ Wl hh + Wh hl + Wh hh, fp32 accumulation: the form the v3.1 / v4 LSTM kernels use,
+// kernels_lstm.hip): 48 v_mfma_f32_16x16x32_f16 per wave and slot instead of 128 fp32 16x16x4 -- 5.0 -> 1.3 us per slot.  h travels through LDS as
+// [stream][unit] halves (hi and lo tiles, pitch 136): a lane's B fragment of a k-block is one 16-byte read per tile, its four new units one
+// 8-byte write per tile.
+typedef _Float16 v5h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 v5h4 __attribute__((ext_vector_type(4)));
+constexpr int kV5HP = kV5Hidden + 8;                 // halves per stream row
+
+__global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__ gx,       // [S * C][512]
+                                                       V5Weights w,
+                                                       float *__restrict__ hs, float *__restrict__ cs,  // [S][128]
+                                                       float *__restrict__ probs,                       // [S][C][2]
+                                                       int n_streams, int n_chunks)
+{
+   __shared__ __attribute__((aligned(16))) _Float16 hh[2][16 * kV5HP], hl[2][16 * kV5HP];   // [parity][stream][unit]: hi / lo halves of h
+   __shared__ float pd[2][8][16];
+   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int col = lane & 15, quad = lane >> 4;
+   const int s0 = blockIdx.x * 16;
+   const int s_col = min(s0 + col, n_streams - 1);
+   const bool col_ok = s0 + col < n_streams;
+   // recurrent weights of this wave's 16 units: gate g = m-tile 8 g + wave; k-block kb: lane holds k = 32 kb + 8 quad + e
+   v5h8 ah[4][4], al[4][4];
+#pragma unroll
+   for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+         const v5h8 *pp = reinterpret_cast<const v5h8 *>(w.whh_h + (((size_t)(8 * g + wave) * 4 + kb) * 64 + lane) * 16);
+         ah[g][kb] = pp[0]; al[g][kb] = pp[1];
+      }
+   float c[4], dw[4], hlast[4];
+   {
+      v5h4 h4, l4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wave + 4 * quad + r;
+         dw[r] = w.dec_w[u];
+         c[r] = cs[(size_t)s_col * kV5Hidden + u];
+         hlast[r] = hs[(size_t)s_col * kV5Hidden + u];
+         h4[r] = (_Float16)hlast[r]; l4[r] = (_Float16)(hlast[r] - (float)h4[r]);
+      }
+      *reinterpret_cast<v5h4 *>(&hh[0][col * kV5HP + 16 * wave + 4 * quad]) = h4;
+      *reinterpret_cast<v5h4 *>(&hl[0][col * kV5HP + 16 * wave + 4 * quad]) = l4;
+   }
+   const float *gx_lane = gx + (size_t)s_col * n_chunks * kV5Gates + 16 * wave + 4 * quad;
+   float4 gn[4];
+#pragma unroll
+   for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + g * kV5Hidden);
+   __syncthreads();
+   int par = 0;
+#pragma unroll 1
+   for (int ch = 0; ch < n_chunks; ++ch) {
+      f4v5 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = (f4v5){gn[g].x, gn[g].y, gn[g].z, gn[g].w};
+      if (ch + 1 < n_chunks) {
+#pragma unroll
+         for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + (size_t)(ch + 1) * kV5Gates + g * kV5Hidden);
+      }
+      v5h8 bh[4], bl[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+         bh[kb] = *reinterpret_cast<const v5h8 *>(&hh[par][col * kV5HP + 32 * kb + 8 * quad]);
+         bl[kb] = *reinterpret_cast<const v5h8 *>(&hl[par][col * kV5HP + 32 * kb + 8 * quad]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+         for (int g = 0; g < 4; ++g) {
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kb], bh[kb], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bl[kb], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bh[kb], acc[g], 0, 0, 0);
+         }
+      float d = 0.0f;
+      v5h4 h4, l4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const float ig = v5_sigmoid(acc[0][r]), fg = v5_sigmoid(acc[1][r]), gg = v5_tanh(acc[2][r]), og = v5_sigmoid(acc[3][r]);
+         c[r] = fmaf(fg, c[r], ig * gg);
+         float hn = og * v5_tanh(c[r]);
+         asm volatile("" : "+v"(hn));                                 // the ROUNDED h is what is split (and what a later call re-splits from the state):
+         hlast[r] = hn;                                               // without this the product is contracted into the subtraction below
+         h4[r] = (_Float16)hn; l4[r] = (_Float16)(hn - (float)h4[r]);
+         d = fmaf(dw[r], fmaxf(hn, 0.0f), d);                         // decoder: ReLU -> conv 128 -> 1 (silero_vad.py:335-338)
+      }
+      *reinterpret_cast<v5h4 *>(&hh[par ^ 1][col * kV5HP + 16 * wave + 4 * quad]) = h4;
+      *reinterpret_cast<v5h4 *>(&hl[par ^ 1][col * kV5HP + 16 * wave + 4 * quad]) = l4;
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      if (quad == 0) pd[ch & 1][wave][col] = d;
+      __syncthreads();
+      par ^= 1;
+      if (wave == 0 && lane < 16 && s0 + lane < n_streams) {
+         const float *p = &pd[ch & 1][0][lane];
+         const float m = ((p[0] + p[16]) + (p[32] + p[48])) + ((p[64] + p[80]) + (p[96] + p[112])) + w.dec_b[0];
+         const float pr = 1.0f / (1.0f + expf(-m));                   // sigmoid; the mean over the one step is the value itself (:412)
+         probs[((size_t)(s0 + lane) * n_chunks + ch) * 2 + 0] = pr;
+         probs[((size_t)(s0 + lane) * n_chunks + ch) * 2 + 1] = pr;
+      }
+   }
+   if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+         const int u = 16 * wave + 4 * quad + r;
+         cs[(size_t)s_col * kV5Hidden + u] = c[r];
+         hs[(size_t)s_col * kV5Hidden + u] = hlast[r];                // fp32: the state a later call (or the caller) sees is not rounded to halves
+      }
+   }
+}
+
 template <typename T>
 __global__ void k_v5_context(const T *__restrict__ pcm, float *__restrict__ ctx, int n_streams, int n_chunks)
 {
@@ -301,23 +413,27 @@ __global__ void k_v5_context(const T *__restrict__ pcm, float *__restrict__ ctx,
    ctx[i] = v5_sample(pcm[((size_t)s * n_chunks + n_chunks - 1) * kV5Window + kV5Window - kV5Context + j]);
 }
 
+// front half of a call: encoder + LSTM input projection -> gx, then the streams' new context (read by the next call's encoder on the same stream)
 template <typename T>
-static void launch_v5_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, hipStream_t st)
+static void launch_v5_enc_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
 {
    const int n_items = n_streams * n_chunks;
    hipLaunchKernelGGL((k_v5_encoder<T>), dim3((n_items + kV5Chunks - 1) / kV5Chunks), dim3(256), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
-   hipLaunchKernelGGL(k_v5_lstm, dim3((n_streams + 15) / 16), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
    hipLaunchKernelGGL((k_v5_context<T>), dim3((n_streams * kV5Context + 255) / 256), dim3(256), 0, st, pcm, ctx, n_streams, n_chunks);
 }
-
-// the whole v5 path for n_streams x n_chunks windows of 512 samples, on one stream
-void launch_v5_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, hipStream_t st)
+void launch_v5_encoder_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
 {
-   launch_v5_t<float>(pcm, ctx, w, gx, hs, cs, probs, n_streams, n_chunks, st);
+   launch_v5_enc_t<float>(pcm, ctx, w, gx, n_streams, n_chunks, st);
 }
-void launch_v5_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, hipStream_t st)
+void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
 {
-   launch_v5_t<int16_t>(pcm, ctx, w, gx, hs, cs, probs, n_streams, n_chunks, st);
+   launch_v5_enc_t<int16_t>(pcm, ctx, w, gx, n_streams, n_chunks, st);
+}
+// back half: the recurrence + decoder over the call's chunks.  fp32 = true (or no split-fp16 weights): W_hh h as fp32 MFMAs
+void launch_v5_lstm(const V5Weights &w, const float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, bool fp32, hipStream_t st)
+{
+   if (fp32 || !w.whh_h) hipLaunchKernelGGL(k_v5_lstm, dim3((n_streams + 15) / 16), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
+   else                  hipLaunchKernelGGL(k_v5_lstm_h3, dim3((n_streams + 15) / 16), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
 }
 
 }  // namespace vadc
