@@ -290,6 +290,7 @@ def run_rank(args, world, rank, local_rank):
             eng.set_profiling(on)
             n_prof += int(on)
         step(i)
+    issued = time.perf_counter() - t0         # host time to ISSUE the K steps (the device is still running them)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -377,6 +378,7 @@ def run_rank(args, world, rank, local_rank):
                                  "algorithmic_* counts (SURVEY.md 8(d))"},
             "kernels": per_kernel,
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
+            "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph
         }
         if world == 1 and not args.no_host_fed:
             # PCIe-inclusive rate of the synchronous host-buffer entry point (what a drop-in backend_run pays); reported, never `value`
