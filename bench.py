@@ -241,6 +241,7 @@ def run_rank(args, world, rank, local_rank):
     # k+1 beside layer 1 of step k (layer-major LSTM, <= 512 streams), or front end + encoder beside the whole LSTM.  Default: all steps issued
     # from streams[0], which a call does not block (defer_join); --strict-join: NB caller streams in turn, each strictly ordered.
     streams = [torch.cuda.Stream() for _ in range(NB)]
+    gathered = [None] * NB                    # per step buffer: the event behind the gather that last read it (multi-GPU only)
 
     if args.defer_join:
         eng.set_option("defer_join", 1)
@@ -249,11 +250,16 @@ def run_rank(args, world, rank, local_rank):
         b = i % NB
         if args.defer_join:
             # ONE issuing stream: the call does not block it; a side stream joins the call (device-side wait) and carries the gather
+            if world > 1 and gathered[b] is not None:
+                streams[0].wait_event(gathered[b])                    # the gather that read d_probs[b] NB steps ago comes before this call rewrites it
             eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), streams[0].cuda_stream)
             if world > 1:
-                eng.join(streams[1 + b % (NB - 1)].cuda_stream)
-                with torch.cuda.stream(streams[1 + b % (NB - 1)]):
+                side = streams[1 + b % (NB - 1)]
+                eng.join(side.cuda_stream)
+                with torch.cuda.stream(side):
                     gather.gather(d_probs[b])
+                    gathered[b] = torch.cuda.Event()
+                    gathered[b].record(side)
             return
         st = streams[b]
         with torch.cuda.stream(st):
