@@ -211,10 +211,16 @@ def run_rank(args, world, rank, local_rank):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path (--dry-run rehearses the rank skeleton over gloo)")
+    rehearsal = args.one_gpu_rehearsal        # N ranks on ONE GPU with gloo (a single-GPU box cannot form an RCCL group): exercises this rank code, not RCCL
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vadc_amd import shard, synth
     from vadc_amd.engine import Engine
@@ -235,7 +241,7 @@ def run_rank(args, world, rank, local_rank):
     pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
     d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
-    gather = shard.ProbabilityGather(S * world, Cn, dev)          # weak scaling: S streams per GPU, contiguous blocks
+    gather = shard.ProbabilityGather(S * world, Cn, "cpu" if rehearsal else dev)          # weak scaling: S streams per GPU, contiguous blocks
     assert gather.hi - gather.lo == S
     # The engine's internal in-order streams overlap the stages of consecutive steps: front end + encoder of step k+2 beside LSTM layer 0 of step
     # k+1 beside layer 1 of step k (layer-major LSTM, <= 512 streams), or front end + encoder beside the whole LSTM.  Default: all steps issued
@@ -257,7 +263,7 @@ def run_rank(args, world, rank, local_rank):
                 side = streams[1 + b % (NB - 1)]
                 eng.join(side.cuda_stream)
                 with torch.cuda.stream(side):
-                    gather.gather(d_probs[b])
+                    gather.gather(d_probs[b].cpu() if rehearsal else d_probs[b])
                     gathered[b] = torch.cuda.Event()
                     gathered[b].record(side)
             return
@@ -265,7 +271,7 @@ def run_rank(args, world, rank, local_rank):
         with torch.cuda.stream(st):
             eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), st.cuda_stream)
             if world > 1:
-                gather.gather(d_probs[b])               # the only collective: final probability gather (RCCL)
+                gather.gather(d_probs[b].cpu() if rehearsal else d_probs[b])               # the only collective: final probability gather (RCCL)
 
     for i in range(2 * NB):                # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
         step(i)
@@ -439,6 +445,8 @@ def main():
                          "probabilities (the RCCL gather, the final synchronize) joins it with vadc_amd_join")
     ap.set_defaults(defer_join=True)
     ap.add_argument("--caller-streams", type=int, default=3, help="step buffers used in turn (= caller streams with --strict-join)")
+    ap.add_argument("--one-gpu-rehearsal", action="store_true",
+                    help="N ranks share GPU 0 and gather over gloo through the host: rehearses the multi-rank code path on a one-GPU box (its numbers mean nothing)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse spawn / rendezvous / sharding / gather / timing over gloo on the CPU")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help=argparse.SUPPRESS)

@@ -51,3 +51,14 @@ def test_cpu_baseline_worker_reports_a_rate():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["kind"] in ("reference", "port") and d["chunks_per_s"] > 100
+
+
+@pytest.mark.gpu
+def test_multi_rank_gpu_code_path_on_one_gpu():
+    """`--one-gpu-rehearsal`: two ranks share GPU 0 and gather over gloo through the host -- a one-GPU box cannot form an RCCL group, but everything
+    else of the multi-rank GPU path runs: per-rank engines, deferred joins, the side-stream gather behind vadc_amd_join, per-buffer gather events,
+    barrier and max-over-ranks timing"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--gpus", "2", "--one-gpu-rehearsal", "--steps", "7", "--warmup", "2", "--streams", "32", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed", env=env)
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["streams_per_gpu"] == 32
