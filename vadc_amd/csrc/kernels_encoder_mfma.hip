@@ -252,7 +252,14 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // workgroups fit a CU's 160 KB -- with one, its single wave per SIMD had nothing to hide MFMA/LDS latency behind.
    // stages without a transformer block (v4) only keep the conv block's input tile (<= 35 rows) or the LSTM-native transpose (52 rows) here:
    // 56 rows instead of 3 D (stage 4: 80 KB -> 38 KB of LDS, 2 -> 4 workgroups per CU)
-   constexpr int ROWS_B = (DIRECT && !HAS_TF) ? 56 : ((DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab);
+   // PHD (D = 64 transformer layer, split-fp16): Q / K / V and the attention one HEAD at a time -- 96 rows instead of 192 (61 -> 30 KB), so that THREE
+   // workgroups fit a CU instead of two; the layer is latency-bound (two waves per SIMD, every GEMM waiting for its weight fragments)
+#ifdef VADC_NO_PHD
+   constexpr bool PHD = false;
+#else
+   constexpr bool PHD = H3 && HAS_TF && D == 64;
+#endif
+   constexpr int ROWS_B = (DIRECT && !HAS_TF) ? 56 : (PHD ? 3 * HD : ((DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab));
    static_assert(!H3 || (DIRECT && HAS_TF && D % 32 == 0), "split-fp16 layer GEMMs: transformer layers with D = 32 / 64");
    constexpr int HP = D + 8, KB = H3 ? D / 32 : 1;       // H3: pitch (halves) of the split activation tiles, k-blocks per GEMM
    __shared__ __attribute__((aligned(16))) _Float16 SH[H3 ? 2 * kCol * HP : 8];   // H3: [hi | lo][column][k]: the B operand of every GEMM of the block, reused in place
@@ -639,6 +646,108 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    }
    PH(1);
    if constexpr (HAS_TF) {
+   if constexpr (PHD) {
+   // ---- QKV and attention, one head at a time (same arithmetic per element as below) --------------------------------------------
+   constexpr int MTH = HD / 16;
+   h8v ybh[KB], ybl[KB];
+   load_b_h3<KB>(ybh, ybl, Sh, Sl, HP, lane, wave);        // y of this wave's columns: in registers for both heads (the attention output overwrites the tiles)
+   const int qcol = 16 * wave + lc;
+   const int qcb = qcol / T;
+   const int qcolp = qcb * TP + (qcol - qcb * T);
+#pragma unroll
+   for (int h = 0; h < 2; ++h) {
+      f4v q[3 * MTH];
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+         for (int j = 0; j < MTH; ++j) {
+            const int mtg = part * MT + h * MTH + j;       // M tile of the full QKV weight
+            const float4 b4 = *reinterpret_cast<const float4 *>(w.qkv_b + 16 * mtg + 4 * quad);
+            f4v a4 = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+               const h8v *pw = reinterpret_cast<const h8v *>(w.qkv_h + (((size_t)mtg * KB + kb) * 64 + lane) * 16);
+               const h8v ah = pw[0], al = pw[1];
+               a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ybh[kb], a4, 0, 0, 0);
+               a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ybl[kb], a4, 0, 0, 0);
+               a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ybh[kb], a4, 0, 0, 0);
+            }
+            q[part * MTH + j] = a4;
+         }
+      if (h > 0) __syncthreads();                          // the previous head's attention is done with the Q / K / V rows
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+         for (int j = 0; j < MTH; ++j) {
+            const int cdst = part == 1 ? qcol : qcolp;     // K rows keep the column layout, Q and V rows the padded-chunk layout (see below)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) QKV[(part * HD + 16 * j + 4 * quad + r) * kPitch + cdst] = q[part * MTH + j][r];
+         }
+      __syncthreads();
+      {
+         // FOUR adjacent lanes share one column's task of this head: lane p takes a quarter of the head's hd dimensions
+         const int p = tid & 3, i = tid >> 2;
+         const int icb = i / T;
+         constexpr int HH = HD / 4, TQ = TP / 4;
+         static_assert(HH == 8, "one 16-byte store of halves per lane");
+         _Float16 *dsh = Sh + i * HP + h * HD + p * HH, *dsl = Sl + i * HP + h * HD + p * HH;
+         float ov[HH];
+         if (i < NCOLV) {
+            const float *Q = QKV + (p * HH) * kPitch + icb * TP, *K = QKV + (HD + p * HH) * kPitch + i;
+            const float *V = QKV + (2 * HD + p * HH) * kPitch + icb * TP;
+            float sc[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) sc[j] = 0.0f;
+#pragma unroll
+            for (int e = 0; e < HH; ++e) {
+               const float ke = K[e * kPitch];
+#pragma unroll
+               for (int q4 = 0; q4 < TQ; ++q4) {
+                  const float4 qv = *reinterpret_cast<const float4 *>(Q + e * kPitch + 4 * q4);
+                  sc[4 * q4 + 0] = fmaf(ke, qv.x, sc[4 * q4 + 0]); sc[4 * q4 + 1] = fmaf(ke, qv.y, sc[4 * q4 + 1]);
+                  sc[4 * q4 + 2] = fmaf(ke, qv.z, sc[4 * q4 + 2]); sc[4 * q4 + 3] = fmaf(ke, qv.w, sc[4 * q4 + 3]);
+               }
+            }
+            const float scale = 1.0f / sqrtf((float)HD);      // transformer.c:114
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+               float v = sc[j] + __shfl_xor(sc[j], 1);
+               v += __shfl_xor(v, 2);
+               sc[j] = v * scale;
+               mx = fmaxf(mx, sc[j]);
+            }
+            float sum = 0.0f;                                 // tensor.h:751-784
+#pragma unroll
+            for (int j = 0; j < T; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int e = 0; e < HH; ++e) {
+               float o = 0.0f;
+#pragma unroll
+               for (int q4 = 0; q4 < TQ; ++q4) {
+                  const float4 vv = *reinterpret_cast<const float4 *>(V + e * kPitch + 4 * q4);
+                  if (4 * q4 + 0 < T) o = fmaf(sc[4 * q4 + 0], vv.x, o);
+                  if (4 * q4 + 1 < T) o = fmaf(sc[4 * q4 + 1], vv.y, o);
+                  if (4 * q4 + 2 < T) o = fmaf(sc[4 * q4 + 2], vv.z, o);
+                  if (4 * q4 + 3 < T) o = fmaf(sc[4 * q4 + 3], vv.w, o);
+               }
+               ov[e] = o * inv;
+            }
+         } else {
+#pragma unroll
+            for (int e = 0; e < HH; ++e) ov[e] = 0.0f;
+         }
+         h8v hi, lo;
+#pragma unroll
+         for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)ov[e]; lo[e] = (_Float16)(ov[e] - (float)hi[e]); }
+         *reinterpret_cast<h8v *>(dsh) = hi;
+         *reinterpret_cast<h8v *>(dsl) = lo;
+      }
+   }
+   __syncthreads();
+   PH(3);
+   } else {
    // ---- QKV = W y + b  -> LDS rows [0,D) Q, [D,2D) K, [2D,3D) V      transformer.c:69-99 -----------------
    {
       f4v q[3 * MT];
@@ -735,6 +844,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    }
    __syncthreads();
    PH(3);
+   }  // !PHD
 
    // ---- out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220 -------------------
    {
