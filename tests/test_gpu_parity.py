@@ -888,3 +888,17 @@ def test_split16_refuses_weights_outside_fp16_range(weights_blob):
         Engine(_blob_with(weights_blob, {95: w}), max_streams=1, max_chunks_per_call=1, device=0, precision=1)
     assert ei.value.code == _lib_code("EWEIGHTS")
 
+
+def test_synchronous_entry_points_join_under_defer_join(weights_blob, orc):
+    """option "defer_join" concerns vadc_amd_run_device_*: the host-buffer entry points (vadc_amd_run_s16 / _f32) copy the probabilities back
+    themselves and must wait for the forked call regardless"""
+    S, Cn = 64, 40                                  # 2560 chunks: a forked call
+    pcm = synth.make_streams(S, Cn, seed0=909)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        e.set_option("defer_join", 1)
+        got = e.run(pcm)[:, :, 1]
+    finally:
+        e.close()
+    ref = orc.forward_streams(pcm)
+    assert float(np.abs(got - ref).max()) < PROB_TOL

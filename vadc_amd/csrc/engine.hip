@@ -1340,6 +1340,7 @@ extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_
    HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, n * e->window * sizeof(float), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
    rc = run_device<float>(e, e->d_in_f32, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
+   if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
@@ -1355,6 +1356,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    HIP_TRY(hipMemcpyAsync(e->d_in_s16, pcm, n * e->window * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
    rc = run_device<int16_t>(e, e->d_in_s16, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
+   if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    return VADC_AMD_OK;
