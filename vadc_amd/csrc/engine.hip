@@ -608,7 +608,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
 {
    if (!e) return;
    (void)hipSetDevice(e->device);
-   if (e->stream) (void)hipStreamSynchronize(e->stream);
+   for (hipStream_t st : {e->stream, e->sA, e->sB, e->sC}) if (st) (void)hipStreamSynchronize(st);   // nothing of this engine is in flight when its buffers go
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
