@@ -680,6 +680,20 @@ def test_cli_raw_probabilities_contract(gold_c, gold_py):
     assert "Running with batch size 96" in err
 
 
+def test_cli_short_lived_processes_exit(gold_py):
+    """create -> one forked call -> destroy, 25 processes in a row, each within seconds: tearing the engine down right behind its CU-masked streams'
+    last work once hung one process in ten (an explicit hipStreamSynchronize on those idle streams in vadc_amd_destroy; bisected)"""
+    import subprocess
+    from conftest import ROOT, WEIGHTS
+    exe = os.path.join(ROOT, "host", "vadc_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
+    pcm = gold_py["pcm_speech0"].tobytes()
+    for _ in range(25):
+        r = subprocess.run([exe, "--model", WEIGHTS], input=pcm, capture_output=True, timeout=30)
+        assert r.returncode == 0 and r.stdout == b"0.07,3.10\n", r.stderr.decode()
+
+
 @pytest.mark.parametrize("args,kw", [
     ((), {}),
     (("--output_centi_seconds", "--min_silence", "100"), {"min_silence_ms": 100.0}),

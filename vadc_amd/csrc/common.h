@@ -71,7 +71,7 @@ __host__ __device__ __forceinline__ size_t lstm_x_index(int stream, int chunk, i
 // log1p(x) for x >= 0 on the hardware transcendental unit instead of libm's ~50-instruction log1pf:
 //   u = fl(1 + x), c = x - (u - 1) the exact rounding error of u;  y0 = ln2 * v_log_f32(u)  (a few ulp);
 //   one Newton step on exp(y) = u:  y1 = y0 + (u * exp(-y0) - 1), the residual formed with one fma (absolute error ~6e-8);
-//   log1p(x) = y1 + c / u.
+//   log1p(x) = y1 + c / u, with 1 / u taken from the step's own E = exp(-y0) (= (1 + 1e-6) / u; c / u <= 6e-8: no reciprocal needed).
 // Absolute error <= ~1e-7 over the whole range (Y <= 16), i.e. libm-grade for what the path needs (Y enters as Y - mean);
 // neither this nor libm is bit-identical to the reference's CRT log1pf (misc.c:42-45).
 __device__ __forceinline__ float log1p_hw(float x)
@@ -81,7 +81,7 @@ __device__ __forceinline__ float log1p_hw(float x)
    float y = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
    const float E = __builtin_amdgcn_exp2f(y * -1.4426950408889634f);
    y += fmaf(u, E, -1.0f);
-   return fmaf(c, __builtin_amdgcn_rcpf(u), y);
+   return fmaf(c, E, y);
 }
 
 // The same without the Newton step: y = ln2 * v_log_f32(u) + c / u.  v_log_f32 is good to ~1 ulp of log2(u), i.e. an absolute error of

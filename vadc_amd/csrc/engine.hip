@@ -608,7 +608,9 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
 {
    if (!e) return;
    (void)hipSetDevice(e->device);
-   for (hipStream_t st : {e->stream, e->sA, e->sB, e->sC}) if (st) (void)hipStreamSynchronize(st);   // nothing of this engine is in flight when its buffers go
+   // The first hipFree below waits for the whole device, the engine's own streams included.  (An explicit hipStreamSynchronize on the idle CU-masked
+   // streams here hung one short-lived process in ten -- bisected, ROCm 7.2 -- so there is none.)
+   if (e->stream) (void)hipStreamSynchronize(e->stream);
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1014,8 +1016,12 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
    int want = lstm_partition_cus(e, n_streams, &shared);
    const bool split = lk == 7;                                  // layer-major LSTM: stream B = layer 0 on one half of the partition, stream C = layer 1 on the other
    if (e->lstm_cus == want && e->lstm_shared == shared && e->streams_split == split && e->sA && e->sB && e->sC) return VADC_AMD_OK;
+   // drain the old streams through the events their last work is marked with (every call ends each stream it used with a record that one of
+   // last_a / last_b / last_c aliases), not with hipStreamSynchronize on the CU-masked streams themselves (see vadc_amd_destroy)
+   if (e->ev_last_valid)
+      for (hipEvent_t ev : {e->last_a, e->last_b, e->last_c}) if (ev) HIP_TRY(hipEventSynchronize(ev), VADC_AMD_EHIP);
    for (hipStream_t *ps : {&e->sA, &e->sB, &e->sC})
-      if (*ps) { HIP_TRY(hipStreamSynchronize(*ps), VADC_AMD_EHIP); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+      if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
    bool masked = false;
    if (want > 0) {
       const int words = (e->n_cus + 31) / 32;
