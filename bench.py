@@ -17,10 +17,12 @@ blocks (vadc_amd/shard.py) with no data-path collective; the per-step speech pro
 (north star), inside the timed region.  `--dry-run` runs the same rank skeleton (spawn, rendezvous, sharding, gather, barrier, max-over-ranks
 timing) over gloo on the CPU with a stand-in for the engine: what tests/test_bench_spawn.py exercises where there is no GPU.
 
-The JSON line also carries
+The JSON line is kept short (the driver reads the tail of stdout); its verbose form -- per-kernel executed / algorithmic FLOP, pipes, notes -- goes to
+`--details` (default gpurun_out/bench_details.json).  Besides the contract fields the line carries
   roofline     -- dominant kernel (by CU-time): EXECUTED FLOP per launch / HIP-event duration against the peak of the pipe that executes them
-                  (events recorded inside the timed region, on the kernel's own stream, on every 4th step); the algorithmic (dense-basis,
+                  (events recorded inside the timed region, on the kernel's own stream, on every 8th step); the algorithmic (dense-basis,
                   SURVEY.md 8(d)) figure rides along
+  kernels_ms   -- HIP-event average launch duration of every kernel of the step
   cpu_baseline -- the reference C backend (oracle/_ref, kind "reference") or the CPU oracle (kind "port") on this box's host cores: all
                   cores (one process per core, value = aggregate), one core at batch 96 and at batch 1 (BASELINE config 1)
   host_fed     -- the same step through vadc_amd_run_s16 (pageable host buffers in and out: PCIe-inclusive); never `value`
@@ -395,6 +397,8 @@ def run_rank(args, world, rank, local_rank):
         if world == 1 and not args.no_host_fed:
             # PCIe-inclusive rate of the synchronous host-buffer entry point (what a drop-in backend_run pays); reported, never `value`
             host = np.ascontiguousarray(pcm[:, : Cn * 1536])
+            eng.set_option("defer_join", 0)                       # what a plain synchronous caller gets: the call pipelines its own chunk groups
+            eng.set_option("groups", 0)
             eng.run(host)
             n_host = 5
             t1 = time.perf_counter()
@@ -405,7 +409,26 @@ def run_rank(args, world, rank, local_rank):
                                "note": "vadc_amd_run_s16: pageable host s16 in, probabilities out, synchronous (H2D 3 KB + D2H 8 B per chunk inside the timed call)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        # The line the driver parses stays SHORT (it reads the tail of stdout): the per-kernel accounting and the long notes go to a details file
+        # (the same object, verbose), the line keeps every contract field plus the per-kernel launch times.
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.details)), exist_ok=True)
+            with open(args.details, "w") as f:
+                json.dump(out, f)
+        except OSError:
+            pass
+        line = dict(out)
+        line["roofline"] = {k: v for k, v in out["roofline"].items() if k != "note"}
+        line["kernels_ms"] = {k: v["ms_per_launch"] for k, v in out["kernels"].items()}
+        del line["kernels"]
+        if "host_fed" in line:
+            line["host_fed"] = {k: v for k, v in out["host_fed"].items() if k != "note"}
+        if "cpu_baseline" in line:
+            c = dict(out["cpu_baseline"])
+            c["sample"] = c["sample"][:120]
+            line["cpu_baseline"] = c
+        line["details"] = os.path.relpath(os.path.abspath(args.details), ROOT)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -434,7 +457,7 @@ def main():
                     help="experiment: no per-kernel HIP events inside the timed region (kernel table then comes from a separate pass)")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="eager launches only.  Default: hipGraph replay of the step's kernel sequences (north star: hipGraph-captured steady-state steps); "
-                         "every 4th step of the timed region is still issued eagerly so that its kernels carry HIP events")
+                         "every 8th step of the timed region is still issued eagerly so that its kernels carry HIP events")
     ap.set_defaults(graph=True)
     ap.add_argument("--groups", type=int, default=1,
                     help="chunk groups per step inside the engine (1: whole step per launch; steps overlap each other "
@@ -445,6 +468,8 @@ def main():
                          "probabilities (the RCCL gather, the final synchronize) joins it with vadc_amd_join")
     ap.set_defaults(defer_join=True)
     ap.add_argument("--caller-streams", type=int, default=3, help="step buffers used in turn (= caller streams with --strict-join)")
+    ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
+                    help="where the verbose form of the line goes (per-kernel executed / algorithmic FLOP, pipes, notes)")
     ap.add_argument("--one-gpu-rehearsal", action="store_true",
                     help="N ranks share GPU 0 and gather over gloo through the host: rehearses the multi-rank code path on a one-GPU box (its numbers mean nothing)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse spawn / rendezvous / sharding / gather / timing over gloo on the CPU")
