@@ -16,8 +16,9 @@
  * Functions replaced (same names, arguments and failure behaviour):
  *   backend_init            silero.h:48 (-> silero_init :21-46)      NULL => run_inference returns -1 (vadc.c:692-695)
  *   backend_create_tensors  silero.h:76                              no-op, as for the C backend
- *   backend_run             silero.h:53-74                           reads buffers.input_samples[batch*1536] f32,
- *                                                                    writes buffers.output[batch*2] (prob at index 1)
+ *   backend_run             silero.h:53-74                           reads buffers.input_samples[batch*1536] f32 (a Silero v5 container:
+ *                                                                    rows of 64 + 512, vadc.c:105-162 -- the windows are taken, the context
+ *                                                                    is device state), writes buffers.output[batch*2] (prob at index 1)
  * Types used from vadc.h: MemoryArena, String8, Silero_Config (:10-43), Tensor_Buffers (:45-58), VADC_Context (:65-70).
  *
  * Weights: the reference embeds silero_v31_16k.testtensor as a C array (silero.h:19,28; cembed.c).  Here either
@@ -95,9 +96,23 @@ static inline void backend_run(MemoryArena *arena, void *context_, Silero_Config
 {
    (void)arena;
    VADC_Context *context = (VADC_Context *)context_;
+   const float *in = context->buffers.input_samples;
+   if (config.is_silero_v5 && config.context_size > 0) {
+      /* process_chunks_v5 (vadc.c:105-162) hands over rows of context_size + input_count samples -- the previous window's tail in front of every
+       * window.  The engine keeps each stream's context on the device (the same 64 samples, zeros before the first window), so only the windows
+       * travel: compact the rows (single caller thread, vadc.c is not re-entrant: one static scratch buffer). */
+      static float *win = 0;
+      static size_t win_cap = 0;
+      const size_t need = (size_t)config.batch_size * (size_t)config.input_count;
+      if (need > win_cap) { free(win); win = (float *)malloc(need * sizeof(float)); win_cap = win ? need : 0; }
+      if (!win) { fprintf(stderr, "vadc_backend_hip: out of memory\n"); abort(); }
+      for (int b = 0; b < config.batch_size; ++b)
+         memcpy(win + (size_t)b * config.input_count, in + (size_t)b * (config.context_size + config.input_count) + config.context_size,
+                (size_t)config.input_count * sizeof(float));
+      in = win;
+   }
    /* `batch_size` consecutive windows of the one stream: silero.h:64-68, lstm.c:275-277 */
-   int rc = vadc_amd_run_f32((vadc_amd_engine *)context->backend, context->buffers.input_samples, 1,
-                             config.batch_size, context->buffers.output);
+   int rc = vadc_amd_run_f32((vadc_amd_engine *)context->backend, in, 1, config.batch_size, context->buffers.output);
    if (rc != VADC_AMD_OK) {                        /* the ORT backend aborts on error (onnx_helpers.h:5-14) */
       fprintf(stderr, "vadc_backend_hip: %s\n", vadc_amd_last_error());
       abort();
