@@ -190,7 +190,8 @@ int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_strea
  *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
  *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = k_frontend_gemm (default), 1 = the tree kernel with the v4 geometry
  *   "encoder"     0 = MFMA layer kernels (default); 2 = first stage as the LDS slab path instead of the K = 1 MFMA form; 3 = fp32 MFMA for the GEMMs of
- *                 layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16)
+ *                 layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per
+ *                 workgroup instead of 8 waves / 5 chunks
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
  *                 1: magnitudes are written by the front end and read by the first stage
  *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream

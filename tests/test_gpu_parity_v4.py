@@ -380,3 +380,21 @@ def test_cli_with_the_8khz_container(gold):
     assert "Running with sequence count 768" in r.stderr.decode()            # the default 1536 clamped to the branch's maximum (vadc.c:743-752)
     got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
     assert float(np.abs(got - g8["probs64_w768_speech0"]).max()) < PROB_TOL + 5e-7
+
+
+def test_first_stage_widths_agree(blob, orc):
+    """the v4 first stage runs 8 waves / 5 chunks per workgroup by default (the middle chunk in two pieces that overlap by four steps, so every
+    lane finds its depthwise-conv neighbours in its own wave); option "encoder" = 4 selects 4 waves / 2 chunks.  Same arithmetic per column (two template
+    instantiations may contract differently: last-bit differences, a few 1e-6 after the LSTM), on every remainder of chunks per workgroup"""
+    for S, Cn in ((3, 13), (64, 40), (1, 1), (2, 5), (7, 6)):
+        pcm = synth.make_streams(S, Cn, seed0=77 + S)
+        out = {}
+        for enc in (0, 4):
+            e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+            try:
+                e.set_option("encoder", enc)
+                out[enc] = e.run(pcm)
+            finally:
+                e.close()
+        assert float(np.abs(out[0] - out[4]).max()) < 2e-5, (S, Cn)        # last-bit differences of the stage, carried through the LSTM
+        assert float(np.abs(out[0][:, :, 1] - orc.forward_streams(pcm)).max()) < PROB_TOL

@@ -39,7 +39,6 @@ __device__ unsigned int g_phase_n[4];
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int kCol = 64;      // columns per workgroup (4 MFMA N-tiles)
 constexpr int kPitch = 80;    // LDS row pitch in floats (80 % 32 == 16: rows k..k+3 of a B fragment hit disjoint banks)
 
 
@@ -94,14 +93,14 @@ __device__ __forceinline__ float dpp_wave_shl1(float v)
 
 // acc[mt] (+)= W[16mt.., :] . X[:, wave's 16 columns]   for mt < MT, K = 4*KK rows of X starting at xrow0.
 // wf: fragment-major weights [MT][KKW][64] (KKW = k-steps per M-tile in memory), kk0 = first k-step to use.
-template <int MT, int KK>
+template <int MT, int KK, int P = kPitch>
 __device__ __forceinline__ void gemm_acc(f4v (&acc)[MT], const float *__restrict__ wf, int KKW, int kk0,
                                          const float *X, int lane, int wave)
 {
    const int quad = lane >> 4, lc = lane & 15;
    float b[KK];
 #pragma unroll
-   for (int kk = 0; kk < KK; ++kk) b[kk] = X[(4 * kk + quad) * kPitch + 16 * wave + lc];
+   for (int kk = 0; kk < KK; ++kk) b[kk] = X[(4 * kk + quad) * P + 16 * wave + lc];
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt) {
       const float *wp = wf + ((size_t)mt * KKW + kk0) * 64 + lane;
@@ -172,14 +171,14 @@ __device__ __forceinline__ void acc_init(f4v (&acc)[MT], const float *__restrict
 }
 
 // accumulator layout <-> LDS [row][col]: lane (quad, lc), reg r  <->  row 16 mt + 4 quad + r, col 16 wave + lc
-template <int MT>
+template <int MT, int P = kPitch>
 __device__ __forceinline__ void acc_store(const f4v (&acc)[MT], float *Y, int lane, int wave)
 {
    const int quad = lane >> 4, lc = lane & 15;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[(16 * mt + 4 * quad + r) * kPitch + 16 * wave + lc] = acc[mt][r];
+      for (int r = 0; r < 4; ++r) Y[(16 * mt + 4 * quad + r) * P + 16 * wave + lc] = acc[mt][r];
 }
 
 // LayerNorm over the D = 16*MT channels of each column, in the accumulator layout (misc.c:143-210)
@@ -228,20 +227,49 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 // 211 MB (v4: 406 MB) per 16,384 chunks of hand-off at 1.5-2 TB/s; the read alone takes 0.033 ms from the infinity cache and 0.077 ms
 // from HBM (tools/yread_probe.hip).
 // H3: the transformer block's GEMMs and the strided conv in the split-fp16 form above (D = 32 / 64 layers; option "encoder" = 3 keeps fp32 MFMA)
-template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false, bool H3 = false>
-__global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
+// WAVES = 8 (Silero v4's first stage with 24 steps per chunk): 128 lanes hold 5 chunks -- 2 chunks fill only 48 of 64 lanes.  A wave's lanes must
+//        hold whole runs of a chunk's steps (the depthwise conv's neighbours are wave shifts), so the middle chunk is cut in two pieces that
+//        OVERLAP by four steps: lanes 48..63 of the first half carry its steps 0..15 (owning 0..13), lanes 0..11 of the second half its steps
+//        12..23 (owning 14..23); the two extra steps on either side are read again from memory and only feed their neighbours.  124 of 128
+//        lanes carry data, 120 own an output column: a fifth less matrix and vector work per chunk.  LDS row pitch 144.
+template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false, bool H3 = false,
+          int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
                                                     int n_chunks, ItemMap map, size_t fm_stride,
                                                     const float *__restrict__ in2 = nullptr)
 {
-   constexpr int NCOLV = NCH * T;                       // valid columns
-   static_assert(NCOLV <= kCol, "too many chunks per workgroup");
+   static_assert(WAVES == 4 || (WAVES == 8 && K1 && !HAS_TF && NCH == 5 && 64 - 2 * T >= 4 && 5 * T - 60 <= 64),
+                 "8 waves: the K = 1 first stage without a transformer block, 5 chunks whose middle one is split with a 4-step overlap");
+   constexpr int kPitchG = kPitch;                        // the 4-wave geometry (file scope)
+   constexpr int kCol = 16 * WAVES;                       // columns per workgroup (one MFMA N tile per wave)
+   constexpr int kPitch = WAVES == 4 ? kPitchG : 144;     // shadows the file-scope pitch from here on; 144 % 32 == 16 as well
+   constexpr int NT = 64 * WAVES;                         // threads
+   constexpr int NCOLV = WAVES == 4 ? NCH * T : kCol;     // columns that may carry data (8 waves: see colmap)
+   static_assert(NCH * T <= kCol, "too many chunks per workgroup");
+   // column -> (chunk slot, step); returns whether the column carries data; `owner`: whether it owns an output (8 waves: the overlap lanes do not)
+   constexpr int P0 = 64 - 2 * T;                         // 8 waves: lanes of the first half that carry the middle chunk's steps 0 .. P0-1
+   auto colmap = [](int col, int &cb, int &t, bool &owner) -> bool {
+      if constexpr (WAVES == 4) { cb = col / T; t = col - cb * T; owner = col < NCH * T; return owner; }
+      else {
+         const int g = col >> 6, l = col & 63;
+         if (g == 0) {
+            if (l < 2 * T) { cb = l / T; t = l - cb * T; owner = true; return true; }
+            cb = 2; t = l - 2 * T; owner = t < P0 - 2; return true;
+         }
+         constexpr int T0 = P0 - 4, L1 = T - T0;           // second half: the middle chunk's steps T0 .. T-1 on lanes 0 .. L1-1
+         if (l < L1) { cb = 2; t = T0 + l; owner = l >= 2; return true; }
+         const int m = l - L1;
+         cb = 3 + m / T; t = m - (m / T) * T; owner = cb < NCH;
+         return owner;
+      }
+   };
    constexpr int TOUT = 1 + (T - 1) / STRIDE;
    constexpr int HD = D / 2;
    constexpr int TP = (T + 3) / 4 * 4;                  // chunk stride of the Q / V rows in LDS (attention layout)
-   static_assert(!HAS_TF || (63 / T) * TP + (63 % T) < kPitch, "padded Q / V rows must fit the LDS row pitch");
+   static_assert(!HAS_TF || ((kCol - 1) / T) * TP + ((kCol - 1) % T) < kPitch, "padded Q / V rows must fit the LDS row pitch");
    constexpr int MT = D / 16;
    constexpr int CINP = (CIN + 3) / 4 * 4;
    constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
@@ -290,13 +318,14 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    float xv[XR];
    const float *xa = in, *xb = in;
    if constexpr (K1) {
-      const int cb0 = lane / T, t0 = lane - cb0 * T;
+      int cb0, t0; bool own0;
+      const bool cm0 = colmap(64 * (wave >> 2) + lane, cb0, t0, own0);   // 8 waves: waves 0-3 = lanes 0..63 of the layout, 4-7 = lanes 64..127; wave & 3 = channel quarter
       const int item0 = blockIdx.x * NCH + cb0;
-      const bool cv0 = (lane < NCOLV) && (item0 < n_chunks);
+      const bool cv0 = cm0 && (item0 < n_chunks);
       const int chunk0 = map(cv0 ? item0 : min(blockIdx.x * NCH, n_chunks - 1));
       xa = in + (size_t)chunk0 * ((FIRST >= 2) ? kBins : CIN) * T + t0;
       xb = FIRST == 2 ? in2 + (size_t)chunk0 * kBins * T + t0 : xa;             // FIRST 3: the magnitude half is read from Y as well
-      const int c0 = wave * CPW, c1 = min(c0 + CPW, CIN);
+      const int c0 = (wave & 3) * CPW, c1 = min(c0 + CPW, CIN);
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
          const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // the same batch as its global loads (as scalar loads they cost one exposed scalar-cache round trip per channel)
    __shared__ __attribute__((aligned(8))) float dws[K1 ? 4 * CPW * 6 : 2];
    if (K1) {
-      for (int i = tid; i < 4 * CPW; i += 256) {
+      for (int i = tid; i < 4 * CPW; i += NT) {
 #pragma unroll
          for (int j = 0; j < 5; ++j) dws[i * 6 + j] = i < CIN ? w.dw_w[i * 5 + j] : 0.0f;
          dws[i * 6 + 5] = i < CIN ? w.dw_b[i] : 0.0f;
@@ -320,11 +349,16 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
       // adaptive normalization offset mm per chunk (misc.c:65-82), spread over the first wave: lane = (chunk, frame) computes its
       // frame mean and its smoothed value; one lane per chunk adds the T smoothed values in the reference's order
       __shared__ float fms[NCH * T], rs[NCH * T];
-      if (tid < NCOLV) {
+      constexpr int NVAL = NCH * T;                        // one thread per (chunk, frame)
+      if (tid < NVAL) {
          const int cbp = tid / T, q = tid - cbp * T;
          const int it = blockIdx.x * NCH + cbp;
          const float *fmp = fm + (size_t)map(it < n_chunks ? it : n_chunks - 1) * T + q;
          fms[tid] = ((fmp[0] + fmp[fm_stride]) + (fmp[2 * fm_stride] + fmp[3 * fm_stride])) / 129.0f;
+      }
+      if (NVAL > 64) __syncthreads();                     // the (chunk, frame) threads span two waves: LDS order no longer does it
+      if (tid < NVAL) {
+         const int cbp = tid / T, q = tid - cbp * T;
          const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                                 0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                                 0.03663284704089164733887f};
@@ -337,6 +371,10 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
             r += fms[cbp * T + qq] * filt[i];             // same wave: LDS is in order
          }
          rs[tid] = r;
+      }
+      if (NVAL > 64) __syncthreads();
+      if (tid < NVAL) {
+         const int cbp = tid / T, q = tid - cbp * T;
          if (q == 0) {
             float total = 0.0f;
             for (int tt = 0; tt < T; ++tt) total += rs[cbp * T + tt];
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    static_assert(CIN * XP + CIN * 6 <= ROWS_B * kPitch, "input tile + depthwise weights must fit the Q / K / V area");
    {
       constexpr int Q4 = CIN * T / 4;                     // 16-byte pieces per chunk
-      for (int i = tid; i < NCH * Q4; i += 256) {
+      for (int i = tid; i < NCH * Q4; i += NT) {
          const int cbs = i / Q4, q = i - cbs * Q4;
          const int its = blockIdx.x * NCH + cbs;
          float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -380,7 +418,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
       }
       // depthwise weights [ch][k0..k4, bias] next to the tile (rows CIN.. of the same area): six LDS reads per k-step instead of six
       // per-lane global loads
-      for (int i = tid; i < CIN; i += 256) {
+      for (int i = tid; i < CIN; i += NT) {
 #pragma unroll
          for (int j = 0; j < 5; ++j) DWS[i * 6 + j] = w.dw_w[i * 5 + j];
          DWS[i * 6 + 5] = w.dw_b[i];
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    PH(9);
 #endif
    if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave);
-   else acc_store<MT>(acc, Yb, lane, wave);               // y: B operand of QKV; also kept in acc as the residual
+   else acc_store<MT, kPitch>(acc, Yb, lane, wave);               // y: B operand of QKV; also kept in acc as the residual
    PH(10);
    __syncthreads();
 
@@ -484,13 +522,13 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // The 4 waves split the input channels; their partial accumulators meet once in LDS (alias of the Q/K/V rows).
    static_assert(!K1 || (D == 16 && HAS_PROJ), "K = 1 form: 16 output channels with projection");
    typedef float f16acc __attribute__((ext_vector_type(16)));
-   const int col = lane;
-   const int cb = col / T, t = col - cb * T;
+   int cb, t; bool cown;
+   const bool cmv = colmap(64 * (wave >> 2) + lane, cb, t, cown);
    const int item_raw = blockIdx.x * NCH + cb;
-   const bool cvalid = (col < NCOLV) && (item_raw < n_chunks);
+   const bool cvalid = cmv && (item_raw < n_chunks);
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
    const bool l2 = t >= 2, l1 = t >= 1, r1 = t + 1 < T, r2 = t + 2 < T;
-   const int ch0 = wave * CPW, ch1 = min(ch0 + CPW, CIN);
+   const int ch0 = (wave & 3) * CPW, ch1 = min(ch0 + CPW, CIN);
    f16acc P = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef VADC_PHASE_PROF
    { float sink = 0; for (int i = 0; i < XR; ++i) sink += xv[i]; asm volatile("" :: "v"(sink)); }
@@ -545,20 +583,21 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    asm volatile("" :: "v"(P[0]), "v"(P[15]));
    PH(9);
 #endif
-   float *PB = Bb;                                        // 4 x 16 x 64 floats = 16 KB (Q/K/V rows are not live yet)
-   static_assert(!K1 || ROWS_B * kPitch >= 4 * 16 * 64, "partial buffer must fit the Q/K/V rows");
+   float *PB = Bb;                                        // WAVES x 16 x 64 floats = 16 / 32 KB (Q/K/V rows are not live yet)
+   static_assert(!K1 || ROWS_B * kPitch >= WAVES * 16 * 64, "partial buffer must fit the Q/K/V rows");
 #pragma unroll
    for (int e = 0; e < 16; ++e) PB[(wave * 16 + e) * 64 + lane] = P[e];
    __syncthreads();
+   // wave w owns the N tile of columns [16 w, 16 w + 16) = block w & 3 of lane group w >> 2: the four channel quarters of that group add up
 #pragma unroll
    for (int r = 0; r < 4; ++r) {
       float v = acc[0][r];                                // bias (acc_init)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) v += PB[(p * 16 + 4 * wave + r) * 64 + lane];
+      for (int p = 0; p < 4; ++p) v += PB[((4 * (wave >> 2) + p) * 16 + 4 * (wave & 3) + r) * 64 + lane];
       acc[0][r] = fmaxf(v, 0.0f);
    }
    __syncthreads();                                       // partial buffer consumed before anyone writes Q/K/V
-   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   acc_store<MT, kPitch>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
    __syncthreads();
 
    } else {
@@ -622,12 +661,12 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
       __syncthreads();
       constexpr int KK_FULL = kSlab / 4;
       if (c0 + kSlab <= CINP) {
-         gemm_acc<MT, KK_FULL>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
-         if (HAS_PROJ) gemm_acc<MT, KK_FULL>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
+         gemm_acc<MT, KK_FULL, kPitch>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
+         if (HAS_PROJ) gemm_acc<MT, KK_FULL, kPitch>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
       } else {
          constexpr int KK_TAIL = (CINP % kSlab) / 4 > 0 ? (CINP % kSlab) / 4 : 1;
-         gemm_acc<MT, KK_TAIL>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
-         if (HAS_PROJ) gemm_acc<MT, KK_TAIL>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
+         gemm_acc<MT, KK_TAIL, kPitch>(acc, w.pw_f, KKW, c0 / 4, DWR, lane, wave);
+         if (HAS_PROJ) gemm_acc<MT, KK_TAIL, kPitch>(acc, w.pj_f, KKW, c0 / 4, XS, lane, wave);
       }
    }
    if (!HAS_PROJ) {                                       // identity residual (CIN == D, single slab): + x
@@ -640,7 +679,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
-   acc_store<MT>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
+   acc_store<MT, kPitch>(acc, Yb, lane, wave);                    // y: B operand of QKV; also kept in acc as the residual
    __syncthreads();                                       // slab buffers free, Yb visible
 
    }
@@ -756,7 +795,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          h8v bh[KB], bl[KB];
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<3 * MT, KB>(q, w.qkv_h, bh, bl, lane);
-      } else gemm_acc<3 * MT, D / 4>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
+      } else gemm_acc<3 * MT, D / 4, kPitch>(q, w.qkv_f, D / 4, 0, Yb, lane, wave);
       // K rows keep the column layout (attention reads K at its own column).  Q and V rows are stored with every chunk's T steps
       // padded to TP = a multiple of 4 (the row pitch has room: NCH TP <= 72), so that the attention below fetches a row's T
       // values of one chunk with T/4 aligned 16-byte reads instead of T scalar ones -- that phase is bound by LDS instructions.
@@ -781,7 +820,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // on two of the four waves: the longest phase of the transformer block.
    {
       const int p = tid & 1, task = tid >> 1;
-      const int h = task >> 6, i = task & 63;
+      const int h = task / kCol, i = task - h * kCol;
       const int icb = i / T;
       constexpr int HH = HD / 2, TQ = TP / 4;
       float *dst = ATT + (h * HD + p * HH) * kPitch + i;
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          h8v bh[KB], bl[KB];
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<MT, KB>(p, w.out_h, bh, bl, lane);
-      } else gemm_acc<MT, D / 4>(p, w.out_f, D / 4, 0, ATT, lane, wave);
+      } else gemm_acc<MT, D / 4, kPitch>(p, w.out_f, D / 4, 0, ATT, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += p[mt];
    }
@@ -866,7 +905,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
    // needed until the epilogue, and the four waves drift apart instead of meeting five times.
    // (H3: one pair of split tiles serves the whole chain in place -- a wave holds ALL of its B fragments of a GEMM in registers
    // before it stores that GEMM's output over them)
-   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT>(acc, Yb, lane, wave);
+   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT, kPitch>(acc, Yb, lane, wave);
    {
       f4v f[MT];
       acc_init<MT>(f, w.l1_b, lane);
@@ -874,13 +913,13 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          h8v bh[KB], bl[KB];
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<MT, KB>(f, w.l1_h, bh, bl, lane);
-      } else gemm_acc<MT, D / 4>(f, w.l1_f, D / 4, 0, Yb, lane, wave);
+      } else gemm_acc<MT, D / 4, kPitch>(f, w.l1_f, D / 4, 0, Yb, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
          for (int r = 0; r < 4; ++r) f[mt][r] = fmaxf(f[mt][r], 0.0f);
       if constexpr (H3) acc_store_h3<MT>(f, Sh, Sl, HP, lane, wave);
-      else acc_store<MT>(f, FFN, lane, wave);             // relu(lin1) goes to the (dead) Q rows
+      else acc_store<MT, kPitch>(f, FFN, lane, wave);             // relu(lin1) goes to the (dead) Q rows
    }
    PH(5);
    {
@@ -890,12 +929,12 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          h8v bh[KB], bl[KB];
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<MT, KB>(g, w.l2_h, bh, bl, lane);
-      } else gemm_acc<MT, D / 4>(g, w.l2_f, D / 4, 0, FFN, lane, wave);
+      } else gemm_acc<MT, D / 4, kPitch>(g, w.l2_f, D / 4, 0, FFN, lane, wave);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
    }
    layer_norm_acc<MT>(acc, w.n2_w, w.n2_b, lane);
-   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT>(acc, Yb, lane, wave);
+   if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT, kPitch>(acc, Yb, lane, wave);
    PH(6);
    }  // HAS_TF
 
@@ -907,10 +946,11 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
          h8v bh[KB], bl[KB];
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<MT, KB>(z, w.cv_h, bh, bl, lane);
-      } else gemm_acc<MT, D / 4>(z, w.cv_f, D / 4, 0, Yb, lane, wave);
+      } else gemm_acc<MT, D / 4, kPitch>(z, w.cv_f, D / 4, 0, Yb, lane, wave);
       // this lane's column in the accumulator layout
       const int ocol = 16 * wave + lc;
-      const int ocb = ocol / T, ot = ocol - ocb * T;
+      int ocb, ot; bool oown;
+      (void)colmap(ocol, ocb, ot, oown);
       const int oitem = blockIdx.x * NCH + ocb;
       if constexpr (LSTM_OUT == 2) {
          static_assert(D == 64 || LSTM_OUT != 2, "split-fp16 LSTM hand-off is the last stage (64 units)");
@@ -943,7 +983,7 @@ __global__ __launch_bounds__(256, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(c
             *reinterpret_cast<h8o *>(dsth + kLstmTile * 64) = lo[0]; *reinterpret_cast<h8o *>(dsth + kLstmTile * 64 + 8) = lo[1];
          }
       } else
-      if (ocol < NCOLV && oitem < n_chunks && (ot % STRIDE) == 0) {
+      if (oown && oitem < n_chunks && (ot % STRIDE) == 0) {
          constexpr int ostride = LSTM_OUT ? kLstmTile : TOUT;
          float *dst;
          if (LSTM_OUT) {
@@ -1015,21 +1055,27 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
 // lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 16 -> 8 -> 4 -> 2 -> 2 (1024), 8 -> 4 -> 2 -> 1 -> 1 (512).
 // chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.  S3 = stride of the third strided conv.
 template <int T0, int NCH, bool SLAB, int FIRSTK>
-static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st)
+static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st, bool narrow)
 {
+   if constexpr (!SLAB && T0 == 24) {                       // 8 waves: 5 chunks per workgroup (120 of 128 lanes own a column instead of 48 of 64)
+      if (!narrow) {
+         hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, 5, false, false, true, false, 8>), dim3((n + 4) / 5), dim3(512), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+         return;
+      }
+   }
    hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, NCH, false, false, !SLAB>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
 }
 template <int T0, int S3>
 static void launch_v4_t(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                        int lstm_layout, size_t fm_stride, hipStream_t st, bool slab)
+                        int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, bool narrow)
 {
    constexpr int T1 = T0 / 2, T2 = T0 / 4, T3 = S3 == 2 ? T0 / 8 : T2;
    constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
    switch (layer) {
    case 0:
-      if (slab)     launch_v4_first<T0, N0, true, 2>(in, in2, fm, w, out, n, map, fm_stride, st);
-      else if (in2) launch_v4_first<T0, N0, false, 2>(in, in2, fm, w, out, n, map, fm_stride, st);
-      else          launch_v4_first<T0, N0, false, 3>(in, in2, fm, w, out, n, map, fm_stride, st);
+      if (slab)     launch_v4_first<T0, N0, true, 2>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
+      else if (in2) launch_v4_first<T0, N0, false, 2>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
+      else          launch_v4_first<T0, N0, false, 3>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
       break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
@@ -1044,17 +1090,17 @@ static void launch_v4_t(int layer, const float *in, const float *in2, const floa
 // frames = STFT frames per chunk; stride3 = stride of the third strided conv: 2 in the 16 kHz branch (frames 24 / 16 / 8 = 1536- / 1024- / 512-sample
 // windows), 1 in the 8 kHz branch (silero_vad.py:178-181; frames 12 / 8 / 4 = 768- / 512- / 256-sample windows: 12 -> 6 -> 3 -> 3 -> 3, ...)
 void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames, int stride3)
+                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames, int stride3, bool narrow)
 {
    if (stride3 == 1) {
-      if (frames == 8)      launch_v4_t<8, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-      else if (frames == 4) launch_v4_t<4, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-      else                  launch_v4_t<12, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+      if (frames == 8)      launch_v4_t<8, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+      else if (frames == 4) launch_v4_t<4, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+      else                  launch_v4_t<12, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
       return;
    }
-   if (frames == 16)     launch_v4_t<16, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-   else if (frames == 8) launch_v4_t<8, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
-   else                  launch_v4_t<24, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab);
+   if (frames == 16)     launch_v4_t<16, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+   else if (frames == 8) launch_v4_t<8, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+   else                  launch_v4_t<24, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
 }
 
 }  // namespace vadc
