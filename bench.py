@@ -110,6 +110,19 @@ def cpu_worker(model, weights_path, seconds, batch):
     print(json.dumps({"kind": kind, "chunks": done, "seconds": dt, "chunks_per_s": done / dt}), flush=True)
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a 1-GPU job 16 of its 256 hardware
+    threads through cpu.max; more busy processes than that only take turns) and by 64."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(model, weights_path, seconds=10.0):
     """Reported baseline, not the target.  Children are plain `python bench.py --cpu-worker` processes started BEFORE this process touches the GPU."""
     def spawn(batch, secs):
@@ -121,7 +134,7 @@ def cpu_baseline(model, weights_path, seconds=10.0):
             o, _ = p.communicate(timeout=600)
             out.append(json.loads(o.strip().splitlines()[-1]))
         return out
-    cores = min(len(os.sched_getaffinity(0)), 64)
+    cores = usable_cores()
     one1 = collect([spawn(1, 3.0)])[0]                  # BASELINE config 1: batch = 1, one core, the machine otherwise idle
     one96 = collect([spawn(96, 3.0)])[0]
     allc = collect([spawn(96, seconds) for _ in range(cores)])
@@ -130,7 +143,7 @@ def cpu_baseline(model, weights_path, seconds=10.0):
             "per_core": round(agg * CHUNK_SECONDS / cores, 2),
             "single_core_batch96": round(one96["chunks_per_s"] * CHUNK_SECONDS, 2),
             "single_core_batch1": round(one1["chunks_per_s"] * CHUNK_SECONDS, 2),
-            "sample": f"one process per core on {cores} cores, each {allc[0]['chunks']} consecutive chunks of one synthetic speech stream at batch 96 "
+            "sample": f"one process per usable core ({cores}: affinity mask capped by the cgroup CPU quota), each {allc[0]['chunks']} consecutive chunks of one synthetic speech stream at batch 96 "
                       f"({sum(r['seconds'] for r in allc):.0f} core-seconds); single-core points: {one96['chunks']} chunks at batch 96, {one1['chunks']} at batch 1 (BASELINE config 1)"}
 
 
