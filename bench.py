@@ -46,7 +46,8 @@ PEAKS = {"valu_nofma": 78.65,     # fp32 vector ALU with every product and every
          "fp16": 2500.0}          # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 # MAC per chunk by kernel: total, and the part that runs as split-fp16 MFMA (3 fp16 MFMAs per fp32 one)
 MAC_V31 = {"k_frontend": (1_651_200, 0), "k_layer1": (181_053, 0), "k_layer2": (112_208, 87_040), "k_layer3": (61_600, 57_344),
-           "k_layer4": (236_768, 229_376), "k_lstm": (458_752 + 896, 458_752)}
+           "k_layer4": (236_768, 229_376), "k_lstm": (458_752 + 896, 458_752),
+           "k_enc234": (112_208 + 61_600 + 236_768, 0)}      # layers 2-4 in one launch (k_enc_fused): executed work counted in kernel_cost
 MAC_V4 = {"k_frontend": (1_585_152, 0), "k_layer1": (232_176, 0), "k_layer2": (19_392, 0), "k_layer3": (10_176, 0), "k_layer4": (25_056, 0),
           "k_lstm": (196_608 + 192, 196_608)}
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
@@ -69,6 +70,10 @@ def kernel_cost(model, name, fe_kernel, layer_major=False):
         if fe_kernel == 2:      # folded real-input DFT: 256 rows x K = 128, three split-fp16 MFMAs per k-block
             return alg, {"fp16": 3 * 2 * 256 * 128 * frames}
         return alg, {"valu_nofma": frames * (129 * 2 * 511 + 129 * 3)}
+    if name == "k_enc234":
+        # k_enc_fused issues v_mfma_f32_16x16x32_f16 only (16,384 FLOP each, zero-padded k and idle columns included): per chunk 60 in layer 2 (one
+        # 16-column tile per chunk), 30 in layer 3 and 105 in layer 4 (one tile per two chunks); depthwise conv, softmax and LayerNorm are vector work
+        return alg, {"fp16": (60 + 30 + 105) * 16384}
     exe = {}
     if mac16:
         exe["fp16"] = 3 * 2 * mac16
@@ -313,7 +318,7 @@ def run_rank(args, world, rank, local_rank):
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not separate_pass:
-            on = (i % prof_every) == 3            # 20 steps: steps 3, 11, 19 (not the pipeline-filling first one)
+            on = (i % prof_every) == min(3, args.steps - 1)   # 20 steps: steps 3, 11, 19 (not the pipeline-filling first one); a run of < 4 steps times its last one
             eng.set_profiling(on)
             n_prof += int(on)
         step(i)

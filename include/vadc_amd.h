@@ -205,6 +205,7 @@ int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */
 enum { VADC_AMD_KERNEL_FRONTEND = 0, VADC_AMD_KERNEL_LAYER1, VADC_AMD_KERNEL_LAYER2, VADC_AMD_KERNEL_LAYER3,
        VADC_AMD_KERNEL_LAYER4, VADC_AMD_KERNEL_LSTM /* both layers, or layer 0 of the layer-major form */, VADC_AMD_KERNEL_LSTM_L1 /* layer 1 + decoder of the layer-major form */,
+       VADC_AMD_KERNEL_ENC234 /* encoder layers 2-4 in one launch (k_enc_fused); LAYER2..4 then stay at zero */,
        VADC_AMD_KERNEL_COUNT };
 /* When enabled every kernel launch of run_* is bracketed by hipEventRecord on its stream. */
 int  vadc_amd_set_profiling(vadc_amd_engine *e, int enabled);

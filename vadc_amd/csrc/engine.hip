@@ -6,6 +6,7 @@
 // except the load-time weight repacking (transposes, basis permutation, BatchNorm folding).
 #include "../../include/vadc_amd.h"
 #include "common.h"
+#include "enc_fused_layout.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -34,6 +35,7 @@ struct LayerWeightsM {
    const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
+void launch_enc_fused(const EncFusedArgs &, int, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
    const float *dec_w; const float *dec_b;
@@ -150,7 +152,12 @@ struct vadc_amd_engine {
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
-   int encoder_variant = 0;                     // 0 = MFMA layers (default), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4
+   int encoder_variant = 0;                     // 0 = default (layers 2-4 fused in one launch when the weights allow), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4, 5 = one launch per layer (split-fp16)
+   // k_enc_fused (kernels_encoder_fused.hip): the two LDS images (layers 2 + 3; layer 4) and the phase A -> phase B scratch
+   void *d_encA = nullptr, *d_encB = nullptr;
+   float *d_enc_scratch = nullptr;
+   std::vector<unsigned char> h_encA, h_encB;   // built by build_weights, uploaded by vadc_amd_create
+   bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
    LstmWeights lstm;
    // workspace
    float *d_in_f32 = nullptr;
@@ -346,38 +353,39 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
             }
       return f;
    };
+   struct RawLayer { std::vector<float> dw_w, dw_b, pw, pw_b, pj, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b; } raw[4];   // for the fused kernel's LDS images (cv: BatchNorm folded)
    for (int l = 0; l < 4; ++l) {
       const LayerShape &s = kLayers[l];
       const int D = s.d, C = s.cin;
       auto take = [&](int n, std::vector<float> &v) -> bool { if (!need(idx, n)) return false; copy_unaligned(v, ts[idx++]); return true; };
       auto transposed = [&](const std::vector<float> &src) { std::vector<float> r((size_t)C * D); for (int o = 0; o < D; ++o) for (int c = 0; c < C; ++c) r[(size_t)c * D + o] = src[(size_t)o * C + c]; return r; };
       std::vector<float> v;
-      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
-      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
+      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size()); raw[l].dw_w = v;
+      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size()); raw[l].dw_b = v;
       std::vector<float> cbb;
       std::vector<float> pwm;
-      if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pw_h = pk.add(h.data(), h.size()); } }
-      if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size()); cbb = v;
+      if (!take(D * C, v)) goto bad; raw[l].pw = v; { auto tr = transposed(v); lo[l].pwT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pw_h = pk.add(h.data(), h.size()); } }
+      if (!take(D, v)) goto bad;     lo[l].pw_b = pk.add(v.data(), v.size()); cbb = v; raw[l].pw_b = v;
       lo[l].pjT = lo[l].pj_b = lo[l].pj_f = (size_t)-1;
       if (s.proj) {
-         if (!take(D * C, v)) goto bad; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pj_h = pk.add(h.data(), h.size()); } }
+         if (!take(D * C, v)) goto bad; raw[l].pj = v; { auto tr = transposed(v); lo[l].pjT = pk.add(tr.data(), tr.size()); auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); if (C == 32) { auto h = frag_h3(v, D, C); lo[l].pj_h = pk.add(h.data(), h.size()); } }
          if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); }
-         if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size());
+         if (!take(D, v)) goto bad;     lo[l].pj_b = pk.add(v.data(), v.size()); raw[l].pj_b = v;
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
       lo[l].cb_b = pk.add(cbb.data(), cbb.size());
-      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size()); { auto f = frag(v, 3 * D, D); lo[l].qkv_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, 3 * D, D); lo[l].qkv_h = pk.add(h.data(), h.size()); } }
-      if (!take(3 * D, v)) goto bad;     lo[l].qkv_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].out_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].out_h = pk.add(h.data(), h.size()); } }
-      if (!take(D, v)) goto bad;         lo[l].out_b = pk.add(v.data(), v.size());
-      if (!take(D, v)) goto bad;         lo[l].n1_w = pk.add(v.data(), v.size());
-      if (!take(D, v)) goto bad;         lo[l].n1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l1_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l1_h = pk.add(h.data(), h.size()); } }
-      if (!take(D, v)) goto bad;         lo[l].l1_b = pk.add(v.data(), v.size());
-      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size()); { auto f = frag(v, D, D); lo[l].l2_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l2_h = pk.add(h.data(), h.size()); } }
-      if (!take(D, v)) goto bad;         lo[l].l2_b = pk.add(v.data(), v.size());
-      if (!take(D, v)) goto bad;         lo[l].n2_w = pk.add(v.data(), v.size());
-      if (!take(D, v)) goto bad;         lo[l].n2_b = pk.add(v.data(), v.size());
+      if (!take(3 * D * D, v)) goto bad; lo[l].qkv_w = pk.add(v.data(), v.size()); raw[l].qkv_w = v; { auto f = frag(v, 3 * D, D); lo[l].qkv_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, 3 * D, D); lo[l].qkv_h = pk.add(h.data(), h.size()); } }
+      if (!take(3 * D, v)) goto bad;     lo[l].qkv_b = pk.add(v.data(), v.size()); raw[l].qkv_b = v;
+      if (!take(D * D, v)) goto bad;     lo[l].out_w = pk.add(v.data(), v.size()); raw[l].out_w = v; { auto f = frag(v, D, D); lo[l].out_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].out_h = pk.add(h.data(), h.size()); } }
+      if (!take(D, v)) goto bad;         lo[l].out_b = pk.add(v.data(), v.size()); raw[l].out_b = v;
+      if (!take(D, v)) goto bad;         lo[l].n1_w = pk.add(v.data(), v.size()); raw[l].n1_w = v;
+      if (!take(D, v)) goto bad;         lo[l].n1_b = pk.add(v.data(), v.size()); raw[l].n1_b = v;
+      if (!take(D * D, v)) goto bad;     lo[l].l1_w = pk.add(v.data(), v.size()); raw[l].l1_w = v; { auto f = frag(v, D, D); lo[l].l1_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l1_h = pk.add(h.data(), h.size()); } }
+      if (!take(D, v)) goto bad;         lo[l].l1_b = pk.add(v.data(), v.size()); raw[l].l1_b = v;
+      if (!take(D * D, v)) goto bad;     lo[l].l2_w = pk.add(v.data(), v.size()); raw[l].l2_w = v; { auto f = frag(v, D, D); lo[l].l2_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(v, D, D); lo[l].l2_h = pk.add(h.data(), h.size()); } }
+      if (!take(D, v)) goto bad;         lo[l].l2_b = pk.add(v.data(), v.size()); raw[l].l2_b = v;
+      if (!take(D, v)) goto bad;         lo[l].n2_w = pk.add(v.data(), v.size()); raw[l].n2_w = v;
+      if (!take(D, v)) goto bad;         lo[l].n2_b = pk.add(v.data(), v.size()); raw[l].n2_b = v;
       {
          // strided 1x1 conv + BatchNorm1d (transformer.c:279-288, misc.c:221-258) folded:
          //   ((W z + b) - mean) / sqrt(var + eps) * gamma + beta  =  (W * s) z + ((b - mean) * s + beta)
@@ -388,12 +396,70 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
             for (int d = 0; d < D; ++d) cw[(size_t)o * D + d] *= sc;
             cb[o] = (cb[o] - mu[o]) * sc + be[o];
          }
+         raw[l].cv_w = cw; raw[l].cv_b = cb;
          lo[l].cv_w = pk.add(cw.data(), cw.size());
          lo[l].cv_b = pk.add(cb.data(), cb.size());
          { auto f = frag(cw, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); if (D % 32 == 0) { auto h = frag_h3(cw, D, D); lo[l].cv_h = pk.add(h.data(), h.size()); } }
       }
    }
    e->enc_h3_ok = h3_ok;
+   if (h3_ok) {
+      // ---- LDS images of k_enc_fused (enc_fused_layout.h): split-fp16 A fragments [hi 64 x 8 | lo 64 x 8] per (M tile, k block) with the k order
+      // of an accumulator tile (enc_sigma), vectors in natural order; Q rows of the QKV weight and bias pre-scaled by log2(e) / sqrt(hd)
+      // (the kernel's softmax is exp2(s - max): transformer.c:104-114, tensor.h:751-784)
+      bool ok = true;
+      auto put_frags = [&ok](unsigned char *dst, const std::vector<float> &W, int M, int K, bool sigma) {
+         const int KB = K / 32;
+         _Float16 *h = reinterpret_cast<_Float16 *>(dst);
+         for (int mt = 0; mt < M / 16; ++mt)
+            for (int kb = 0; kb < KB; ++kb)
+               for (int l = 0; l < 64; ++l)
+                  for (int el = 0; el < 8; ++el) {
+                     const int q = l >> 4, k = sigma ? enc_sigma(kb, q, el) : 32 * kb + 8 * q + el;
+                     const float v = W[(size_t)(16 * mt + (l & 15)) * K + k];
+                     if (!(fabsf(v) < 60000.0f)) ok = false;
+                     const _Float16 hi = (_Float16)v;
+                     const size_t base = ((size_t)mt * KB + kb) * 1024;
+                     h[base + l * 8 + el] = hi;
+                     h[base + 512 + l * 8 + el] = (_Float16)(v - (float)hi);
+                  }
+      };
+      auto put_vec = [](float *dst, const std::vector<float> &v) { memcpy(dst, v.data(), v.size() * sizeof(float)); };
+      auto build_layer = [&](int l, unsigned char *fbase, float *vbase, auto L) {
+         typedef decltype(L) LL;
+         const RawLayer &r = raw[l];
+         const int D = kLayers[l].d, C = kLayers[l].cin;
+         if (C == 16) {                                        // layer 2: [pointwise | projection] stacked over K = 16 + 16, hardware k order
+            std::vector<float> st((size_t)D * 32);
+            for (int o = 0; o < D; ++o)
+               for (int c = 0; c < 16; ++c) { st[(size_t)o * 32 + c] = r.pw[(size_t)o * 16 + c]; st[(size_t)o * 32 + 16 + c] = r.pj[(size_t)o * 16 + c]; }
+            put_frags(fbase + LL::f_pw, st, D, 32, false);
+         } else {
+            put_frags(fbase + LL::f_pw, r.pw, D, 32, true);
+            if (kLayers[l].proj) put_frags(fbase + LL::f_pj, r.pj, D, 32, true);
+         }
+         std::vector<float> qw = r.qkv_w, qb = r.qkv_b;
+         const float sc = 1.4426950408889634f / sqrtf((float)(D / 2));
+         for (int o = 0; o < D; ++o) { for (int c = 0; c < D; ++c) qw[(size_t)o * D + c] *= sc; qb[o] *= sc; }
+         put_frags(fbase + LL::f_qkv, qw, 3 * D, D, true);
+         put_frags(fbase + LL::f_out, r.out_w, D, D, true);
+         put_frags(fbase + LL::f_l1, r.l1_w, D, D, true);
+         put_frags(fbase + LL::f_l2, r.l2_w, D, D, true);
+         put_frags(fbase + LL::f_cv, r.cv_w, D, D, true);
+         for (int t = 0; t < 5; ++t) for (int c = 0; c < C; ++c) vbase[LL::v_dw + t * C + c] = r.dw_w[(size_t)c * 5 + t];
+         for (int c = 0; c < C; ++c) vbase[LL::v_dw + 5 * C + c] = r.dw_b[c];
+         for (int o = 0; o < D; ++o) vbase[LL::v_cb_b + o] = r.pw_b[o] + (kLayers[l].proj ? r.pj_b[o] : 0.0f);
+         put_vec(vbase + LL::v_qkv_b, qb);
+         put_vec(vbase + LL::v_out_b, r.out_b); put_vec(vbase + LL::v_n1_w, r.n1_w); put_vec(vbase + LL::v_n1_b, r.n1_b);
+         put_vec(vbase + LL::v_l1_b, r.l1_b);   put_vec(vbase + LL::v_l2_b, r.l2_b);
+         put_vec(vbase + LL::v_n2_w, r.n2_w);   put_vec(vbase + LL::v_n2_b, r.n2_b); put_vec(vbase + LL::v_cv_b, r.cv_b);
+      };
+      e->h_encA.assign(kEncA_Bytes, 0); e->h_encB.assign(kEncB_Bytes, 0);
+      build_layer(1, e->h_encA.data() + kEncA_L2F, reinterpret_cast<float *>(e->h_encA.data() + kEncA_V2), EncL2());
+      build_layer(2, e->h_encA.data() + kEncA_L3F, reinterpret_cast<float *>(e->h_encA.data() + kEncA_V3), EncL3());
+      build_layer(3, e->h_encB.data() + kEncB_L4F, reinterpret_cast<float *>(e->h_encB.data() + kEncB_V4), EncL4());
+      if (!ok) { e->h_encA.clear(); e->h_encB.clear(); }       // a pre-scaled Q row left fp16's range: the per-layer kernels serve
+   }
    {
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 128) || !need(idx + 3, 2)) goto bad;
       std::vector<float> W, B, dw, db;
@@ -615,7 +681,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
@@ -698,6 +764,14 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       if (he == hipSuccess) he = hipMemset(e->d_xpair[p], 0, padded_streams * max_chunks * 448 * sizeof(float));
    }
    e->d_act[3] = e->d_xpair[0];
+   if (he == hipSuccess && !e->h_encA.empty()) {
+      he = hipMalloc(&e->d_encA, e->h_encA.size());
+      if (he == hipSuccess) he = hipMalloc(&e->d_encB, e->h_encB.size());
+      if (he == hipSuccess) he = hipMemcpy(e->d_encA, e->h_encA.data(), e->h_encA.size(), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy(e->d_encB, e->h_encB.data(), e->h_encB.size(), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMalloc(&e->d_enc_scratch, (N + 4) * kEncScratchPerChunk * sizeof(float));   // batches of up to 4 chunks: the last one may be partial
+      e->h_encA.clear(); e->h_encA.shrink_to_fit(); e->h_encB.clear(); e->h_encB.shrink_to_fit();
+   }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
@@ -809,7 +883,7 @@ extern "C" int vadc_amd_reset_kernel_times(vadc_amd_engine *e)
 
 extern "C" const char *vadc_amd_kernel_name(int kernel)
 {
-   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1"};
+   static const char *names[VADC_AMD_KERNEL_COUNT] = {"k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1", "k_enc234"};
    return (kernel >= 0 && kernel < VADC_AMD_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
@@ -836,7 +910,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4))) { e->encoder_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
       // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
@@ -899,12 +973,34 @@ static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const ch
 // Silero v4: the first stage (K = 1 form) takes the magnitude half of its input from Y = log(1 + 2^20 m) instead of a second array
 static bool v4_mag_from_y(const vadc_amd_engine *e) { return e->model == VADC_AMD_MODEL_V4 && e->encoder_variant != 2 && e->v4_mag == 0; }
 
+// CUs a persistent grid on the front end + encoder stream may count on: the LSTM chain's workgroups keep theirs for a whole call, and an
+// 8-wave workgroup of k_enc_fused (216 registers, 132 KB of LDS) never fits beside one -- a workgroup sent there would wait for the chain
+static int encoder_cus(const vadc_amd_engine *e, hipStream_t st)
+{
+   const int taken = (st == e->sA && e->lstm_cus > 0) ? e->lstm_cus : 0;
+   return e->n_cus - taken > 8 ? e->n_cus - taken : 8;
+}
+
 // lstm_layout: the last layer writes the LSTM-native tile layout (hot path) instead of [n][64][7] (stage taps)
-static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st)
+// `in_stage`: input of layer `first` when it is not the engine's own buffer (stage taps fed from the host)
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st, const float *in_stage = nullptr)
 {
    for (int l = first; l <= last; ++l) {
+      const float *in = (l == first && in_stage) ? in_stage : ((l == 0) ? e->d_Y : e->d_act[l - 1]);
+      if (l >= 1 && e->use_enc_fused() && !(last == 3 && lstm_layout == 1)) {      // (fp32 LSTM tiles: the per-layer kernel writes those)
+         // layers 2..4 (here: l .. last) in one launch; intermediate layer outputs are written only when they are what the caller asked for
+         KernelTimer t(e, VADC_AMD_KERNEL_ENC234, st);
+         EncFusedArgs a;
+         a.in = in; a.imgA = e->d_encA; a.imgB = e->d_encB; a.scratch = e->d_enc_scratch;
+         a.out = e->d_act[3];
+         a.tap2 = last == 1 ? e->d_act[1] : nullptr;
+         a.tap3 = last == 2 ? e->d_act[2] : nullptr;
+         a.tap4 = (last == 3 && lstm_layout == 0) ? e->d_act[3] : nullptr;
+         a.n_chunks = n; a.first = l + 1; a.last = last + 1; a.map = map;
+         launch_enc_fused(a, encoder_cus(e, st), st);
+         return;
+      }
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
-      const float *in = (l == 0) ? e->d_Y : e->d_act[l - 1];
       if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames, e->stride3(), e->encoder_variant == 4);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
@@ -945,8 +1041,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          else                launch_frontend_fl_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
       }
    }
-   run_encoder_layers(e, 0, 2, n, map, 0, st);
-   run_encoder_layers(e, 3, 3, n, map, lstm_kernel >= 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3 / k_lstm_layer, 1: fp32 tiles for the fp32 kernel
+   run_encoder_layers(e, 0, 3, n, map, lstm_kernel >= 6 ? 2 : 1, st);      // 2: split-fp16 tiles for k_lstm_wavefront_h3 / k_lstm_layer, 1: fp32 tiles for the fp32 kernel
 }
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of

@@ -1,0 +1,553 @@
+// kernels_encoder_fused.hip -- encoder layers 2, 3 and 4 of Silero v3.1 in ONE launch, every activation in registers.
+//
+// Replaces (reference file:line) for layers 2-4: conv_block conv.c:761-814 (dw :17-113, pw/proj :532-589); transformer_block
+// transformer.c:13-234 (tensor_linear tensor.h:675-723, softmax :751-784, layer_norm misc.c:143-210); conv k=1 stride s + BatchNorm
+// + ReLU transformer.c:237-295 (conv.c:597-709, misc.c:221-258).  Same arithmetic as k_layer_mfma's split-fp16 form
+// (W . X ~= Wl . Xh + Wh . Xl + Wh . Xh on v_mfma_f32_16x16x32_f16, fp32 accumulation), re-mapped:
+//
+// * A WAVE owns its chunks from the layer-1 output to the LSTM hand-off and never meets another wave: no workgroup barrier, no
+//   activation in LDS.  A 16-column MFMA N tile holds ONE chunk at 13 steps (layer 2: lanes 13..15 idle) or TWO chunks at 7 steps
+//   (layers 3, 4: columns 0..6 and 8..14, 7 and 15 idle), so a chunk's steps are lanes of one DPP row: the depthwise conv's time
+//   neighbours are row shifts (zero fill at the row ends = the conv's zero padding).
+// * An accumulator tile IS the next GEMM's B operand: lane (q, column) holds rows 16 mt + 4 q + r, and the host stores every weight's
+//   k in that order (enc_fused_layout.h: enc_sigma), so registers go from MFMA to split (v_cvt_pk_f16_f32) to MFMA.
+// * Attention on the matrix cores, per head and tile: S^T = Q^T K (A = Q registers, B = K registers: lane (q, i) gets
+//   s[i][j = 4 q + r], so the softmax over j runs over a lane's 4 registers and the 4 lane-quads), V is produced TRANSPOSED by swapping
+//   the operands of its projection MFMA (lane = channel, registers = steps), and att = V . a^T lands in the accumulator layout again.
+//   Cross-chunk and idle columns are masked in the softmax (k . q^T order and 1/sqrt(hd): transformer.c:104-114; the scale and log2(e)
+//   are folded into the Q rows of the weight by the host).
+// * Weights live in LDS, copied once per workgroup: the kernel is PERSISTENT (one 8-wave workgroup per CU, waves take batches of
+//   chunks round-robin).  192 KB of split weights do not fit 160 KB, so it runs in two phases -- layers 2 + 3 of all its batches with
+//   image A (69 KB), then layer 4 with image B (132 KB) -- the layer-3 output of a batch waits in a scratch buffer in its register
+//   order (written and read back by the same wave).  A fragments are conflict-free 16-byte LDS reads (hi and lo blocks lane-linear).
+#include "common.h"
+#include "enc_fused_layout.h"
+#include <cstdlib>
+
+namespace vadc {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct Frag { h8 hi, lo; };       // one MFMA operand (8 k elements per lane), split: x = hi + lo to 22 significant bits
+
+__device__ __forceinline__ void split2(float a, float b, h2 &hi, h2 &lo)
+{
+   const f2 ab = {a, b};
+   hi = __builtin_convertvector(ab, h2);                    // v_cvt_pk_f16_f32
+   const f2 r = {a - (float)hi[0], b - (float)hi[1]};
+   lo = __builtin_convertvector(r, h2);
+}
+__device__ __forceinline__ Frag split8(const f4 &u, const f4 &v)
+{
+   h2 hi[4], lo[4];
+   split2(u[0], u[1], hi[0], lo[0]); split2(u[2], u[3], hi[1], lo[1]);
+   split2(v[0], v[1], hi[2], lo[2]); split2(v[2], v[3], hi[3], lo[3]);
+   Frag f;
+   f.hi = h8{hi[0][0], hi[0][1], hi[1][0], hi[1][1], hi[2][0], hi[2][1], hi[3][0], hi[3][1]};
+   f.lo = h8{lo[0][0], lo[0][1], lo[1][0], lo[1][1], lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
+   return f;
+}
+// k elements 4..7 zero: a K = 16 contraction on the K = 32 instruction
+__device__ __forceinline__ Frag split4z(const f4 &u)
+{
+   h2 hi[2], lo[2];
+   split2(u[0], u[1], hi[0], lo[0]); split2(u[2], u[3], hi[1], lo[1]);
+   const _Float16 z = (_Float16)0.0f;
+   Frag f;
+   f.hi = h8{hi[0][0], hi[0][1], hi[1][0], hi[1][1], z, z, z, z};
+   f.lo = h8{lo[0][0], lo[0][1], lo[1][0], lo[1][1], z, z, z, z};
+   return f;
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// one weight fragment (M tile, k block) of a GEMM from the LDS image
+__device__ __forceinline__ Frag lds_frag(const char *base, int idx, int lane)
+{
+   const h8 *p = reinterpret_cast<const h8 *>(base + (size_t)idx * kFragBytes);
+   Frag f;
+   f.hi = p[lane];
+   f.lo = p[64 + lane];
+   return f;
+}
+__device__ __forceinline__ f4 lds_vec4(const float *v, int off) { return *reinterpret_cast<const f4 *>(v + off); }
+
+// acc[nt][mt] += W[16 mt .., :] . B[nt]      W: MT x KB fragments at `wf` (first M tile = mt0), B: KB operands per tile
+template <int NT, int MT, int KB, int MTA>
+__device__ __forceinline__ void gemm(f4 (&acc)[NT][MTA], const char *wf, int mt0, const Frag (&b)[NT][KB], int lane)
+{
+   // software pipeline, one fragment ahead; the scheduling barriers keep hipcc from hoisting every fragment read of the (fully unrolled)
+   // layer to the top of the kernel (it did: 950 spilled registers)
+   Frag a = lds_frag(wf, mt0 * KB, lane);
+#pragma unroll
+   for (int i = 0; i < MT * KB; ++i) {
+      const int mt = i / KB, kb = i % KB;
+      Frag an = a;
+      if (i + 1 < MT * KB) an = lds_frag(wf, mt0 * KB + i + 1, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.lo, b[nt][kb].hi, acc[nt][mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.hi, b[nt][kb].lo, acc[nt][mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.hi, b[nt][kb].hi, acc[nt][mt]);
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+   }
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void init_bias(f4 (&acc)[NT][MT], const float *bias, int q)
+{
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      const f4 b = lds_vec4(bias, 16 * mt + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = b;
+   }
+}
+
+// sum / max over the four lane-quads (lanes l, l ^ 16, l ^ 32, l ^ 48): gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// rows of TWO registers -- (p, p) -> ([p0 p0 p2 p2], [p1 p1 p3 p3]) and ([lo lo], [hi hi]) -- so the two results add up to the pair
+// sums in every lane.  Inline asm: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) folds the two results into one register
+// (tools/enc_prims_test.hip); the s_nop covers the VALU-write -> swap wait states hipcc pads its own swaps with.
+__device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+template <bool MAX>
+__device__ __forceinline__ float quads_reduce(float v)
+{
+   float a = v, b = v;
+   swap16(a, b);
+   v = MAX ? fmaxf(a, b) : a + b;
+   a = v; b = v;
+   swap32(a, b);
+   return MAX ? fmaxf(a, b) : a + b;
+}
+__device__ __forceinline__ float quads_sum(float v) { return quads_reduce<false>(v); }
+__device__ __forceinline__ float quads_max(float v) { return quads_reduce<true>(v); }
+
+// LayerNorm over the D = 16 MT channels of each column in the accumulator layout (misc.c:143-210: biased variance, eps 1e-5)
+template <int MT>
+__device__ __forceinline__ void layer_norm(f4 (&x)[MT], const float *w, const float *b, int q)
+{
+   constexpr int D = 16 * MT;
+   float s = 0.0f;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) s += (x[mt][0] + x[mt][1]) + (x[mt][2] + x[mt][3]);
+   s = quads_sum(s);
+   const float mean = s * (1.0f / D);
+   float vs = 0.0f;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = x[mt][r] - mean; vs = fmaf(d, d, vs); }
+   vs = quads_sum(vs);
+   const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / D) + 1e-5f);
+   const float mr = mean * rstd;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt) {
+      const f4 w4 = lds_vec4(w, 16 * mt + 4 * q), b4 = lds_vec4(b, 16 * mt + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[mt][r] = fmaf(fmaf(x[mt][r], rstd, -mr), w4[r], b4[r]);
+   }
+}
+
+// DPP row shifts inside the 16 lanes of a column tile's quad (0 shifted in at the row ends)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v)
+{
+   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kRowShl1 = 0x101, kRowShl2 = 0x102, kRowShr1 = 0x111, kRowShr2 = 0x112;
+
+// depthwise k = 5, zero pad 2, + bias, ReLU (conv.c:17-53) of one register: x at this lane's step, neighbours by row shifts.
+// PAIR: two 7-step chunks share the row (columns 0..6, 8..14; 7 and 15 hold zeros): only the distance-2 taps can reach the other chunk.
+template <bool PAIR>
+__device__ __forceinline__ float dw5(float x, float k0, float k1, float k2, float k3, float k4, float bias, int lc)
+{
+   float xm2 = dpp_row<kRowShr2>(x), xp2 = dpp_row<kRowShl2>(x);
+   const float xm1 = dpp_row<kRowShr1>(x), xp1 = dpp_row<kRowShl1>(x);
+   if (PAIR) { xm2 = lc == 8 ? 0.0f : xm2; xp2 = lc == 6 ? 0.0f : xp2; }
+   float dv = bias;
+   dv = fmaf(xm2, k0, dv); dv = fmaf(xm1, k1, dv); dv = fmaf(x, k2, dv); dv = fmaf(xp1, k3, dv); dv = fmaf(xp2, k4, dv);
+   return fmaxf(dv, 0.0f);
+}
+
+// ---- transformer block + strided 1x1 conv (BatchNorm folded) + ReLU on NT column tiles --------------------------------------------
+// acc: y = the conv block's output (residual stream) on entry, z = relu(conv(LN2(...))) on return.
+// PAIR: column layout (false: one 13-step chunk per tile, true: two 7-step chunks) -- decides the softmax mask only.
+template <typename L, int D, int NT, bool PAIR>
+__device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, const float *lv, int lane)
+{
+   constexpr int MT = D / 16, KB = D / 32, HT = D / 32;      // HT = M tiles per head (hd = D / 2)
+   const int q = lane >> 4, lc = lane & 15;
+   Frag yf[NT][KB];
+#pragma unroll
+   for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) yf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
+   // softmax mask of this lane's four j = 4 q + r (transformer.c:104-113: a_i = softmax_j(k_i . q_j))
+   bool jv[4];
+#pragma unroll
+   for (int r = 0; r < 4; ++r) jv[r] = PAIR ? ((q >> 1) == (lc >> 3) && ((4 * q + r) & 7) != 7) : (4 * q + r < 13);
+   f4 att[NT][MT];
+#pragma unroll
+   for (int h = 0; h < 2; ++h) {
+      f4 Q[NT][HT], K[NT][HT], Vt[NT][HT];
+      {
+#pragma unroll
+         for (int j = 0; j < HT; ++j) {
+            const f4 bq = lds_vec4(lv, L::v_qkv_b + 16 * (h * HT + j) + 4 * q), bk = lds_vec4(lv, L::v_qkv_b + D + 16 * (h * HT + j) + 4 * q);
+            const float bv = lv[L::v_qkv_b + 2 * D + 16 * (h * HT + j) + lc];          // V^T: the output channel is the LANE
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { Q[nt][j] = bq; K[nt][j] = bk; Vt[nt][j] = f4{bv, bv, bv, bv}; }
+         }
+      }
+      gemm<NT, HT, KB, HT>(Q, lf + L::f_qkv, h * HT, yf, lane);
+      gemm<NT, HT, KB, HT>(K, lf + L::f_qkv, MT + h * HT, yf, lane);
+      // V^T[step][channel] = y^T . Wv^T: the same fragments with the operands swapped
+#pragma unroll
+      for (int j = 0; j < HT; ++j)
+#pragma unroll
+         for (int kb = 0; kb < KB; ++kb) {
+            const Frag wv = lds_frag(lf + L::f_qkv, (2 * MT + h * HT + j) * KB + kb, lane);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].lo, wv.hi, Vt[nt][j]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].hi, wv.lo, Vt[nt][j]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].hi, wv.hi, Vt[nt][j]);
+         }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+         // S^T[j][i] = sum_c Q[c][j] K[c][i]: lane (q, i) holds s[i][j = 4 q + r], already scaled by log2(e) / sqrt(hd)
+         const Frag qa = HT == 2 ? split8(Q[nt][0], Q[nt][HT - 1]) : split4z(Q[nt][0]);
+         const Frag kb_ = HT == 2 ? split8(K[nt][0], K[nt][HT - 1]) : split4z(K[nt][0]);
+         f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+         s = MFMA16(qa.lo, kb_.hi, s); s = MFMA16(qa.hi, kb_.lo, s); s = MFMA16(qa.hi, kb_.hi, s);
+         float m = -3.0e38f;
+#pragma unroll
+         for (int r = 0; r < 4; ++r) m = jv[r] ? fmaxf(m, s[r]) : m;
+         m = quads_max(m);
+         f4 p;
+         float sum = 0.0f;                                    // tensor.h:751-784
+#pragma unroll
+         for (int r = 0; r < 4; ++r) { p[r] = jv[r] ? __builtin_amdgcn_exp2f(s[r] - m) : 0.0f; sum += p[r]; }
+         sum = quads_sum(sum);
+         const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+         for (int r = 0; r < 4; ++r) p[r] *= inv;
+         // att[c][i] = sum_j V[c][j] a[i][j]: A = V^T registers (lane = channel, k = step j = 4 q + r), B = a (lane = column i)
+         const Frag af = split4z(p);
+#pragma unroll
+         for (int j = 0; j < HT; ++j) {
+            const Frag vf = split4z(Vt[nt][j]);
+            f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+            o = MFMA16(vf.lo, af.hi, o); o = MFMA16(vf.hi, af.lo, o); o = MFMA16(vf.hi, af.hi, o);
+            att[nt][h * HT + j] = o;
+         }
+      }
+   }
+   // out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220
+   {
+      Frag af[NT][KB];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int kb = 0; kb < KB; ++kb) af[nt][kb] = split8(att[nt][2 * kb], att[nt][2 * kb + 1]);
+      f4 p[NT][MT];
+      init_bias<NT, MT>(p, lv + L::v_out_b, q);
+      gemm<NT, MT, KB, MT>(p, lf + L::f_out, 0, af, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += p[nt][mt];
+   }
+#pragma unroll
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], lv + L::v_n1_w, lv + L::v_n1_b, q);
+   {
+      Frag xf[NT][KB];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
+      f4 f[NT][MT];
+      init_bias<NT, MT>(f, lv + L::v_l1_b, q);
+      gemm<NT, MT, KB, MT>(f, lf + L::f_l1, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[nt][mt][r] = fmaxf(f[nt][mt][r], 0.0f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(f[nt][2 * kb], f[nt][2 * kb + 1]);
+      f4 g[NT][MT];
+      init_bias<NT, MT>(g, lv + L::v_l2_b, q);
+      gemm<NT, MT, KB, MT>(g, lf + L::f_l2, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += g[nt][mt];
+   }
+#pragma unroll
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], lv + L::v_n2_w, lv + L::v_n2_b, q);
+   // conv k = 1 (+ folded BatchNorm) -> ReLU, every step (the caller keeps the surviving ones)      transformer.c:279-290
+   {
+      Frag xf[NT][KB];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
+      init_bias<NT, MT>(acc, lv + L::v_cv_b, q);
+      gemm<NT, MT, KB, MT>(acc, lf + L::f_cv, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][mt][r] = fmaxf(acc[nt][mt][r], 0.0f);
+   }
+}
+
+// ---- conv block of layers 3 / 4 on register inputs: y = relu(pw(relu(dw(x))) + (proj(x) | x))        conv.c:761-814 ---------------
+// x: [NT][2] accumulator-layout tiles of the 32 input channels (idle columns 7, 15 zeroed here); y: [NT][D / 16]
+template <typename L, int D, int NT, bool PROJ>
+__device__ __forceinline__ void conv_block_regs(f4 (&x)[NT][2], f4 (&y)[NT][D / 16], const char *lf, const float *lv, int lane)
+{
+   constexpr int MT = D / 16;
+   const int q = lane >> 4, lc = lane & 15;
+   const bool idle = (lc & 7) == 7;
+   Frag xf[NT][1], df[NT][1];
+   f4 k[6][2];
+#pragma unroll
+   for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) k[t][mt] = lds_vec4(lv, L::v_dw + t * 32 + 16 * mt + 4 * q);
+#pragma unroll
+   for (int nt = 0; nt < NT; ++nt) {
+      f4 d[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) {
+            x[nt][mt][r] = idle ? 0.0f : x[nt][mt][r];
+            d[mt][r] = dw5<true>(x[nt][mt][r], k[0][mt][r], k[1][mt][r], k[2][mt][r], k[3][mt][r], k[4][mt][r], k[5][mt][r], lc);
+         }
+      df[nt][0] = split8(d[0], d[1]);
+      if (PROJ) xf[nt][0] = split8(x[nt][0], x[nt][1]);
+   }
+   init_bias<NT, MT>(y, lv + L::v_cb_b, q);
+   gemm<NT, MT, 1, MT>(y, lf + L::f_pw, 0, df, lane);
+   if (PROJ) gemm<NT, MT, 1, MT>(y, lf + L::f_pj, 0, xf, lane);
+#pragma unroll
+   for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+         for (int r = 0; r < 4; ++r) {
+            if (!PROJ) y[nt][mt][r] += x[nt][mt < 2 ? mt : 0][r];            // identity residual (32 -> 32)
+            y[nt][mt][r] = fmaxf(y[nt][mt][r], 0.0f);
+         }
+}
+
+// [n][D][7] fp32 <-> the pair layout (lane (q, lc): chunk 2 tile + (lc >> 3), step lc & 7, channels 16 mt + 4 q + r)
+template <int MT>
+__device__ __forceinline__ void load_chw7(f4 (&x)[MT], const float *in, int item, int n_chunks, const ItemMap &map, int lane)
+{
+   const int q = lane >> 4, lc = lane & 15, t = lc & 7;
+   const bool ok = t < 7 && item + (lc >> 3) < n_chunks;
+   const float *p = in + (size_t)map(ok ? item + (lc >> 3) : 0) * (16 * MT * 7) + t;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[mt][r] = ok ? p[(16 * mt + 4 * q + r) * 7] : 0.0f;
+}
+template <int MT>
+__device__ __forceinline__ void store_chw7(const f4 (&x)[MT], float *out, int item, int n_chunks, const ItemMap &map, int lane)
+{
+   const int q = lane >> 4, lc = lane & 15, t = lc & 7;
+   if (!(t < 7 && item + (lc >> 3) < n_chunks)) return;
+   float *p = out + (size_t)map(item + (lc >> 3)) * (16 * MT * 7) + t;
+#pragma unroll
+   for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * q + r) * 7] = x[mt][r];
+}
+
+// NP = column tiles per batch in layers 3 / 4 = pairs of chunks; a batch = 2 NP chunks
+template <int NP>
+__global__ __launch_bounds__(512) void k_enc_fused(EncFusedArgs a)
+{
+   __shared__ __attribute__((aligned(16))) char lds[kEncLdsBytes];
+   const int tid = threadIdx.x;
+   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, lc = lane & 15;
+   const int slot = blockIdx.x * 8 + wave, nslots = gridDim.x * 8;
+   const int nb = (a.n_chunks + 2 * NP - 1) / (2 * NP);
+
+   auto copy_image = [&](const void *img, int bytes) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(img);
+      uint4 *dst = reinterpret_cast<uint4 *>(lds);
+      for (int i = tid; i < bytes / 16; i += 512) dst[i] = src[i];
+   };
+
+   if (a.first <= 3) {
+      copy_image(a.imgA, kEncA_Bytes);
+      __syncthreads();
+      const char *f2 = lds + kEncA_L2F, *f3 = lds + kEncA_L3F;
+      const float *v2 = reinterpret_cast<const float *>(lds + kEncA_V2), *v3 = reinterpret_cast<const float *>(lds + kEncA_V3);
+      for (int b = slot; b < nb; b += nslots) {
+         const int item0 = b * 2 * NP;
+         f4 x3[NP][2];
+         if (a.first == 2) {
+            // ---- layer 2 on 2 tiles (one 13-step chunk each) per pass; the surviving even steps of a pass make ONE tile of layer 3 ----
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+               f4 y[2][2];
+               {
+                  // conv block, inputs from memory: lane (q, t) takes channels 8 (q & 1) + e; quads 0, 1 feed relu(dw(x)), quads 2, 3 feed x
+                  // into the stacked [pointwise | projection] GEMM (K = 32)
+                  Frag bf[2][1];
+                  f4 k[6][2];
+#pragma unroll
+                  for (int t = 0; t < 6; ++t)
+#pragma unroll
+                     for (int e4 = 0; e4 < 2; ++e4) k[t][e4] = lds_vec4(v2, EncL2::v_dw + t * 16 + 8 * (q & 1) + 4 * e4);
+#pragma unroll
+                  for (int nt = 0; nt < 2; ++nt) {
+                     const int item = item0 + 2 * p + nt;
+                     const bool ok = lc < 13 && item < a.n_chunks;
+                     const float *xp = a.in + (size_t)a.map(item < a.n_chunks ? item : 0) * (16 * 13) + (8 * (q & 1)) * 13 + lc;
+                     f4 xv[2], d[2];
+#pragma unroll
+                     for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = ok ? xp[e * 13] : 0.0f;
+#pragma unroll
+                     for (int e = 0; e < 8; ++e)
+                        d[e >> 2][e & 3] = dw5<false>(xv[e >> 2][e & 3], k[0][e >> 2][e & 3], k[1][e >> 2][e & 3], k[2][e >> 2][e & 3], k[3][e >> 2][e & 3],
+                                                      k[4][e >> 2][e & 3], k[5][e >> 2][e & 3], lc);
+                     const bool usex = q >= 2;
+#pragma unroll
+                     for (int e = 0; e < 8; ++e) d[e >> 2][e & 3] = usex ? xv[e >> 2][e & 3] : d[e >> 2][e & 3];
+                     bf[nt][0] = split8(d[0], d[1]);
+                  }
+                  init_bias<2, 2>(y, v2 + EncL2::v_cb_b, q);
+                  gemm<2, 2, 1, 2>(y, f2 + EncL2::f_pw, 0, bf, lane);
+#pragma unroll
+                  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                     for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[nt][mt][r] = fmaxf(y[nt][mt][r], 0.0f);
+               }
+               tf_block<EncL2, 32, 2, false>(y, f2, v2, lane);
+               // stride 2: step 2 t' of tile (lc' >> 3) -> column lc' = 8 (chunk in pair) + t' of the pair tile; same quad, same registers
+               const int src = 4 * (16 * q + 2 * (lc & 7));
+               const bool second = lc >= 8, idle = (lc & 7) == 7;
+               f4 xn[2];
+#pragma unroll
+               for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                     const float y0 = y[0][mt][r], y1 = y[1][mt][r];     // (a bit_cast applied to the vector-element lvalue itself read element 0 for every r)
+                     const int v0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, y0));
+                     const int v1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, y1));
+                     xn[mt][r] = idle ? 0.0f : __builtin_bit_cast(float, second ? v1 : v0);
+                  }
+               if (a.tap2) store_chw7<2>(xn, a.tap2, item0 + 2 * p, a.n_chunks, a.map, lane);
+               // x3[p] = xn with p a loop variable: select without dynamic register indexing
+#pragma unroll
+               for (int pp = 0; pp < NP; ++pp)
+                  if (pp == p) { x3[pp][0] = xn[0]; x3[pp][1] = xn[1]; }
+            }
+         } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) load_chw7<2>(x3[p], a.in, item0 + 2 * p, a.n_chunks, a.map, lane);
+         }
+         if (a.last >= 3) {
+            f4 y3[NP][2];
+            conv_block_regs<EncL3, 32, NP, false>(x3, y3, f3, v3, lane);
+            tf_block<EncL3, 32, NP, true>(y3, f3, v3, lane);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+               if (a.tap3) store_chw7<2>(y3[p], a.tap3, item0 + 2 * p, a.n_chunks, a.map, lane);
+               float *sp = a.scratch + ((size_t)b * NP + p) * 512 + lane;
+#pragma unroll
+               for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) sp[(4 * mt + r) * 64] = y3[p][mt][r];
+            }
+         }
+      }
+      __syncthreads();                                     // every wave is done with image A
+   }
+   if (a.last < 4) return;
+   copy_image(a.imgB, kEncB_Bytes);
+   __syncthreads();
+   {
+      const char *f4_ = lds + kEncB_L4F;
+      const float *v4 = reinterpret_cast<const float *>(lds + kEncB_V4);
+      for (int b = slot; b < nb; b += nslots) {
+         const int item0 = b * 2 * NP;
+         f4 x4[NP][2];
+         if (a.first <= 3) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+               const float *sp = a.scratch + ((size_t)b * NP + p) * 512 + lane;
+#pragma unroll
+               for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) x4[p][mt][r] = __builtin_nontemporal_load(sp + (4 * mt + r) * 64);
+            }
+         } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) load_chw7<2>(x4[p], a.in, item0 + 2 * p, a.n_chunks, a.map, lane);
+         }
+         f4 y4[NP][4];
+         conv_block_regs<EncL4, 64, NP, true>(x4, y4, f4_, v4, lane);
+         tf_block<EncL4, 64, NP, true>(y4, f4_, v4, lane);
+#pragma unroll
+         for (int p = 0; p < NP; ++p) {
+            if (a.tap4) { store_chw7<4>(y4[p], a.tap4, item0 + 2 * p, a.n_chunks, a.map, lane); continue; }
+            // split-fp16 LSTM-native tiles (common.h lstm_xh_index): a (chunk, step) row = 64 units x {hi, lo}; this lane owns units 16 mt + 4 q .. + 3
+            const int item = item0 + 2 * p + (lc >> 3), t = lc & 7;
+            if (t < 7 && item < a.n_chunks) {
+               int st_, ch_;
+               a.map.split(item, st_, ch_);
+               _Float16 *dst = reinterpret_cast<_Float16 *>(a.out) + lstm_xh_index(st_, ch_, a.map.C, t, 4 * q, 7);
+#pragma unroll
+               for (int mt = 0; mt < 4; ++mt) {
+                  h2 hi[2], lo[2];
+                  split2(y4[p][mt][0], y4[p][mt][1], hi[0], lo[0]); split2(y4[p][mt][2], y4[p][mt][3], hi[1], lo[1]);
+                  *reinterpret_cast<h4 *>(dst + 16 * mt) = h4{hi[0][0], hi[0][1], hi[1][0], hi[1][1]};
+                  *reinterpret_cast<h4 *>(dst + kLstmTile * 64 + 16 * mt) = h4{lo[0][0], lo[0][1], lo[1][0], lo[1][1]};
+               }
+            }
+         }
+      }
+   }
+}
+
+// grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its 8 waves
+void launch_enc_fused(const EncFusedArgs &a, int max_wgs, hipStream_t st)
+{
+   if (a.n_chunks <= 0) return;
+   // two pairs (4 chunks) per batch halve the LDS weight traffic per chunk and double a wave's independent MFMA chains; one pair keeps the
+   // waves balanced when a wave would get fewer than ~6 batches
+   const int nb2 = (a.n_chunks + 3) / 4;
+   static const char *force = getenv("VADC_ENC_NP");          // bring-up: 1 / 2 forces the batch size
+   const bool two = force ? force[0] == '2' : nb2 >= 6 * 8 * max_wgs;
+   const int nb = two ? nb2 : (a.n_chunks + 1) / 2;
+   int g = (nb + 7) / 8;
+   if (g > max_wgs) g = max_wgs;
+   if (g < 1) g = 1;
+   if (two) hipLaunchKernelGGL((k_enc_fused<2>), dim3(g), dim3(512), 0, st, a);
+   else     hipLaunchKernelGGL((k_enc_fused<1>), dim3(g), dim3(512), 0, st, a);
+}
+
+}  // namespace vadc

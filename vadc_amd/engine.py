@@ -24,7 +24,7 @@ STAGES = {"magnitude": 0, "normalized": 1, "layer1": 2, "layer2": 3, "layer3": 4
 STAGE_SHAPES = {0: (129, 25), 1: (129, 25), 2: (16, 13), 3: (32, 7), 4: (32, 7), 5: (64, 7)}          # Silero v3.1
 STAGE_SHAPES_V4 = {0: (129, 24), 1: (129, 24), 2: (16, 12), 3: (32, 6), 4: (32, 3), 5: (64, 3)}       # Silero v4
 MODEL_V31, MODEL_V4, MODEL_V5 = 0, 1, 2
-KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1"]
+KERNELS = ["k_frontend", "k_layer1", "k_layer2", "k_layer3", "k_layer4", "k_lstm", "k_lstm_l1", "k_enc234"]
 
 
 class VadcAmdError(RuntimeError):
