@@ -450,7 +450,16 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          for (int c = 0; c < C; ++c) vbase[LL::v_dw + 5 * C + c] = r.dw_b[c];
          for (int o = 0; o < D; ++o) vbase[LL::v_cb_b + o] = r.pw_b[o] + (kLayers[l].proj ? r.pj_b[o] : 0.0f);
          put_vec(vbase + LL::v_qkv_b, qb);
-         put_vec(vbase + LL::v_out_b, r.out_b); put_vec(vbase + LL::v_n1_w, r.n1_w); put_vec(vbase + LL::v_n1_b, r.n1_b);
+         {  // a softmax row sums to 1, so the V bias passes through the attention unchanged: out_b' = out_b + Wo . bv (the kernel adds no V bias)
+            std::vector<float> ob = r.out_b;
+            for (int o = 0; o < D; ++o) {
+               double acc = 0.0;
+               for (int c = 0; c < D; ++c) acc += (double)r.out_w[(size_t)o * D + c] * (double)r.qkv_b[2 * D + c];
+               ob[o] += (float)acc;
+            }
+            put_vec(vbase + LL::v_out_b, ob);
+         }
+         put_vec(vbase + LL::v_n1_w, r.n1_w); put_vec(vbase + LL::v_n1_b, r.n1_b);
          put_vec(vbase + LL::v_l1_b, r.l1_b);   put_vec(vbase + LL::v_l2_b, r.l2_b);
          put_vec(vbase + LL::v_n2_w, r.n2_w);   put_vec(vbase + LL::v_n2_b, r.n2_b); put_vec(vbase + LL::v_cv_b, r.cv_b);
       };

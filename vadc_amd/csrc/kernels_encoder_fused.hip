@@ -36,9 +36,17 @@ struct Frag { h8 hi, lo; };       // one MFMA operand (8 k elements per lane), s
 
 __device__ __forceinline__ void split2(float a, float b, h2 &hi, h2 &lo)
 {
+#ifdef VADC_ENC_ABL_NOSPLIT     // timing-only ablation: hi only, lo = hi (one instruction per pair instead of four)
+   { const f2 ab_ = {a, b}; hi = __builtin_convertvector(ab_, h2); lo = hi; return; }
+#endif
    const f2 ab = {a, b};
    hi = __builtin_convertvector(ab, h2);                    // v_cvt_pk_f16_f32
-   const f2 r = {a - (float)hi[0], b - (float)hi[1]};
+   // residual a - (float)hi straight from the packed halves (v_fma_mix_f32: f16 source selected by op_sel): one instruction per element where
+   // hipcc emits v_cvt_f32_f16 + half a v_pk_add_f32.  Both asm inputs come out of the v_cvt_pk above, never directly out of an MFMA.
+   float ra, rb;
+   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+   const f2 r = {ra, rb};
    lo = __builtin_convertvector(r, h2);
 }
 __device__ __forceinline__ Frag split8(const f4 &u, const f4 &v)
@@ -51,19 +59,37 @@ __device__ __forceinline__ Frag split8(const f4 &u, const f4 &v)
    f.lo = h8{lo[0][0], lo[0][1], lo[1][0], lo[1][1], lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
    return f;
 }
-// k elements 4..7 zero: a K = 16 contraction on the K = 32 instruction
-__device__ __forceinline__ Frag split4z(const f4 &u)
+// K = 16 operand (v_mfma_f32_16x16x16_f16: lane (q, row) holds k = 4 q + e, e < 4 -- the four registers of one accumulator tile)
+struct Frag4 { h4 hi, lo; };
+__device__ __forceinline__ Frag4 split4(const f4 &u)
 {
    h2 hi[2], lo[2];
    split2(u[0], u[1], hi[0], lo[0]); split2(u[2], u[3], hi[1], lo[1]);
-   const _Float16 z = (_Float16)0.0f;
-   Frag f;
-   f.hi = h8{hi[0][0], hi[0][1], hi[1][0], hi[1][1], z, z, z, z};
-   f.lo = h8{lo[0][0], lo[0][1], lo[1][0], lo[1][1], z, z, z, z};
+   Frag4 f;
+   f.hi = h4{hi[0][0], hi[0][1], hi[1][0], hi[1][1]};
+   f.lo = h4{lo[0][0], lo[0][1], lo[1][0], lo[1][1]};
    return f;
 }
 
+// max(x, 0) as ONE instruction (fmaxf costs a canonicalising v_max_f32 x, x in front of the v_max_f32)
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
+
+// precision study (tests/reports/enc_terms_report.py): which of the two correction terms of W . X ~= Wl . Xh + Wh . Xl + Wh . Xh the parity bar needs
+#ifndef VADC_ENC_WLO
+#define VADC_ENC_WLO 1
+#endif
+#ifndef VADC_ENC_XLO
+#define VADC_ENC_XLO 1
+#endif
+#ifdef VADC_ENC_ABL_NOMFMA      // timing-only ablation (tools/enc_ablate.sh): every MFMA replaced by one dependent vector add per operand pair -- results are wrong
+__device__ __forceinline__ f4 fake_mfma(const h8 &a, const h8 &b, f4 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
+__device__ __forceinline__ f4 fake_mfma(const h4 &a, const h4 &b, f4 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
+#define MFMA16(a, b, c) fake_mfma((a), (b), (c))
+#define MFMA16K16(a, b, c) fake_mfma((a), (b), (c))
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define MFMA16K16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16((a), (b), (c), 0, 0, 0)
+#endif
 
 // one weight fragment (M tile, k block) of a GEMM from the LDS image
 __device__ __forceinline__ Frag lds_frag(const char *base, int idx, int lane)
@@ -76,27 +102,62 @@ __device__ __forceinline__ Frag lds_frag(const char *base, int idx, int lane)
 }
 __device__ __forceinline__ f4 lds_vec4(const float *v, int off) { return *reinterpret_cast<const f4 *>(v + off); }
 
+// The first two fragments of a GEMM, requested ahead of the vector work (operand split, LayerNorm, softmax) that precedes it: LDS answers
+// after 100-200 cycles with twelve waves reading, and a wave has nothing else to issue meanwhile
+struct Pre { Frag a0, a1; };
+template <int N>
+__device__ __forceinline__ Pre prefetch(const char *wf, int idx0, int lane)
+{
+   Pre p;
+   p.a0 = lds_frag(wf, idx0, lane);
+   p.a1 = N > 1 ? lds_frag(wf, idx0 + 1, lane) : p.a0;
+   return p;
+}
+
 // acc[nt][mt] += W[16 mt .., :] . B[nt]      W: MT x KB fragments at `wf` (first M tile = mt0), B: KB operands per tile
+// Software pipeline, two fragments ahead (`pre` = fragments mt0 * KB + 0, 1, already on their way); the scheduling barriers keep hipcc from hoisting
+// every fragment read of the (fully unrolled) layer to the top of the kernel (it did: 950 spilled registers).  A single accumulation chain of
+// v_mfma_f32_16x16x32_f16 issues back to back at the pipe's rate, so the three terms of a tile need no interleaving with other tiles.
+template <int NT, int MT, int KB, int MTA>
+__device__ __forceinline__ void gemm(f4 (&acc)[NT][MTA], const char *wf, int mt0, const Frag (&b)[NT][KB], int lane, Pre pre)
+{
+   constexpr int N = MT * KB;
+   Frag a0 = pre.a0, a1 = pre.a1;
+#pragma unroll
+   for (int i = 0; i < N; ++i) {
+      const int mt = i / KB, kb = i % KB;
+      Frag a2 = a1;
+      if (i + 2 < N) a2 = lds_frag(wf, mt0 * KB + i + 2, lane);
+#if VADC_ENC_WLO
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a0.lo, b[nt][kb].hi, acc[nt][mt]);
+#endif
+#if VADC_ENC_XLO
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a0.hi, b[nt][kb].lo, acc[nt][mt]);
+#endif
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a0.hi, b[nt][kb].hi, acc[nt][mt]);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1; a1 = a2;
+   }
+}
 template <int NT, int MT, int KB, int MTA>
 __device__ __forceinline__ void gemm(f4 (&acc)[NT][MTA], const char *wf, int mt0, const Frag (&b)[NT][KB], int lane)
 {
-   // software pipeline, one fragment ahead; the scheduling barriers keep hipcc from hoisting every fragment read of the (fully unrolled)
-   // layer to the top of the kernel (it did: 950 spilled registers)
-   Frag a = lds_frag(wf, mt0 * KB, lane);
+   gemm<NT, MT, KB, MTA>(acc, wf, mt0, b, lane, prefetch<MT * KB>(wf, mt0 * KB, lane));
+}
+
+// MT float4 rows of a vector (this lane's accumulator rows), requested ahead of use
+template <int MT>
+struct Vec { f4 v[MT]; };
+template <int MT>
+__device__ __forceinline__ Vec<MT> load_vec(const float *p, int q)
+{
+   Vec<MT> r;
 #pragma unroll
-   for (int i = 0; i < MT * KB; ++i) {
-      const int mt = i / KB, kb = i % KB;
-      Frag an = a;
-      if (i + 1 < MT * KB) an = lds_frag(wf, mt0 * KB + i + 1, lane);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.lo, b[nt][kb].hi, acc[nt][mt]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.hi, b[nt][kb].lo, acc[nt][mt]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = MFMA16(a.hi, b[nt][kb].hi, acc[nt][mt]);
-      __builtin_amdgcn_sched_barrier(0);
-      a = an;
-   }
+   for (int mt = 0; mt < MT; ++mt) r.v[mt] = lds_vec4(p, 16 * mt + 4 * q);
+   return r;
 }
 
 template <int NT, int MT>
@@ -116,22 +177,24 @@ __device__ __forceinline__ void init_bias(f4 (&acc)[NT][MT], const float *bias, 
 // (tools/enc_prims_test.hip); the s_nop covers the VALU-write -> swap wait states hipcc pads its own swaps with.
 __device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// max of two finite values as one v_med3_f32 (fmaxf puts a canonicalising v_max_f32 x, x in front of values that come out of inline asm)
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 template <bool MAX>
 __device__ __forceinline__ float quads_reduce(float v)
 {
    float a = v, b = v;
    swap16(a, b);
-   v = MAX ? fmaxf(a, b) : a + b;
+   v = MAX ? max2(a, b) : a + b;
    a = v; b = v;
    swap32(a, b);
-   return MAX ? fmaxf(a, b) : a + b;
+   return MAX ? max2(a, b) : a + b;
 }
 __device__ __forceinline__ float quads_sum(float v) { return quads_reduce<false>(v); }
 __device__ __forceinline__ float quads_max(float v) { return quads_reduce<true>(v); }
 
 // LayerNorm over the D = 16 MT channels of each column in the accumulator layout (misc.c:143-210: biased variance, eps 1e-5)
 template <int MT>
-__device__ __forceinline__ void layer_norm(f4 (&x)[MT], const float *w, const float *b, int q)
+__device__ __forceinline__ void layer_norm(f4 (&x)[MT], const Vec<MT> &w, const Vec<MT> &b)
 {
    constexpr int D = 16 * MT;
    float s = 0.0f;
@@ -149,7 +212,7 @@ __device__ __forceinline__ void layer_norm(f4 (&x)[MT], const float *w, const fl
    const float mr = mean * rstd;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt) {
-      const f4 w4 = lds_vec4(w, 16 * mt + 4 * q), b4 = lds_vec4(b, 16 * mt + 4 * q);
+      const f4 w4 = w.v[mt], b4 = b.v[mt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[mt][r] = fmaf(fmaf(x[mt][r], rstd, -mr), w4[r], b4[r]);
    }
@@ -173,7 +236,7 @@ __device__ __forceinline__ float dw5(float x, float k0, float k1, float k2, floa
    if (PAIR) { xm2 = lc == 8 ? 0.0f : xm2; xp2 = lc == 6 ? 0.0f : xp2; }
    float dv = bias;
    dv = fmaf(xm2, k0, dv); dv = fmaf(xm1, k1, dv); dv = fmaf(x, k2, dv); dv = fmaf(xp1, k3, dv); dv = fmaf(xp2, k4, dv);
-   return fmaxf(dv, 0.0f);
+   return relu(dv);
 }
 
 // ---- transformer block + strided 1x1 conv (BatchNorm folded) + ReLU on NT column tiles --------------------------------------------
@@ -183,75 +246,115 @@ template <typename L, int D, int NT, bool PAIR>
 __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, const float *lv, int lane)
 {
    constexpr int MT = D / 16, KB = D / 32, HT = D / 32;      // HT = M tiles per head (hd = D / 2)
+   constexpr int NQ = 3 * HT * KB;                           // fragments of one head's Q, K, V rows
    const int q = lane >> 4, lc = lane & 15;
+   // fragment index of step i of a head's Q | K | V sequence
+   auto qkv_idx = [](int h, int i) { const int part = i / (HT * KB), j = (i / KB) % HT, kb = i % KB; return (part * MT + h * HT + j) * KB + kb; };
+   Pre pq = {lds_frag(lf + L::f_qkv, qkv_idx(0, 0), lane), lds_frag(lf + L::f_qkv, qkv_idx(0, 1), lane)};
+   f4 bqk[2][HT];                                            // Q and K bias rows of the head in work
+#pragma unroll
+   for (int j = 0; j < HT; ++j) { bqk[0][j] = lds_vec4(lv, L::v_qkv_b + 16 * j + 4 * q); bqk[1][j] = lds_vec4(lv, L::v_qkv_b + D + 16 * j + 4 * q); }
    Frag yf[NT][KB];
 #pragma unroll
    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) yf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
-   // softmax mask of this lane's four j = 4 q + r (transformer.c:104-113: a_i = softmax_j(k_i . q_j))
-   bool jv[4];
+   // softmax mask of this lane's four j = 4 q + r (transformer.c:104-113: a_i = softmax_j(k_i . q_j)): the score MFMA starts from 0 or -1e30,
+   // so masked scores never win the max and their exp2 is 0
+   f4 smask;
 #pragma unroll
-   for (int r = 0; r < 4; ++r) jv[r] = PAIR ? ((q >> 1) == (lc >> 3) && ((4 * q + r) & 7) != 7) : (4 * q + r < 13);
+   for (int r = 0; r < 4; ++r) smask[r] = (PAIR ? ((q >> 1) == (lc >> 3) && ((4 * q + r) & 7) != 7) : (4 * q + r < 13)) ? 0.0f : -1.0e30f;
    f4 att[NT][MT];
+   Pre po;                                                   // first fragments of the out projection, requested under the last head's attention
+   Vec<MT> b_out;
 #pragma unroll
    for (int h = 0; h < 2; ++h) {
-      f4 Q[NT][HT], K[NT][HT], Vt[NT][HT];
-      {
-#pragma unroll
-         for (int j = 0; j < HT; ++j) {
-            const f4 bq = lds_vec4(lv, L::v_qkv_b + 16 * (h * HT + j) + 4 * q), bk = lds_vec4(lv, L::v_qkv_b + D + 16 * (h * HT + j) + 4 * q);
-            const float bv = lv[L::v_qkv_b + 2 * D + 16 * (h * HT + j) + lc];          // V^T: the output channel is the LANE
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { Q[nt][j] = bq; K[nt][j] = bk; Vt[nt][j] = f4{bv, bv, bv, bv}; }
-         }
-      }
-      gemm<NT, HT, KB, HT>(Q, lf + L::f_qkv, h * HT, yf, lane);
-      gemm<NT, HT, KB, HT>(K, lf + L::f_qkv, MT + h * HT, yf, lane);
-      // V^T[step][channel] = y^T . Wv^T: the same fragments with the operands swapped
+      // Q, K (rows = channels) and V^T (the same fragments with the operands swapped: lane = channel, registers = steps) of head h as ONE
+      // pipelined fragment sequence.  No V bias: a softmax row sums to 1, so bv passes through the attention unchanged -- the host adds
+      // Wo . bv to the out-projection bias.
+      f4 QKV[3][NT][HT];
 #pragma unroll
       for (int j = 0; j < HT; ++j)
 #pragma unroll
-         for (int kb = 0; kb < KB; ++kb) {
-            const Frag wv = lds_frag(lf + L::f_qkv, (2 * MT + h * HT + j) * KB + kb, lane);
+         for (int nt = 0; nt < NT; ++nt) { QKV[0][nt][j] = bqk[0][j]; QKV[1][nt][j] = bqk[1][j]; QKV[2][nt][j] = f4{0.0f, 0.0f, 0.0f, 0.0f}; }
+      {
+         Frag a0 = pq.a0, a1 = pq.a1;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].lo, wv.hi, Vt[nt][j]);
+         for (int i = 0; i < NQ; ++i) {
+            const int part = i / (HT * KB), j = (i / KB) % HT, kb = i % KB;
+            Frag a2 = a1;
+            if (i + 2 < NQ) a2 = lds_frag(lf + L::f_qkv, qkv_idx(h, i + 2), lane);
+            else if (h == 0) a2 = lds_frag(lf + L::f_qkv, qkv_idx(1, i + 2 - NQ), lane);      // the next head's first fragments
+            else if (i + 2 == NQ) { po = prefetch<MT * KB>(lf + L::f_out, 0, lane); b_out = load_vec<MT>(lv + L::v_out_b, q); }
+            if (part < 2) {
+#if VADC_ENC_WLO
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].hi, wv.lo, Vt[nt][j]);
+               for (int nt = 0; nt < NT; ++nt) QKV[part][nt][j] = MFMA16(a0.lo, yf[nt][kb].hi, QKV[part][nt][j]);
+#endif
+#if VADC_ENC_XLO
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Vt[nt][j] = MFMA16(yf[nt][kb].hi, wv.hi, Vt[nt][j]);
+               for (int nt = 0; nt < NT; ++nt) QKV[part][nt][j] = MFMA16(a0.hi, yf[nt][kb].lo, QKV[part][nt][j]);
+#endif
+#pragma unroll
+               for (int nt = 0; nt < NT; ++nt) QKV[part][nt][j] = MFMA16(a0.hi, yf[nt][kb].hi, QKV[part][nt][j]);
+            } else {
+#if VADC_ENC_XLO
+#pragma unroll
+               for (int nt = 0; nt < NT; ++nt) QKV[2][nt][j] = MFMA16(yf[nt][kb].lo, a0.hi, QKV[2][nt][j]);
+#endif
+#if VADC_ENC_WLO
+#pragma unroll
+               for (int nt = 0; nt < NT; ++nt) QKV[2][nt][j] = MFMA16(yf[nt][kb].hi, a0.lo, QKV[2][nt][j]);
+#endif
+#pragma unroll
+               for (int nt = 0; nt < NT; ++nt) QKV[2][nt][j] = MFMA16(yf[nt][kb].hi, a0.hi, QKV[2][nt][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1; a1 = a2;
          }
+         pq.a0 = a0; pq.a1 = a1;                             // head 0: the next head's first two fragments
+      }
+      if (h == 0) {
+#pragma unroll
+         for (int j = 0; j < HT; ++j) { bqk[0][j] = lds_vec4(lv, L::v_qkv_b + 16 * (HT + j) + 4 * q); bqk[1][j] = lds_vec4(lv, L::v_qkv_b + D + 16 * (HT + j) + 4 * q); }
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
          // S^T[j][i] = sum_c Q[c][j] K[c][i]: lane (q, i) holds s[i][j = 4 q + r], already scaled by log2(e) / sqrt(hd)
-         const Frag qa = HT == 2 ? split8(Q[nt][0], Q[nt][HT - 1]) : split4z(Q[nt][0]);
-         const Frag kb_ = HT == 2 ? split8(K[nt][0], K[nt][HT - 1]) : split4z(K[nt][0]);
-         f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-         s = MFMA16(qa.lo, kb_.hi, s); s = MFMA16(qa.hi, kb_.lo, s); s = MFMA16(qa.hi, kb_.hi, s);
-         float m = -3.0e38f;
-#pragma unroll
-         for (int r = 0; r < 4; ++r) m = jv[r] ? fmaxf(m, s[r]) : m;
+         f4 s = smask;
+         if constexpr (HT == 2) {
+            const Frag qa = split8(QKV[0][nt][0], QKV[0][nt][1]), kf = split8(QKV[1][nt][0], QKV[1][nt][1]);
+            s = MFMA16(qa.lo, kf.hi, s); s = MFMA16(qa.hi, kf.lo, s); s = MFMA16(qa.hi, kf.hi, s);
+         } else {
+            const Frag4 qa = split4(QKV[0][nt][0]), kf = split4(QKV[1][nt][0]);
+            s = MFMA16K16(qa.lo, kf.hi, s); s = MFMA16K16(qa.hi, kf.lo, s); s = MFMA16K16(qa.hi, kf.hi, s);
+         }
+         float m = max2(max2(s[0], s[1]), max2(s[2], s[3]));
          m = quads_max(m);
          f4 p;
-         float sum = 0.0f;                                    // tensor.h:751-784
 #pragma unroll
-         for (int r = 0; r < 4; ++r) { p[r] = jv[r] ? __builtin_amdgcn_exp2f(s[r] - m) : 0.0f; sum += p[r]; }
+         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] - m);      // tensor.h:751-784
+         float sum = (p[0] + p[1]) + (p[2] + p[3]);
          sum = quads_sum(sum);
          const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
          for (int r = 0; r < 4; ++r) p[r] *= inv;
          // att[c][i] = sum_j V[c][j] a[i][j]: A = V^T registers (lane = channel, k = step j = 4 q + r), B = a (lane = column i)
-         const Frag af = split4z(p);
+         const Frag4 af = split4(p);
 #pragma unroll
          for (int j = 0; j < HT; ++j) {
-            const Frag vf = split4z(Vt[nt][j]);
+            const Frag4 vf = split4(QKV[2][nt][j]);
             f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-            o = MFMA16(vf.lo, af.hi, o); o = MFMA16(vf.hi, af.lo, o); o = MFMA16(vf.hi, af.hi, o);
+            o = MFMA16K16(vf.lo, af.hi, o); o = MFMA16K16(vf.hi, af.lo, o); o = MFMA16K16(vf.hi, af.hi, o);
             att[nt][h * HT + j] = o;
          }
       }
    }
    // out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220
+   // every stage requests the NEXT stage's first fragments and vectors before its own MFMAs
+   Vec<MT> n1w = load_vec<MT>(lv + L::v_n1_w, q), n1b = load_vec<MT>(lv + L::v_n1_b, q);
+   Pre p1;
+   Vec<MT> b_l1;
    {
       Frag af[NT][KB];
 #pragma unroll
@@ -259,15 +362,22 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
 #pragma unroll
          for (int kb = 0; kb < KB; ++kb) af[nt][kb] = split8(att[nt][2 * kb], att[nt][2 * kb + 1]);
       f4 p[NT][MT];
-      init_bias<NT, MT>(p, lv + L::v_out_b, q);
-      gemm<NT, MT, KB, MT>(p, lf + L::f_out, 0, af, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) p[nt][mt] = b_out.v[mt];
+      p1 = prefetch<MT * KB>(lf + L::f_l1, 0, lane);
+      b_l1 = load_vec<MT>(lv + L::v_l1_b, q);
+      gemm<NT, MT, KB, MT>(p, lf + L::f_out, 0, af, lane, po);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += p[nt][mt];
    }
 #pragma unroll
-   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], lv + L::v_n1_w, lv + L::v_n1_b, q);
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], n1w, n1b);
+   Vec<MT> n2w, n2b, b_cv;
+   Pre pc;
    {
       Frag xf[NT][KB];
 #pragma unroll
@@ -275,28 +385,39 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
 #pragma unroll
          for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
       f4 f[NT][MT];
-      init_bias<NT, MT>(f, lv + L::v_l1_b, q);
-      gemm<NT, MT, KB, MT>(f, lf + L::f_l1, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) f[nt][mt] = b_l1.v[mt];
+      const Pre p2 = prefetch<MT * KB>(lf + L::f_l2, 0, lane);
+      const Vec<MT> b_l2 = load_vec<MT>(lv + L::v_l2_b, q);
+      gemm<NT, MT, KB, MT>(f, lf + L::f_l1, 0, xf, lane, p1);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) f[nt][mt][r] = fmaxf(f[nt][mt][r], 0.0f);
+            for (int r = 0; r < 4; ++r) f[nt][mt][r] = relu(f[nt][mt][r]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(f[nt][2 * kb], f[nt][2 * kb + 1]);
       f4 g[NT][MT];
-      init_bias<NT, MT>(g, lv + L::v_l2_b, q);
-      gemm<NT, MT, KB, MT>(g, lf + L::f_l2, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) g[nt][mt] = b_l2.v[mt];
+      n2w = load_vec<MT>(lv + L::v_n2_w, q); n2b = load_vec<MT>(lv + L::v_n2_b, q);
+      pc = prefetch<MT * KB>(lf + L::f_cv, 0, lane);
+      b_cv = load_vec<MT>(lv + L::v_cv_b, q);
+      gemm<NT, MT, KB, MT>(g, lf + L::f_l2, 0, xf, lane, p2);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += g[nt][mt];
    }
 #pragma unroll
-   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], lv + L::v_n2_w, lv + L::v_n2_b, q);
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], n2w, n2b);
    // conv k = 1 (+ folded BatchNorm) -> ReLU, every step (the caller keeps the surviving ones)      transformer.c:279-290
    {
       Frag xf[NT][KB];
@@ -304,14 +425,17 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int kb = 0; kb < KB; ++kb) xf[nt][kb] = split8(acc[nt][2 * kb], acc[nt][2 * kb + 1]);
-      init_bias<NT, MT>(acc, lv + L::v_cv_b, q);
-      gemm<NT, MT, KB, MT>(acc, lf + L::f_cv, 0, xf, lane);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b_cv.v[mt];
+      gemm<NT, MT, KB, MT>(acc, lf + L::f_cv, 0, xf, lane, pc);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nt][mt][r] = fmaxf(acc[nt][mt][r], 0.0f);
+            for (int r = 0; r < 4; ++r) acc[nt][mt][r] = relu(acc[nt][mt][r]);
    }
 }
 
@@ -352,7 +476,7 @@ __device__ __forceinline__ void conv_block_regs(f4 (&x)[NT][2], f4 (&y)[NT][D / 
 #pragma unroll
          for (int r = 0; r < 4; ++r) {
             if (!PROJ) y[nt][mt][r] += x[nt][mt < 2 ? mt : 0][r];            // identity residual (32 -> 32)
-            y[nt][mt][r] = fmaxf(y[nt][mt][r], 0.0f);
+            y[nt][mt][r] = relu(y[nt][mt][r]);
          }
 }
 
@@ -381,20 +505,29 @@ __device__ __forceinline__ void store_chw7(const f4 (&x)[MT], float *out, int it
 }
 
 // NP = column tiles per batch in layers 3 / 4 = pairs of chunks; a batch = 2 NP chunks
-template <int NP>
-__global__ __launch_bounds__(512) void k_enc_fused(EncFusedArgs a)
+// NW = waves per workgroup (one workgroup per CU: the LDS image allows no second one)
+template <int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
 {
    __shared__ __attribute__((aligned(16))) char lds[kEncLdsBytes];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, lc = lane & 15;
-   const int slot = blockIdx.x * 8 + wave, nslots = gridDim.x * 8;
+   const int slot = blockIdx.x * NW + wave, nslots = gridDim.x * NW;
    const int nb = (a.n_chunks + 2 * NP - 1) / (2 * NP);
 
+   // image -> LDS, 8 loads in flight per thread (one load per trip made 6 + 11 dependent round trips to L2 per workgroup)
    auto copy_image = [&](const void *img, int bytes) {
       const uint4 *src = reinterpret_cast<const uint4 *>(img);
       uint4 *dst = reinterpret_cast<uint4 *>(lds);
-      for (int i = tid; i < bytes / 16; i += 512) dst[i] = src[i];
+      const int n = bytes / 16;
+      for (int i0 = 0; i0 < n; i0 += 8 * 64 * NW) {
+         uint4 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 * NW + tid; v[u] = src[i < n ? i : 0]; }
+#pragma unroll
+         for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 * NW + tid; if (i < n) dst[i] = v[u]; }
+      }
    };
 
    if (a.first <= 3) {
@@ -443,7 +576,7 @@ __global__ __launch_bounds__(512) void k_enc_fused(EncFusedArgs a)
 #pragma unroll
                      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) y[nt][mt][r] = fmaxf(y[nt][mt][r], 0.0f);
+                        for (int r = 0; r < 4; ++r) y[nt][mt][r] = relu(y[nt][mt][r]);
                }
                tf_block<EncL2, 32, 2, false>(y, f2, v2, lane);
                // stride 2: step 2 t' of tile (lc' >> 3) -> column lc' = 8 (chunk in pair) + t' of the pair tile; same quad, same registers
@@ -533,21 +666,24 @@ __global__ __launch_bounds__(512) void k_enc_fused(EncFusedArgs a)
    }
 }
 
-// grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its 8 waves
+// grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its waves
 void launch_enc_fused(const EncFusedArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   // two pairs (4 chunks) per batch halve the LDS weight traffic per chunk and double a wave's independent MFMA chains; one pair keeps the
-   // waves balanced when a wave would get fewer than ~6 batches
+   static const char *force = getenv("VADC_ENC_NP");          // bring-up: "1" / "2" forces the batch size, a second character "8" / "c" the waves (8 / 12)
+   // two pairs (4 chunks) per batch halve the LDS weight traffic per chunk and double a wave's independent MFMA chains, but need 216 registers:
+   // 8 waves; one pair fits 168 registers: 12 waves, three per SIMD to hide each other's LDS, matrix-pipe and memory latency
    const int nb2 = (a.n_chunks + 3) / 4;
-   static const char *force = getenv("VADC_ENC_NP");          // bring-up: 1 / 2 forces the batch size
-   const bool two = force ? force[0] == '2' : nb2 >= 6 * 8 * max_wgs;
+   const bool two = force ? force[0] == '2' : false;
+   const int nw = (force && force[1]) ? (force[1] == 'c' ? 12 : (force[1] == 'g' ? 16 : 8)) : (two ? 8 : 12);
    const int nb = two ? nb2 : (a.n_chunks + 1) / 2;
-   int g = (nb + 7) / 8;
+   int g = (nb + nw - 1) / nw;
    if (g > max_wgs) g = max_wgs;
    if (g < 1) g = 1;
-   if (two) hipLaunchKernelGGL((k_enc_fused<2>), dim3(g), dim3(512), 0, st, a);
-   else     hipLaunchKernelGGL((k_enc_fused<1>), dim3(g), dim3(512), 0, st, a);
+   if (two)           hipLaunchKernelGGL((k_enc_fused<2, 8>), dim3(g), dim3(512), 0, st, a);
+   else if (nw == 16) hipLaunchKernelGGL((k_enc_fused<1, 16>), dim3(g), dim3(1024), 0, st, a);
+   else if (nw == 12) hipLaunchKernelGGL((k_enc_fused<1, 12>), dim3(g), dim3(768), 0, st, a);
+   else               hipLaunchKernelGGL((k_enc_fused<1, 8>), dim3(g), dim3(512), 0, st, a);
 }
 
 }  // namespace vadc
