@@ -23,6 +23,7 @@
 // or v4 (3, one-output sigmoid-then-mean).  (Round 1 also carried a one-wave-per-stream bring-up kernel, a step-sequential MFMA
 // kernel and forms with layer 0's input projection hoisted into a GEMM of its own; all measured slower -- DESIGN.md 4.3 -- and removed.)
 #include "common.h"
+#include <cstdint>
 
 namespace vadc {
 
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
 {
    // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
+   __shared__ __attribute__((aligned(16))) _Float16 xr[4][2][kTileS * 64];   // input ring: [step & 3][hi / lo][16-byte segment 0..7][stream] (LDS-DMA, see below)
    __shared__ float pd[2][8][2][kTileS];
 
    const int tid = threadIdx.x;
@@ -488,16 +490,44 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
    }
    // input sequence: 4 KB per step; a lane's B fragments of k-block kb: 16 bytes at (row col) + 32 kb + 8 quad of the hi and of the lo tile
    constexpr int kStepHalves = 2 * kTileS * 64;
-   const _Float16 *in_lane = in_tiles + ((size_t)tile * n_chunks + c0) * TS * kStepHalves + col * 64 + 8 * quad;
    _Float16 *out_seq = h0seq + ((size_t)tile * n_chunks + c0) * TS * kStepHalves;
    const int total = TS * cg;
-   h8v xnh[2], xnl[2];
+   // The input half of the gate GEMM (k-blocks 0, 1: W_x . x_t) does not depend on the recurrence: it is computed ONE SLOT AHEAD, into the
+   // accumulators the next slot starts from (bias + W_x . x_{k+1}), in the shadow of this slot's gate arithmetic -- only the 12 MFMAs of
+   // W_h . h_{k-1} per wave are left between the barrier and the gates.  The MFMA sequence on an accumulator is unchanged (bias, k-blocks
+   // 0, 1, 2, 3, each al.bh, ah.bl, ah.bh), so the bits are k_lstm_wavefront_h3's.
+   // The input tiles travel global -> LDS by LDS-DMA into a ring of four steps, FOUR slots ahead (fetched into registers one slot ahead, the
+   // loop-carried register rotation made every slot wait for the load it had just issued: 0.27 of the 0.96 us slot).  Waves 0-3 issue one
+   // 1 KB piece each per slot; lane l of piece h of a tile fetches row (l & 15), 16-byte segment 4 h + (l >> 4), so that the LDS image is
+   // [segment][stream] and a B-fragment read (stream = lane & 15, segment = 4 kb + quad) is conflict-free.
+   const _Float16 *in_seq = in_tiles + ((size_t)tile * n_chunks + c0) * TS * kStepHalves;
+   auto issue_x = [&](int step, int slot) {                   // waves 0-3 only
+      const int tl = wave >> 1, hf = wave & 1;
+      const _Float16 *g = in_seq + (size_t)min(step, total - 1) * kStepHalves + tl * (kTileS * 64) + (lane & 15) * 64 + (4 * hf + (lane >> 4)) * 8;
+      const unsigned dst = (unsigned)(uintptr_t)(lds_void_t *)&xr[slot & 3][tl][hf * 512];
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
+   };
+   auto xfrag = [&](int slot, int part, int kb) -> h8v { return *reinterpret_cast<const h8v *>(&xr[slot & 3][part][((4 * kb + quad) * 16 + col) * 8]); };
+   if (wave < 4) {
 #pragma unroll
-   for (int kb = 0; kb < 2; ++kb) {
-      xnh[kb] = *reinterpret_cast<const h8v *>(in_lane + 32 * kb);
-      xnl[kb] = *reinterpret_cast<const h8v *>(in_lane + kTileS * 64 + 32 * kb);
+      for (int i = 0; i < 4; ++i) issue_x(i, i);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    }
    __syncthreads();
+   f4v accx[2];
+#pragma unroll
+   for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+         const h8v bh = xfrag(0, 0, kb), bl = xfrag(0, 1, kb);
+         accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], bh, accx[m], 0, 0, 0);
+         accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bl, accx[m], 0, 0, 0);
+         accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bh, accx[m], 0, 0, 0);
+      }
+   }
+   __syncthreads();                                           // ring slot 0 is free for step 4
 
    int par = 0;
    float rsum[2] = {0.0f, 0.0f};
@@ -508,20 +538,10 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
    for (int k = 0; k < total; ++k) {
       const int chi = k / TS, t = k - chi * TS;
       f4v acc[2];
-      h8v xch[2], xcl[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-         for (int r = 0; r < 4; ++r) acc[m][r] = bias_r[m][r];
-      xch[0] = xnh[0]; xch[1] = xnh[1]; xcl[0] = xnl[0]; xcl[1] = xnl[1];
-      if (k + 1 < total) {                                    // next step's input, one slot ahead
-         const _Float16 *p = in_lane + (size_t)(k + 1) * kStepHalves;
-#pragma unroll
-         for (int kb = 0; kb < 2; ++kb) {
-            xnh[kb] = *reinterpret_cast<const h8v *>(p + 32 * kb);
-            xnl[kb] = *reinterpret_cast<const h8v *>(p + kTileS * 64 + 32 * kb);
-         }
-      }
+      acc[0] = accx[0]; acc[1] = accx[1];
+#ifndef VADC_LSTM_ABL_NOXLOAD     // (timing-only ablation: the slot without its input fetch)
+      if (wave < 4) issue_x(k + 4, k);                        // step k + 4 into the ring slot step k was read from (one slot ago)
+#endif
       // layer 0: write the h tile of slot k - 1 (LDS parity `par`, complete since the last barrier) to the h0 sequence while this slot computes.
       // Issued AFTER the input loads: vector-memory operations retire in order, so a store in front of them would put its completion on the
       // path of the next slot's input (measured: 0.96 instead of 0.70 ms per 672 slots)
@@ -532,15 +552,12 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
             *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
          __builtin_amdgcn_sched_barrier(0);
       }
+#ifndef VADC_LSTM_ABL_NOMFMA
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-         h8v bh, bl;
-         if (kb < 2) { bh = xch[kb]; bl = xcl[kb]; }          // k-blocks 0, 1: the layer's input; 2, 3: its own h
-         else {
-            const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
-            bh = *reinterpret_cast<const h8v *>(&hb[par][0][off]);
-            bl = *reinterpret_cast<const h8v *>(&hb[par][1][off]);
-         }
+      for (int kb = 2; kb < 4; ++kb) {                        // the layer's own h (k-blocks 2, 3)
+         const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
+         const h8v bh = *reinterpret_cast<const h8v *>(&hb[par][0][off]);
+         const h8v bl = *reinterpret_cast<const h8v *>(&hb[par][1][off]);
 #pragma unroll
          for (int m = 0; m < 2; ++m) {
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], bh, acc[m], 0, 0, 0);
@@ -548,13 +565,35 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bh, acc[m], 0, 0, 0);
          }
       }
+      // bias + W_x . x_{k+1}: the next slot's starting accumulators (the last slot computes one nobody uses)
+      h8v xbh[2], xbl[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) { xbh[kb] = xfrag(k + 1, 0, kb); xbl[kb] = xfrag(k + 1, 1, kb); }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+         for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
+#pragma unroll
+         for (int kb = 0; kb < 2; ++kb) {
+            accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], xbh[kb], accx[m], 0, 0, 0);
+            accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], xbl[kb], accx[m], 0, 0, 0);
+            accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], xbh[kb], accx[m], 0, 0, 0);
+         }
+      }
+#else
+      { const int off = col * kHPitch + 8 * quad; const h8v bh = *reinterpret_cast<const h8v *>(&hb[par][0][off]); acc[0][0] += (float)bh[0] + (float)xfrag(k + 1, 0, 0)[0]; }
+#endif
       _Float16 hi2[2], lo2[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
+#ifndef VADC_LSTM_ABL_NOGATES
          const float ig = fast_sigmoid(acc[m][0]), fg = fast_sigmoid(acc[m][1]);
          const float gg = fast_tanh(acc[m][2]), og = fast_sigmoid(acc[m][3]);
          c[m] = fmaf(fg, c[m], ig * gg);                       // as k_lstm_wavefront_h3
          const float hn = og * fast_tanh(c[m]);
+#else
+         const float hn = (acc[m][0] + acc[m][1]) * 0.01f + (acc[m][2] + acc[m][3]) * 0.01f;
+#endif
          hlast[m] = hn;
          hi2[m] = (_Float16)hn;
          lo2[m] = (_Float16)(hn - (float)hi2[m]);
@@ -585,6 +624,9 @@ __global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restric
          }
          if (quad == 1) { pd[k & 1][wave][0][col] = d0; if (DEC == 0) pd[k & 1][wave][1][col] = d1; }
       }
+      // waves 0-3: the piece of step k + 2 (issued two slots ago; read in the next slot) has landed -- newer operations may stay in flight: two
+      // pieces (layer 1), plus layer 0's h0-tile stores (counted together, retired in order)
+      if (wave < 4) { if (L == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
       __syncthreads();                                        // one barrier per slot
       par ^= 1;
       if (L == 1) {
