@@ -26,6 +26,8 @@ The JSON line is kept short (the driver reads the tail of stdout); its verbose f
   cpu_baseline -- the reference C backend (oracle/_ref, kind "reference") or the CPU oracle (kind "port") on this box's host cores: all
                   cores (one process per core, value = aggregate), one core at batch 96 and at batch 1 (BASELINE config 1)
   host_fed     -- the same step through vadc_amd_run_s16 (pageable host buffers in and out: PCIe-inclusive); never `value`
+  configs      -- {"4096x16": ...}: the largest single-GPU configuration (BASELINE config 3: 4096 streams x 16 chunks, SPLIT16 precision, graph replay)
+                  timed in the same run after the headline's timed region: value, ms_per_step, the dominant kernel's roofline fraction
 """
 import argparse
 import json
@@ -217,6 +219,53 @@ def dry_run(args, world, rank):
     return 0 if ok else 1
 
 
+# ------------------------------------------------------------------------------------------------- the largest single-GPU configuration, beside the headline
+def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20, warmup=5):
+    """BASELINE config 3 (4096 streams x 16 chunks per step, SPLIT16 precision, graph replay) timed in the same run, after the headline's timed
+    region: same step discipline (deferred joins, one issuing stream, three input buffers), device time from torch's synchronize on both sides.
+    Reported beside `value`, never instead of it."""
+    from vadc_amd import synth
+    from vadc_amd.engine import Engine
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=precision)
+    NB = 3
+    base = synth.make_streams(16, NB * Cn, seed0=777)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 16 + 1, 1))[:S])
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
+    d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
+    st = torch.cuda.Stream()
+    eng.set_option("defer_join", 1)
+    eng.set_option("groups", 1)
+
+    def step(i):
+        eng.run_device(d_in[i % NB].data_ptr(), np.int16, S, Cn, d_out[i % NB].data_ptr(), st.cuda_stream)
+    for i in range(2 * NB):
+        step(i)
+    torch.cuda.synchronize()
+    eng.set_option("graph", 1)
+    for i in range(2 * NB + warmup):
+        step(i)
+    torch.cuda.synchronize()
+    eng.reset_kernel_times()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.set_profiling(i % 8 == min(3, steps - 1))
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
+    fe_kernel = eng.get_option("frontend_kernel")
+    dom = max(kt, key=kt.get)
+    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt)
+    pipe = max(exe, key=lambda p_: exe[p_] / PEAKS[p_])
+    out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
+           "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
+           "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
+    eng.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- one rank
 def run_rank(args, world, rank, local_rank):
     weights_path = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor")
@@ -390,7 +439,8 @@ def run_rank(args, world, rank, local_rank):
                       "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32", 1: "split-f16 (2 x fp16 operands, fp32 accumulate), exact f32 STFT, f32 LSTM state", 2: "split-f16 GEMM STFT + f32"}[mode], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32 STFT + split-f16x3 GEMMs (f32 accumulate)", 1: "f32 STFT + split-f16x3 GEMMs (f32 accumulate), f32-MFMA fallbacks refused",
+                                                     2: "split-f16x3 GEMM STFT + split-f16x3 GEMMs (f32 accumulate)"}[mode], "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
                                    f"{ {0: 'fp32', 1: 'SPLIT16 precision mode (BASELINE config 3)', 2: 'FAST_STFT throughput mode (outside the 1e-4 bar)'}[mode]}, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
@@ -398,6 +448,11 @@ def run_rank(args, world, rank, local_rank):
             "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
                          "unit": "TFLOP/s", "frac": d["frac_of_pipe_peak"], "traffic": traffic,
                          "avg_launch_ms": d["ms_per_launch"], "chunks_per_launch": d["chunks_per_launch"], "pipe": d["pipe"],
+                         # the same rate against the fp32 FMA peak (what the vector ALU could do if the reference's tree allowed contraction), and the
+                         # measured HBM bytes of the launch over its algorithmic bytes (the front end: 3,072 B of s16 samples per chunk; others: the whole path's 3.1 KB)
+                         "frac_of_fma_peak": round(d["executed_tflops"] / PEAKS["fp32"], 4),
+                         "algorithmic_bytes_per_launch": d["chunks_per_launch"] * (3072 if dom == "k_frontend" else 3136),
+                         "traffic_over_algorithmic": (round(traffic / (d["chunks_per_launch"] * (3072 if dom == "k_frontend" else 3136)), 2) if traffic else None),
                          "executed_flop_per_chunk": d["executed_flop_per_chunk"][d["pipe"]],
                          "algorithmic_flop_per_chunk": d["algorithmic_flop_per_chunk"], "algorithmic_tflops": d["algorithmic_tflops"],
                          # the whole path in the dense formulation of SURVEY.md 8(d), as a rate only (no fraction: the kernels execute fewer FLOP than it counts)
@@ -413,18 +468,38 @@ def run_rank(args, world, rank, local_rank):
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph
         }
         if world == 1 and not args.no_host_fed:
-            # PCIe-inclusive rate of the synchronous host-buffer entry point (what a drop-in backend_run pays); reported, never `value`
-            host = np.ascontiguousarray(pcm[:, : Cn * 1536])
+            # PCIe-inclusive rates of the host-buffer entry points (what a drop-in backend_run caller pays); reported, never `value`.
+            #   value       -- vadc_amd_run_s16_async: page-locked host buffers, H2D of call k+1 beside the kernels of call k beside the D2H of call k-1
+            #   synchronous -- vadc_amd_run_s16: pageable buffers, copy -> run -> copy
+            host = [np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(NB)]
+            outs = [np.empty((S, Cn, 2), np.float32) for _ in range(NB)]
+            eng.set_option("groups", 1)
+            for i in range(2 * NB):
+                eng.run_async(host[i % NB], outs[i % NB])
+            eng.wait_async()
+            n_host = 12
+            t1 = time.perf_counter()
+            for i in range(n_host):
+                eng.run_async(host[i % NB], outs[i % NB])
+            eng.wait_async()
+            dta = time.perf_counter() - t1
             eng.set_option("defer_join", 0)                       # what a plain synchronous caller gets: the call pipelines its own chunk groups
             eng.set_option("groups", 0)
-            eng.run(host)
-            n_host = 5
+            eng.run(host[0])
+            n_sync = 4
             t1 = time.perf_counter()
-            for _ in range(n_host):
-                eng.run(host)
-            dt = time.perf_counter() - t1
-            out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dt, 1), "unit": "audio-seconds/sec", "ms_per_step": round(dt / n_host * 1e3, 3),
-                               "note": "vadc_amd_run_s16: pageable host s16 in, probabilities out, synchronous (H2D 3 KB + D2H 8 B per chunk inside the timed call)"}
+            for _ in range(n_sync):
+                eng.run(host[0])
+            dts = time.perf_counter() - t1
+            out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dta, 1), "unit": "audio-seconds/sec", "ms_per_step": round(dta / n_host * 1e3, 3),
+                               "pcie_gb_per_s": round(S * Cn * 3072 * n_host / dta / 1e9, 1),
+                               "synchronous": round(S * Cn * n_sync * CHUNK_SECONDS / dts, 1),
+                               "note": "vadc_amd_run_s16_async: page-locked host s16 in, probabilities out, three calls in flight (H2D 3 KB + D2H 8 B per chunk inside the "
+                                       "timed region); `synchronous` = vadc_amd_run_s16 on pageable buffers (copy -> run -> copy)"}
+        if world == 1 and not args.no_side_config and args.model == "v31" and not (S == 4096 and Cn == 16):
+            eng.close()
+            eng = None
+            out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         # The line the driver parses stays SHORT (it reads the tail of stdout): the per-kernel accounting and the long notes go to a details file
@@ -446,8 +521,11 @@ def run_rank(args, world, rank, local_rank):
             c["sample"] = c["sample"][:120]
             line["cpu_baseline"] = c
         line["details"] = os.path.relpath(os.path.abspath(args.details), ROOT)
+        if "configs" in line:
+            line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk != "kernels_ms"} for k, v in out["configs"].items()}
         print(json.dumps(line, separators=(",", ":")), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -464,6 +542,7 @@ def main():
     ap.add_argument("--chunks-per-step", type=int, default=96, help="chunks per stream and step (default 96 = vadc's window, vadc.c:799)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--no-side-config", action="store_true", help="skip the 4096 x 16 (BASELINE config 3) measurement that rides along with the default line")
     ap.add_argument("--model", choices=["v31", "v4"], default="v31",
                     help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")
     ap.add_argument("--precision", choices=["fp32", "split16", "fast_stft"], default="fp32",

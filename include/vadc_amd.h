@@ -147,11 +147,26 @@ int  vadc_amd_synchronize(vadc_amd_engine *e);
  * beside LSTM layer 0 of call k+1 beside layer 1 of call k) -- and this is how a consumer of the probabilities orders itself behind them. */
 int  vadc_amd_join(vadc_amd_engine *e, void *hip_stream);
 
+/* Host buffers, ASYNCHRONOUS: what a real backend_run caller holds -- host samples in, host probabilities out (vadc.c:873-909: the stream reader fills
+ * host memory; silero.h:53-74 hands it to the backend) -- without the copy -> run -> copy serialisation of vadc_amd_run_*.  A call returns as soon as its
+ * work is enqueued: the H2D copy on a copy stream of its own, the kernels behind it, the 8 bytes per chunk of probabilities back on a third stream
+ * behind the call's completion; up to three calls are in flight (the fourth waits, on the host, for the first).  Both host buffers are page-locked on
+ * first sight (hipHostRegister; ranges that are page-locked already are taken as they are) and must stay valid and unmodified until
+ * vadc_amd_wait_async.  Results are bit-identical to vadc_amd_run_device_* on the same inputs.  host_probs: [n_streams][n_chunks][2]. */
+int  vadc_amd_run_s16_async(vadc_amd_engine *e, const int16_t *host_pcm, int n_streams, int n_chunks, float *host_probs);
+int  vadc_amd_run_f32_async(vadc_amd_engine *e, const float *host_samples, int n_streams, int n_chunks, float *host_probs);
+/* Host-synchronous: every asynchronous call issued so far has delivered its probabilities. */
+int  vadc_amd_wait_async(vadc_amd_engine *e);
+
 /* ---- per-stream state (the reference has one implicit stream; silero.h:36-37) ---------------- */
 /* Zero the state of the listed streams (stream_ids == NULL: all max_streams). */
 int  vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *stream_ids, int n);
 int  vadc_amd_get_state(vadc_amd_engine *e, int stream, float *h /*[2][64]*/, float *c /*[2][64]*/);
 int  vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h, const float *c);
+/* Silero v5 only (caps.context_size = 64): the stream's 64-sample context, i.e. the tail of its previous window (vadc.c:697-701, 105-162) -- the third
+ * piece of per-stream state next to h and c; a stream saved with get_state + get_context and restored elsewhere continues bit-identically. */
+int  vadc_amd_get_context(vadc_amd_engine *e, int stream, float *ctx /*[64]*/);
+int  vadc_amd_set_context(vadc_amd_engine *e, int stream, const float *ctx /*[64]*/);
 
 /* ---- stage taps: the counterpart of the reference's bottom-up known-answer tests (test.c) ----- */
 enum {

@@ -387,14 +387,15 @@ def test_hipgraph_replay_matches_eager(weights_blob):
     assert np.array_equal(bits(want), bits(np.concatenate(outs, axis=1)))
 
 
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("S,Cn", [(256, 96), (4096, 16)])
-def test_hipgraph_replay_at_bench_sizes(weights_blob, S, Cn):
-    """the configurations bench.py runs (256 x 96: BASELINE config 2; 4096 x 16: config 3): graph replay on two alternating caller streams
-    and buffers, exactly as bench.py drives it, is bit-identical to eager calls"""
+def test_hipgraph_replay_at_bench_sizes(weights_blob, S, Cn, precision):
+    """the configurations bench.py runs (256 x 96: BASELINE config 2; 4096 x 16: config 3), in the fp32 and in the SPLIT16 precision mode (config 3's):
+    graph replay on two alternating caller streams and buffers, exactly as bench.py drives it, is bit-identical to eager calls"""
     import torch
     base = synth.make_streams(16, 4 * Cn, seed0=4100 + S)
     pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
-    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0, precision=precision)
     try:
         d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(4)]
         sts = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -916,3 +917,27 @@ def test_synchronous_entry_points_join_under_defer_join(weights_blob, orc):
         e.close()
     ref = orc.forward_streams(pcm)
     assert float(np.abs(got - ref).max()) < PROB_TOL
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.float32])
+def test_async_host_entry_points_bit_identical_to_the_device_path(weights_blob, dtype):
+    """vadc_amd_run_*_async (host buffers, H2D / kernels / D2H of consecutive calls overlapping, three calls in flight) delivers the bits of
+    vadc_amd_run_* for the same sequence of calls -- more calls than staging slots, forked and small calls mixed, state carried across them"""
+    S = 64
+    cuts = [(0, 40), (40, 41), (41, 80), (80, 120), (120, 125), (125, 160)]          # 2560-chunk calls fork; 64- and 320-chunk calls stay on the engine's stream
+    pcm = synth.make_streams(S, 160, seed0=515)
+    x = pcm if dtype == np.int16 else (pcm.astype(np.float32) / np.float32(32768))
+    parts = [np.ascontiguousarray(x[:, a * 1536:b * 1536]) for a, b in cuts]
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=40, device=0)
+    try:
+        want = np.concatenate([e.run(p) for p in parts], axis=1)
+        e.reset_streams()
+        outs = [np.full((S, b - a, 2), np.nan, np.float32) for a, b in cuts]
+        for p, o in zip(parts, outs):
+            e.run_async(p, o)
+        e.wait_async()
+        got = np.concatenate(outs, axis=1)
+        e.wait_async()                                       # idempotent
+    finally:
+        e.close()
+    assert np.array_equal(bits(want), bits(got))

@@ -171,3 +171,26 @@ def test_cli_with_v5_weights(gold):
     got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
     assert got.size == gold["probs64_speech0"].size
     assert float(np.abs(got - gold["probs64_speech0"]).max()) <= PROB_TOL + 5e-7        # %f quantises to 5e-7
+
+
+def test_save_and_restore_a_stream_onto_another_slot(eng):
+    """h, c AND the 64-sample context are the state of a v5 stream: saved after 20 windows and restored onto another slot, the stream continues
+    bit-identically; without the context it does not (vadc_amd_get_context / vadc_amd_set_context)"""
+    n = 40
+    pcm = streams512(3, n, seed0=321)
+    eng.reset_streams()
+    whole = eng.run(pcm)
+    eng.reset_streams()
+    eng.run(pcm[:, :20 * 512])
+    h, c = eng.get_state(1)
+    ctx = eng.get_context(1)
+    assert np.array_equal(ctx, pcm[1, 20 * 512 - 64:20 * 512].astype(np.float32) / np.float32(32768))
+    eng.reset_streams()
+    other = np.ascontiguousarray(pcm[[2, 1, 0]])               # stream 1's continuation now runs in slot 1 of a freshly reset engine ...
+    eng.set_state(1, h, c)
+    eng.set_context(1, ctx)
+    cont = eng.run(other[:, 20 * 512:])
+    assert np.array_equal(cont[1], whole[1, 20:])
+    eng.reset_streams()
+    eng.set_state(1, h, c)                                     # ... and differs when the context is left behind
+    assert not np.array_equal(eng.run(other[:, 20 * 512:])[1, :1], whole[1, 20:21])

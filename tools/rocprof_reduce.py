@@ -18,6 +18,11 @@ FE_SEEN = set()
 
 
 def short_name(full):
+    if "k_enc_fused" in full:
+        return "k_enc234"
+    m = re.search(r"k_lstm_layer<\d+, \d+, (\d)>", full) or re.search(r"k_lstm_layerILi\d+ELi\d+ELi(\d)E", full)     # rocprofv3 leaves some names mangled
+    if m:
+        return "k_lstm" if m.group(1) == "0" else "k_lstm_l1"
     m = re.search(r"k_layer_mfma<(\d+), (\d+), (\d+)", full) or re.search(r"k_layer<(\d+), (\d+), (\d+)", full)
     if m:
         return {("129", "16"): "k_layer1", ("258", "16"): "k_layer1", ("16", "32"): "k_layer2", ("32", "32"): "k_layer3", ("32", "64"): "k_layer4"}[(m.group(1), m.group(2))]
@@ -64,7 +69,7 @@ def main():
         src = find(a.kernel_trace, "*_kernel_stats.csv")
         with open(src) as f, open(os.path.join(a.out, a.tag + "_kernel_stats.csv"), "w") as g:
             for i, line in enumerate(f):
-                if i == 0 or "vadc::" in line:
+                if i == 0 or "vadc::" in line or "_ZN4vadc" in line:      # rocprofv3 leaves long template names mangled (k_lstm_layer)
                     g.write(line)
         print("wrote", os.path.join(a.out, a.tag + "_kernel_stats.csv"))
     if a.fetch and a.write:

@@ -8,9 +8,11 @@
 #include "common.h"
 #include "enc_fused_layout.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -157,6 +159,17 @@ struct vadc_amd_engine {
    void *d_encA = nullptr, *d_encB = nullptr;
    float *d_enc_scratch = nullptr;
    std::vector<unsigned char> h_encA, h_encB;   // built by build_weights, uploaded by vadc_amd_create
+   // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
+   // the D2H of call k-1, each on a stream of its own
+   struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
+   static constexpr int kAsyncSlots = 3;
+   AsyncSlot aslot[kAsyncSlots];
+   hipStream_t s_h2d = nullptr, s_d2h = nullptr, s_h2dx[3] = {nullptr, nullptr, nullptr};
+   hipEvent_t ev_h2dx[3] = {nullptr, nullptr, nullptr};
+   int h2d_parts = 1;                            // option "h2d_streams": pieces (= copy streams) of an asynchronous call's H2D copy
+   unsigned anext = 0;
+   struct HostRange { const char *p; size_t n; bool ours; };
+   std::vector<HostRange> pinned;                // host ranges already seen by the async entry points (ours: registered here, unregistered at destroy)
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
    LstmWeights lstm;
    // workspace
@@ -692,6 +705,16 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch};
    for (void *p : ptrs) if (p) (void)hipFree(p);
+   for (auto &sl : e->aslot) {
+      if (sl.d_in) (void)hipFree(sl.d_in);
+      if (sl.d_probs) (void)hipFree(sl.d_probs);
+      if (sl.in_done) (void)hipEventDestroy(sl.in_done);
+      if (sl.out_done) (void)hipEventDestroy(sl.out_done);
+   }
+   for (auto &r : e->pinned) if (r.ours) (void)hipHostUnregister(const_cast<char *>(r.p));
+   for (int i = 0; i < 3; ++i) { if (e->s_h2dx[i]) (void)hipStreamDestroy(e->s_h2dx[i]); if (e->ev_h2dx[i]) (void)hipEventDestroy(e->ev_h2dx[i]); }
+   if (e->s_h2d) (void)hipStreamDestroy(e->s_h2d);
+   if (e->s_d2h) (void)hipStreamDestroy(e->s_d2h);
    if (e->stream) (void)hipStreamDestroy(e->stream);
    for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
    if (e->sA) (void)hipStreamDestroy(e->sA);
@@ -935,6 +958,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return VADC_AMD_OK;
    }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
+   if (strcmp(key, "h2d_streams") == 0 && value >= 1 && value <= 4) { e->h2d_parts = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -1472,6 +1496,100 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    return VADC_AMD_OK;
 }
 
+// ---- asynchronous host-buffer entry points: the shape a real backend_run caller has (host buffers in and out, vadc.c:873-909) without the
+// synchronous copy -> run -> copy of vadc_amd_run_*.  A call returns once its work is enqueued; vadc_amd_wait_async returns when the probabilities of
+// every call issued so far are in their host buffers.
+static void pin_host_range(vadc_amd_engine *e, const void *ptr, size_t bytes)
+{
+   const char *p = static_cast<const char *>(ptr);
+   for (auto &r : e->pinned) if (p >= r.p && p + bytes <= r.p + r.n) return;
+   // page-locked memory lets the copy engine read / write the caller's buffer directly (pageable memory goes through a staging copy: 3x slower)
+   hipError_t he = hipHostRegister(const_cast<char *>(p), bytes, hipHostRegisterDefault);
+   if (he != hipSuccess) (void)hipGetLastError();          // already page-locked by the caller (hipHostMalloc, a pinned torch tensor), or not registrable: copy as is
+   e->pinned.push_back({p, bytes, he == hipSuccess});
+}
+
+template <typename T>
+static int run_async(vadc_amd_engine *e, const T *host_in, int n_streams, int n_chunks, float *host_probs, const char *who)
+{
+   int rc = check_shape(e, n_streams, n_chunks, who);
+   if (rc) return rc;
+   if (!host_in || !host_probs) return fail(VADC_AMD_EINVAL, "%s: NULL buffer", who);
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   if (!e->s_h2d) {
+      // The copy streams get a priority of their own (the lowest: a copy never needs to overtake a kernel): HIP multiplexes the streams of one priority
+      // onto a handful of hardware queues, and a copy queued behind the front end's kernels waits for them (measured, 256 x 96: 24-29 GB/s from
+      // normal-priority copy streams, 39-43 GB/s from these; tools/host_fed_probe.py)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      auto mk = [&](hipStream_t *st) -> hipError_t { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo); };
+      HIP_TRY(mk(&e->s_h2d), VADC_AMD_EHIP);
+      HIP_TRY(mk(&e->s_d2h), VADC_AMD_EHIP);
+      for (int i = 0; i < 3; ++i) {
+         HIP_TRY(mk(&e->s_h2dx[i]), VADC_AMD_EHIP);
+         HIP_TRY(hipEventCreateWithFlags(&e->ev_h2dx[i], hipEventDisableTiming), VADC_AMD_EHIP);
+      }
+   }
+   vadc_amd_engine::AsyncSlot &sl = e->aslot[e->anext++ % vadc_amd_engine::kAsyncSlots];
+   if (!sl.d_in) {
+      HIP_TRY(hipMalloc(&sl.d_in, e->max_items * kChunk * sizeof(float)), VADC_AMD_ENOMEM);
+      HIP_TRY(hipMalloc(&sl.d_probs, e->max_items * 2 * sizeof(float)), VADC_AMD_ENOMEM);
+      HIP_TRY(hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming), VADC_AMD_EHIP);
+      HIP_TRY(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming), VADC_AMD_EHIP);
+   }
+   if (sl.busy) HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP);      // the call that used this slot three calls ago: back-pressure
+   const size_t n = (size_t)n_streams * n_chunks;
+   pin_host_range(e, host_in, n * e->window * sizeof(T));
+   pin_host_range(e, host_probs, n * 2 * sizeof(float));
+   {
+      // option "h2d_streams" > 1: the input goes in that many pieces on as many copy streams (several copy engines on the link: up to 50 GB/s when the
+      // pieces land on different hardware queues, 30 when they do not -- one piece is the steadier default)
+      const size_t bytes = n * e->window * sizeof(T);
+      const int parts = (bytes >= (size_t)8 << 20) ? e->h2d_parts : 1;
+      const size_t piece = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+      for (int i = 0; i < parts; ++i) {
+         const size_t off = (size_t)i * piece;
+         if (off >= bytes) break;
+         hipStream_t cs = i == 0 ? e->s_h2d : e->s_h2dx[i - 1];
+         HIP_TRY(hipMemcpyAsync(static_cast<char *>(sl.d_in) + off, reinterpret_cast<const char *>(host_in) + off, std::min(piece, bytes - off), hipMemcpyHostToDevice, cs), VADC_AMD_EHIP);
+         if (i > 0) { HIP_TRY(hipEventRecord(e->ev_h2dx[i - 1], cs), VADC_AMD_EHIP); HIP_TRY(hipStreamWaitEvent(e->s_h2d, e->ev_h2dx[i - 1], 0), VADC_AMD_EHIP); }
+      }
+   }
+   HIP_TRY(hipEventRecord(sl.in_done, e->s_h2d), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamWaitEvent(e->stream, sl.in_done, 0), VADC_AMD_EHIP);
+   const int dj = e->defer_join;
+   e->defer_join = 1;                                       // consecutive calls overlap inside the engine; the D2H stream joins this one
+   rc = run_device<T>(e, static_cast<const T *>(sl.d_in), n_streams, n_chunks, sl.d_probs, e->stream);
+   e->defer_join = dj;
+   if (rc) return rc;
+   wait_last_all(e, e->s_d2h);
+   HIP_TRY(hipMemcpyAsync(host_probs, sl.d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_d2h), VADC_AMD_EHIP);
+   HIP_TRY(hipEventRecord(sl.out_done, e->s_d2h), VADC_AMD_EHIP);
+   sl.busy = true;
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_run_s16_async(vadc_amd_engine *e, const int16_t *host_pcm, int n_streams, int n_chunks, float *host_probs)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "run_s16_async: NULL engine");
+   return run_async<int16_t>(e, host_pcm, n_streams, n_chunks, host_probs, "run_s16_async");
+}
+
+extern "C" int vadc_amd_run_f32_async(vadc_amd_engine *e, const float *host_samples, int n_streams, int n_chunks, float *host_probs)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "run_f32_async: NULL engine");
+   return run_async<float>(e, host_samples, n_streams, n_chunks, host_probs, "run_f32_async");
+}
+
+extern "C" int vadc_amd_wait_async(vadc_amd_engine *e)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "wait_async: NULL engine");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   for (auto &sl : e->aslot)
+      if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP); sl.busy = false; }
+   return VADC_AMD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-stream state
 // ---------------------------------------------------------------------------------------------------
@@ -1529,6 +1647,28 @@ extern "C" int vadc_amd_set_state(vadc_amd_engine *e, int stream, const float *h
    { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    HIP_TRY(hipMemcpy(e->d_h + (size_t)stream * 128, h, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpy(e->d_c + (size_t)stream * 128, c, 128 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+// Silero v5: the third piece of per-stream state, the last 64 samples of the previous window (vadc.c:697-701 keeps it on the host; here it lives on the
+// device next to h and c) -- saving or migrating a stream needs it too
+extern "C" int vadc_amd_get_context(vadc_amd_engine *e, int stream, float *ctx)
+{
+   if (!e || !ctx || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "get_context: bad argument");
+   if (e->model != VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "get_context: only Silero v5 keeps a sample context (caps.context_size = 0)");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
+   HIP_TRY(hipMemcpy(ctx, e->d_ctx5 + (size_t)stream * 64, 64 * sizeof(float), hipMemcpyDeviceToHost), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_set_context(vadc_amd_engine *e, int stream, const float *ctx)
+{
+   if (!e || !ctx || stream < 0 || stream >= e->max_streams) return fail(VADC_AMD_EINVAL, "set_context: bad argument");
+   if (e->model != VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "set_context: only Silero v5 keeps a sample context (caps.context_size = 0)");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
+   HIP_TRY(hipMemcpy(e->d_ctx5 + (size_t)stream * 64, ctx, 64 * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
 

@@ -119,6 +119,20 @@ class Engine:
         x = np.ascontiguousarray(input_samples, dtype=np.float32).reshape(1, batch_size * self.window)
         return self.run(x)[0]
 
+    def run_async(self, samples: np.ndarray, out: np.ndarray):
+        """asynchronous host-buffer call (vadc_amd_run_*_async): `samples` (int16 or float32, C-contiguous [S, C*window]) and `out` (float32 [S, C, 2])
+        must stay alive and untouched until wait_async(); up to three calls are in flight"""
+        if not (samples.flags.c_contiguous and out.flags.c_contiguous and out.dtype == np.float32):
+            raise ValueError("run_async needs C-contiguous buffers and a float32 output")
+        S, Cn = samples.shape[0], samples.reshape(samples.shape[0], -1).shape[1] // self.window
+        if out.shape != (S, Cn, 2):
+            raise ValueError("out must be [streams, chunks, 2]")
+        fn = {np.dtype(np.int16): self._L.vadc_amd_run_s16_async, np.dtype(np.float32): self._L.vadc_amd_run_f32_async}[samples.dtype]
+        self._check(fn(self._h, _ptr(samples), S, Cn, _ptr(out)))
+
+    def wait_async(self):
+        self._check(self._L.vadc_amd_wait_async(self._h))
+
     def run_device(self, d_in_ptr: int, dtype, n_streams: int, n_chunks: int, d_probs_ptr: int, hip_stream: int = 0):
         fn = self._L.vadc_amd_run_device_s16 if np.dtype(dtype) == np.int16 else self._L.vadc_amd_run_device_f32
         self._check(fn(self._h, C.c_void_p(d_in_ptr), n_streams, n_chunks, C.c_void_p(d_probs_ptr),
@@ -150,6 +164,16 @@ class Engine:
         h = np.ascontiguousarray(h, dtype=np.float32).reshape(2, 64)
         c = np.ascontiguousarray(c, dtype=np.float32).reshape(2, 64)
         self._check(self._L.vadc_amd_set_state(self._h, stream, _ptr(h), _ptr(c)))
+
+    def get_context(self, stream: int) -> np.ndarray:
+        """Silero v5: the stream's 64-sample context (tail of its previous window)"""
+        ctx = np.empty(64, np.float32)
+        self._check(self._L.vadc_amd_get_context(self._h, stream, _ptr(ctx)))
+        return ctx
+
+    def set_context(self, stream: int, ctx: np.ndarray):
+        ctx = np.ascontiguousarray(ctx, dtype=np.float32).reshape(64)
+        self._check(self._L.vadc_amd_set_context(self._h, stream, _ptr(ctx)))
 
     # ---- stage taps ----
     def stage_from_samples(self, samples_f32: np.ndarray, stage: str) -> np.ndarray:
