@@ -297,6 +297,10 @@ def run_rank(args, world, rank, local_rank):
     dev = f"cuda:{local_rank}"
     blob = open(weights_path, "rb").read()
     S, Cn = args.streams, args.chunks_per_step
+    total_streams = args.total_streams if args.total_streams > 0 else S * world
+    if args.total_streams > 0:                       # a ragged total (--verify-dump runs): this rank's block of the contiguous partition
+        lo_, hi_ = shard.stream_block(rank, world, total_streams)
+        S = hi_ - lo_
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision={"fp32": 0, "split16": 1, "fast_stft": 2}[args.precision])
     mode = eng.caps()["precision"]
     eng.set_option("groups", args.groups)
@@ -306,11 +310,15 @@ def run_rank(args, world, rank, local_rank):
 
     # synthetic input: 16 distinct speech-like streams per rank tiled over S, NB step buffers used in turn
     NB = args.caller_streams
-    base = synth.make_streams(min(S, 16), NB * Cn, seed0=1234 + 100 * rank)
-    pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+    if args.verify_dump:                              # every GLOBAL stream its own signal (seed = 5000 + global id): what tests/test_bench_spawn.py re-creates
+        lo_, _ = shard.stream_block(rank, world, total_streams)
+        pcm = np.concatenate([synth.make_streams(1, NB * Cn, seed0=5000 + lo_ + i) for i in range(S)])
+    else:
+        base = synth.make_streams(min(S, 16), NB * Cn, seed0=1234 + 100 * rank)
+        pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
     d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
-    gather = shard.ProbabilityGather(S * world, Cn, "cpu" if rehearsal else dev)          # weak scaling: S streams per GPU, contiguous blocks
+    gather = shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev)      # weak scaling: S streams per GPU, contiguous blocks
     assert gather.hi - gather.lo == S
     # The engine's internal in-order streams overlap the stages of consecutive steps: front end + encoder of step k+2 beside LSTM layer 0 of step
     # k+1 beside layer 1 of step k (layer-major LSTM, <= 512 streams), or front end + encoder beside the whole LSTM.  Default: all steps issued
@@ -321,7 +329,7 @@ def run_rank(args, world, rank, local_rank):
     if args.defer_join:
         eng.set_option("defer_join", 1)
 
-    def step(i):
+    def step(i, gather=gather):
         b = i % NB
         if args.defer_join:
             # ONE issuing stream: the call does not block it; a side stream joins the call (device-side wait) and carries the gather
@@ -392,8 +400,30 @@ def run_rank(args, world, rank, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if args.verify_dump:
+        # The N-rank path proves its answers: from reset state, K steps issued back to back exactly as in the timed region (deferred joins, side-stream
+        # gathers behind vadc_amd_join, no host synchronisation in between), each step gathered into a buffer set of its own; rank 0 writes the K gathered
+        # [total_streams, chunks, 2] tensors.  tests/test_bench_spawn.py recomputes sampled streams of EVERY rank with the CPU oracle.
+        K = 2 * NB - 1
+        eng.synchronize(); torch.cuda.synchronize()
+        eng.set_option("graph", 1 if args.graph else 0)
+        eng.reset_streams()
+        for b_ in range(NB):
+            gathered[b_] = None
+        gv = [shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev) for _ in range(K)]
+        if world > 1:
+            dist.barrier()
+        for i in range(K):
+            step(i, gv[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            res = np.stack([(g.result() if world > 1 else d_probs[i % NB]).detach().cpu().numpy().copy() for i, g in enumerate(gv)])
+            np.savez(args.verify_dump, probs=res, total_streams=total_streams, world=world, chunks=Cn, buffers=NB, steps=K)
+
     if rank == 0:
-        chunks_per_step = S * Cn * world
+        chunks_per_step = total_streams * Cn
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
         kt = eng.kernel_times()
         fe_kernel = eng.get_option("frontend_kernel")
@@ -496,7 +526,7 @@ def run_rank(args, world, rank, local_rank):
                                "synchronous": round(S * Cn * n_sync * CHUNK_SECONDS / dts, 1),
                                "note": "vadc_amd_run_s16_async: page-locked host s16 in, probabilities out, three calls in flight (H2D 3 KB + D2H 8 B per chunk inside the "
                                        "timed region); `synchronous` = vadc_amd_run_s16 on pageable buffers (copy -> run -> copy)"}
-        if world == 1 and not args.no_side_config and args.model == "v31" and not (S == 4096 and Cn == 16):
+        if world == 1 and not args.no_side_config and not args.verify_dump and args.model == "v31" and not (S == 4096 and Cn == 16):
             eng.close()
             eng = None
             out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1)}
@@ -542,6 +572,10 @@ def main():
     ap.add_argument("--chunks-per-step", type=int, default=96, help="chunks per stream and step (default 96 = vadc's window, vadc.c:799)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--total-streams", type=int, default=0, help="(with --verify-dump) total streams over all ranks, partitioned in contiguous blocks -- may be ragged")
+    ap.add_argument("--verify-dump", default="", metavar="FILE.npz",
+                    help="after the timed region: reset the state, run 2 x buffers - 1 steps with one distinct signal per GLOBAL stream and write rank 0's gathered "
+                         "probabilities of every step (what tests/test_bench_spawn.py checks against the CPU oracle)")
     ap.add_argument("--no-side-config", action="store_true", help="skip the 4096 x 16 (BASELINE config 3) measurement that rides along with the default line")
     ap.add_argument("--model", choices=["v31", "v4"], default="v31",
                     help="v31 = Silero v3.1 (BASELINE headline, default); v4 = Silero v4 16k (BASELINE config 4, not the headline)")

@@ -92,6 +92,20 @@ static inline void *backend_init(MemoryArena *arena, String8 model_path_arg, Sil
    return engine;
 }
 
+/* The caller picks the window after backend_init -- `--sequence_count` clamped to [input_size_min, input_size_max] (vadc.c:743-752) -- and sizes
+ * buffers.input_samples as input_count x batch floats (vadc.c:773-781).  The engine must run THAT window: the Silero v4 graph takes 512 ... 1536
+ * samples (onnx_helpers.c:164-170), of which this engine builds 512 / 1024 / 1536 (8 kHz branch: 256 / 512 / 768).  Any other size aborts with a
+ * message, like an onnxruntime error would (onnx_helpers.h:5-14) -- never a silent read past the caller's buffer. */
+static void vadc_hip_sync_window(vadc_amd_engine *engine, int input_count)
+{
+   vadc_amd_caps caps;
+   if (vadc_amd_get_caps(engine, &caps) != VADC_AMD_OK || caps.window_samples == input_count) return;
+   if (vadc_amd_set_option(engine, "window", input_count) != VADC_AMD_OK) {
+      fprintf(stderr, "vadc_backend_hip: --sequence_count %d is not a window this backend runs: %s\n", input_count, vadc_amd_last_error());
+      abort();
+   }
+}
+
 static inline void backend_run(MemoryArena *arena, void *context_, Silero_Config config)
 {
    (void)arena;
@@ -111,6 +125,7 @@ static inline void backend_run(MemoryArena *arena, void *context_, Silero_Config
                 (size_t)config.input_count * sizeof(float));
       in = win;
    }
+   vadc_hip_sync_window((vadc_amd_engine *)context->backend, config.input_count);      /* a no-op after backend_create_tensors; one caps query */
    /* `batch_size` consecutive windows of the one stream: silero.h:64-68, lstm.c:275-277 */
    int rc = vadc_amd_run_f32((vadc_amd_engine *)context->backend, in, 1, config.batch_size, context->buffers.output);
    if (rc != VADC_AMD_OK) {                        /* the ORT backend aborts on error (onnx_helpers.h:5-14) */
@@ -121,7 +136,8 @@ static inline void backend_run(MemoryArena *arena, void *context_, Silero_Config
 
 static inline void backend_create_tensors(Silero_Config config, void *backend, Tensor_Buffers buffers)
 {
-   (void)config; (void)backend; (void)buffers;     /* silero.h:76-81: nothing to bind, buffers are copied per run */
+   (void)buffers;                                  /* silero.h:76-81: nothing to bind, buffers are copied per run */
+   vadc_hip_sync_window((vadc_amd_engine *)backend, config.input_count);
 }
 
 #endif /* VADC_BACKEND_HIP_H */

@@ -87,3 +87,22 @@ def test_adapter_header_compiles_against_the_reference_vadc_h():
     r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-fsyntax-only", "-include", "stddef.h", "-DONNX_INFERENCE_ENABLED=0",
                         "-I", ref, "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_layout_mirrors_match_the_reference_headers():
+    """tests/c/vadc_layout_mirror.h (what tests/c/adapter_run.c drives the backend trio with on the GPU box) against the reference's vadc.h / string8.h:
+    sizeof and every field's offset and width, by _Static_assert (tests/c/layout_check.c).  Build container only."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "vadc.h")):
+        pytest.skip("reference tree not present")
+    r = subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", "-include", "stddef.h", "-DONNX_INFERENCE_ENABLED=0", "-I", ref,
+                        "-I", os.path.join(ROOT, "tests", "c"), os.path.join(ROOT, "tests", "c", "layout_check.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_adapter_runner_compiles_over_the_mirrors():
+    """tests/c/adapter_run.c = the backend trio driven like vadc.c:686-795 / 56-162 over the layout mirrors: must compile wherever gcc is (it RUNS in
+    tests/test_gpu_adapter.py)"""
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "c"),
+                        os.path.join(ROOT, "tests", "c", "adapter_run.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -62,3 +62,45 @@ def test_multi_rank_gpu_code_path_on_one_gpu():
     d = _run("--gpus", "2", "--one-gpu-rehearsal", "--steps", "7", "--warmup", "2", "--streams", "32", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed", env=env)
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["streams_per_gpu"] == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,total", [(2, 37), (3, 100)])
+def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
+    """the N > 1 rank path PROVES its answers on one GPU: `--one-gpu-rehearsal --verify-dump` runs the rank code (per-rank engines on a RAGGED
+    contiguous partition of the streams, deferred joins, side-stream gathers behind vadc_amd_join, five steps back to back from reset state) and
+    writes rank 0's gathered [total_streams, chunks, 2] of every step; streams of EVERY rank -- first, middle and last of its block -- are recomputed
+    with the CPU oracle.  A wrong stream -> rank mapping, a gather that reads a buffer before its call has finished, or state that does not carry
+    from step to step fails here."""
+    import numpy as np
+    from oracle import oracle as O
+    from vadc_amd import shard, synth
+    dump = str(tmp_path / "gathered.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    Cn = 6
+    d = _run("--gpus", str(world), "--one-gpu-rehearsal", "--steps", "3", "--warmup", "1", "--streams", str(-(-total // world)), "--total-streams", str(total),
+             "--chunks-per-step", str(Cn), "--no-cpu-baseline", "--no-host-fed", "--verify-dump", dump, env=env)
+    assert d["n_gpus"] == world
+    g = np.load(dump)
+    probs, NB, K = g["probs"], int(g["buffers"]), int(g["steps"])
+    assert probs.shape == (K, total, Cn, 2) and int(g["world"]) == world
+    blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
+    orc = O.Oracle(blob)
+    for r in range(world):
+        lo, hi = shard.stream_block(r, world, total)
+        for s in sorted({lo, (lo + hi) // 2, hi - 1}):
+            pcm = synth.make_streams(1, NB * Cn, seed0=5000 + s)[0]                     # bench.py --verify-dump: seed = 5000 + global stream id
+            seq = np.concatenate([pcm[(k % NB) * Cn * 1536:((k % NB) + 1) * Cn * 1536] for k in range(K)])
+            want = orc.forward_stream(seq).reshape(K, Cn, 2)
+            assert float(np.abs(probs[:, s] - want).max()) <= 1e-4, (r, s)
+
+
+@pytest.mark.gpu
+def test_rccl_gather_between_two_gpus():
+    """the real collective: two ranks on two GPUs, backend nccl (= RCCL), the path's ProbabilityGather.  Needs two visible GPUs -- a one-GPU box skips."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL needs two")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run("--gpus", "2", "--steps", "5", "--warmup", "2", "--streams", "64", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed", env=env)
+    assert d["n_gpus"] == 2 and d["value"] > 0
