@@ -186,6 +186,10 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
+/* The first encoder layer's transformer block in isolation, for the reference's op-level fixtures (test.c:931, 1105, 1143): `y` [n][16][25] enters
+ * the layer's own kernel behind its conv block; what = 1: dual_head_attention incl. the out projection (transformer.c:13-153), 2: transformer_block
+ * (:160-234), 3: layer_norm with the block's norm1 parameters (misc.c:143-210).  out [n][16][25].  Silero v3.1 only. */
+int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, int n, float *out);
 /* Switches (all int-valued; an unknown key or value is VADC_AMD_EINVAL):
  *   "graph"       1: kernel sequences (a whole small call; the front end + encoder of one chunk group of a forked call) are captured into hipGraphs on
  *                 first use and replayed afterwards -- the fork / join and the call-to-call ordering stay outside the graphs, so replays of consecutive

@@ -38,6 +38,7 @@ struct LayerWeightsM {
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_enc_fused(const EncFusedArgs &, int, hipStream_t);
+void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
    const float *dec_w; const float *dec_b;
@@ -1736,6 +1737,23 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, ItemMap{n, 0, n}, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * e->stage_elems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, int n, float *out)
+{
+   if (!e || !y || !out || what < 1 || what > 3) return fail(VADC_AMD_EINVAL, "debug_layer1_block: bad argument");
+   if (e->model != VADC_AMD_MODEL_V31) return fail(VADC_AMD_EINVAL, "debug_layer1_block: Silero v3.1 only (the other models carry no transformer block)");
+   if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_layer1_block: n=%d out of range", n);
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
+   hipStream_t st = e->stream;
+   const size_t bytes = (size_t)n * 16 * 25 * sizeof(float);
+   HIP_TRY(hipMemcpyAsync(e->d_tap, y, bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   launch_layer1_tap(what, e->d_tap, e->lwm[0], e->d_Y, n, ItemMap{n, 0, n}, st);
+   HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(out, e->d_Y, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }

@@ -232,8 +232,11 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 //        OVERLAP by four steps: lanes 48..63 of the first half carry its steps 0..15 (owning 0..13), lanes 0..11 of the second half its steps
 //        12..23 (owning 14..23); the two extra steps on either side are read again from memory and only feed their neighbours.  124 of 128
 //        lanes carry data, 120 own an output column: a fifth less matrix and vector work per chunk.  LDS row pitch 144.
+// TAP (stage taps for the reference's op-level fixtures, vadc_amd_debug_layer1_block): the first layer's OWN instantiation entered behind the conv block --
+//        `in` is y [n][16][25] -- and left after 1 = the attention incl. its out projection (transformer.c:13-153), 2 = the transformer block
+//        (:160-234), 3 = LayerNorm 1 alone (misc.c:143-210); `out` is [n][16][25].  TAP = 0 compiles to the hot kernel unchanged.
 template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false, bool H3 = false,
-          int WAVES = 4>
+          int WAVES = 4, int TAP = 0>
 __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    constexpr int XR = K1 ? (CPW <= 40 ? CPW : 24) : 1;
    float xv[XR];
    const float *xa = in, *xb = in;
-   if constexpr (K1) {
+   if constexpr (K1 && !TAP) {
       int cb0, t0; bool own0;
       const bool cm0 = colmap(64 * (wave >> 2) + lane, cb0, t0, own0);   // 8 waves: waves 0-3 = lanes 0..63 of the layout, 4-7 = lanes 64..127; wave & 3 = channel quarter
       const int item0 = blockIdx.x * NCH + cb0;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    // K = 1 form: depthwise weights [ch][k0..k4, bias] in LDS, so that a channel's six values are broadcast LDS reads that sit in
    // the same batch as its global loads (as scalar loads they cost one exposed scalar-cache round trip per channel)
    __shared__ __attribute__((aligned(8))) float dws[K1 ? 4 * CPW * 6 : 2];
-   if (K1) {
+   if (K1 && !TAP) {
       for (int i = tid; i < 4 * CPW; i += NT) {
 #pragma unroll
          for (int j = 0; j < 5; ++j) dws[i * 6 + j] = i < CIN ? w.dw_w[i * 5 + j] : 0.0f;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       }
       if (!FIRST) __syncthreads();
    }
-   if (FIRST) {
+   if (FIRST && !TAP) {
       // adaptive normalization offset mm per chunk (misc.c:65-82), spread over the first wave: lane = (chunk, frame) computes its
       // frame mean and its smoothed value; one lane per chunk adds the T smoothed values in the reference's order
       __shared__ float fms[NCH * T], rs[NCH * T];
@@ -386,6 +389,25 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    PH(0);
    f4v acc[MT];
    acc_init<MT>(acc, w.cb_b, lane);
+   // this lane's column in the accumulator layout and its place in the [n][D][T] tap tensors
+   [[maybe_unused]] int tap_off = -1;
+   if constexpr (TAP != 0) {
+      static_assert(!TAP || (K1 && WAVES == 4 && D == 16 && HAS_TF), "taps enter the first layer's K = 1 instantiation");
+      const int tcol = 16 * wave + lc;
+      int tcb, tt; bool town;
+      const bool tv = colmap(tcol, tcb, tt, town) && (blockIdx.x * NCH + tcb < n_chunks);
+      if (tv) tap_off = map(blockIdx.x * NCH + tcb) * (D * T) + tt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[0][r] = tap_off >= 0 ? in[tap_off + (4 * quad + r) * T] : 0.0f;     // y, as the conv block would have left it
+      if constexpr (TAP == 3) {
+         layer_norm_acc<MT>(acc, w.n1_w, w.n1_b, lane);
+#pragma unroll
+         for (int r = 0; r < 4; ++r) if (tap_off >= 0) out[tap_off + (4 * quad + r) * T] = acc[0][r];
+         return;
+      }
+      acc_store<MT, kPitch>(acc, Yb, lane, wave);
+      __syncthreads();
+   } else
    if constexpr (DIRECT) {
    // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x) | x)        conv.c:761-814 ---------------------------
    // The workgroup's input tile -- NCH chunks x CIN channels x T steps, one CONTIGUOUS run of CIN T floats per chunk -- is staged once
@@ -894,6 +916,11 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
          load_b_h3<KB>(bh, bl, Sh, Sl, HP, lane, wave);
          gemm_acc_h3<MT, KB>(p, w.out_h, bh, bl, lane);
       } else gemm_acc<MT, D / 4, kPitch>(p, w.out_f, D / 4, 0, ATT, lane, wave);
+      if constexpr (TAP == 1) {                               // dual_head_attention's result: softmax(k q^T) v through the out projection
+#pragma unroll
+         for (int r = 0; r < 4; ++r) if (tap_off >= 0) out[tap_off + (4 * quad + r) * T] = p[0][r];
+         return;
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] += p[mt];
    }
@@ -934,6 +961,11 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       for (int mt = 0; mt < MT; ++mt) acc[mt] += g[mt];
    }
    layer_norm_acc<MT>(acc, w.n2_w, w.n2_b, lane);
+   if constexpr (TAP == 2) {                                  // transformer_block's result
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (tap_off >= 0) out[tap_off + (4 * quad + r) * T] = acc[0][r];
+      return;
+   }
    if constexpr (H3) acc_store_h3<MT>(acc, Sh, Sl, HP, lane, wave); else acc_store<MT, kPitch>(acc, Yb, lane, wave);
    PH(6);
    }  // HAS_TF
@@ -1048,6 +1080,17 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
       else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 1, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
       else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 0, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
       break;
+   }
+}
+
+// stage taps of the first layer (vadc_amd_debug_layer1_block): y [n][16][25] -> [n][16][25]
+void launch_layer1_tap(int what, const float *y, const LayerWeightsM &w, float *out, int n, ItemMap map, hipStream_t st)
+{
+   const dim3 grid((n + 1) / 2), block(256);
+   switch (what) {
+   case 1: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true, false, 4, 1>), grid, block, 0, st, y, nullptr, w, out, n, map, 0); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true, false, 4, 2>), grid, block, 0, st, y, nullptr, w, out, n, map, 0); break;
+   default: hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true, false, 4, 3>), grid, block, 0, st, y, nullptr, w, out, n, map, 0); break;
    }
 }
 

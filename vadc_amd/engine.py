@@ -190,6 +190,13 @@ class Engine:
         self._check(self._L.vadc_amd_debug_stage_from_stage(self._h, _ptr(x), x.shape[0], f, t, _ptr(out)))
         return out
 
+    def layer1_block(self, y: np.ndarray, what: str) -> np.ndarray:
+        """the first layer's transformer block in isolation: y [n, 16, 25] -> [n, 16, 25]; what = "attention" | "transformer_block" | "layer_norm" """
+        y = np.ascontiguousarray(y, dtype=np.float32).reshape(-1, 16, 25)
+        out = np.empty_like(y)
+        self._check(self._L.vadc_amd_debug_layer1_block(self._h, {"attention": 1, "transformer_block": 2, "layer_norm": 3}[what], _ptr(y), y.shape[0], _ptr(out)))
+        return out
+
     def lstm_decoder(self, enc: np.ndarray) -> np.ndarray:
         """enc: [S, C, 64, steps] (steps = 7 for v3.1, 3 for v4) -> probs [S, C, 2] (uses and updates the per-stream state)."""
         enc = np.ascontiguousarray(enc, dtype=np.float32)
