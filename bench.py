@@ -172,11 +172,32 @@ def spawn_ranks(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    # supervise every rank: one that dies at start-up (bad device, out of memory) would leave the others in the rendezvous or in the gather until the
+    # collective's timeout -- stop them and report its return code instead
+    import threading
+    out_box = []
+    reader = threading.Thread(target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + 3600
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0].returncode if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(out_box[0] if out_box else "")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return abs(failed) if failed else max(abs(p.returncode or 0) for p in procs)
 
 
 # ------------------------------------------------------------------------------------------------- dry run (CPU, gloo)
@@ -615,6 +636,8 @@ def main():
         return 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.caller_streams < 1 or (args.gpus > 1 and args.defer_join and args.caller_streams < 2):
+        raise SystemExit("--caller-streams must be >= 1, and >= 2 on several GPUs with deferred joins (one issuing stream + at least one side stream for the gather)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)                  # nothing above imported torch or touched HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -398,3 +398,37 @@ def test_first_stage_widths_agree(blob, orc):
                 e.close()
         assert float(np.abs(out[0] - out[4]).max()) < 2e-5, (S, Cn)        # last-bit differences of the stage, carried through the LSTM
         assert float(np.abs(out[0][:, :, 1] - orc.forward_streams(pcm)).max()) < PROB_TOL
+
+
+def test_8khz_container_without_dft_symmetries_is_refused():
+    """the 8 kHz branch runs on the GEMM front end only (the tree kernel is built for the 1536-sample / 24-frame geometry of the 16 kHz branch); a 37-tensor
+    container whose basis lacks the real-DFT symmetries that front end needs used to be accepted and would have read 1536-sample chunks from
+    768-sample buffers: vadc_amd_create refuses it"""
+    from vadc_amd import testtensor as tt
+    ts = tt.load(V4_8K_WEIGHTS)
+    basis = ts[0][1].copy()
+    basis.reshape(-1).view(np.uint32)[5 * 256 + 37] += 1          # one ulp in one tap breaks the mirror symmetry
+    ts[0] = (ts[0][0], basis)
+    with pytest.raises(VadcAmdError) as ei:
+        Engine(tt.dumps(ts), max_streams=2, max_chunks_per_call=4, device=0)
+    assert ei.value.code == -2 and "8 kHz" in str(ei.value)
+
+
+def test_a_rejected_option_leaves_captured_graphs_alone(blob):
+    """vadc_amd_set_option validates before it drops the captured graphs: after a rejected call the next replay is a replay (same bits, and the
+    engine still reports graph mode)"""
+    pcm = synth.make_streams(4, 6, seed0=77)
+    e = Engine(blob, max_streams=4, max_chunks_per_call=6, device=0)
+    try:
+        e.set_option("graph", 1)
+        a = e.run(pcm)
+        with pytest.raises(VadcAmdError):
+            e.set_option("window", 777)
+        with pytest.raises(VadcAmdError):
+            e.set_option("no_such_option", 1)
+        e.reset_streams()
+        b = e.run(pcm)
+        assert e.get_option("graph") == 1
+    finally:
+        e.close()
+    assert np.array_equal(a, b)

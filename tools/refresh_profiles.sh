@@ -4,8 +4,8 @@
 # rocprofv3 rules on this pool: program directly after `--`, PMC passes separate from tracing, one counter group per pass.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
-rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC
-NB="--no-cpu-baseline --no-host-fed"
+rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC $O/pmcD
+NB="--no-cpu-baseline --no-host-fed --no-side-config"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py $NB > $O/prof_kt.log 2>&1
 echo "kernel trace done"
 B="python3 bench.py --steps 3 --warmup 1 $NB"
@@ -15,6 +15,7 @@ echo "traffic passes done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB -- $B > $O/pmcB.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmcC -- $B > $O/pmcC.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $O/pmcD -- $B > $O/pmcD.log 2>&1
 echo "compute passes done"
 # HBM traffic of the 4096-stream workloads (BASELINE configs 3 and 4)
 for w in "v4 fp32" "v31 split16"; do

@@ -772,6 +772,11 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    else memcpy(e->stage_elems, kStageElemsV31, sizeof(kStageElemsV31));
    int rc = e->model == VADC_AMD_MODEL_V4 ? build_weights_v4(e, ts) : (e->model == VADC_AMD_MODEL_V5 ? build_weights_v5(e, ts) : build_weights(e, ts));
    if (rc != VADC_AMD_OK) { vadc_amd_destroy(e); return rc; }
+   if (e->model == VADC_AMD_MODEL_V4 && e->sample_rate == 8000 && !e->gemm_ok) {
+      // the v4 tree front end exists for the 1536-sample / 24-frame geometry of the 16 kHz branch only; it would read n x 1536 samples from an n x 768 buffer
+      vadc_amd_destroy(e);
+      return fail(VADC_AMD_EWEIGHTS, "create: the 8 kHz branch of Silero v4 runs on the GEMM front end only, and this container's STFT basis lacks the real-DFT symmetries that front end needs");
+   }
    if (precision == VADC_AMD_PRECISION_SPLIT16 && (!e->lstm_h3_ok || (e->model != VADC_AMD_MODEL_V4 && !e->enc_h3_ok))) {
       vadc_amd_destroy(e);
       return fail(VADC_AMD_EWEIGHTS, "create: SPLIT16 precision runs every GEMM with split-fp16 operands, but a weight of this container does not fit fp16's range; use VADC_AMD_PRECISION_FP32");
@@ -928,11 +933,22 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d exists for Silero v3.1 only (the v4 stages carry no split-fp16 GEMMs)", key, value);
    if (e->precision == VADC_AMD_PRECISION_SPLIT16 && value == 3 && (strcmp(key, "encoder") == 0 || strcmp(key, "lstm") == 0))
       return fail(VADC_AMD_EINVAL, "set_option: %s=3 selects fp32 MFMA; the SPLIT16 precision mode runs split-fp16 GEMMs only", key);
-   // every switch below changes the launch sequence a captured graph replays: drop the captured graphs (after their last replay has finished)
-   if (strcmp(key, "graph") != 0 && !e->graphs.empty()) {
-      if (e->ev_last_valid && e->last_a) HIP_TRY(hipEventSynchronize(e->last_a), VADC_AMD_EHIP);   // every replay is followed by the record last_a points at
-      for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
-      e->graphs.clear();
+   // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
+   // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
+   {
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams"};
+      bool known = false;
+      for (const char *k : keys) known = known || strcmp(key, k) == 0;
+      if (known && !e->graphs.empty()) {
+         vadc_amd_engine probe = *e;                        // validate on a copy: same checks, no side effects on the device
+         probe.graphs.clear();
+         const int rc_probe = vadc_amd_set_option(&probe, key, value);
+         probe.pinned.clear();
+         if (rc_probe != VADC_AMD_OK) return rc_probe;
+         if (e->ev_last_valid && e->last_a) HIP_TRY(hipEventSynchronize(e->last_a), VADC_AMD_EHIP);   // every replay is followed by the record last_a points at
+         for (auto &ge : e->graphs) { (void)hipGraphExecDestroy(ge.x); (void)hipGraphDestroy(ge.g); }
+         e->graphs.clear();
+      }
    }
    if (e->model == VADC_AMD_MODEL_V4 && strcmp(key, "frontend") == 0 && value == 1 && (e->window != kChunk || e->sample_rate != 16000))
       return fail(VADC_AMD_EINVAL, "set_option: the v4 tree front end exists for 1536-sample windows of the 16 kHz branch only");

@@ -250,12 +250,16 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    constexpr int kCol = 16 * WAVES;                       // columns per workgroup (one MFMA N tile per wave)
    constexpr int kPitch = WAVES == 4 ? kPitchG : 144;     // shadows the file-scope pitch from here on; 144 % 32 == 16 as well
    constexpr int NT = 64 * WAVES;                         // threads
-   constexpr int NCOLV = WAVES == 4 ? NCH * T : kCol;     // columns that may carry data (8 waves: see colmap)
+   // TS = column stride of a chunk.  K = 1 first stage, 4 waves: TWO DEAD COLUMNS between the chunks (T + 2; they hold zeros), so that the depthwise
+   // conv's wave shifts bring in the zero padding at both ends of a chunk by themselves -- no per-tap select -- and the shifted taps can ride on the
+   // multiply-adds as DPP operands (9 vector instructions per channel instead of 19)
+   constexpr int TS = (K1 && WAVES == 4 && NCH * (T + 2) - 2 <= kCol) ? T + 2 : T;
+   constexpr int NCOLV = WAVES == 4 ? NCH * TS : kCol;    // columns that may carry data (8 waves: see colmap; TS > T: the dead columns among them do not)
    static_assert(NCH * T <= kCol, "too many chunks per workgroup");
    // column -> (chunk slot, step); returns whether the column carries data; `owner`: whether it owns an output (8 waves: the overlap lanes do not)
    constexpr int P0 = 64 - 2 * T;                         // 8 waves: lanes of the first half that carry the middle chunk's steps 0 .. P0-1
    auto colmap = [](int col, int &cb, int &t, bool &owner) -> bool {
-      if constexpr (WAVES == 4) { cb = col / T; t = col - cb * T; owner = col < NCH * T; return owner; }
+      if constexpr (WAVES == 4) { cb = col / TS; t = col - cb * TS; owner = cb < NCH && t < T; return owner; }
       else {
          const int g = col >> 6, l = col & 63;
          if (g == 0) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    constexpr int TOUT = 1 + (T - 1) / STRIDE;
    constexpr int HD = D / 2;
    constexpr int TP = (T + 3) / 4 * 4;                  // chunk stride of the Q / V rows in LDS (attention layout)
-   static_assert(!HAS_TF || ((kCol - 1) / T) * TP + ((kCol - 1) % T) < kPitch, "padded Q / V rows must fit the LDS row pitch");
+   static_assert(!HAS_TF || (TS > T ? (NCH - 1) * TP + (T - 1) : ((kCol - 1) / T) * TP + ((kCol - 1) % T)) < kPitch, "padded Q / V rows must fit the LDS row pitch");
    constexpr int MT = D / 16;
    constexpr int CINP = (CIN + 3) / 4 * 4;
    constexpr int KKW = CINP / 4;                        // k-steps of the pw / proj weights
@@ -333,7 +337,11 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       for (int i = 0; i < XR; ++i) {
          const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
          const bool first_half = (FIRST >= 2) && ch < kBins;  // magnitude half of the v4 input
+#ifdef VADC_L1_ABL_NOLOAD
+         xv[i] = (float)(ch + lane) * 0.01f;
+#else
          xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)((FIRST >= 2) ? ch - kBins : ch) * T];
+#endif
       }
    }
    __shared__ float mm_s[FIRST ? NCH : 1];
@@ -584,20 +592,43 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       }
       const float xfh = FIRST == 3 ? fmaf(__builtin_amdgcn_exp2f(xraw * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f) : xraw;   // magnitude from log1p(2^20 m)
       const float x = cvalid ? (first_half ? xfh : xraw - mm) : 0.0f;                                 // misc.c:84-96
-      const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
-      const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
       const float2 k01 = k01r[i % WR], k23 = k23r[i % WR], k45 = k45r[i % WR];
       const float a = wra[i % WR], b = wrb[i % WR];
       if (i + WR < CPW) request(i + WR, i % WR);
       float dv = k45.y;                                    // conv.c:17-53
-      dv = fmaf(l2 ? xm2 : 0.0f, k01.x, dv);
-      dv = fmaf(l1 ? xm1 : 0.0f, k01.y, dv);
+#ifdef VADC_L1_ABL_NODW
       dv = fmaf(x, k23.x, dv);
-      dv = fmaf(r1 ? xp1 : 0.0f, k23.y, dv);
-      dv = fmaf(r2 ? xp2 : 0.0f, k45.x, dv);
-      dv = fmaxf(dv, 0.0f);          // not masked for invalid columns: columns never mix outside a chunk's attention, dead columns stay dead
+      if constexpr (false) {
+#else
+      if constexpr (TS > T) {
+#endif
+         // two dead (zero) columns on either side of every chunk: the shifted registers ARE the zero-padded taps, and the distance-2 taps ride on
+         // the multiply-add as its DPP operand (a wave shift of the distance-1 register).  Same order of the five products as below: same bits.
+         // (inline asm: hipcc does not fold a wave shift into v_fmac; the s_nop covers the VALU-write -> DPP-read wait states it would pad)
+         const float xm1 = dpp_wave_shr1(x);
+         asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(xm1), "v"(k01.x));
+         dv = fmaf(xm1, k01.y, dv);
+         dv = fmaf(x, k23.x, dv);
+         const float xp1 = dpp_wave_shl1(x);
+         dv = fmaf(xp1, k23.y, dv);
+         asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(xp1), "v"(k45.x));
+         dv = __builtin_amdgcn_fmed3f(dv, 0.0f, 3.0e38f);  // max(dv, 0) in one instruction
+      } else if constexpr (TS == T) {
+         const float xm1 = dpp_wave_shr1(x), xm2 = dpp_wave_shr1(xm1);
+         const float xp1 = dpp_wave_shl1(x), xp2 = dpp_wave_shl1(xp1);
+         dv = fmaf(l2 ? xm2 : 0.0f, k01.x, dv);
+         dv = fmaf(l1 ? xm1 : 0.0f, k01.y, dv);
+         dv = fmaf(x, k23.x, dv);
+         dv = fmaf(r1 ? xp1 : 0.0f, k23.y, dv);
+         dv = fmaf(r2 ? xp2 : 0.0f, k45.x, dv);
+         dv = fmaxf(dv, 0.0f);       // not masked for invalid columns: columns never mix outside a chunk's attention, dead columns stay dead
+      }
+#ifdef VADC_L1_ABL_NOMFMA       // timing-only ablations of the first stage's channel loop (tools/l1_ablate.sh; results wrong)
+      P[0] += a * dv; P2[0] += b * x;
+#else
       P = __builtin_amdgcn_mfma_f32_16x16x1f32(a, dv, P, 0, 0, 0);      // channels past CIN: zero weight rows (host padding)
       P2 = __builtin_amdgcn_mfma_f32_16x16x1f32(b, x, P2, 0, 0, 0);
+#endif
    }
 #pragma unroll
    for (int e = 0; e < 16; ++e) P[e] += P2[e];
@@ -713,8 +744,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    h8v ybh[KB], ybl[KB];
    load_b_h3<KB>(ybh, ybl, Sh, Sl, HP, lane, wave);        // y of this wave's columns: in registers for both heads (the attention output overwrites the tiles)
    const int qcol = 16 * wave + lc;
-   const int qcb = qcol / T;
-   const int qcolp = qcb * TP + (qcol - qcb * T);
+   const int qcb = qcol / TS;
+   const int qcolp = qcb * TP + (qcol - qcb * TS);
 #pragma unroll
    for (int h = 0; h < 2; ++h) {
       f4v q[3 * MTH];
@@ -748,7 +779,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       {
          // FOUR adjacent lanes share one column's task of this head: lane p takes a quarter of the head's hd dimensions
          const int p = tid & 3, i = tid >> 2;
-         const int icb = i / T;
+         const int icb = i / TS;
          constexpr int HH = HD / 4, TQ = TP / 4;
          static_assert(HH == 8, "one 16-byte store of halves per lane");
          _Float16 *dsh = Sh + i * HP + h * HD + p * HH, *dsl = Sl + i * HP + h * HD + p * HH;
@@ -822,8 +853,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
       // padded to TP = a multiple of 4 (the row pitch has room: NCH TP <= 72), so that the attention below fetches a row's T
       // values of one chunk with T/4 aligned 16-byte reads instead of T scalar ones -- that phase is bound by LDS instructions.
       const int qcol = 16 * wave + lc;
-      const int qcb = qcol / T;
-      const int qcolp = qcb * TP + (qcol - qcb * T);
+      const int qcb = qcol / TS;
+      const int qcolp = min(qcb * TP + (qcol - qcb * TS), kPitch - 1);      // (dead columns past the last chunk stay inside the row)
 #pragma unroll
       for (int mt = 0; mt < 3 * MT; ++mt) {
          const int cdst = (mt >= MT && mt < 2 * MT) ? qcol : qcolp;
@@ -843,12 +874,12 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    {
       const int p = tid & 1, task = tid >> 1;
       const int h = task / kCol, i = task - h * kCol;
-      const int icb = i / T;
+      const int icb = i / TS;
       constexpr int HH = HD / 2, TQ = TP / 4;
       float *dst = ATT + (h * HD + p * HH) * kPitch + i;
       _Float16 *dsh = Sh + i * HP + h * HD + p * HH, *dsl = Sl + i * HP + h * HD + p * HH;    // H3: this lane's HH consecutive k of column i
       float ov[HH];
-      if (i < NCOLV) {
+      if (i < NCOLV && i - icb * TS < T) {
          const float *Q = QKV + (h * HD + p * HH) * kPitch + icb * TP, *K = QKV + (D + h * HD + p * HH) * kPitch + i;
          const float *V = QKV + (2 * D + h * HD + p * HH) * kPitch + icb * TP;
          float sc[TP];
@@ -1071,7 +1102,11 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
    switch (layer) {
    case 0:
       if (slab) hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+#ifdef VADC_L1_ABL_NOTF
+      else      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+#else
       else      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+#endif
       break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
