@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
          const int ch = min(c0 + i, c1 - 1);               // wave-uniform; channels past the range repeat the last one (zero weights)
          const bool first_half = (FIRST >= 2) && ch < kBins;  // magnitude half of the v4 input
 #ifdef VADC_L1_ABL_NOLOAD
-         xv[i] = (float)(ch + lane) * 0.01f;
+         xv[i] = (float)(ch + lane) * 0.01f; (void)first_half;
 #else
          xv[i] = first_half ? xb[(size_t)ch * T] : xa[(size_t)((FIRST >= 2) ? ch - kBins : ch) * T];
 #endif
