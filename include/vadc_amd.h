@@ -208,9 +208,11 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "frontend"    Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins 0..32, the other 96 bins from the basis'
  *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
  *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = k_frontend_gemm (default), 1 = the tree kernel with the v4 geometry
- *   "encoder"     0 = MFMA layer kernels (default); 2 = first stage as the LDS slab path instead of the K = 1 MFMA form; 3 = fp32 MFMA for the GEMMs of
- *                 layers 2-4 instead of split-fp16 MFMA (also what runs when a weight does not fit fp16); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per
- *                 workgroup instead of 8 waves / 5 chunks
+ *   "encoder"     0 (default) = first layer as one launch, layers 2-4 of Silero v3.1 fused into ONE persistent launch (k_enc_fused: activations in registers,
+ *                 split-fp16 MFMA; falls back to one launch per layer when a weight does not fit fp16); 2 = first stage as the LDS slab path instead of the
+ *                 K = 1 MFMA form; 3 = one launch per layer with fp32 MFMA for the GEMMs of layers 2-4; 5 (Silero v3.1) = one launch per layer with split-fp16
+ *                 MFMA (round 2's hot path); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per workgroup instead of 8 waves / 5 chunks
+ *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
  *                 1: magnitudes are written by the front end and read by the first stage
  *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream
