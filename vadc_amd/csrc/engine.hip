@@ -1096,11 +1096,11 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
 // one stream tile, and whole-chip front-end + encoder time per chunk.
-static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 1.0 : (lk == 6 ? 1.6 : 3.9); }
+static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9); }
 static double enc_us_per_chunk(const vadc_amd_engine *e)
 {
    if (e->model == VADC_AMD_MODEL_V4) return 0.022;
-   return e->use_gemm_frontend() ? 0.027 : (e->sym_ok && e->frontend_variant == 0 ? 0.038 : 0.080);
+   return e->use_gemm_frontend() ? 0.022 : (e->sym_ok && e->frontend_variant == 0 ? 0.033 : 0.075);      // round 3: layers 2-4 fused (0.010 -> 0.0046 us per chunk)
 }
 
 // LSTM kernel for this call: option "lstm" 0 = auto.  3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when
@@ -1142,8 +1142,13 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    // (round 1, 256 streams: 1.038 M -> 1.089 M, chain 1.13 -> 1.14 ms; 512: 1.092 -> 1.140 M; 1024 on 64 CUs: 1.074 -> 1.151 M).  Not with
    // several workgroups per CU (1024 streams on 24 shared CUs: chain 1.13 -> 2.76 ms), not when the chain is the critical path (128
    // streams: 955 K -> 943 K): then the masks are DISJOINT.
-   const int w1 = (lstm_wgs + 7) / 8 * 8;
-   if (e->cu_partition == 1 && e->lstm_steps * slot_us <= 0.7 * 0.9 * n_streams * per_chunk_us) *shared = true;
+   // whole groups of 8 CUs PER STREAM: the layer-major form splits the partition in two halves (layer 0 / layer 1), and a half of 12 or 20 CUs
+   // put two workgroups on one CU while another idled (192 / 320 streams: layer 1's chain 1.1 - 1.2 ms instead of 0.6)
+   const int tiles_ = (n_streams + 15) / 16;
+   const int w1 = lk == 7 ? 2 * ((tiles_ + 7) / 8 * 8) : (lstm_wgs + 7) / 8 * 8;
+   // (round 3: on shared CUs the chain runs 2.0 - 2.3 x slower than alone -- 256 streams: layer chains 0.51 / 0.60 -> 0.84 / 0.90 ms and the step 0.81 ->
+   // 0.91 ms -- so sharing needs that much slack, not the 1.6 x of the round-2 kernels)
+   if (e->cu_partition == 1 && 2.3 * e->lstm_steps * slot_us <= n_streams * per_chunk_us) *shared = true;
    // Silero v5: the recurrence's workgroup (8 waves x 205 VGPRs) needs a CU to itself; on a shared CU the encoder grid's workgroups keep taking each
    // other's place and it only starts when that grid has drained (measured: encoder 1.58 + recurrence 0.58 ms back to back)
    if (e->model == VADC_AMD_MODEL_V5 && e->cu_partition != 2) *shared = false;
