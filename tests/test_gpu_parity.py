@@ -588,6 +588,23 @@ def test_encoder_gemm_forms_agree(eng, gold_py, stage):
     assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
 
 
+@pytest.mark.parametrize("stage", ["layer2", "layer3", "layer4"])
+def test_fused_encoder_forms_agree_with_the_per_layer_kernels(eng, gold_py, stage):
+    """layers 2-4 in one launch (k_enc_fused, the default; both of its batch forms) against one launch per layer (option encoder=5, round 2's hot path):
+    different kernels -- activations in registers and attention on the matrix cores vs LDS tiles and vector attention -- the same math to fp32 rounding;
+    23 chunks = ragged last batches in both forms"""
+    x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
+    eng.set_option("encoder", 5); ref = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 0)
+    outs = []
+    for form in (1, 2):
+        eng.set_option("encoder_batch", form); outs.append(eng.stage_from_samples(x, stage))
+    eng.set_option("encoder_batch", 0)
+    assert not np.array_equal(bits(outs[0]), bits(ref))
+    assert np.array_equal(bits(outs[0]), bits(outs[1]))               # the two batch forms run the same arithmetic per chunk
+    assert float(np.abs(outs[0] - ref).max()) < 5e-5, float(np.abs(outs[0] - ref).max())
+
+
 def test_split_fp16_encoder_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):
     """a layer GEMM weight that does not fit fp16: the engine keeps the fp32 MFMA form for the encoder (bit-identical to option encoder=3)"""
     ts = tt.loads(weights_blob)
@@ -972,3 +989,35 @@ def test_async_host_entry_points_bit_identical_to_the_device_path(weights_blob, 
     finally:
         e.close()
     assert np.array_equal(bits(want), bits(got))
+
+
+def test_three_engines_alive_in_one_process(weights_blob, orc):
+    """a long-lived host with several engines: three engines (different workspace sizes, forked and small calls, deferred joins on one of them) are
+    created, used interleaved, destroyed in another order than they were created, and a fourth one is created afterwards -- every result is the
+    oracle's, and teardown (which relies on hipFree's device-wide wait instead of synchronising the CU-masked streams) does not hang or disturb the others"""
+    import torch
+    pcm = synth.make_streams(48, 48, seed0=4242)
+    engines = [Engine(weights_blob, max_streams=s, max_chunks_per_call=c, device=0) for s, c in ((48, 48), (16, 24), (48, 8))]
+    try:
+        engines[2].set_option("defer_join", 1)
+        d_in = torch.from_numpy(np.ascontiguousarray(pcm[:, : 8 * 1536])).cuda()
+        d_out = torch.empty((48, 8, 2), dtype=torch.float32, device="cuda")
+        st = torch.cuda.Stream()
+        a = engines[0].run(pcm)                                                # 2304 chunks: forks
+        engines[2].run_device(d_in.data_ptr(), np.int16, 48, 8, d_out.data_ptr(), st.cuda_stream)
+        b0 = engines[1].run(pcm[:16, : 24 * 1536])                             # 384 chunks: on the engine's own stream
+        engines[2].join(st.cuda_stream); st.synchronize()
+        c = d_out.cpu().numpy()
+        engines[0].close()                                                    # first created, first destroyed, the others keep working
+        b1 = engines[1].run(pcm[:16, 24 * 1536:])
+        engines[2].close()
+        late = Engine(weights_blob, max_streams=8, max_chunks_per_call=4, device=0)
+        d = late.run(pcm[:8, : 4 * 1536])
+        late.close()
+    finally:
+        for e in engines:
+            e.close()
+    ref = orc.forward_streams(pcm)
+    assert float(np.abs(a[:, :, 1] - ref).max()) < PROB_TOL
+    assert float(np.abs(np.concatenate([b0, b1], axis=1)[:, :, 1] - ref[:16]).max()) < PROB_TOL
+    assert float(np.abs(c[:, :, 1] - ref[:, :8]).max()) < PROB_TOL and float(np.abs(d[:, :, 1] - ref[:8, :4]).max()) < PROB_TOL

@@ -37,7 +37,7 @@ struct LayerWeightsM {
    const _Float16 *pw_h, *pj_h;
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
-void launch_enc_fused(const EncFusedArgs &, int, hipStream_t);
+void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
@@ -171,6 +171,7 @@ struct vadc_amd_engine {
    unsigned anext = 0;
    struct HostRange { const char *p; size_t n; bool ours; };
    std::vector<HostRange> pinned;                // host ranges already seen by the async entry points (ours: registered here, unregistered at destroy)
+   int enc_batch = 0;                           // option "encoder_batch": form of k_enc_fused (0 / 1: 12 waves x one pair tile per batch, 2: 8 waves x two)
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
    LstmWeights lstm;
    // workspace
@@ -936,7 +937,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -976,6 +977,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "h2d_streams") == 0 && value >= 1 && value <= 4) { e->h2d_parts = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder_batch") == 0 && value >= 0 && value <= 2) { e->enc_batch = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -989,6 +991,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
+   else if (strcmp(key, "encoder_batch") == 0) *value = e->enc_batch;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
    else if (strcmp(key, "window") == 0) *value = e->window;
@@ -1047,7 +1050,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          a.tap3 = last == 2 ? e->d_act[2] : nullptr;
          a.tap4 = (last == 3 && lstm_layout == 0) ? e->d_act[3] : nullptr;
          a.n_chunks = n; a.first = l + 1; a.last = last + 1; a.map = map;
-         launch_enc_fused(a, encoder_cus(e, st), st);
+         launch_enc_fused(a, encoder_cus(e, st), e->enc_batch, st);
          return;
       }
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);

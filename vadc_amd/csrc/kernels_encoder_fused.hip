@@ -22,7 +22,6 @@
 //   order (written and read back by the same wave).  A fragments are conflict-free 16-byte LDS reads (hi and lo blocks lane-linear).
 #include "common.h"
 #include "enc_fused_layout.h"
-#include <cstdlib>
 
 namespace vadc {
 
@@ -666,24 +665,21 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
    }
 }
 
-// grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its waves
-void launch_enc_fused(const EncFusedArgs &a, int max_wgs, hipStream_t st)
+// grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its waves.
+// form 0 / 1: 12 waves, one pair tile (two chunks) per batch -- 168 registers, three waves per SIMD; form 2: 8 waves, two pair tiles per batch (half the
+// LDS weight traffic per chunk, two independent MFMA chains per wave, 212 registers).  Measured alone on the chip per 24,576 / 65,536 chunks:
+// 0.110 / 0.329 ms against 0.117 / 0.326 ms (tools/enc_rate.py); 16 waves spill (0.114).  Option "encoder_batch" selects.
+void launch_enc_fused(const EncFusedArgs &a, int max_wgs, int form, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   static const char *force = getenv("VADC_ENC_NP");          // bring-up: "1" / "2" forces the batch size, a second character "8" / "c" the waves (8 / 12)
-   // two pairs (4 chunks) per batch halve the LDS weight traffic per chunk and double a wave's independent MFMA chains, but need 216 registers:
-   // 8 waves; one pair fits 168 registers: 12 waves, three per SIMD to hide each other's LDS, matrix-pipe and memory latency
-   const int nb2 = (a.n_chunks + 3) / 4;
-   const bool two = force ? force[0] == '2' : false;
-   const int nw = (force && force[1]) ? (force[1] == 'c' ? 12 : (force[1] == 'g' ? 16 : 8)) : (two ? 8 : 12);
-   const int nb = two ? nb2 : (a.n_chunks + 1) / 2;
+   const bool two = form == 2;
+   const int nw = two ? 8 : 12;
+   const int nb = two ? (a.n_chunks + 3) / 4 : (a.n_chunks + 1) / 2;
    int g = (nb + nw - 1) / nw;
    if (g > max_wgs) g = max_wgs;
    if (g < 1) g = 1;
-   if (two)           hipLaunchKernelGGL((k_enc_fused<2, 8>), dim3(g), dim3(512), 0, st, a);
-   else if (nw == 16) hipLaunchKernelGGL((k_enc_fused<1, 16>), dim3(g), dim3(1024), 0, st, a);
-   else if (nw == 12) hipLaunchKernelGGL((k_enc_fused<1, 12>), dim3(g), dim3(768), 0, st, a);
-   else               hipLaunchKernelGGL((k_enc_fused<1, 8>), dim3(g), dim3(512), 0, st, a);
+   if (two) hipLaunchKernelGGL((k_enc_fused<2, 8>), dim3(g), dim3(512), 0, st, a);
+   else     hipLaunchKernelGGL((k_enc_fused<1, 12>), dim3(g), dim3(768), 0, st, a);
 }
 
 }  // namespace vadc
