@@ -29,6 +29,16 @@
 
 namespace vadc {
 
+// The first stage (K = 1 form, Silero v3.1) is compiled for SIX waves per SIMD = six workgroups per CU: 80 registers (the input ring holds 8 channels
+// ahead instead of all 33) and 25 KB of LDS.  Measured in the step (tools/l1_occupancy.sh): 5 workgroups / whole input up front 0.225 ms, 6 / ring of 16
+// 0.224, 6 / ring of 8 0.218, 6 / ring of 24 0.279 (spills).
+#ifndef VADC_L1_XR
+#define VADC_L1_XR 8
+#endif
+#ifndef VADC_L1_WAVES
+#define VADC_L1_WAVES 6
+#endif
+
 #ifdef VADC_PHASE_PROF
 __device__ unsigned long long g_phase[4][16];      // [layer][phase] accumulated cycles of (workgroup 0 mod 64, thread 0)
 __device__ unsigned int g_phase_n[4];
@@ -237,7 +247,7 @@ __device__ __forceinline__ void layer_norm_acc(f4v (&x)[MT], const float *__rest
 //        (:160-234), 3 = LayerNorm 1 alone (misc.c:143-210); `out` is [n][16][25].  TAP = 0 compiles to the hot kernel unchanged.
 template <int CIN, int D, int T, int STRIDE, bool HAS_PROJ, int FIRST, int LSTM_OUT, int NCH, bool DIRECT, bool HAS_TF = true, bool K1 = false, bool H3 = false,
           int WAVES = 4, int TAP = 0>
-__global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
+__global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) void k_layer_mfma(const float *__restrict__ in,   // [n][CIN][T]
                                                     const float *__restrict__ fm,   // [4][fm_stride] partial bin sums (FIRST) or null
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
@@ -294,7 +304,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
 #else
    constexpr bool PHD = H3 && HAS_TF && D == 64;
 #endif
-   constexpr int ROWS_B = (DIRECT && !HAS_TF) ? 56 : (PHD ? 3 * HD : ((DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab));
+   // (K = 1 first stage with 4 waves: 52 rows = the 16 KB of the partial-sum exchange; with 64 the sixth workgroup did not fit a CU's LDS)
+   constexpr int ROWS_B = (DIRECT && !HAS_TF) ? 56 : (PHD ? 3 * HD : ((K1 && WAVES == 4 && 3 * D <= 52) ? 52 : ((DIRECT || 3 * D > 2 * kSlab) ? 3 * D : 2 * kSlab)));
    static_assert(!H3 || (DIRECT && HAS_TF && D % 32 == 0), "split-fp16 layer GEMMs: transformer layers with D = 32 / 64");
    constexpr int HP = D + 8, KB = H3 ? D / 32 : 1;       // H3: pitch (halves) of the split activation tiles, k-blocks per GEMM
    __shared__ __attribute__((aligned(16))) _Float16 SH[H3 ? 2 * kCol * HP : 8];   // H3: [hi | lo][column][k]: the B operand of every GEMM of the block, reused in place
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? 5 : 1) void k_layer
    constexpr int CPW = K1 ? (CIN + 3) / 4 : 1;           // input channels per wave
    // x travels through a ring of XR registers: the first XR channels are requested here, channel i + XR when channel i has been
    // consumed (v3.1: XR = CPW = 33, everything up front; v4's 65 channels per wave would cost 65 VGPRs and an occupancy step)
-   constexpr int XR = K1 ? (CPW <= 40 ? CPW : 24) : 1;
+   constexpr int XR = K1 ? ((CPW <= 40 && VADC_L1_WAVES <= 5) ? CPW : (CPW <= 40 ? VADC_L1_XR : 24)) : 1;
    float xv[XR];
    const float *xa = in, *xb = in;
    if constexpr (K1 && !TAP) {
