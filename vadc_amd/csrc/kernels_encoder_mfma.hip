@@ -887,21 +887,26 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
       const int h = task / kCol, i = task - h * kCol;
       const int icb = i / TS;
       constexpr int HH = HD / 2, TQ = TP / 4;
-      float *dst = ATT + (h * HD + p * HH) * kPitch + i;
+      // which HH of the head's HD dimensions lane p takes.  H3: the consecutive half p HH .. (its outputs are one 16-byte store of halves).  fp32 form
+      // (the first layer): the INTERLEAVED ones p, p + 2, ... -- the pair's rows are then one row apart instead of HH: HH kPitch is a multiple of the 64
+      // banks, so with halves both lanes of a pair hit the same bank at different addresses on every K, Q and V read (2-way conflicts on all of them)
+      constexpr int RS = H3 ? 1 : 2;                        // row stride of a lane's dimensions
+      const int r0 = H3 ? p * HH : p;                       // its first one
+      float *dst = ATT + (h * HD + r0) * kPitch + i;
       _Float16 *dsh = Sh + i * HP + h * HD + p * HH, *dsl = Sl + i * HP + h * HD + p * HH;    // H3: this lane's HH consecutive k of column i
       float ov[HH];
       if (i < NCOLV && i - icb * TS < T) {
-         const float *Q = QKV + (h * HD + p * HH) * kPitch + icb * TP, *K = QKV + (D + h * HD + p * HH) * kPitch + i;
-         const float *V = QKV + (2 * D + h * HD + p * HH) * kPitch + icb * TP;
+         const float *Q = QKV + (h * HD + r0) * kPitch + icb * TP, *K = QKV + (D + h * HD + r0) * kPitch + i;
+         const float *V = QKV + (2 * D + h * HD + r0) * kPitch + icb * TP;
          float sc[TP];
 #pragma unroll
          for (int j = 0; j < TP; ++j) sc[j] = 0.0f;
 #pragma unroll
          for (int e = 0; e < HH; ++e) {
-            const float ke = K[e * kPitch];
+            const float ke = K[e * RS * kPitch];
 #pragma unroll
             for (int q4 = 0; q4 < TQ; ++q4) {
-               const float4 qv = *reinterpret_cast<const float4 *>(Q + e * kPitch + 4 * q4);
+               const float4 qv = *reinterpret_cast<const float4 *>(Q + e * RS * kPitch + 4 * q4);
                sc[4 * q4 + 0] = fmaf(ke, qv.x, sc[4 * q4 + 0]); sc[4 * q4 + 1] = fmaf(ke, qv.y, sc[4 * q4 + 1]);
                sc[4 * q4 + 2] = fmaf(ke, qv.z, sc[4 * q4 + 2]); sc[4 * q4 + 3] = fmaf(ke, qv.w, sc[4 * q4 + 3]);
             }
@@ -922,17 +927,17 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
             float o = 0.0f;
 #pragma unroll
             for (int q4 = 0; q4 < TQ; ++q4) {
-               const float4 vv = *reinterpret_cast<const float4 *>(V + e * kPitch + 4 * q4);
+               const float4 vv = *reinterpret_cast<const float4 *>(V + e * RS * kPitch + 4 * q4);
                if (4 * q4 + 0 < T) o = fmaf(sc[4 * q4 + 0], vv.x, o);
                if (4 * q4 + 1 < T) o = fmaf(sc[4 * q4 + 1], vv.y, o);
                if (4 * q4 + 2 < T) o = fmaf(sc[4 * q4 + 2], vv.z, o);
                if (4 * q4 + 3 < T) o = fmaf(sc[4 * q4 + 3], vv.w, o);
             }
-            if constexpr (H3) ov[e] = o * inv; else dst[e * kPitch] = o * inv;
+            if constexpr (H3) ov[e] = o * inv; else dst[e * RS * kPitch] = o * inv;
          }
       } else {
 #pragma unroll
-         for (int e = 0; e < HH; ++e) { if constexpr (H3) ov[e] = 0.0f; else dst[e * kPitch] = 0.0f; }
+         for (int e = 0; e < HH; ++e) { if constexpr (H3) ov[e] = 0.0f; else dst[e * RS * kPitch] = 0.0f; }
       }
       if constexpr (H3) {
 #pragma unroll
