@@ -460,7 +460,14 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          put_frags(fbase + LL::f_out, r.out_w, D, D, true);
          put_frags(fbase + LL::f_l1, r.l1_w, D, D, true);
          put_frags(fbase + LL::f_l2, r.l2_w, D, D, true);
-         put_frags(fbase + LL::f_cv, r.cv_w, D, D, true);
+         // LayerNorm 2 feeds the strided conv only: its scale goes into the conv's columns, its shift into the conv's bias (the kernel normalises without them)
+         std::vector<float> cvw = r.cv_w, cvb = r.cv_b;
+         for (int o = 0; o < D; ++o) {
+            double acc = 0.0;
+            for (int c = 0; c < D; ++c) { acc += (double)r.cv_w[(size_t)o * D + c] * (double)r.n2_b[c]; cvw[(size_t)o * D + c] = r.cv_w[(size_t)o * D + c] * r.n2_w[c]; }
+            cvb[o] += (float)acc;
+         }
+         put_frags(fbase + LL::f_cv, cvw, D, D, true);
          for (int t = 0; t < 5; ++t) for (int c = 0; c < C; ++c) vbase[LL::v_dw + t * C + c] = r.dw_w[(size_t)c * 5 + t];
          for (int c = 0; c < C; ++c) vbase[LL::v_dw + 5 * C + c] = r.dw_b[c];
          for (int o = 0; o < D; ++o) vbase[LL::v_cb_b + o] = r.pw_b[o] + (kLayers[l].proj ? r.pj_b[o] : 0.0f);
@@ -476,7 +483,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
          }
          put_vec(vbase + LL::v_n1_w, r.n1_w); put_vec(vbase + LL::v_n1_b, r.n1_b);
          put_vec(vbase + LL::v_l1_b, r.l1_b);   put_vec(vbase + LL::v_l2_b, r.l2_b);
-         put_vec(vbase + LL::v_n2_w, r.n2_w);   put_vec(vbase + LL::v_n2_b, r.n2_b); put_vec(vbase + LL::v_cv_b, r.cv_b);
+         put_vec(vbase + LL::v_n2_w, r.n2_w);   put_vec(vbase + LL::v_n2_b, r.n2_b); put_vec(vbase + LL::v_cv_b, cvb);
       };
       e->h_encA.assign(kEncA_Bytes, 0); e->h_encB.assign(kEncB_Bytes, 0);
       build_layer(1, e->h_encA.data() + kEncA_L2F, reinterpret_cast<float *>(e->h_encA.data() + kEncA_V2), EncL2());

@@ -7,8 +7,8 @@
 //
 // * A WAVE owns its chunks from the layer-1 output to the LSTM hand-off and never meets another wave: no workgroup barrier, no
 //   activation in LDS.  A 16-column MFMA N tile holds ONE chunk at 13 steps (layer 2: lanes 13..15 idle) or TWO chunks at 7 steps
-//   (layers 3, 4: columns 0..6 and 8..14, 7 and 15 idle), so a chunk's steps are lanes of one DPP row: the depthwise conv's time
-//   neighbours are row shifts (zero fill at the row ends = the conv's zero padding).
+//   (layers 3, 4: columns 0..6 and 8..14, 7 and 15 dead), so a chunk's steps are lanes of one DPP row: the depthwise conv's time
+//   neighbours are row shifts riding on the multiply-adds as DPP operands (zero fill at the row ends and the dead columns = the conv's zero padding).
 // * An accumulator tile IS the next GEMM's B operand: lane (q, column) holds rows 16 mt + 4 q + r, and the host stores every weight's
 //   k in that order (enc_fused_layout.h: enc_sigma), so registers go from MFMA to split (v_cvt_pk_f16_f32) to MFMA.
 // * Attention on the matrix cores, per head and tile: S^T = Q^T K (A = Q registers, B = K registers: lane (q, i) gets
@@ -170,71 +170,90 @@ __device__ __forceinline__ void init_bias(f4 (&acc)[NT][MT], const float *bias, 
    }
 }
 
-// sum / max over the four lane-quads (lanes l, l ^ 16, l ^ 32, l ^ 48): gfx950's v_permlane16_swap / v_permlane32_swap exchange
-// rows of TWO registers -- (p, p) -> ([p0 p0 p2 p2], [p1 p1 p3 p3]) and ([lo lo], [hi hi]) -- so the two results add up to the pair
-// sums in every lane.  Inline asm: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) folds the two results into one register
-// (tools/enc_prims_test.hip); the s_nop covers the VALU-write -> swap wait states hipcc pads its own swaps with.
-__device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-// max of two finite values as one v_med3_f32 (fmaxf puts a canonicalising v_max_f32 x, x in front of values that come out of inline asm)
-__device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
+// sum / max over the four lane-quads (lanes l, l ^ 16, l ^ 32, l ^ 48) through the LDS crossbar (no LDS memory): ds_swizzle for l ^ 16 (bit mode,
+// xor mask 0x10 inside each half of the wave), ds_bpermute for l ^ 32 -- two vector instructions per reduction.  (gfx950's v_permlane16_swap /
+// v_permlane32_swap do it without LDS in six: a copy, the swap and the add, twice; this kernel is bound by vector-instruction issue, the LDS pipe
+// is a quarter busy.  Through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) ties both operands to one register or folds the two results into
+// one: tools/enc_prims_test.hip keeps the inline-asm form that works.)
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }   // one v_med3_f32, no canonicalising v_max_f32 x, x
 template <bool MAX>
-__device__ __forceinline__ float quads_reduce(float v)
+__device__ __forceinline__ float quads_reduce(float v, int lane)
 {
-   float a = v, b = v;
-   swap16(a, b);
-   v = MAX ? max2(a, b) : a + b;
-   a = v; b = v;
-   swap32(a, b);
-   return MAX ? max2(a, b) : a + b;
+   const float a = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+   v = MAX ? max2(v, a) : v + a;
+   const float b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __builtin_bit_cast(int, v)));
+   return MAX ? max2(v, b) : v + b;
 }
-__device__ __forceinline__ float quads_sum(float v) { return quads_reduce<false>(v); }
-__device__ __forceinline__ float quads_max(float v) { return quads_reduce<true>(v); }
+__device__ __forceinline__ float quads_sum(float v, int lane) { return quads_reduce<false>(v, lane); }
+__device__ __forceinline__ float quads_max(float v, int lane) { return quads_reduce<true>(v, lane); }
 
 // LayerNorm over the D = 16 MT channels of each column in the accumulator layout (misc.c:143-210: biased variance, eps 1e-5)
-template <int MT>
-__device__ __forceinline__ void layer_norm(f4 (&x)[MT], const Vec<MT> &w, const Vec<MT> &b)
+// AFFINE = false: the scale and shift live in the next GEMM's weights and bias (LayerNorm 2 feeds the strided conv only: folded by the host)
+template <int MT, bool AFFINE = true>
+__device__ __forceinline__ void layer_norm(f4 (&x)[MT], const Vec<MT> &w, const Vec<MT> &b, int lane)
 {
    constexpr int D = 16 * MT;
    float s = 0.0f;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt) s += (x[mt][0] + x[mt][1]) + (x[mt][2] + x[mt][3]);
-   s = quads_sum(s);
+   s = quads_sum(s, lane);
    const float mean = s * (1.0f / D);
    float vs = 0.0f;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float d = x[mt][r] - mean; vs = fmaf(d, d, vs); }
-   vs = quads_sum(vs);
+   vs = quads_sum(vs, lane);
    const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / D) + 1e-5f);
    const float mr = mean * rstd;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt) {
       const f4 w4 = w.v[mt], b4 = b.v[mt];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[mt][r] = fmaf(fmaf(x[mt][r], rstd, -mr), w4[r], b4[r]);
+      for (int r = 0; r < 4; ++r) x[mt][r] = AFFINE ? fmaf(fmaf(x[mt][r], rstd, -mr), w4[r], b4[r]) : fmaf(x[mt][r], rstd, -mr);
    }
 }
 
-// DPP row shifts inside the 16 lanes of a column tile's quad (0 shifted in at the row ends)
+// The pair layout of layers 3 / 4: two 7-step chunks in a 16-column tile at columns 0..6 and 8..14, columns 7 and 15 dead (zero).  The second chunk sits
+// EXACTLY 8 columns behind the first: the attention's MFMAs and the softmax sum over the tile's 16 positions in a fixed internal grouping, and a chunk's
+// bits must not depend on whether it is the first or the second of its pair (a stream's results are bit-identical for any split into calls:
+// test_backend_run_shape_and_batch_invariance -- columns 0..6 / 9..15 with two dead columns between them failed exactly that).
+__device__ __forceinline__ int pair_chunk(int lc) { return lc >> 3; }
+__device__ __forceinline__ int pair_step(int lc) { return lc & 7; }                             // 7: the dead column
+__device__ __forceinline__ bool pair_live(int lc) { return (lc & 7) != 7; }
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v)
 {
    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-constexpr int kRowShl1 = 0x101, kRowShl2 = 0x102, kRowShr1 = 0x111, kRowShr2 = 0x112;
 
-// depthwise k = 5, zero pad 2, + bias, ReLU (conv.c:17-53) of one register: x at this lane's step, neighbours by row shifts.
-// PAIR: two 7-step chunks share the row (columns 0..6, 8..14; 7 and 15 hold zeros): only the distance-2 taps can reach the other chunk.
+// depthwise k = 5, zero pad 2, + bias, ReLU (conv.c:17-53) of one register: x at this lane's step, neighbours by row shifts of x itself, carried by the
+// multiply-adds as their DPP operand (hipcc does not fold a row shift into v_fmac: inline asm; the s_nop covers the VALU-write -> DPP-read wait states
+// for x, which the caller has just written).  Columns outside a chunk hold zeros, so the zero padding comes with the shift -- except, in the pair layout
+// (one dead column between the chunks), for the distance-2 taps of columns 6 and 8, which would reach the other chunk: those two taps are shifted into
+// a register and masked.  The same order of the five products as the reference's loop.
 template <bool PAIR>
 __device__ __forceinline__ float dw5(float x, float k0, float k1, float k2, float k3, float k4, float bias, int lc)
 {
-   float xm2 = dpp_row<kRowShr2>(x), xp2 = dpp_row<kRowShl2>(x);
-   const float xm1 = dpp_row<kRowShr1>(x), xp1 = dpp_row<kRowShl1>(x);
-   if (PAIR) { xm2 = lc == 8 ? 0.0f : xm2; xp2 = lc == 6 ? 0.0f : xp2; }
    float dv = bias;
-   dv = fmaf(xm2, k0, dv); dv = fmaf(xm1, k1, dv); dv = fmaf(x, k2, dv); dv = fmaf(xp1, k3, dv); dv = fmaf(xp2, k4, dv);
+   if (PAIR) {
+      const float sm2 = dpp_row<0x112>(x);                       // row_shr:2; shifted FIRST, by every lane: inside `lc == 8 ? 0 : shift` the shift is
+      const float xm2 = lc == 8 ? 0.0f : sm2;                    // the arm of a branch, and a lane the branch has switched off reads as 0 to its neighbours
+      dv = fmaf(xm2, k0, dv);
+      asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(x), "v"(k1));   // (behind the shift, the select and the multiply-add above)
+   } else {
+      asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(x), "v"(k0));
+      asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(x), "v"(k1));
+   }
+   dv = fmaf(x, k2, dv);
+   asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(x), "v"(k3));
+   if (PAIR) {
+      const float sp2 = dpp_row<0x102>(x);                       // row_shl:2
+      const float xp2 = lc == 6 ? 0.0f : sp2;
+      dv = fmaf(xp2, k4, dv);
+   } else {
+      asm("v_fmac_f32_dpp %0, %1, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(dv) : "v"(x), "v"(k4));
+   }
    return relu(dv);
 }
 
@@ -262,7 +281,7 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
    // so masked scores never win the max and their exp2 is 0
    f4 smask;
 #pragma unroll
-   for (int r = 0; r < 4; ++r) smask[r] = (PAIR ? ((q >> 1) == (lc >> 3) && ((4 * q + r) & 7) != 7) : (4 * q + r < 13)) ? 0.0f : -1.0e30f;
+   for (int r = 0; r < 4; ++r) smask[r] = (PAIR ? (pair_live(4 * q + r) && pair_chunk(4 * q + r) == pair_chunk(lc)) : (4 * q + r < 13)) ? 0.0f : -1.0e30f;
    f4 att[NT][MT];
    Pre po;                                                   // first fragments of the out projection, requested under the last head's attention
    Vec<MT> b_out;
@@ -329,12 +348,12 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
             s = MFMA16K16(qa.lo, kf.hi, s); s = MFMA16K16(qa.hi, kf.lo, s); s = MFMA16K16(qa.hi, kf.hi, s);
          }
          float m = max2(max2(s[0], s[1]), max2(s[2], s[3]));
-         m = quads_max(m);
+         m = quads_max(m, lane);
          f4 p;
 #pragma unroll
          for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] - m);      // tensor.h:751-784
          float sum = (p[0] + p[1]) + (p[2] + p[3]);
-         sum = quads_sum(sum);
+         sum = quads_sum(sum, lane);
          const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
          for (int r = 0; r < 4; ++r) p[r] *= inv;
@@ -374,8 +393,8 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += p[nt][mt];
    }
 #pragma unroll
-   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], n1w, n1b);
-   Vec<MT> n2w, n2b, b_cv;
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], n1w, n1b, lane);
+   Vec<MT> n2w = {}, n2b = {}, b_cv;           // (LayerNorm 2's scale and shift are folded into the strided conv)
    Pre pc;
    {
       Frag xf[NT][KB];
@@ -406,7 +425,6 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
          for (int mt = 0; mt < MT; ++mt) g[nt][mt] = b_l2.v[mt];
-      n2w = load_vec<MT>(lv + L::v_n2_w, q); n2b = load_vec<MT>(lv + L::v_n2_b, q);
       pc = prefetch<MT * KB>(lf + L::f_cv, 0, lane);
       b_cv = load_vec<MT>(lv + L::v_cv_b, q);
       gemm<NT, MT, KB, MT>(g, lf + L::f_l2, 0, xf, lane, p2);
@@ -416,7 +434,7 @@ __device__ __forceinline__ void tf_block(f4 (&acc)[NT][D / 16], const char *lf, 
          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += g[nt][mt];
    }
 #pragma unroll
-   for (int nt = 0; nt < NT; ++nt) layer_norm<MT>(acc[nt], n2w, n2b);
+   for (int nt = 0; nt < NT; ++nt) layer_norm<MT, false>(acc[nt], n2w, n2b, lane);
    // conv k = 1 (+ folded BatchNorm) -> ReLU, every step (the caller keeps the surviving ones)      transformer.c:279-290
    {
       Frag xf[NT][KB];
@@ -445,7 +463,7 @@ __device__ __forceinline__ void conv_block_regs(f4 (&x)[NT][2], f4 (&y)[NT][D / 
 {
    constexpr int MT = D / 16;
    const int q = lane >> 4, lc = lane & 15;
-   const bool idle = (lc & 7) == 7;
+   const bool idle = !pair_live(lc);
    Frag xf[NT][1], df[NT][1];
    f4 k[6][2];
 #pragma unroll
@@ -479,13 +497,13 @@ __device__ __forceinline__ void conv_block_regs(f4 (&x)[NT][2], f4 (&y)[NT][D / 
          }
 }
 
-// [n][D][7] fp32 <-> the pair layout (lane (q, lc): chunk 2 tile + (lc >> 3), step lc & 7, channels 16 mt + 4 q + r)
+// [n][D][7] fp32 <-> the pair layout (lane (q, lc): chunk 2 tile + pair_chunk(lc), step pair_step(lc), channels 16 mt + 4 q + r)
 template <int MT>
 __device__ __forceinline__ void load_chw7(f4 (&x)[MT], const float *in, int item, int n_chunks, const ItemMap &map, int lane)
 {
-   const int q = lane >> 4, lc = lane & 15, t = lc & 7;
-   const bool ok = t < 7 && item + (lc >> 3) < n_chunks;
-   const float *p = in + (size_t)map(ok ? item + (lc >> 3) : 0) * (16 * MT * 7) + t;
+   const int q = lane >> 4, lc = lane & 15, t = pair_step(lc);
+   const bool ok = pair_live(lc) && item + pair_chunk(lc) < n_chunks;
+   const float *p = in + (size_t)map(ok ? item + pair_chunk(lc) : 0) * (16 * MT * 7) + (ok ? t : 0);
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -494,9 +512,9 @@ __device__ __forceinline__ void load_chw7(f4 (&x)[MT], const float *in, int item
 template <int MT>
 __device__ __forceinline__ void store_chw7(const f4 (&x)[MT], float *out, int item, int n_chunks, const ItemMap &map, int lane)
 {
-   const int q = lane >> 4, lc = lane & 15, t = lc & 7;
-   if (!(t < 7 && item + (lc >> 3) < n_chunks)) return;
-   float *p = out + (size_t)map(item + (lc >> 3)) * (16 * MT * 7) + t;
+   const int q = lane >> 4, lc = lane & 15, t = pair_step(lc);
+   if (!(pair_live(lc) && item + pair_chunk(lc) < n_chunks)) return;
+   float *p = out + (size_t)map(item + pair_chunk(lc)) * (16 * MT * 7) + t;
 #pragma unroll
    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -578,9 +596,9 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
                         for (int r = 0; r < 4; ++r) y[nt][mt][r] = relu(y[nt][mt][r]);
                }
                tf_block<EncL2, 32, 2, false>(y, f2, v2, lane);
-               // stride 2: step 2 t' of tile (lc' >> 3) -> column lc' = 8 (chunk in pair) + t' of the pair tile; same quad, same registers
-               const int src = 4 * (16 * q + 2 * (lc & 7));
-               const bool second = lc >= 8, idle = (lc & 7) == 7;
+               // stride 2: step 2 t' of the first / second tile -> column t' / 8 + t' of the pair tile; same quad, same registers
+               const int src = 4 * (16 * q + 2 * (pair_live(lc) ? pair_step(lc) : 0));
+               const bool second = pair_chunk(lc) == 1, idle = !pair_live(lc);
                f4 xn[2];
 #pragma unroll
                for (int mt = 0; mt < 2; ++mt)
@@ -647,8 +665,8 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
          for (int p = 0; p < NP; ++p) {
             if (a.tap4) { store_chw7<4>(y4[p], a.tap4, item0 + 2 * p, a.n_chunks, a.map, lane); continue; }
             // split-fp16 LSTM-native tiles (common.h lstm_xh_index): a (chunk, step) row = 64 units x {hi, lo}; this lane owns units 16 mt + 4 q .. + 3
-            const int item = item0 + 2 * p + (lc >> 3), t = lc & 7;
-            if (t < 7 && item < a.n_chunks) {
+            const int item = item0 + 2 * p + pair_chunk(lc), t = pair_step(lc);
+            if (pair_live(lc) && item < a.n_chunks) {
                int st_, ch_;
                a.map.split(item, st_, ch_);
                _Float16 *dst = reinterpret_cast<_Float16 *>(a.out) + lstm_xh_index(st_, ch_, a.map.C, t, 4 * q, 7);
