@@ -72,4 +72,51 @@ struct EncFusedArgs {
    ItemMap map;
 };
 
+// ---- layer 1 (k_layer1_regs, kernels_layer1_regs.hip): ONE image ------------------------------------------------------------------------
+// conv block 129 -> 16: the [pointwise | projection] weights as K = 32 split-fp16 A fragments (2 KB each) over k blocks
+//   0..3: relu(dw(x)) of channels 32 kb + ..,   4..7: x of channels 32 (kb - 4) + ..
+// with lane quad q of the B operand taking channels l1_channel(kb, q, e), e = 0..7: quads 0 / 1 and 2 / 3 sit 16 channels apart, so that the two quads
+// of a 32-lane half read their 16 consecutive steps of a [channel][25] chunk image from disjoint LDS banks (25 * 16 = 16 mod 32).  Channel 128 (the
+// Nyquist bin) is a K = 16 fragment of its own (k = 0: relu(dw(x128)), k = 1: x128, the rest zero).  The transformer block's GEMMs (D = 16) are
+// K = 16 fragments (v_mfma_f32_16x16x16_f16, 1 KB each: [hi: 64 lanes x 4 halves][lo]), lane (q, m) holding W[m][4 q + e] -- an accumulator tile's
+// four registers are the operand as they are.
+__host__ __device__ constexpr int l1_channel(int kb, int q, int e) { return 32 * kb + 16 * (q & 1) + 8 * (q >> 1) + e; }
+constexpr int kFrag4Bytes = 1024;
+struct L1Layout {
+   static constexpr int f_conv = 0;                                  // 8 x 2 KB
+   static constexpr int f_tail = f_conv + 8 * kFragBytes;
+   static constexpr int f_qkv  = f_tail + kFrag4Bytes;               // Q (rows pre-scaled by log2(e) / sqrt(8)), K, V
+   static constexpr int f_out  = f_qkv + 3 * kFrag4Bytes;
+   static constexpr int f_l1   = f_out + kFrag4Bytes;
+   static constexpr int f_l2   = f_l1 + kFrag4Bytes;
+   static constexpr int f_cv   = f_l2 + kFrag4Bytes;                 // LayerNorm 2's scale folded into its columns
+   static constexpr int f_end  = f_cv + kFrag4Bytes;
+   // vectors (floats, relative to the vector base at byte f_end)
+   static constexpr int v_taps = 0;                                  // [4 kb][4 q][8 e][8]: k0 k1 k2 k3 | k4 bias bias 0
+   static constexpr int v_tail = v_taps + 4 * 4 * 8 * 8;             // channel 128: the same 8 floats
+   static constexpr int v_cb_b = v_tail + 8;
+   static constexpr int v_q_b  = v_cb_b + 16, v_k_b = v_q_b + 16;
+   static constexpr int v_out_b = v_k_b + 16;                        // + Wo . bv (the kernel adds no V bias)
+   static constexpr int v_n1_w = v_out_b + 16, v_n1_b = v_n1_w + 16;
+   static constexpr int v_l1_b = v_n1_b + 16, v_l2_b = v_l1_b + 16;
+   static constexpr int v_n2_w = v_l2_b + 16, v_n2_b = v_n2_w + 16;  // (stage tap 2 only: the hot path has them folded into the strided conv)
+   static constexpr int v_cv_b = v_n2_b + 16;
+   static constexpr int v_end  = (v_cv_b + 16 + 3) / 4 * 4;
+};
+constexpr int kL1ImgBytes = L1Layout::f_end + L1Layout::v_end * 4;
+static_assert(kL1ImgBytes % 16 == 0, "the image is copied in 16-byte pieces");
+constexpr int kL1ChunkFloats = 129 * 25;
+constexpr int kL1BufBytes = 808 * 16;        // a wave's chunk image: 12,900 bytes from the 16-byte boundary below the chunk (<= 12 bytes of lead)
+constexpr int kL1YSlackBytes = 64;           // the DMA of the last chunk reads up to 28 bytes past it
+
+struct L1RegsArgs {
+   const float *y;           // [n][129][25] log-magnitudes (tap: [n][16][25], the conv block's output)
+   const float *fm;          // [4][fm_stride] partial per-frame bin sums
+   size_t fm_stride;
+   const void *img;
+   float *out;               // [n][16][13] (tap: [n][16][25])
+   int n_chunks;
+   ItemMap map;
+};
+
 }  // namespace vadc

@@ -39,6 +39,8 @@ struct LayerWeightsM {
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
+void launch_layer1_regs(const L1RegsArgs &, int, int, hipStream_t);
+void launch_layer1_regs_tap(int, const L1RegsArgs &, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
    const float *dec_w; const float *dec_b;
@@ -160,6 +162,12 @@ struct vadc_amd_engine {
    void *d_encA = nullptr, *d_encB = nullptr;
    float *d_enc_scratch = nullptr;
    std::vector<unsigned char> h_encA, h_encB;   // built by build_weights, uploaded by vadc_amd_create
+   // k_layer1_regs (kernels_layer1_regs.hip): its LDS image
+   void *d_l1img = nullptr;
+   std::vector<unsigned char> h_l1img;
+   int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
+   int layer1_waves = 8;                        // option "layer1_waves": waves per workgroup of k_layer1_regs (8 or 10)
+   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2; }   // ("encoder" = 2: the first stage as the LDS slab path)
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
@@ -492,6 +500,62 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       if (!ok) { e->h_encA.clear(); e->h_encB.clear(); }       // a pre-scaled Q row left fp16's range: the per-layer kernels serve
    }
    {
+      // ---- LDS image of k_layer1_regs (enc_fused_layout.h: L1Layout) ----
+      bool ok = true;
+      const RawLayer &r = raw[0];
+      const int C = kBins, D = 16;
+      auto put_h = [&ok](_Float16 *hi, _Float16 *lo, float v) {
+         if (!(fabsf(v) < 60000.0f)) ok = false;
+         *hi = (_Float16)v;
+         *lo = (_Float16)(v - (float)*hi);
+      };
+      e->h_l1img.assign(kL1ImgBytes, 0);
+      unsigned char *img = e->h_l1img.data();
+      for (int kb = 0; kb < 8; ++kb) {                       // conv block: k blocks 0..3 relu(dw(x)) . pointwise, 4..7 x . projection
+         _Float16 *h = reinterpret_cast<_Float16 *>(img + L1Layout::f_conv + kb * kFragBytes);
+         const std::vector<float> &W = kb < 4 ? r.pw : r.pj;
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el)
+               put_h(&h[l * 8 + el], &h[512 + l * 8 + el], W[(size_t)(l & 15) * C + l1_channel(kb & 3, l >> 4, el)]);
+      }
+      auto put_frag4 = [&](int off, auto W) {                 // W(m, k): K = 16 fragment, lane (q, m) holds k = 4 q + e
+         _Float16 *h = reinterpret_cast<_Float16 *>(img + off);
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 4; ++el) put_h(&h[l * 4 + el], &h[256 + l * 4 + el], W(l & 15, 4 * (l >> 4) + el));
+      };
+      put_frag4(L1Layout::f_tail, [&](int m, int k) { return k == 0 ? r.pw[(size_t)m * C + 128] : (k == 1 ? r.pj[(size_t)m * C + 128] : 0.0f); });
+      const float sc = 1.4426950408889634f / sqrtf(8.0f);    // log2(e) / sqrt(hd): the kernel's softmax is exp2(s - max)
+      put_frag4(L1Layout::f_qkv, [&](int m, int k) { return r.qkv_w[(size_t)m * D + k] * sc; });
+      put_frag4(L1Layout::f_qkv + kFrag4Bytes, [&](int m, int k) { return r.qkv_w[(size_t)(D + m) * D + k]; });
+      put_frag4(L1Layout::f_qkv + 2 * kFrag4Bytes, [&](int m, int k) { return r.qkv_w[(size_t)(2 * D + m) * D + k]; });
+      put_frag4(L1Layout::f_out, [&](int m, int k) { return r.out_w[(size_t)m * D + k]; });
+      put_frag4(L1Layout::f_l1, [&](int m, int k) { return r.l1_w[(size_t)m * D + k]; });
+      put_frag4(L1Layout::f_l2, [&](int m, int k) { return r.l2_w[(size_t)m * D + k]; });
+      put_frag4(L1Layout::f_cv, [&](int m, int k) { return r.cv_w[(size_t)m * D + k] * r.n2_w[k]; });      // LayerNorm 2's scale
+      float *v = reinterpret_cast<float *>(img + L1Layout::f_end);
+      auto put_taps = [&](float *d, int ch) {
+         for (int t = 0; t < 4; ++t) d[t] = r.dw_w[(size_t)ch * 5 + t];
+         d[4] = r.dw_w[(size_t)ch * 5 + 4]; d[5] = d[6] = r.dw_b[ch]; d[7] = 0.0f;
+      };
+      for (int kb = 0; kb < 4; ++kb)
+         for (int q = 0; q < 4; ++q)
+            for (int el = 0; el < 8; ++el) put_taps(v + L1Layout::v_taps + ((kb * 4 + q) * 8 + el) * 8, l1_channel(kb, q, el));
+      put_taps(v + L1Layout::v_tail, 128);
+      for (int o = 0; o < D; ++o) {
+         v[L1Layout::v_cb_b + o] = r.pw_b[o] + r.pj_b[o];
+         v[L1Layout::v_q_b + o] = r.qkv_b[o] * sc;
+         v[L1Layout::v_k_b + o] = r.qkv_b[D + o];
+         double ob = 0.0, cb = 0.0;
+         for (int c = 0; c < D; ++c) { ob += (double)r.out_w[(size_t)o * D + c] * (double)r.qkv_b[2 * D + c]; cb += (double)r.cv_w[(size_t)o * D + c] * (double)r.n2_b[c]; }
+         v[L1Layout::v_out_b + o] = r.out_b[o] + (float)ob;   // a softmax row sums to 1: the V bias passes through the attention unchanged
+         v[L1Layout::v_n1_w + o] = r.n1_w[o]; v[L1Layout::v_n1_b + o] = r.n1_b[o];
+         v[L1Layout::v_l1_b + o] = r.l1_b[o]; v[L1Layout::v_l2_b + o] = r.l2_b[o];
+         v[L1Layout::v_n2_w + o] = r.n2_w[o]; v[L1Layout::v_n2_b + o] = r.n2_b[o];
+         v[L1Layout::v_cv_b + o] = r.cv_b[o] + (float)cb;     // LayerNorm 2's shift
+      }
+      if (!ok) e->h_l1img.clear();                            // a weight outside fp16's range: k_layer_mfma's fp32 form serves
+   }
+   {
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 128) || !need(idx + 3, 2)) goto bad;
       std::vector<float> W, B, dw, db;
       copy_unaligned(W, ts[idx]); copy_unaligned(B, ts[idx + 1]); copy_unaligned(dw, ts[idx + 2]); copy_unaligned(db, ts[idx + 3]);
@@ -712,7 +776,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
@@ -797,7 +861,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
-   if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float));
+   if (he == hipSuccess) he = hipMalloc(&e->d_Y, N * kBins * kFrames * sizeof(float) + kL1YSlackBytes);
    if (he == hipSuccess) he = hipMalloc(&e->d_FM, kBinSplit * N * kFrames * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V4) he = hipMalloc(&e->d_MAG, N * kBins * kFrames * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_tap, N * kBins * kFrames * sizeof(float));
@@ -817,6 +881,11 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       if (he == hipSuccess) he = hipMemcpy(e->d_encB, e->h_encB.data(), e->h_encB.size(), hipMemcpyHostToDevice);
       if (he == hipSuccess) he = hipMalloc(&e->d_enc_scratch, (N + 4) * kEncScratchPerChunk * sizeof(float));   // batches of up to 4 chunks: the last one may be partial
       e->h_encA.clear(); e->h_encA.shrink_to_fit(); e->h_encB.clear(); e->h_encB.shrink_to_fit();
+   }
+   if (he == hipSuccess && !e->h_l1img.empty()) {
+      he = hipMalloc(&e->d_l1img, e->h_l1img.size());
+      if (he == hipSuccess) he = hipMemcpy(e->d_l1img, e->h_l1img.data(), e->h_l1img.size(), hipMemcpyHostToDevice);
+      e->h_l1img.clear(); e->h_l1img.shrink_to_fit();
    }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
@@ -944,7 +1013,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "layer1_waves"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -984,6 +1053,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "h2d_streams") == 0 && value >= 1 && value <= 4) { e->h2d_parts = value; return VADC_AMD_OK; }
+   if (strcmp(key, "layer1") == 0 && (value == 0 || value == 1)) { e->layer1_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "layer1_waves") == 0 && (value == 8 || value == 10)) { e->layer1_waves = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder_batch") == 0 && value >= 0 && value <= 2) { e->enc_batch = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
@@ -998,6 +1069,8 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
+   else if (strcmp(key, "layer1") == 0) *value = e->layer1_variant;
+   else if (strcmp(key, "layer1_waves") == 0) *value = e->layer1_waves;
    else if (strcmp(key, "encoder_batch") == 0) *value = e->enc_batch;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
@@ -1061,6 +1134,12 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          return;
       }
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
+      if (l == 0 && e->use_l1_regs()) {
+         L1RegsArgs a;
+         a.y = in; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_act[0]; a.n_chunks = n; a.map = map;
+         launch_layer1_regs(a, encoder_cus(e, st), e->layer1_waves, st);
+         continue;
+      }
       if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames, e->stride3(), e->encoder_variant == 4);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
                                                      e->encoder_variant != 3 && e->enc_h3_ok);
@@ -1782,6 +1861,11 @@ extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const f
    hipStream_t st = e->stream;
    const size_t bytes = (size_t)n * 16 * 25 * sizeof(float);
    HIP_TRY(hipMemcpyAsync(e->d_tap, y, bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   if (e->use_l1_regs()) {
+      L1RegsArgs a;
+      a.y = e->d_tap; a.fm = nullptr; a.fm_stride = 0; a.img = e->d_l1img; a.out = e->d_Y; a.n_chunks = n; a.map = ItemMap{n, 0, n};
+      launch_layer1_regs_tap(what, a, st);
+   } else
    launch_layer1_tap(what, e->d_tap, e->lwm[0], e->d_Y, n, ItemMap{n, 0, n}, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, e->d_Y, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
