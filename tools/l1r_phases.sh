@@ -1,0 +1,28 @@
+#!/bin/bash
+# cycle stamps inside k_layer1_regs (one wave per workgroup): share of a chunk's time spent waiting for its DMA, in the normalization offset, the conv
+# block, the transformer block and the store.  gpurun -- 'bash tools/l1r_phases.sh'   (rebuilds the library with -DVADC_L1R_PHASE_PROF, then restores it)
+cd "$(dirname "$0")/.." || exit 1
+build() { (cd vadc_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c kernels_layer1_regs.hip -o build/kernels_layer1_regs.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libvadc_amd.so build/engine.o build/kernels_frontend.o build/kernels_frontend_gemm.o build/kernels_encoder_mfma.o build/kernels_encoder_fused.o build/kernels_layer1_regs.o build/kernels_lstm.o build/kernels_v5.o); }
+build -DVADC_L1R_PHASE_PROF
+python - <<'PY'
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from vadc_amd.engine import Engine
+from vadc_amd import _lib
+blob = open("tests/golden/reference_fixtures/silero_v31_16k.testtensor", "rb").read()
+n = 24576
+e = Engine(blob, max_streams=256, max_chunks_per_call=96, device=0)
+x = (np.random.default_rng(1).standard_normal((n, 129, 25)) * 2.0).astype(np.float32)
+L = C.CDLL(os.path.join("vadc_amd", "libvadc_amd.so"))
+out = (C.c_ulonglong * 8)()
+e.stage_from_stage(x, "normalized", "layer1")
+L.vadc_amd_debug_l1r_phases(out, 1)
+for _ in range(3): e.stage_from_stage(x, "normalized", "layer1")
+L.vadc_amd_debug_l1r_phases(out, 1)
+v = np.array(list(out)[:6], dtype=np.float64)
+names = ["loop top (store drain)", "wait for the DMA", "normalization offset", "conv block (+ DMA issue)", "transformer block", "store"]
+for nm, c in zip(names, v): print(f"{nm:28s} {c / v.sum() * 100:5.1f} %   {c / (3 * 256 * 12):9.0f} cycles per chunk")
+e.close()
+PY
+build

@@ -78,10 +78,10 @@ struct EncFusedArgs {
 // with lane quad q of the B operand taking channels l1_channel(kb, q, e), e = 0..7: quads 0 / 1 and 2 / 3 sit 16 channels apart, so that the two quads
 // of a 32-lane half read their 16 consecutive steps of a [channel][25] chunk image from disjoint LDS banks (25 * 16 = 16 mod 32).  Channel 128 (the
 // Nyquist bin) is a K = 16 fragment of its own (k = 0: relu(dw(x128)), k = 1: x128, the rest zero).  The transformer block's GEMMs (D = 16) are
-// K = 16 fragments (v_mfma_f32_16x16x16_f16, 1 KB each: [hi: 64 lanes x 4 halves][lo]), lane (q, m) holding W[m][4 q + e] -- an accumulator tile's
-// four registers are the operand as they are.
+// K = 16 fragments of 2 KB: lane (q, m) holds W[m][4 q + e], e < 4, twice -- as 16 bytes [lo x 4 | hi x 4] (block LH, 1 KB) and as [hi x 4 | 0 x 4]
+// (block H0, 1 KB): kernels_layer1_regs.hip, mm() -- an accumulator tile's four registers are the other operand as they are.
 __host__ __device__ constexpr int l1_channel(int kb, int q, int e) { return 32 * kb + 16 * (q & 1) + 8 * (q >> 1) + e; }
-constexpr int kFrag4Bytes = 1024;
+constexpr int kFrag4Bytes = 2048;
 struct L1Layout {
    static constexpr int f_conv = 0;                                  // 8 x 2 KB
    static constexpr int f_tail = f_conv + 8 * kFragBytes;

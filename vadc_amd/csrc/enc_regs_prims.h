@@ -166,6 +166,20 @@ __device__ __forceinline__ float quads_reduce(float v, int lane)
    const float b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __builtin_bit_cast(int, v)));
    return MAX ? max2(v, b) : v + b;
 }
+// N independent reductions in lockstep: the N swizzles, then the N permutes are in flight together -- one LDS-crossbar round trip per step instead of N
+template <bool MAX, int N>
+__device__ __forceinline__ void quads_reduce_n(float (&v)[N], int lane)
+{
+   float a[N];
+#pragma unroll
+   for (int i = 0; i < N; ++i) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v[i]), 0x401F));
+#pragma unroll
+   for (int i = 0; i < N; ++i) v[i] = MAX ? max2(v[i], a[i]) : v[i] + a[i];
+#pragma unroll
+   for (int i = 0; i < N; ++i) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __builtin_bit_cast(int, v[i])));
+#pragma unroll
+   for (int i = 0; i < N; ++i) v[i] = MAX ? max2(v[i], a[i]) : v[i] + a[i];
+}
 __device__ __forceinline__ float quads_sum(float v, int lane) { return quads_reduce<false>(v, lane); }
 __device__ __forceinline__ float quads_max(float v, int lane) { return quads_reduce<true>(v, lane); }
 
@@ -193,6 +207,32 @@ __device__ __forceinline__ void layer_norm(f4 (&x)[MT], const Vec<MT> &w, const 
       const f4 w4 = w.v[mt], b4 = b.v[mt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[mt][r] = AFFINE ? fmaf(fmaf(x[mt][r], rstd, -mr), w4[r], b4[r]) : fmaf(x[mt][r], rstd, -mr);
+   }
+}
+
+// LayerNorm of N tiles with D = 16 in lockstep (the same arithmetic per tile as layer_norm<1>): the tiles' reductions share their round trips
+template <int N, bool AFFINE>
+__device__ __forceinline__ void layer_norm16_n(f4 (&x)[N], const f4 &w4, const f4 &b4, int lane)
+{
+   float s[N];
+#pragma unroll
+   for (int i = 0; i < N; ++i) s[i] = 0.0f + ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3]));
+   quads_reduce_n<false, N>(s, lane);
+   float mean[N], vs[N];
+#pragma unroll
+   for (int i = 0; i < N; ++i) {
+      mean[i] = s[i] * (1.0f / 16);
+      vs[i] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = x[i][r] - mean[i]; vs[i] = fmaf(d, d, vs[i]); }
+   }
+   quads_reduce_n<false, N>(vs, lane);
+#pragma unroll
+   for (int i = 0; i < N; ++i) {
+      const float rstd = __builtin_amdgcn_rsqf(vs[i] * (1.0f / 16) + 1e-5f);
+      const float mr = mean[i] * rstd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[i][r] = AFFINE ? fmaf(fmaf(x[i][r], rstd, -mr), w4[r], b4[r]) : fmaf(x[i][r], rstd, -mr);
    }
 }
 

@@ -39,7 +39,7 @@ struct LayerWeightsM {
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
-void launch_layer1_regs(const L1RegsArgs &, int, int, hipStream_t);
+void launch_layer1_regs(const L1RegsArgs &, int, hipStream_t);
 void launch_layer1_regs_tap(int, const L1RegsArgs &, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
@@ -166,7 +166,6 @@ struct vadc_amd_engine {
    void *d_l1img = nullptr;
    std::vector<unsigned char> h_l1img;
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
-   int layer1_waves = 8;                        // option "layer1_waves": waves per workgroup of k_layer1_regs (8 or 10)
    bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2; }   // ("encoder" = 2: the first stage as the LDS slab path)
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
@@ -521,7 +520,10 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       auto put_frag4 = [&](int off, auto W) {                 // W(m, k): K = 16 fragment, lane (q, m) holds k = 4 q + e
          _Float16 *h = reinterpret_cast<_Float16 *>(img + off);
          for (int l = 0; l < 64; ++l)
-            for (int el = 0; el < 4; ++el) put_h(&h[l * 4 + el], &h[256 + l * 4 + el], W(l & 15, 4 * (l >> 4) + el));
+            for (int el = 0; el < 4; ++el) {                  // block LH: per lane [lo x 4 | hi x 4]; block H0: [hi x 4 | 0 x 4]
+               put_h(&h[l * 8 + 4 + el], &h[l * 8 + el], W(l & 15, 4 * (l >> 4) + el));
+               h[512 + l * 8 + el] = h[l * 8 + 4 + el];
+            }
       };
       put_frag4(L1Layout::f_tail, [&](int m, int k) { return k == 0 ? r.pw[(size_t)m * C + 128] : (k == 1 ? r.pj[(size_t)m * C + 128] : 0.0f); });
       const float sc = 1.4426950408889634f / sqrtf(8.0f);    // log2(e) / sqrt(hd): the kernel's softmax is exp2(s - max)
@@ -1013,7 +1015,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "layer1_waves"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1054,7 +1056,6 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "h2d_streams") == 0 && value >= 1 && value <= 4) { e->h2d_parts = value; return VADC_AMD_OK; }
    if (strcmp(key, "layer1") == 0 && (value == 0 || value == 1)) { e->layer1_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "layer1_waves") == 0 && (value == 8 || value == 10)) { e->layer1_waves = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder_batch") == 0 && value >= 0 && value <= 2) { e->enc_batch = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
    if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
@@ -1070,7 +1071,6 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "layer1") == 0) *value = e->layer1_variant;
-   else if (strcmp(key, "layer1_waves") == 0) *value = e->layer1_waves;
    else if (strcmp(key, "encoder_batch") == 0) *value = e->enc_batch;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
@@ -1137,7 +1137,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
       if (l == 0 && e->use_l1_regs()) {
          L1RegsArgs a;
          a.y = in; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_act[0]; a.n_chunks = n; a.map = map;
-         launch_layer1_regs(a, encoder_cus(e, st), e->layer1_waves, st);
+         launch_layer1_regs(a, encoder_cus(e, st), st);
          continue;
       }
       if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames, e->stride3(), e->encoder_variant == 4);

@@ -18,7 +18,7 @@
 //   k block kb are channels l1_channel(kb, q, e): conflict-free 4-byte LDS reads (enc_fused_layout.h).
 // * K = 258 = relu(dw(x)) of 129 channels | x of 129 channels: 4 + 4 k blocks of 32 and one K = 16 MFMA for the Nyquist channel.
 // * D = 16: every GEMM of the transformer block is one v_mfma_f32_16x16x16_f16 M tile (K = 16: an accumulator tile's four registers are the operand).
-//   Attention over 25 steps = 2 x 2 score tiles per head; the heads (8 channels each = two lane quads) are separated by zeroing the other head's quads of
+//   The three split terms of such a product are two matrix instructions (see mm).  Attention over 25 steps = 2 x 2 score tiles per head; the heads (8 channels each = two lane quads) are separated by zeroing the other head's quads of
 //   the K operand, the softmax of a column runs over its 8 registers (two query tiles) and the four lane quads.
 #include "common.h"
 #include "enc_fused_layout.h"
@@ -28,75 +28,104 @@
 namespace vadc {
 
 typedef L1Layout LL;
+
+#ifdef VADC_L1R_PHASE_PROF      // cycle stamps of one wave per workgroup (tools/l1r_phases.sh): where a chunk's time goes
+__device__ unsigned long long g_l1r_phase[8];
+#define L1R_PH(i) do { if (ph_on) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_l1r_phase[i], t_ - ph_t); ph_t = t_; } } while (0)
+#else
+#define L1R_PH(i) do { } while (0)
+#endif
 typedef __attribute__((address_space(3))) void l1_lds_void_t;
 
-__device__ __forceinline__ Frag4 lds_frag4(const char *base, int lane)
+// ---- K = 16 GEMMs of the transformer block -------------------------------------------------------------------------------------------------
+// The three split terms of a K = 16 product as TWO v_mfma_f32_16x16x32_f16 instead of three v_mfma_f32_16x16x16_f16 (which occupy the pipe just as
+// long): the instruction's 32 k slots are the 16 channels twice.  With operand B as (hi, lo) of a lane's four channels (HL),
+//   A as (lo, hi) (LH) gives  a.lo . b.hi + a.hi . b.lo   -- both cross terms,
+//   A as (hi, 0)  (H0) gives  a.hi . b.hi                 -- on the same accumulator, the same instruction back to back.
+// (A K = 16 instruction for hi . hi behind the K = 32 one on the same accumulator returned stale accumulators: hipcc pads no wait states between
+// the two shapes, and the hardware forwards an accumulator only between equal ones.)  Weights are stored in both forms (two 16-byte LDS reads per
+// lane); an activation that is the A operand of a product (Q, V^T) is split into both, one that is the B operand into HL.
+struct AOp { h8 lh, h0; };
+__device__ __forceinline__ AOp lds_aop(const char *base, int lane)
 {
-   const h4 *p = reinterpret_cast<const h4 *>(base);
-   Frag4 f;
-   f.hi = p[lane];
-   f.lo = p[64 + lane];
-   return f;
+   const h8 *p = reinterpret_cast<const h8 *>(base);
+   AOp w;
+   w.lh = p[lane];
+   w.h0 = p[64 + lane];
+   return w;
 }
-// c += A . B in the three split terms, in k_enc_fused's order (A = weights: lo . hi, hi . lo, hi . hi)
-__device__ __forceinline__ f4 mm3(const Frag4 &a, const Frag4 &b, f4 c)
+__device__ __forceinline__ h8 split4_hl(const f4 &u) { const Frag4 f = split4(u); return __builtin_shufflevector(f.hi, f.lo, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ AOp split4_a(const f4 &u)
 {
-   c = MFMA16K16(a.lo, b.hi, c);
-   c = MFMA16K16(a.hi, b.lo, c);
-   c = MFMA16K16(a.hi, b.hi, c);
-   return c;
+   const Frag4 f = split4(u);
+   const h4 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+   AOp r;
+   r.lh = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+   r.h0 = __builtin_shufflevector(f.hi, z, 0, 1, 2, 3, 4, 5, 6, 7);
+   return r;
 }
-// the same with the ACTIVATION as the A operand (transposed output): lo term of the activation first, as k_enc_fused's V^T
-__device__ __forceinline__ f4 mm3t(const Frag4 &x, const Frag4 &w, f4 c)
+// c += A . B
+__device__ __forceinline__ f4 mm(const AOp &a, const h8 &b, f4 c)
 {
-   c = MFMA16K16(x.lo, w.hi, c);
-   c = MFMA16K16(x.hi, w.lo, c);
-   c = MFMA16K16(x.hi, w.hi, c);
-   return c;
+   c = MFMA16(a.lh, b, c);
+   return MFMA16(a.h0, b, c);
 }
-__device__ __forceinline__ f4 mm3(const Frag &a, const Frag &b, f4 c)
+// c += X^T-style product with the ACTIVATION x (HL) as the A operand and the weight as B: x.hi . w.lo + x.lo . w.hi, then x.hi . w.hi + x.lo . 0
+__device__ __forceinline__ f4 mmt(const h8 &x, const AOp &w, f4 c)
 {
-   c = MFMA16(a.lo, b.hi, c);
-   c = MFMA16(a.hi, b.lo, c);
-   c = MFMA16(a.hi, b.hi, c);
-   return c;
+   c = MFMA16(x, w.lh, c);
+   return MFMA16(x, w.h0, c);
 }
-__device__ __forceinline__ h4 keep(const h4 &v, bool k)
+__device__ __forceinline__ h8 keep(const h8 &v, bool k)
 {
-   typedef int i2 __attribute__((ext_vector_type(2)));
-   i2 u = __builtin_bit_cast(i2, v);
-   u[0] = k ? u[0] : 0; u[1] = k ? u[1] : 0;
-   return __builtin_bit_cast(h4, u);
+   typedef int i4 __attribute__((ext_vector_type(4)));
+   i4 u = __builtin_bit_cast(i4, v);
+#pragma unroll
+   for (int i = 0; i < 4; ++i) u[i] = k ? u[i] : 0;
+   return __builtin_bit_cast(h8, u);
 }
 
 // four input channels of a k block (half of a B operand): x at this lane's step in both tiles, and the channels' depthwise taps
-struct L1Stage { float x0[4], x1[4]; f4 ka[4], kb[4]; };
+struct L1Stage { f2 x[4]; f4 ka[4], kb[4]; };      // x[c] = (tile 0, tile 1)
 __device__ __forceinline__ L1Stage l1_load_stage(const float *xb, const float *tp, int kb, int half)
 {
    L1Stage s;
 #pragma unroll
    for (int c = 0; c < 4; ++c) {
       const int e = 4 * half + c;
-      s.x0[c] = xb[(32 * kb + e) * 25];
-      s.x1[c] = xb[(32 * kb + e) * 25 + 9];
+      s.x[c] = f2{xb[(32 * kb + e) * 25], xb[(32 * kb + e) * 25 + 9]};
       s.ka[c] = lds_vec4(tp, (kb * 32 + e) * 8);
       s.kb[c] = lds_vec4(tp, (kb * 32 + e) * 8 + 4);
    }
    return s;
 }
-// x - offset (misc.c:84-96), relu(dw(x) + bias) (conv.c:17-53) for the stage's four channels in both tiles
-__device__ __forceinline__ void l1_stage_math(const L1Stage &s, float off, int lc, f4 &x0, f4 &x1, f4 &d0, f4 &d1)
+// depthwise k = 5, zero pad 2, + bias (conv.c:17-53) of one channel in BOTH tiles: the time neighbours are row shifts of x itself, carried by the
+// multiply-adds as their DPP operand (enc_regs_prims.h: dw5); the two tiles' chains alternate.  The centre tap goes first, as a three-address
+// multiply-add onto the bias (the taps come out of LDS as float4s: accumulating into the bias's own register costs a copy per channel), then taps
+// -2, -1, +1, +2; the centre tap's two instructions also are the VALU-write -> DPP-read wait states of x.
+__device__ __forceinline__ void dw5x2(float x0, float x1, float k0, float k1, float k2, float k3, float k4, float bias, float &d0, float &d1)
 {
-#pragma unroll
-   for (int c = 0; c < 4; ++c) {
-      x0[c] = s.x0[c] - off;
-      x1[c] = s.x1[c] - off;
-   }
-#pragma unroll
-   for (int c = 0; c < 4; ++c) {
-      d0[c] = dw5<false>(x0[c], s.ka[c][0], s.ka[c][1], s.ka[c][2], s.ka[c][3], s.kb[c][0], s.kb[c][1], lc);
-      d1[c] = dw5<false>(x1[c], s.ka[c][0], s.ka[c][1], s.ka[c][2], s.ka[c][3], s.kb[c][0], s.kb[c][2], lc);
-   }
+   asm("v_fma_f32 %0, %2, %6, %9\n\t"
+       "v_fma_f32 %1, %3, %6, %9\n\t"
+       "v_fmac_f32_dpp %0, %2, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %1, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %0, %2, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %1, %3, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %0, %2, %7 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %1, %3, %7 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %0, %2, %8 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+       "v_fmac_f32_dpp %1, %3, %8 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+       : "=&v"(d0), "=&v"(d1) : "v"(x0), "v"(x1), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(k4), "v"(bias));
+}
+// x - offset (misc.c:84-96), relu(dw(x) + bias) for channel c of the stage in both tiles; (x0, x1) of a channel are one register pair as they come out
+// of the LDS read: the subtraction is one packed instruction
+__device__ __forceinline__ void l1_channel_math(const L1Stage &s, int c, float off, f4 &x0, f4 &x1, f4 &d0, f4 &d1)
+{
+   const f2 xp = s.x[c] - f2{off, off};
+   x0[c] = xp[0]; x1[c] = xp[1];
+   float a, b;
+   dw5x2(xp[0], xp[1], s.ka[c][0], s.ka[c][1], s.ka[c][2], s.ka[c][3], s.kb[c][0], s.kb[c][1], a, b);
+   d0[c] = relu(a); d1[c] = relu(b);
 }
 
 // step of column lc of tile t, and whether the tile owns it
@@ -111,87 +140,94 @@ template <int TAP>
 __device__ __forceinline__ void l1_block(f4 (&y)[2], const char *img, const float *vec, int lane)
 {
    const int q = lane >> 4;
-   const Frag4 wq = lds_frag4(img + LL::f_qkv, lane), wk = lds_frag4(img + LL::f_qkv + kFrag4Bytes, lane), wv = lds_frag4(img + LL::f_qkv + 2 * kFrag4Bytes, lane);
+   const AOp wq = lds_aop(img + LL::f_qkv, lane), wk = lds_aop(img + LL::f_qkv + kFrag4Bytes, lane), wv = lds_aop(img + LL::f_qkv + 2 * kFrag4Bytes, lane);
    const f4 bq = lds_vec4(vec, LL::v_q_b + 4 * q), bk = lds_vec4(vec, LL::v_k_b + 4 * q);
-   Frag4 qf[2], kf[2], vf[2];
+   AOp qf[2], vf[2];
+   h8 kf[2];
 #pragma unroll
    for (int t = 0; t < 2; ++t) {
-      const Frag4 yf = split4(y[t]);
-      const f4 Q = mm3(wq, yf, bq), K = mm3(wk, yf, bk);
+      const h8 yf = split4_hl(y[t]);
+      const f4 Q = mm(wq, yf, bq), K = mm(wk, yf, bk);
       // V^T (lane = channel, registers = steps) by swapping the operands; no V bias: a softmax row sums to 1, the host adds Wo . bv to the out bias
-      const f4 VT = mm3t(yf, wv, f4{0.0f, 0.0f, 0.0f, 0.0f});
-      qf[t] = split4(Q); kf[t] = split4(K); vf[t] = split4(VT);
+      const f4 VT = mmt(yf, wv, f4{0.0f, 0.0f, 0.0f, 0.0f});
+      qf[t] = split4_a(Q); kf[t] = split4_hl(K); vf[t] = split4_a(VT);
    }
-   const Frag4 wo = lds_frag4(img + LL::f_out, lane);
+   const AOp wo = lds_aop(img + LL::f_out, lane);
    const f4 bo = lds_vec4(vec, LL::v_out_b + 4 * q);
    // softmax mask of this lane's j = 4 q + r in query tile 0 / 1 (transformer.c:104-113: a_i = softmax_j(k_i . q_j)): columns a tile does not own
    f4 smask[2];
 #pragma unroll
    for (int r = 0; r < 4; ++r) { smask[0][r] = l1_owns(0, 4 * q + r) ? 0.0f : -1.0e30f; smask[1][r] = l1_owns(1, 4 * q + r) ? 0.0f : -1.0e30f; }
+   // The four (head, key tile) softmaxes run in LOCKSTEP: each is a chain of four LDS-crossbar round trips (max and sum over the lane quads) that a
+   // wave can only wait for; side by side the four chains share their waits.
+   f4 s[4][2];                                                  // [2 h + b][query tile]
+#pragma unroll
+   for (int hb = 0; hb < 4; ++hb) {
+      const h8 kh = keep(kf[hb & 1], (q >> 1) == (hb >> 1));    // channels 4 q + e of head h live in quads 2 h, 2 h + 1
+      // S^T[j][i] = sum_c Q[c][j] K[c][i]: lane (q, i) holds s[i][j = 4 q + r] of both query tiles, already scaled by log2(e) / sqrt(hd)
+      s[hb][0] = mm(qf[0], kh, smask[0]);
+      s[hb][1] = mm(qf[1], kh, smask[1]);
+   }
+   float m[4];
+#pragma unroll
+   for (int hb = 0; hb < 4; ++hb)
+      m[hb] = max2(max2(max2(s[hb][0][0], s[hb][0][1]), max2(s[hb][0][2], s[hb][0][3])), max2(max2(s[hb][1][0], s[hb][1][1]), max2(s[hb][1][2], s[hb][1][3])));
+   quads_reduce_n<true, 4>(m, lane);
+   float sum[4];
+#pragma unroll
+   for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[hb][0][r] = __builtin_amdgcn_exp2f(s[hb][0][r] - m[hb]); s[hb][1][r] = __builtin_amdgcn_exp2f(s[hb][1][r] - m[hb]); }      // tensor.h:751-784
+      sum[hb] = ((s[hb][0][0] + s[hb][0][1]) + (s[hb][0][2] + s[hb][0][3])) + ((s[hb][1][0] + s[hb][1][1]) + (s[hb][1][2] + s[hb][1][3]));
+   }
+   quads_reduce_n<false, 4>(sum, lane);
    f4 att[2];
 #pragma unroll
-   for (int h = 0; h < 2; ++h) {
-      const bool mine = (q >> 1) == h;                         // channels 4 q + e of head h live in quads 2 h, 2 h + 1
+   for (int hb = 0; hb < 4; ++hb) {
+      const int h = hb >> 1, b = hb & 1;
+      const bool mine = (q >> 1) == h;
+      const float inv = __builtin_amdgcn_rcpf(sum[hb]);
+      // att[c][i] = sum_j V[c][j] a[i][j]: A = V^T registers (lane = channel, k = step 4 q + r of tile a), B = exp2(s - max) (lane = column i);
+      // the division by the row sum on the four results instead of the eight weights
+      f4 o = mm(vf[0], split4_hl(s[hb][0]), f4{0.0f, 0.0f, 0.0f, 0.0f});
+      o = mm(vf[1], split4_hl(s[hb][1]), o);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-         Frag4 kh;
-         kh.hi = keep(kf[b].hi, mine); kh.lo = keep(kf[b].lo, mine);
-         // S^T[j][i] = sum_c Q[c][j] K[c][i]: lane (q, i) holds s[i][j = 4 q + r] of both query tiles, already scaled by log2(e) / sqrt(hd)
-         f4 s0 = mm3(qf[0], kh, smask[0]);
-         f4 s1 = mm3(qf[1], kh, smask[1]);
-         float m = max2(max2(max2(s0[0], s0[1]), max2(s0[2], s0[3])), max2(max2(s1[0], s1[1]), max2(s1[2], s1[3])));
-         m = quads_max(m, lane);
-#pragma unroll
-         for (int r = 0; r < 4; ++r) { s0[r] = __builtin_amdgcn_exp2f(s0[r] - m); s1[r] = __builtin_amdgcn_exp2f(s1[r] - m); }      // tensor.h:751-784
-         float sum = ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
-         sum = quads_sum(sum, lane);
-         const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-         for (int r = 0; r < 4; ++r) { s0[r] *= inv; s1[r] *= inv; }
-         // att[c][i] = sum_j V[c][j] a[i][j]: A = V^T registers (lane = channel, k = step 4 q + r of tile a), B = a (lane = column i)
-         f4 o = mm3(vf[0], split4(s0), f4{0.0f, 0.0f, 0.0f, 0.0f});
-         o = mm3(vf[1], split4(s1), o);
-         if (h == 0) att[b] = o;
-         else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) att[b][r] = mine ? o[r] : att[b][r];
-         }
-      }
+      for (int r = 0; r < 4; ++r) att[b][r] = (h == 0 || mine) ? o[r] * inv : att[b][r];
    }
    // out projection + residual, LN1, FFN, residual, LN2          transformer.c:202-220
-   const Frag4 w1 = lds_frag4(img + LL::f_l1, lane), w2 = lds_frag4(img + LL::f_l2, lane);
+   const AOp w1 = lds_aop(img + LL::f_l1, lane), w2 = lds_aop(img + LL::f_l2, lane);
    const f4 b1 = lds_vec4(vec, LL::v_l1_b + 4 * q), b2 = lds_vec4(vec, LL::v_l2_b + 4 * q);
    Vec<1> n1w = load_vec<1>(vec + LL::v_n1_w, q), n1b = load_vec<1>(vec + LL::v_n1_b, q);
 #pragma unroll
    for (int b = 0; b < 2; ++b) {
-      const f4 p = mm3(wo, split4(att[b]), bo);
+      const f4 p = mm(wo, split4_hl(att[b]), bo);
       if (TAP == 1) y[b] = p; else y[b] += p;
    }
    if (TAP == 1) return;
-   f4 yy[2][1] = {{y[0]}, {y[1]}};
-#pragma unroll
-   for (int b = 0; b < 2; ++b) layer_norm<1>(yy[b], n1w, n1b, lane);
-   const Frag4 wc = lds_frag4(img + LL::f_cv, lane);
+   f4 yy[2] = {y[0], y[1]};
+   layer_norm16_n<2, true>(yy, n1w.v[0], n1b.v[0], lane);
+   const AOp wc = lds_aop(img + LL::f_cv, lane);
    const f4 bc = lds_vec4(vec, LL::v_cv_b + 4 * q);
    Vec<1> n2w = {}, n2b = {};
    if (TAP == 2) { n2w = load_vec<1>(vec + LL::v_n2_w, q); n2b = load_vec<1>(vec + LL::v_n2_b, q); }
+   {
+      f4 f[2];
 #pragma unroll
-   for (int b = 0; b < 2; ++b) {
-      f4 f = mm3(w1, split4(yy[b][0]), b1);
+      for (int b = 0; b < 2; ++b) {
+         f[b] = mm(w1, split4_hl(yy[b]), b1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) f[r] = relu(f[r]);
-      yy[b][0] += mm3(w2, split4(f), b2);
+         for (int r = 0; r < 4; ++r) f[b][r] = relu(f[b][r]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) yy[b] += mm(w2, split4_hl(f[b]), b2);
    }
-#pragma unroll
-   for (int b = 0; b < 2; ++b) {
-      if (TAP == 2) { layer_norm<1, true>(yy[b], n2w, n2b, lane); y[b] = yy[b][0]; }
-      else layer_norm<1, false>(yy[b], n2w, n2b, lane);       // scale and shift: folded into the conv below by the host
-   }
+   if (TAP == 2) { layer_norm16_n<2, true>(yy, n2w.v[0], n2b.v[0], lane); y[0] = yy[0]; y[1] = yy[1]; }
+   else layer_norm16_n<2, false>(yy, n2w.v[0], n2b.v[0], lane);      // scale and shift: folded into the conv below by the host
    if (TAP == 2) return;
    // conv k = 1 (+ folded BatchNorm) -> ReLU, every step (the store keeps the even ones)      transformer.c:279-290
 #pragma unroll
    for (int b = 0; b < 2; ++b) {
-      f4 z = mm3(wc, split4(yy[b][0]), bc);
+      const f4 z = mm(wc, split4_hl(yy[b]), bc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[b][r] = relu(z[r]);
    }
@@ -210,23 +246,48 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
    const float *vec = reinterpret_cast<const float *>(lds + LL::f_end);
    char *buf = lds + kL1ImgBytes + (TAP ? 0 : wave * kL1BufBytes);
 
-   // the chunk's bytes, from the 16-byte boundary below its first one, into this wave's buffer (13 x 1 KB, the last piece 40 lanes), and the
-   // four partial bin sums of its frames (lanes 0..24)
+   // ---- the input pipeline -----------------------------------------------------------------------------------------------------------------
+   // A chunk's bytes travel from the 16-byte boundary below its first one into this wave's buffer as 13 LDS-DMA pieces of 1 KB in four GROUPS --
+   // 16-byte units [0, 192), [192, 384), [384, 576), [576, 808) -- and group g of the NEXT chunk is issued as soon as k block g of the current one
+   // has been read: k block g reads bytes [lead + 3200 g, lead + 3200 (g + 1)), lead <= 12, so units below 192 (g + 1) hold consumed bytes only.
+   // Every piece so has most of a chunk's time to arrive (issued in one go behind the conv block, the copy had the transformer block's time only and
+   // a wave spent a quarter of its time waiting for it).  K block g of the next chunk needs units below 200 (g + 1) + 1: groups 0 .. g and the FIRST
+   // piece of group g + 1.  The four partial bin sums of the chunk's frames (lanes 0..24) are loaded ahead of group 0, by inline asm as well: hipcc
+   // does not count the DMA pieces, and its own s_waitcnt for a load it knows would wait for every piece issued before it.
+   // Vector-memory operations complete in issue order; per iteration a wave issues, in this order: 4 loads (sums), 3 + 3 + 3 + 4 pieces, 4 stores =
+   // 21.  The waits below count from that (see L1R_WAIT); the first iteration starts behind a full drain, where every counted wait passes at once.
    float fmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-   auto issue_chunk = [&](int item) {
-      const int n = a.map(item);
-      const size_t cb = (size_t)n * (kL1ChunkFloats * 4);
-      const char *g = reinterpret_cast<const char *>(a.y) + (cb & ~(size_t)15) + lane * 16;
-      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf;
-#pragma unroll
-      for (int j = 0; j < 12; ++j)
-         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst + j * 1024), "v"(g + j * 1024) : "memory");
-      if (lane < 40) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst + 12 * 1024), "v"(g + 12 * 1024) : "memory");
-      const float *fmp = a.fm + (size_t)n * kFrames + (lane < kFrames ? lane : 0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) fmv[k] = fmp[k * a.fm_stride];
+   const int lo16 = lane * 16;
+   auto chunk_base = [&](int nn) -> const char * {
+      const size_t cb = (size_t)nn * (kL1ChunkFloats * 4);
+      return reinterpret_cast<const char *>(a.y) + (cb & ~(size_t)15);              // wave-uniform: scalar base + lane offset, no vector address arithmetic
    };
-   if (!TAP && slot < a.n_chunks) issue_chunk(slot);
+   auto issue_sums = [&](int nn) {                             // nn = the chunk's index map(item)
+      const float *fmp = a.fm + (size_t)nn * kFrames;
+      const int lo4 = (lane < kFrames ? lane : 0) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("global_load_dword %0, %1, %2" : "=v"(fmv[k]) : "v"(lo4), "s"(fmp + k * a.fm_stride) : "memory");
+   };
+   auto issue_group = [&](int nn, int g) {
+      const char *src = chunk_base(nn);
+      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf;
+#ifndef VADC_L1R_ABL_NODMA        // (timing-only ablations, tools/l1r_ablate.sh: results are wrong)
+#pragma unroll
+      for (int j = 3 * g; j < 3 * g + 3; ++j)
+         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + j * 1024), "v"(lo16), "s"(src + j * 1024) : "memory");
+      if (g == 3 && lane < 40) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 12 * 1024), "v"(lo16), "s"(src + 12 * 1024) : "memory");
+#else
+      asm volatile("" :: "s"(dst), "s"(src), "v"(lo16));
+#endif
+   };
+// wait until at most N of the wave's vector-memory operations are outstanding; `more`: whether this iteration issues for a next chunk
+#define L1R_WAIT(more, n_more, n_last) do { if (more) asm volatile("s_waitcnt vmcnt(" #n_more ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n_last ")" ::: "memory"); } while (0)
+   if (!TAP && slot < a.n_chunks) {
+      const int n0 = a.map(slot);
+      issue_sums(n0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) issue_group(n0, g);
+   }
    {  // image -> LDS, 8 loads in flight per thread
       const uint4 *src = reinterpret_cast<const uint4 *>(a.img);
       uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -240,7 +301,12 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
       }
    }
    __syncthreads();
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef VADC_L1R_PHASE_PROF
+   const bool ph_on = lane == 0 && wave == 3;
+   unsigned long long ph_t = __builtin_readcyclecounter();
+#endif
    for (int item = slot; item < a.n_chunks; item += nslots) {
       f4 y[2];
       const int n = a.map(item);
@@ -261,109 +327,183 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
                if (l1_owns(t, lc)) a.out[(size_t)n * (16 * kFrames) + (4 * q + r) * kFrames + l1_step(t, lc)] = y[t][r];
          continue;
       } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's image and partial sums have landed
+      const bool more = item + nslots < a.n_chunks;           // wave-uniform
+      const int nnext = more ? a.map(item + nslots) : n;      // (the index arithmetic of the next chunk once per iteration, in scalar registers)
+      L1R_PH(0);
+      // outstanding, oldest first: sums 4, groups 3 3 3 4, stores 4.  The sums have landed when 17 are left.
+      asm volatile("s_waitcnt vmcnt(17)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
+      L1R_PH(1);
       // ---- adaptive normalization offset of the chunk (misc.c:65-82): frame means, 7-tap smoothing with reflect padding, mean over the frames ----
       float off;
+#ifdef VADC_L1R_ABL_NONORM
+      off = fmv[0];
+#else
       {
          const float fms = ((fmv[0] + fmv[1]) + (fmv[2] + fmv[3])) / 129.0f;
          const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                                 0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                                 0.03663284704089164733887f};
          const int t = lane < kFrames ? lane : 0;
-         float r = 0.0f;
+         float nb[7];
 #pragma unroll
          for (int i = 0; i < 7; ++i) {
             int qq = t + i - 3;                                 // reflect pad 3, no edge repeat
             qq = qq < 0 ? -qq : qq;
             qq = qq >= kFrames ? 2 * (kFrames - 1) - qq : qq;
-            r += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * qq, __builtin_bit_cast(int, fms))) * filt[i];
+            nb[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * qq, __builtin_bit_cast(int, fms)));
          }
-         float total = 0.0f;
+         float r = 0.0f;
 #pragma unroll
-         for (int tt = 0; tt < kFrames; ++tt) total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), tt));   // the reference's order
+         for (int i = 0; i < 7; ++i) r += nb[i] * filt[i];
+         r = lane < kFrames ? r : 0.0f;
+         // the sum of the 25 smoothed means as a tree over the lanes (row shifts, then the two rows): the reference adds them one after the other,
+         // which as 25 v_readlane + add pairs took a fifth of a wave's time (each a trip through the scalar registers); the two orders differ by
+         // a few units in the last place of an offset that is subtracted from values of its own size
+         r += dpp_row<0x111>(r); r += dpp_row<0x112>(r); r += dpp_row<0x114>(r); r += dpp_row<0x118>(r);     // row_shr:1, 2, 4, 8: lane 15 of a row = its sum
+         const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 15)) +
+                             __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 31));
          off = total / (float)kFrames;
       }
+#endif
+      L1R_PH(2);
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x))        conv.c:761-814 ----
       const int lead = (int)(((size_t)n * (kL1ChunkFloats * 4)) & 15);
       const float *xb = reinterpret_cast<const float *>(buf + lead) + (16 * (q & 1) + 8 * (q >> 1)) * 25 + lc;
       const float *tp = vec + LL::v_taps + q * 64;
       f4 acc[2];
       acc[0] = acc[1] = lds_vec4(vec, LL::v_cb_b + 4 * q);
+      asm volatile("s_waitcnt vmcnt(13)" ::: "memory");        // k block 0: group 0 and the first piece of group 1 (8 done)
       L1Stage sa = l1_load_stage(xb, tp, 0, 0), sb;
       Frag wd = lds_frag(img + LL::f_conv, 0, lane), wx = lds_frag(img + LL::f_conv, 4, lane);
+      // The 12 MFMAs of k block kb - 1 are issued ONE AT A TIME between the channel groups of k block kb (about 14 vector instructions each), not in
+      // a clump behind their operands' splits.  The scheduling barriers pin that order.
+      Frag pd0, pd1, px0, px1, pwd, pwx;                         // pending: operands and weights of the previous k block
+      auto pending_mfma = [&](int i) {
+         const int t = i & 1, term = i >> 1;
+         const Frag &w = term < 3 ? pwd : pwx;
+         const Frag &o = term < 3 ? (t ? pd1 : pd0) : (t ? px1 : px0);
+         const int k = term % 3;
+         acc[t] = k == 0 ? MFMA16(w.lo, o.hi, acc[t]) : (k == 1 ? MFMA16(w.hi, o.lo, acc[t]) : MFMA16(w.hi, o.hi, acc[t]));
+      };
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
+         const bool have = kb > 0;
          sb = l1_load_stage(xb, tp, kb, 1);
          __builtin_amdgcn_sched_barrier(0);
          f4 xl0, xl1, dl0, dl1, xh0, xh1, dh0, dh1;
-         l1_stage_math(sa, off, lc, xl0, xl1, dl0, dl1);
+#pragma unroll
+         for (int c = 0; c < 4; ++c) {
+            l1_channel_math(sa, c, off, xl0, xl1, dl0, dl1);
+            if (have) pending_mfma(c);
+            __builtin_amdgcn_sched_barrier(0);
+         }
          Frag wdn = wd, wxn = wx;
+         // k block kb + 1 needs its groups 0 .. kb + 1 and the first piece of group kb + 2.  Done so far must be 11 / 14 / 17 of the 21 operations
+         // of the last iteration; this one has issued 0 / 7 / 10 more (if it issues at all)
+         if (kb == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+         if (kb == 1) L1R_WAIT(more, 14, 7);
+         if (kb == 2) L1R_WAIT(more, 14, 4);
          if (kb < 3) {
             sa = l1_load_stage(xb, tp, kb + 1, 0);
             wdn = lds_frag(img + LL::f_conv, kb + 1, lane); wxn = lds_frag(img + LL::f_conv, 4 + kb + 1, lane);
          } else {
             // the Nyquist channel (128), for every lane: k = 0 relu(dw(x)), k = 1 x; only quad 0's weights are not zero
             const float *xt = reinterpret_cast<const float *>(buf + lead) + 128 * 25 + lc;
-            sa.x0[0] = xt[0]; sa.x1[0] = xt[9];
+            sa.x[0] = f2{xt[0], xt[9]};
             sa.ka[0] = lds_vec4(vec, LL::v_tail); sa.kb[0] = lds_vec4(vec, LL::v_tail + 4);
          }
          __builtin_amdgcn_sched_barrier(0);
-         l1_stage_math(sb, off, lc, xh0, xh1, dh0, dh1);
-         {
-            const Frag df0 = split8(dl0, dh0), xf0 = split8(xl0, xh0);
-            const Frag df1 = split8(dl1, dh1), xf1 = split8(xl1, xh1);
-            acc[0] = MFMA16(wd.lo, df0.hi, acc[0]); acc[1] = MFMA16(wd.lo, df1.hi, acc[1]);
-            acc[0] = MFMA16(wd.hi, df0.lo, acc[0]); acc[1] = MFMA16(wd.hi, df1.lo, acc[1]);
-            acc[0] = MFMA16(wd.hi, df0.hi, acc[0]); acc[1] = MFMA16(wd.hi, df1.hi, acc[1]);
-            acc[0] = MFMA16(wx.lo, xf0.hi, acc[0]); acc[1] = MFMA16(wx.lo, xf1.hi, acc[1]);
-            acc[0] = MFMA16(wx.hi, xf0.lo, acc[0]); acc[1] = MFMA16(wx.hi, xf1.lo, acc[1]);
-            acc[0] = MFMA16(wx.hi, xf0.hi, acc[0]); acc[1] = MFMA16(wx.hi, xf1.hi, acc[1]);
+#pragma unroll
+         for (int c = 0; c < 4; ++c) {
+            l1_channel_math(sb, c, off, xh0, xh1, dh0, dh1);
+            if (have) pending_mfma(4 + c);
+            __builtin_amdgcn_sched_barrier(0);
          }
+         // k block kb has been read (every value of its two stages has been used): group kb of the next chunk may overwrite it
+         if (more && kb < 3) {
+            if (kb == 0) issue_sums(nnext);
+            issue_group(nnext, kb);
+         }
+         const Frag df0 = split8(dl0, dh0);
+         if (have) pending_mfma(8);
          __builtin_amdgcn_sched_barrier(0);
+         const Frag df1 = split8(dl1, dh1);
+         if (have) pending_mfma(9);
+         __builtin_amdgcn_sched_barrier(0);
+         const Frag xf0 = split8(xl0, xh0);
+         if (have) pending_mfma(10);
+         __builtin_amdgcn_sched_barrier(0);
+         const Frag xf1 = split8(xl1, xh1);
+         if (have) pending_mfma(11);
+         __builtin_amdgcn_sched_barrier(0);
+         pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1; pwd = wd; pwx = wx;
          wd = wdn; wx = wxn;
       }
       {
-         const Frag4 wt = lds_frag4(img + LL::f_tail, lane);
-         const float x0 = sa.x0[0] - off, x1 = sa.x1[0] - off;
-         const float d0 = dw5<false>(x0, sa.ka[0][0], sa.ka[0][1], sa.ka[0][2], sa.ka[0][3], sa.kb[0][0], sa.kb[0][1], lc);
-         const float d1 = dw5<false>(x1, sa.ka[0][0], sa.ka[0][1], sa.ka[0][2], sa.ka[0][3], sa.kb[0][0], sa.kb[0][2], lc);
-         const Frag4 b0 = split4(f4{d0, x0, 0.0f, 0.0f}), b1 = split4(f4{d1, x1, 0.0f, 0.0f});
-         acc[0] = mm3(wt, b0, acc[0]);
-         acc[1] = mm3(wt, b1, acc[1]);
+         const AOp wt = lds_aop(img + LL::f_tail, lane);
+         const float x0 = sa.x[0][0] - off, x1 = sa.x[0][1] - off;      // (uses the last LDS read of the chunk)
+         if (more) issue_group(nnext, 3);
+#pragma unroll
+         for (int i = 0; i < 4; ++i) pending_mfma(i);
+         float d0, d1;
+         dw5x2(x0, x1, sa.ka[0][0], sa.ka[0][1], sa.ka[0][2], sa.ka[0][3], sa.kb[0][0], sa.kb[0][1], d0, d1);
+         d0 = relu(d0); d1 = relu(d1);
+#pragma unroll
+         for (int i = 4; i < 8; ++i) pending_mfma(i);
+         const h8 b0 = split4_hl(f4{d0, x0, 0.0f, 0.0f}), b1 = split4_hl(f4{d1, x1, 0.0f, 0.0f});
+#pragma unroll
+         for (int i = 8; i < 12; ++i) pending_mfma(i);
+         acc[0] = mm(wt, b0, acc[0]);
+         acc[1] = mm(wt, b1, acc[1]);
       }
-      // the conv block has read the chunk: the next one may land in the buffer while the transformer block runs
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (item + nslots < a.n_chunks) issue_chunk(item + nslots);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
          for (int r = 0; r < 4; ++r) y[t][r] = relu(acc[t][r]);
+#ifdef VADC_L1R_PHASE_PROF
+      asm volatile("" :: "v"(y[0][0]), "v"(y[1][3]));
+#endif
+      L1R_PH(3);
+#ifndef VADC_L1R_ABL_NOBLOCK
       l1_block<0>(y, img, vec, lane);
-      // stride 2: the even steps -- tile 0 lanes 0, 2, .. 12 (steps 0..12), tile 1 lanes 5, 7, .. 15 (steps 14..24)
-      float *op = a.out + (size_t)n * (16 * 13) + (4 * q) * 13;
-      if ((lc & 1) == 0 && lc <= 12) {
+#endif
+#ifdef VADC_L1R_PHASE_PROF
+      asm volatile("" :: "v"(y[0][0]), "v"(y[1][3]));
+#endif
+      L1R_PH(4);
+      // stride 2: the even steps -- tile 0 lanes 0, 2, .. 12 (steps 0..12), tile 1 lanes 5, 7, .. 15 (steps 14..24).  A lane owns at most one of the
+      // two: FOUR stores per iteration (the waits above count them), in one branch that every wave takes
+      {
+         const bool odd = lc & 1;
+         const int step = odd ? 9 + lc : lc;
+         float *op = a.out + (size_t)n * (16 * 13) + (4 * q) * 13 + (step >> 1);
+         if (odd ? lc >= 5 : lc <= 12) {
 #pragma unroll
-         for (int r = 0; r < 4; ++r) op[r * 13 + (lc >> 1)] = y[0][r];
+            for (int r = 0; r < 4; ++r) op[r * 13] = odd ? y[1][r] : y[0][r];
+         }
       }
-      if ((lc & 1) == 1 && lc >= 5) {
-#pragma unroll
-         for (int r = 0; r < 4; ++r) op[r * 13 + ((9 + lc) >> 1)] = y[1][r];
-      }
+      L1R_PH(5);
       }
    }
 }
 
-// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain).  waves: 8 or 10 per workgroup.
-void launch_layer1_regs(const L1RegsArgs &a, int max_wgs, int waves, hipStream_t st)
+#ifdef VADC_L1R_PHASE_PROF
+extern "C" int vadc_amd_debug_l1r_phases(unsigned long long *out, int reset)
+{
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_l1r_phase), sizeof(g_l1r_phase)) != hipSuccess) return -1;
+   if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_l1r_phase), z, sizeof(z)) != hipSuccess) return -1; }
+   return 0;
+}
+#endif
+
+// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain).  8 waves per workgroup: 2 per SIMD, up to 256 registers each -- the counted
+// waits of the input pipeline rely on a register allocation without spills (an in-flight load's destination must not be moved); 10 waves (168
+// registers: 45 spilled) were also slower, 0.14 against 0.12 ms.
+void launch_layer1_regs(const L1RegsArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   if (waves == 10) {
-      const int g = std::min(max_wgs, (a.n_chunks + 9) / 10);
-      hipLaunchKernelGGL((k_layer1_regs<10, 0>), dim3(g), dim3(640), 0, st, a);
-   } else {
-      const int g = std::min(max_wgs, (a.n_chunks + 7) / 8);
-      hipLaunchKernelGGL((k_layer1_regs<8, 0>), dim3(g), dim3(512), 0, st, a);
-   }
+   const int g = std::min(max_wgs, (a.n_chunks + 7) / 8);
+   hipLaunchKernelGGL((k_layer1_regs<8, 0>), dim3(g), dim3(512), 0, st, a);
 }
 
 // stage taps for the op-level fixtures (vadc_amd_debug_layer1_block): a.y = [n][16][25], a.out = [n][16][25]
