@@ -56,7 +56,7 @@ PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole p
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)"}
 
 
-def kernel_cost(model, name, fe_kernel, layer_major=False):
+def kernel_cost(model, name, fe_kernel, layer_major=False, layer1_regs=False):
     """-> (algorithmic FLOP per chunk, {pipe: executed FLOP per chunk}).  Executed = what the kernel issues: the symmetric front end
     evaluates 33 of the 129 bins' trees, split-fp16 GEMMs issue three fp16 MFMAs per fp32 product, the folded GEMM front end half the taps."""
     if name in ("k_lstm", "k_lstm_l1") and layer_major:      # k_lstm_layer: "k_lstm" is layer 0 alone, "k_lstm_l1" layer 1 + decoder
@@ -72,6 +72,11 @@ def kernel_cost(model, name, fe_kernel, layer_major=False):
         if fe_kernel == 2:      # folded real-input DFT: 256 rows x K = 128, three split-fp16 MFMAs per k-block
             return alg, {"fp16": 3 * 2 * 256 * 128 * frames}
         return alg, {"valu_nofma": frames * (129 * 2 * 511 + 129 * 3)}
+    if name == "k_layer1" and layer1_regs:
+        # k_layer1_regs issues v_mfma_f32_16x16x32_f16 only, per chunk (two 16-column tiles for its 25 steps, idle columns and zero k slots included):
+        # 48 for the 258 -> 16 conv block (8 k blocks x 3 split terms x 2 tiles), 4 for the Nyquist channel, 60 for the D = 16 transformer block and the
+        # strided conv (two instructions per K = 16 product); depthwise conv, operand splits, softmax and LayerNorm are vector work
+        return alg, {"fp16": (48 + 4 + 60) * 16384}
     if name == "k_enc234":
         # k_enc_fused issues v_mfma_f32_16x16x32_f16 only (16,384 FLOP each, zero-padded k and idle columns included): per chunk 60 in layer 2 (one
         # 16-column tile per chunk), 30 in layer 3 and 105 in layer 4 (one tile per two chunks); depthwise conv, softmax and LayerNorm are vector work
@@ -277,7 +282,7 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
     fe_kernel = eng.get_option("frontend_kernel")
     dom = max(kt, key=kt.get)
-    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt)
+    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, model == "v31" and eng.get_option("layer1") == 0)
     pipe = max(exe, key=lambda p_: exe[p_] / PEAKS[p_])
     out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
@@ -374,7 +379,13 @@ def run_rank(args, world, rank, local_rank):
     for i in range(2 * NB):                # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
         step(i)
     torch.cuda.synchronize()
-    for i in range(args.warmup):
+    eng.set_profiling(False)
+    if args.graph:                        # setup as well: capture and instantiate every (input buffer, hand-off buffer) pairing -- host work, the GPU mostly idles
+        eng.set_option("graph", 1)
+        for i in range(2 * NB):
+            step(i)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):          # the W warm-up steps run what the timed steps run (graph replay), right before them
         step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -382,12 +393,6 @@ def run_rank(args, world, rank, local_rank):
     torch.cuda.synchronize()
     eng.reset_kernel_times()
     separate_pass = args.no_kernel_timing
-    eng.set_profiling(False)
-    if args.graph:
-        eng.set_option("graph", 1)
-        for i in range(2 * NB):           # capture every (input buffer, hand-off buffer) pairing outside the timed region
-            step(i)
-        torch.cuda.synchronize()
     # Per-kernel HIP events (two hipEventRecord per launch, on the launch's stream) cost ~2.5 % of the step when every launch
     # of the timed region carries them (each boundary between two timed kernels costs ~12 us); they are recorded on every 8th step of the
     # timed region instead (still "live", still on the kernel's own stream), which keeps `value` within ~0.6 % of an event-free run.
@@ -461,7 +466,7 @@ def run_rank(args, world, rank, local_rank):
         for k, (n_l, ms) in kt.items():
             if not n_l:
                 continue
-            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major)
+            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major, args.model == "v31" and eng.get_option("layer1") == 0)
             per_launch = S * Cn * n_prof / n_l                    # chunks one launch processes (a step may be split into chunk groups)
             sec = ms / n_l / 1e3
             # binding pipe = the one whose executed FLOP take longest at its peak (the pipes can overlap: this is the LOWER bound on the kernel's time)

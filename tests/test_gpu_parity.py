@@ -213,26 +213,32 @@ def test_reference_fixture_transformer_block_16_16_48(weights_blob, fixture_path
     qkv_w, qkv_b, out_w, out_b, n1w, n1b, n2w, n2b, l1w, l1b, l2w, l2b, x, ref = [a for _, a in tt.load(fixture_path("transformer_block_test_16_16_48"))]
     rep = dict(zip(range(7, 19), [qkv_w, qkv_b, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b]))
     e = Engine(_blob_with(weights_blob, rep), max_streams=1, max_chunks_per_call=4, device=0)
-    got = e.layer1_block(np.stack([x, 0.5 * x, x[:, ::-1]]), "transformer_block")          # three chunks: two share a workgroup, the third is alone in its own
+    for form in (0, 1):                                                                        # k_layer1_regs / the K = 1 form of k_layer_mfma
+        e.set_option("layer1", form)
+        got = e.layer1_block(np.stack([x, 0.5 * x, x[:, ::-1]]), "transformer_block")       # three chunks: two share a workgroup, the third is alone in its own
+        assert float(np.abs(got[0] - ref).max()) < 1e-4, form
     e.close()
-    assert float(np.abs(got[0] - ref).max()) < 1e-4
 
 
 def test_reference_fixture_dual_head_attention(weights_blob, fixture_path):               # test.c:1105
     """dual_head_attention_test: input and result are [T = 25, D = 16] (the reference transposes around the attention, transformer.c:172-199)"""
     x, w, b, pw, pb, ref = [a for _, a in tt.load(fixture_path("dual_head_attention_test"))]
     e = Engine(_blob_with(weights_blob, {7: w, 8: b, 9: pw, 10: pb}), max_streams=1, max_chunks_per_call=4, device=0)
-    got = e.layer1_block(x.T[None], "attention")
+    for form in (0, 1):
+        e.set_option("layer1", form)
+        got = e.layer1_block(x.T[None], "attention")
+        assert float(np.abs(got[0].T - ref).max()) < 1e-4, form
     e.close()
-    assert float(np.abs(got[0].T - ref).max()) < 1e-4
 
 
 def test_reference_fixture_layer_norm(weights_blob, fixture_path):                        # test.c:931
     x, w, b, ref = [a for _, a in tt.load(fixture_path("layernorm_test"))]
     e = Engine(_blob_with(weights_blob, {11: w, 12: b}), max_streams=1, max_chunks_per_call=4, device=0)
-    got = e.layer1_block(x.T[None], "layer_norm")
+    for form in (0, 1):
+        e.set_option("layer1", form)
+        got = e.layer1_block(x.T[None], "layer_norm")
+        assert float(np.abs(got[0].T - ref).max()) < 1e-4, form
     e.close()
-    assert float(np.abs(got[0].T - ref).max()) < 1e-4
 
 
 def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):               # test.c:1071
@@ -603,6 +609,41 @@ def test_fused_encoder_forms_agree_with_the_per_layer_kernels(eng, gold_py, stag
     assert not np.array_equal(bits(outs[0]), bits(ref))
     assert np.array_equal(bits(outs[0]), bits(outs[1]))               # the two batch forms run the same arithmetic per chunk
     assert float(np.abs(outs[0] - ref).max()) < 5e-5, float(np.abs(outs[0] - ref).max())
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 23, 100])
+def test_layer1_forms_agree(eng, orc, gold_py, n):
+    """layer 1 as k_layer1_regs (the default: the chunk by LDS-DMA into the wave's own buffer, two overlapping 16-column tiles, split-fp16 MFMAs,
+    attention on the matrix cores) against the K = 1 fp32-MFMA form of k_layer_mfma (option layer1=1, rounds 1-2): different kernels, the same math to
+    fp32 rounding, and both the oracle's.  n: 1 chunk (one wave of one workgroup), 7 / 8 / 9 (around a workgroup's 8 waves), 23 and 100 (several
+    chunks per wave when the grid is capped; every 16-byte phase of a chunk's first byte: 12,900 n mod 16 = 0, 4, 8, 12)"""
+    x = np.tile(f32(gold_py["pcm_speech2"])[: 25 * 1536], 4)[: n * 1536]
+    eng.set_option("layer1", 1); a = eng.stage_from_samples(x, "layer1")
+    eng.set_option("layer1", 0); b = eng.stage_from_samples(x, "layer1")
+    assert not np.array_equal(bits(a), bits(b))                       # two different kernels did run
+    assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
+    want = []
+    for i in range(n):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        want.append(taps["l1"])
+    assert float(np.abs(b - np.stack(want)).max()) < 1e-4
+
+
+def test_layer1_regs_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):
+    """a layer-1 weight that does not fit fp16: no LDS image is built, the engine keeps the fp32 form for the first stage (bit-identical to option layer1=1)"""
+    ts = tt.loads(weights_blob)
+    idx = next(i for i, (_, a) in enumerate(ts) if a.size == 16 * 129)          # the layer-1 pointwise weight
+    w = ts[idx][1].copy(); w.reshape(-1)[77] = 7.0e4
+    blob = _blob_with(weights_blob, {idx: w})
+    x = f32(gold_py["pcm_speech2"])[: 5 * 1536]
+    e = Engine(blob, max_streams=4, max_chunks_per_call=8, device=0)
+    try:
+        a = e.stage_from_samples(x, "layer1")
+        e.set_option("layer1", 1); b = e.stage_from_samples(x, "layer1")
+        assert np.array_equal(bits(a), bits(b)) and np.isfinite(a).all()
+    finally:
+        e.close()
 
 
 def test_split_fp16_encoder_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):

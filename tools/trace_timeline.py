@@ -10,7 +10,7 @@ def kind(n):
     if "k_frontend" in n: return "fe"
     if "k_enc_fused" in n: return "enc"
     if "k_lstm_layer" in n: return "l0" if "ELi0EEE" in n or ", 0>" in n else "l1"
-    if "k_layer_mfma" in n: return "l1k"
+    if "k_layer_mfma" in n or "k_layer1_regs" in n: return "l1k"
     return "other"
 fe = [e for e in ev if kind(e[2]) == "fe"][-K:]
 t0 = fe[0][0]
@@ -26,3 +26,7 @@ print("drain: last encoder end -> last LSTM end %.3f ms" % ((max(e[1] for e in l
 for k in ("fe", "l1k", "enc", "l0", "l1"):
     ds = [(e[1] - e[0]) / 1e3 for e in sel if kind(e[2]) == k]
     if ds: print(k, "n=%d avg %.0f us  first %.0f  last %.0f" % (len(ds), sum(ds) / len(ds), ds[0], ds[-1]))
+fd = [(e[1] - e[0]) / 1e3 for e in sel if kind(e[2]) == "fe"]
+print("front-end durations us:", " ".join("%.0f" % v for v in fd))
+l1d = [(e[1] - e[0]) / 1e3 for e in sel if kind(e[2]) == "l1k"]
+print("layer-1 durations us:", " ".join("%.0f" % v for v in l1d))
