@@ -72,7 +72,7 @@ def test_kernel_stats_list_every_kernel_of_the_step():
     """the tracked rocprofv3 summary carries all five kernels of the step, the two k_lstm_layer launches (whose names rocprofv3 leaves mangled) included"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_256x96_kernel_stats.csv")))
     txt = open(files[-1]).read()
-    for name in ("k_frontend_sym", "k_layer_mfma<129", "k_enc_fused", "k_lstm_layer"):
+    for name in ("k_frontend_sym", "k_layer1_regs", "k_enc_fused", "k_lstm_layer"):
         assert name in txt, name
     assert txt.count("k_lstm_layer") == 2
 
