@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 // i, f, g, o of a unit are the 4 accumulator registers of one lane), 24 MFMAs and 2 cells per lane and slot -- half of the two-layer kernel's.
 // Measured slot: 1.0 us against 1.54 us (tools: bench.py --opt lstm=6 / 7).
 template <int TS, int DEC, int L>
-__global__ __launch_bounds__(512, 1) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
+__global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
                                                        _Float16 *__restrict__ h0seq,            // L = 0: the h0 sequence, same layout
                                                        LstmWeights w,
                                                        float *__restrict__ hs, float *__restrict__ cs,
