@@ -1,0 +1,60 @@
+// The invariants k_layer1_regs (vadc_amd/csrc/kernels_layer1_regs.hip) builds on, checked at compile time on the host from the header both the
+// kernel and the engine's image packer use.  g++ -std=c++17 -fsyntax-only (tests/test_abi.py).
+#define __host__
+#define __device__
+#include <cstddef>
+namespace vadc { struct ItemMap { int C, c0, cg; }; }
+#include "enc_fused_layout.h"
+using namespace vadc;
+
+// every input channel 0..127 is the (kb, q, e) of exactly one B-operand slot
+constexpr bool channels_are_a_bijection()
+{
+   bool seen[128] = {};
+   for (int kb = 0; kb < 4; ++kb)
+      for (int q = 0; q < 4; ++q)
+         for (int e = 0; e < 8; ++e) {
+            const int c = l1_channel(kb, q, e);
+            if (c < 0 || c >= 128 || seen[c]) return false;
+            seen[c] = true;
+         }
+   return true;
+}
+static_assert(channels_are_a_bijection(), "l1_channel");
+
+// ds_read_b32 banks = (byte / 4) mod 32, conflicts inside a 32-lane half: the half's two lane quads read 16 consecutive floats each of a [channel][25]
+// image -- their first floats must sit 16 banks apart, whatever the chunk's lead (a multiple of 4 bytes)
+constexpr bool quads_of_a_half_hit_disjoint_banks()
+{
+   for (int kb = 0; kb < 4; ++kb)
+      for (int e = 0; e < 8; ++e)
+         for (int half = 0; half < 2; ++half) {
+            const int a = l1_channel(kb, 2 * half, e) * 25, b = l1_channel(kb, 2 * half + 1, e) * 25;
+            if (((b - a) % 32 + 32) % 32 != 16) return false;
+         }
+   return true;
+}
+static_assert(quads_of_a_half_hit_disjoint_banks(), "LDS banks");
+
+// the chunk image: 12,900 bytes from the 16-byte boundary below the chunk's first byte (lead <= 12) fit 808 units of 16 bytes = 13 pieces of 64 lanes,
+// the last one 40 lanes
+static_assert(kL1ChunkFloats * 4 + 12 <= kL1BufBytes && kL1BufBytes == 808 * 16 && 12 * 64 + 40 == 808, "chunk image");
+static_assert(kL1YSlackBytes >= kL1BufBytes - kL1ChunkFloats * 4, "the last chunk's copy stays inside the allocation");
+// group g of the next chunk (units [192 g, 192 (g + 1))) overwrites only bytes k block g has consumed (k block g reads [lead + 3200 g, lead + 3200 (g + 1)));
+// k block g of the next chunk needs units below ceil((12 + 3200 (g + 1)) / 16) = 200 (g + 1) + 1: groups 0 .. g and the FIRST piece of group g + 1
+constexpr bool dma_groups_are_safe()
+{
+   for (int g = 0; g < 3; ++g) {
+      if (192 * (g + 1) * 16 > 3200 * (g + 1)) return false;                 // overwritten <= consumed (lead = 0 is the tight case)
+      if (200 * (g + 1) + 1 > 192 * (g + 1) + 64) return false;              // needed <= groups 0..g + one piece
+   }
+   return true;
+}
+static_assert(dma_groups_are_safe(), "DMA groups");
+// the image and eight wave buffers fit a CU's 160 KB of LDS; fragments and vectors are 16-byte aligned
+static_assert(kL1ImgBytes + 8 * kL1BufBytes + 64 <= 160 * 1024, "LDS budget");
+static_assert(L1Layout::f_tail % 16 == 0 && L1Layout::f_qkv % 16 == 0 && L1Layout::f_end % 16 == 0 && L1Layout::v_tail % 4 == 0 && L1Layout::v_cb_b % 4 == 0 &&
+              L1Layout::v_q_b % 4 == 0 && L1Layout::v_cv_b % 4 == 0, "alignment of 16-byte LDS reads");
+// k_enc_fused's images: phase B is the larger one and fits beside nothing else
+static_assert(kEncLdsBytes <= 160 * 1024 && kEncA_Bytes <= kEncLdsBytes, "k_enc_fused LDS");
+int main() { return 0; }

@@ -106,3 +106,11 @@ def test_adapter_runner_compiles_over_the_mirrors():
     r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "c"),
                         os.path.join(ROOT, "tests", "c", "adapter_run.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_layer1_kernel_layout_invariants():
+    """what k_layer1_regs relies on, as static_asserts over the header the kernel and the engine's image packer share (tests/c/l1_layout_check.cpp): the
+    channel -> operand-slot map is a bijection and bank-conflict free, the DMA groups overwrite consumed bytes only, image + wave buffers fit the LDS"""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "vadc_amd", "csrc"), os.path.join(ROOT, "tests", "c", "l1_layout_check.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
