@@ -72,6 +72,9 @@ def kernel_cost(model, name, fe_kernel, layer_major=False, layer1_regs=False):
         if fe_kernel == 2:      # folded real-input DFT: 256 rows x K = 128, three split-fp16 MFMAs per k-block
             return alg, {"fp16": 3 * 2 * 256 * 128 * frames}
         return alg, {"valu_nofma": frames * (129 * 2 * 511 + 129 * 3)}
+    if name == "k_layer1" and model == "v4" and layer1_regs:
+        # k_layer1_regs_v4: 96 v_mfma_f32_16x16x32_f16 for K = 516 (16 k blocks x 3 split terms x 2 tiles) + 4 for bin 128 + 4 for the strided conv
+        return alg, {"fp16": (96 + 4 + 4) * 16384}
     if name == "k_layer1" and layer1_regs:
         # k_layer1_regs issues v_mfma_f32_16x16x32_f16 only, per chunk (two 16-column tiles for its 25 steps, idle columns and zero k slots included):
         # 48 for the 258 -> 16 conv block (8 k blocks x 3 split terms x 2 tiles), 4 for the Nyquist channel, 60 for the D = 16 transformer block and the
@@ -282,7 +285,7 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
     fe_kernel = eng.get_option("frontend_kernel")
     dom = max(kt, key=kt.get)
-    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, model == "v31" and eng.get_option("layer1") == 0)
+    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, eng.get_option("layer1") == 0)
     pipe = max(exe, key=lambda p_: exe[p_] / PEAKS[p_])
     out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
@@ -466,7 +469,7 @@ def run_rank(args, world, rank, local_rank):
         for k, (n_l, ms) in kt.items():
             if not n_l:
                 continue
-            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major, args.model == "v31" and eng.get_option("layer1") == 0)
+            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major, eng.get_option("layer1") == 0)
             per_launch = S * Cn * n_prof / n_l                    # chunks one launch processes (a step may be split into chunk groups)
             sec = ms / n_l / 1e3
             # binding pipe = the one whose executed FLOP take longest at its peak (the pipes can overlap: this is the LOWER bound on the kernel's time)

@@ -213,8 +213,8 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 K = 1 MFMA form; 3 = one launch per layer with fp32 MFMA for the GEMMs of layers 2-4; 5 (Silero v3.1) = one launch per layer with split-fp16
  *                 MFMA (round 2's hot path); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per workgroup instead of 8 waves / 5 chunks
  *   "encoder_batch" form of the fused launch: 0 / 1 (default) = 12 waves per workgroup, two chunks per wave and batch; 2 = 8 waves, four chunks
- *   "layer1"      Silero v3.1, the first encoder layer: 0 (default) = k_layer1_regs (input by LDS-DMA, split-fp16 MFMAs, activations in registers) when
- *                 its weights fit fp16's range, 1 = the K = 1 fp32-MFMA form of k_layer_mfma (rounds 1 - 2)
+ *   "layer1"      the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4 (Silero v4, default window): input by LDS-DMA,
+ *                 split-fp16 MFMAs, activations in registers -- when its weights fit fp16's range; 1 = the K = 1 fp32-MFMA form of k_layer_mfma (rounds 1 - 2)
  *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
  *                 1: magnitudes are written by the front end and read by the first stage

@@ -173,12 +173,33 @@ def test_frontend_variants(eng, orc, gold):
 
 
 def test_first_stage_forms_agree(eng, gold):
-    """first encoder stage (258 channels): K = 1 MFMA form (default) vs the LDS slab path (option encoder=2)"""
+    """first encoder stage (258 channels): k_layer1_regs_v4 (default) vs the LDS slab path of k_layer_mfma (option encoder=2)"""
     x = f32(gold["pcm_speech1"])[:11 * 1536]
     eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
     eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")
     eng.set_option("encoder", 0)
     assert float(np.abs(a - b).max()) < 5e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("n", [1, 7, 9, 23, 100])
+def test_first_stage_register_kernel_agrees_with_the_k1_form(eng, orc, gold, n):
+    """k_layer1_regs_v4 (the default at the 1536-sample window: the chunk by LDS-DMA into the wave's own buffer, two overlapping 16-column tiles,
+    split-fp16 MFMAs over K = 516) against the K = 1 fp32-MFMA form of k_layer_mfma (option layer1=1): different kernels, the same math to fp32
+    rounding; both the oracle's.  n: one chunk .. several chunks per wave of the persistent grid"""
+    x = np.tile(f32(gold["pcm_speech1"])[: 25 * 1536], 4)[: n * 1536]
+    try:
+        eng.set_option("layer1", 1); a = eng.stage_from_samples(x, "layer1")
+        eng.set_option("layer1", 0); b = eng.stage_from_samples(x, "layer1")
+    finally:
+        eng.set_option("layer1", 0)
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))       # two different kernels did run
+    assert float(np.abs(a - b).max()) < 5e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
+    want = []
+    for i in range(n):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        want.append(taps["l1"])
+    assert float(np.abs(b - np.stack(want)).max()) < TAP_TOL * max(1.0, float(np.abs(b).max()))
 
 
 def test_magnitude_recovered_from_log_magnitude_agrees_with_stored_magnitude(eng, gold):
@@ -383,8 +404,9 @@ def test_cli_with_the_8khz_container(gold):
 
 
 def test_first_stage_widths_agree(blob, orc):
-    """the v4 first stage runs 8 waves / 5 chunks per workgroup by default (the middle chunk in two pieces that overlap by four steps, so every
-    lane finds its depthwise-conv neighbours in its own wave); option "encoder" = 4 selects 4 waves / 2 chunks.  Same arithmetic per column (two template
+    """k_layer_mfma's K = 1 form of the v4 first stage (option "layer1" = 1; the default is k_layer1_regs_v4) runs 8 waves / 5 chunks per workgroup (the
+    middle chunk in two pieces that overlap by four steps, so every lane finds its depthwise-conv neighbours in its own wave); option "encoder" = 4 selects 4
+    waves / 2 chunks.  Same arithmetic per column (two template
     instantiations may contract differently: last-bit differences, a few 1e-6 after the LSTM), on every remainder of chunks per workgroup"""
     for S, Cn in ((3, 13), (64, 40), (1, 1), (2, 5), (7, 6)):
         pcm = synth.make_streams(S, Cn, seed0=77 + S)
@@ -392,6 +414,7 @@ def test_first_stage_widths_agree(blob, orc):
         for enc in (0, 4):
             e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
             try:
+                e.set_option("layer1", 1)
                 e.set_option("encoder", enc)
                 out[enc] = e.run(pcm)
             finally:

@@ -119,4 +119,26 @@ struct L1RegsArgs {
    ItemMap map;
 };
 
+// ---- Silero v4, first stage (k_layer1_regs_v4, kernels_layer1_regs_v4.hip) ---------------------------------------------------------------
+// Input channels 0..128 = magnitude (recovered from the log-magnitudes), 129..257 = normalized log-magnitude, both made from the SAME element of Y:
+// 8 "virtual" k blocks vb = 2 kb + which (which = 0 magnitude, 1 normalized) of 32 channels l1_channel(kb, q, e) each; fragment vb = relu(dw(.)) .
+// pointwise, fragment 8 + vb = (.) . projection.  Bin 128 of both halves is a K = 16 fragment: k = 0 relu(dw(m128)), 1 relu(dw(n128)), 2 m128, 3 n128.
+struct L1V4Layout {
+   static constexpr int f_conv = 0;                                  // 16 x 2 KB
+   static constexpr int f_tail = f_conv + 16 * kFragBytes;
+   static constexpr int f_cv   = f_tail + kFrag4Bytes;               // strided 1x1 conv (BatchNorm folded by the exporter)
+   static constexpr int f_end  = f_cv + kFrag4Bytes;
+   static constexpr int v_taps = 0;                                  // [8 vb][4 q][8 e][8]: k0 k1 k2 k3 | k4 bias bias 0
+   static constexpr int v_tail = v_taps + 8 * 4 * 8 * 8;             // bin 128: magnitude's 8 floats, normalized's 8 floats
+   static constexpr int v_cb_b = v_tail + 16;
+   static constexpr int v_cv_b = v_cb_b + 16;
+   static constexpr int v_end  = v_cv_b + 16;
+};
+constexpr int kL1V4ImgBytes = L1V4Layout::f_end + L1V4Layout::v_end * 4;
+static_assert(kL1V4ImgBytes % 16 == 0, "the image is copied in 16-byte pieces");
+constexpr int kL1V4Frames = 24;
+constexpr int kL1V4ChunkFloats = 129 * kL1V4Frames;                  // 12,384 bytes = 774 units of 16: a chunk always starts on a 16-byte boundary
+constexpr int kL1V4BufBytes = 774 * 16;
+static_assert(kL1V4ChunkFloats * 4 == kL1V4BufBytes && 32 * kL1V4Frames * 4 == 192 * 16, "a k block's 32 channels are exactly one DMA group of 192 units");
+
 }  // namespace vadc

@@ -41,6 +41,7 @@ void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
 void launch_layer1_regs(const L1RegsArgs &, int, hipStream_t);
 void launch_layer1_regs_tap(int, const L1RegsArgs &, hipStream_t);
+void launch_layer1_regs_v4(const L1RegsArgs &, int, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
    const float *dec_w; const float *dec_b;
@@ -166,7 +167,9 @@ struct vadc_amd_engine {
    void *d_l1img = nullptr;
    std::vector<unsigned char> h_l1img;
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
-   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2; }   // ("encoder" = 2: the first stage as the LDS slab path)
+   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2; }
+   // Silero v4: k_layer1_regs_v4 serves the default window (24 frames) with the magnitude half of the input recovered from Y ("v4_mag" = 0)
+   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && v4_mag == 0; }   // ("encoder" = 2: the first stage as the LDS slab path)
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
@@ -635,26 +638,74 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       return f;
    };
    struct LOff { size_t dw_w, dw_b, pw_f, pj_f, cb_b, cv_f, cv_b, pwj_k1; } lo[4];
+   struct { std::vector<float> dw_w, dw_b, pw, pj, cb_b, cv_w, cv_b; } r0;      // the first stage's weights as they come, for k_layer1_regs_v4's LDS image
    for (int l = 0; l < 4; ++l) {
       const LayerShape &s = kLayersV4[l];
       const int D = s.d, C = s.cin;
       auto take = [&](int n, std::vector<float> &v) -> bool { if (!need(idx, n)) return false; copy_unaligned(v, ts[idx++]); return true; };
       std::vector<float> v, cbb;
-      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size());
-      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size());
+      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size()); if (l == 0) r0.dw_w = v;
+      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size()); if (l == 0) r0.dw_b = v;
       std::vector<float> pwm;
       if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; }
       if (!take(D, v)) goto bad;     cbb = v;
       lo[l].pj_f = (size_t)-1;
       if (s.proj) {
          if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
-         if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); }
+         if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); r0.pw = pwm; r0.pj = v; }
          if (!take(D, v)) goto bad;
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
       lo[l].cb_b = pk.add(cbb.data(), cbb.size());
+      if (l == 0) r0.cb_b = cbb;
       if (!take(D * D, v)) goto bad; { auto f = frag(v, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); }   // BatchNorm folded by the exporter
+      if (l == 0) r0.cv_w = v;
       if (!take(D, v)) goto bad;     lo[l].cv_b = pk.add(v.data(), v.size());
+      if (l == 0) r0.cv_b = v;
+   }
+   if (kLayersV4[0].cin == 2 * kBins && kLayersV4[0].d == 16 && r0.pj.size() == (size_t)16 * 2 * kBins) {
+      // ---- LDS image of k_layer1_regs_v4 (enc_fused_layout.h: L1V4Layout) ----
+      bool ok = true;
+      const int C = 2 * kBins, D = 16;
+      auto put_h = [&ok](_Float16 *hi, _Float16 *lo, float v) {
+         if (!(fabsf(v) < 60000.0f)) ok = false;
+         *hi = (_Float16)v;
+         *lo = (_Float16)(v - (float)*hi);
+      };
+      e->h_l1img.assign(kL1V4ImgBytes, 0);
+      unsigned char *img = e->h_l1img.data();
+      for (int f = 0; f < 16; ++f) {                         // fragments 0..7: relu(dw(.)) . pointwise of virtual k block vb = f, 8..15: (.) . projection
+         _Float16 *h = reinterpret_cast<_Float16 *>(img + L1V4Layout::f_conv + f * kFragBytes);
+         const std::vector<float> &W = f < 8 ? r0.pw : r0.pj;
+         const int vb = f & 7, kb = vb >> 1, which = vb & 1;
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 8; ++el)
+               put_h(&h[l * 8 + el], &h[512 + l * 8 + el], W[(size_t)(l & 15) * C + which * kBins + l1_channel(kb, l >> 4, el)]);
+      }
+      auto put_frag4 = [&](int off, auto W) {                 // W(m, k): K = 16 fragment, lane (q, m) holds k = 4 q + e: block LH [lo x 4 | hi x 4], block H0 [hi x 4 | 0 x 4]
+         _Float16 *h = reinterpret_cast<_Float16 *>(img + off);
+         for (int l = 0; l < 64; ++l)
+            for (int el = 0; el < 4; ++el) {
+               put_h(&h[l * 8 + 4 + el], &h[l * 8 + el], W(l & 15, 4 * (l >> 4) + el));
+               h[512 + l * 8 + el] = h[l * 8 + 4 + el];
+            }
+      };
+      put_frag4(L1V4Layout::f_tail, [&](int m, int k) {
+         return k == 0 ? r0.pw[(size_t)m * C + 128] : (k == 1 ? r0.pw[(size_t)m * C + kBins + 128] : (k == 2 ? r0.pj[(size_t)m * C + 128] : (k == 3 ? r0.pj[(size_t)m * C + kBins + 128] : 0.0f)));
+      });
+      put_frag4(L1V4Layout::f_cv, [&](int m, int k) { return r0.cv_w[(size_t)m * D + k]; });
+      float *v = reinterpret_cast<float *>(img + L1V4Layout::f_end);
+      auto put_taps = [&](float *d, int ch) {
+         for (int t = 0; t < 4; ++t) d[t] = r0.dw_w[(size_t)ch * 5 + t];
+         d[4] = r0.dw_w[(size_t)ch * 5 + 4]; d[5] = d[6] = r0.dw_b[ch]; d[7] = 0.0f;
+      };
+      for (int vb = 0; vb < 8; ++vb)
+         for (int q = 0; q < 4; ++q)
+            for (int el = 0; el < 8; ++el) put_taps(v + L1V4Layout::v_taps + ((vb * 4 + q) * 8 + el) * 8, (vb & 1) * kBins + l1_channel(vb >> 1, q, el));
+      put_taps(v + L1V4Layout::v_tail, 128);
+      put_taps(v + L1V4Layout::v_tail + 8, kBins + 128);
+      for (int o = 0; o < D; ++o) { v[L1V4Layout::v_cb_b + o] = r0.cb_b[o]; v[L1V4Layout::v_cv_b + o] = r0.cv_b[o]; }
+      if (!ok) e->h_l1img.clear();                            // a weight outside fp16's range: k_layer_mfma's fp32 form serves
    }
    {
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 64) || !need(idx + 3, 1) || !need(idx + 4, 7)) goto bad;
@@ -1134,6 +1185,12 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          return;
       }
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
+      if (l == 0 && e->use_l1_regs_v4()) {
+         L1RegsArgs a;
+         a.y = in; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_act[0]; a.n_chunks = n; a.map = map;
+         launch_layer1_regs_v4(a, encoder_cus(e, st), st);
+         continue;
+      }
       if (l == 0 && e->use_l1_regs()) {
          L1RegsArgs a;
          a.y = in; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_act[0]; a.n_chunks = n; a.map = map;
