@@ -1162,6 +1162,14 @@ static bool v4_mag_from_y(const vadc_amd_engine *e) { return e->model == VADC_AM
 static int encoder_cus(const vadc_amd_engine *e, hipStream_t st)
 {
    const int taken = (st == e->sA && e->lstm_cus > 0) ? e->lstm_cus : 0;
+   if (e->n_cus == 256 && taken > 0) {
+      // A CU-mask bit i selects a CU of XCD i % 8, and inside an XCD consecutive bits rotate over its 4 shader engines (tools/cumask_probe.hip).  A grid
+      // of one workgroup per CU is dealt to the XCDs and their shader engines in turn, so it must not be larger than 32 x the CUs the most depleted
+      // shader engine keeps: with 48 CUs taken (6 per XCD: shader engines keep 6, 6, 7, 7) a grid of 208 sent a seventh workgroup to engines with six
+      // CUs, and both persistent kernels took two rounds (320 streams: k_layer1 0.27 instead of 0.15 ms)
+      const int per_xcd = (taken + 7) / 8, per_se = (per_xcd + 3) / 4;
+      return 32 * (8 - per_se) > 8 ? 32 * (8 - per_se) : 8;
+   }
    return e->n_cus - taken > 8 ? e->n_cus - taken : 8;
 }
 
@@ -1280,7 +1288,10 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/2 tiles the chain is throughput work and gets the whole chip
-   if (lstm_wgs > e->n_cus / 2) return 0;
+   // Round 3, tree front end (v3.1): beyond a quarter of the chip the partition costs more than it saves -- the persistent encoder kernels scale with
+   // the CUs they get and a shared chain slows down 3 - 4 x there (1280 x 32: 2.92 M with 80 CUs set aside, 3.21 M without a partition) -- and the
+   // calls are NOT run back to back any more (see the fork).  GEMM front end (Silero v4, FAST_STFT): round 2's half chip.
+   if (lstm_wgs > (e->use_gemm_frontend() ? e->n_cus / 2 : e->n_cus / 4)) return 0;
    const double slot_us = lstm_slot_us(e, lk), per_chunk_us = enc_us_per_chunk(e);
    // SHARED partition: when every workgroup can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
@@ -1519,7 +1530,9 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          // With more stream tiles than half the CUs the LSTM is throughput work that fills the chip by itself: the next call's front end beside it
          // only loses (the persistent GEMM front end cannot place its two workgroups per CU: 0.57 -> 0.80 ms per 65,536 chunks, v4 4.02 M -> 3.65 M
          // audio-s/s at 4096 x 16), so the calls run back to back
-         if ((n_streams + kLstmTile - 1) / kLstmTile > e->n_cus / 2) { wait_last(e, e->sA, e->last_b, e->last_b_on); wait_last(e, e->sA, e->last_c, e->last_c_on); }
+         // (Round 3: only with the GEMM front end -- v4 5.96 M -> 4.92 M at 4096 x 16 when overlapped.  The tree front end of v3.1 gains from the overlap,
+         // although the chain then stretches over the whole front end: 1664 x 32 3.01 -> 3.19 M, 2560 x 32 3.18 -> 3.37 M, 4096 x 16 3.43 -> 3.49 M.)
+         if (e->use_gemm_frontend() && (n_streams + kLstmTile - 1) / kLstmTile > e->n_cus / 2) { wait_last(e, e->sA, e->last_b, e->last_b_on); wait_last(e, e->sA, e->last_c, e->last_c_on); }
          wait_last(e, e->sB, e->last_b, e->last_b_on);
          wait_last(e, split ? e->sC : e->sB, e->last_c, e->last_c_on);
       }
