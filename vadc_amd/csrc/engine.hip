@@ -1271,6 +1271,9 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
    if (e->lstm_variant >= 6) return e->lstm_variant;
    if (!forked) return 6;
    const int tiles = (n_streams + kLstmTile - 1) / kLstmTile;
+   // Tree front end (Silero v3.1), round-3 sweep: the layer-major pair on a small partition of its own is the best or within 1 % of it
+   // up to half a chip of tiles (2048 streams), whether or not the chain is the critical path; beyond, one workgroup per tile beside the next call's front end
+   if (!e->use_gemm_frontend()) return tiles <= e->n_cus / 2 ? 7 : 6;
    const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
    return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
 }
@@ -1288,10 +1291,17 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/2 tiles the chain is throughput work and gets the whole chip
-   // Round 3, tree front end (v3.1): beyond a quarter of the chip the partition costs more than it saves -- the persistent encoder kernels scale with
-   // the CUs they get and a shared chain slows down 3 - 4 x there (1280 x 32: 2.92 M with 80 CUs set aside, 3.21 M without a partition) -- and the
-   // calls are NOT run back to back any more (see the fork).  GEMM front end (Silero v4, FAST_STFT): round 2's half chip.
-   if (lstm_wgs > (e->use_gemm_frontend() ? e->n_cus / 2 : e->n_cus / 4)) return 0;
+   // Round 3, tree front end (v3.1), from a sweep over 64 .. 4096 streams: with more than 16 stream tiles the layer-major pair gets
+   // 32 CUs of its OWN (16 per layer; the mask's 4 CUs per XCD, one per shader engine) and its workgroups share them -- two co-resident, the rest in turn: a
+   // slot then costs 1.3 - 3 us instead of 0.75, which the chain can afford as soon as the encoder's time per call exceeds it (320 streams: 3.10 -> 3.21 M,
+   // 832: 2.48 -> 3.33 M, 1280: 2.94 -> 3.40 M, 2048: 2.96 -> 3.43 M).  Larger or shared partitions lost everywhere: the persistent encoder kernels scale
+   // with the CUs they keep, and a chain that shares its CUs with the front end slows 2 - 4 x.  Beyond half a chip of tiles: no partition.
+   if (!e->use_gemm_frontend() && e->cu_partition == 1) {
+      const int tiles = (n_streams + 15) / 16;
+      if (tiles > e->n_cus / 2) return 0;
+      if (lk == 7 && tiles >= 20) { *shared = false; return 32; }         // (17 .. 19 tiles: two co-resident chains would be the step -- 288 streams 2.96 M against 3.08 M with 2 x 24 CUs)
+   }
+   if (lstm_wgs > e->n_cus / 2) return 0;
    const double slot_us = lstm_slot_us(e, lk), per_chunk_us = enc_us_per_chunk(e);
    // SHARED partition: when every workgroup can have a CU of its own and the chain then has slack (<= 0.7 of the other stream's time), the
    // chain is pinned to those CUs but the front end + encoder stream keeps the WHOLE chip in its mask: its workgroups fill what the
