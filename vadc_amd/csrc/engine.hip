@@ -1274,6 +1274,7 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
    // Tree front end (Silero v3.1), round-3 sweep: the layer-major pair on a small partition of its own is the best or within 1 % of it
    // up to half a chip of tiles (2048 streams), whether or not the chain is the critical path; beyond, one workgroup per tile beside the next call's front end
    if (!e->use_gemm_frontend()) return tiles <= e->n_cus / 2 ? 7 : 6;
+   if (tiles >= 20 && tiles <= e->n_cus / 2) return 6;      // GEMM front end (Silero v4), same sweep: one workgroup per tile on the small partition is 1 % ahead of the pair
    const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
    return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
 }
@@ -1296,10 +1297,12 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    // slot then costs 1.3 - 3 us instead of 0.75, which the chain can afford as soon as the encoder's time per call exceeds it (320 streams: 3.10 -> 3.21 M,
    // 832: 2.48 -> 3.33 M, 1280: 2.94 -> 3.40 M, 2048: 2.96 -> 3.43 M).  Larger or shared partitions lost everywhere: the persistent encoder kernels scale
    // with the CUs they keep, and a chain that shares its CUs with the front end slows 2 - 4 x.  Beyond half a chip of tiles: no partition.
-   if (!e->use_gemm_frontend() && e->cu_partition == 1) {
+   // Silero v4 (GEMM front end): the same 32 CUs between 20 tiles and half a chip -- 768 x 32 4.34 -> 4.57 M, 1024 x 32 4.55 -> 4.74 M, 2048 x 32 4.30 -> 5.01 M;
+   // at 4096 streams it keeps no partition and back-to-back calls (5.98 M; 3.15 M with the partition).
+   if (e->cu_partition == 1) {
       const int tiles = (n_streams + 15) / 16;
-      if (tiles > e->n_cus / 2) return 0;
-      if (lk == 7 && tiles >= 20) { *shared = false; return 32; }         // (17 .. 19 tiles: two co-resident chains would be the step -- 288 streams 2.96 M against 3.08 M with 2 x 24 CUs)
+      if (!e->use_gemm_frontend() && tiles > e->n_cus / 2) return 0;
+      if (tiles >= 20 && tiles <= e->n_cus / 2) { *shared = false; return 32; }      // (17 .. 19 tiles: two co-resident chains would be the step -- 288 streams 2.96 M against 3.08 M with 2 x 24 CUs)
    }
    if (lstm_wgs > e->n_cus / 2) return 0;
    const double slot_us = lstm_slot_us(e, lk), per_chunk_us = enc_us_per_chunk(e);
