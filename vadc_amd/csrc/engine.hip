@@ -1503,7 +1503,9 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       return VADC_AMD_OK;
    }
    const int G = pick_groups(e, n_chunks);
-   const bool forked = !(G == 1 && (long)n_streams * n_chunks < 2048);
+   // small calls stay on the caller's stream -- unless the caller pipelines calls (defer_join) and the recurrence is long: then the layer-major pair on the
+   // internal streams runs layer 1 of one call beside layer 0 of the next (16 x 96: 0.13 -> 0.27 M audio-s/s)
+   const bool forked = !(G == 1 && (long)n_streams * n_chunks < 2048 && !(e->defer_join && n_chunks >= 32));
    const int lk = resolve_lstm(e, n_streams, forked);
    e->last_lstm_kernel = lk;
    e->last_frontend_kernel = pick_frontend(e, d_in);
