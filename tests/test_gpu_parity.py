@@ -646,6 +646,23 @@ def test_layer1_regs_is_not_used_for_weights_outside_fp16_range(weights_blob, go
         e.close()
 
 
+@pytest.mark.parametrize("S,kernel,cus", [(256, 7, 32), (288, 7, 48), (320, 7, 32), (832, 7, 32), (2048, 7, 32), (2064, 6, 0)])
+def test_lstm_schedule_by_stream_count(weights_blob, orc, S, kernel, cus):
+    """round 3's sweep, pinned: a large call's LSTM is the layer-major pair on CUs of its own -- one CU per workgroup up to 16 stream
+    tiles (and for 17 .. 19), a fixed 32 CUs from 20 tiles to half a chip of tiles -- and one workgroup per tile with no partition beyond; whatever the schedule,
+    the answers are the oracle's (first, a middle and the last stream)"""
+    Cn = 8                                                       # S x 8 >= 2048 chunk items: the call forks onto the engine's streams
+    pcm = synth.make_streams(S, Cn, seed0=4321 + S)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        got = e.run(pcm)
+        assert e.get_option("lstm_kernel") == kernel and e.get_option("lstm_cus") == cus
+    finally:
+        e.close()
+    for s_ in (0, S // 2, S - 1):
+        assert float(np.abs(got[s_] - orc.forward_stream(pcm[s_])).max()) <= PROB_TOL, s_
+
+
 def test_split_fp16_encoder_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):
     """a layer GEMM weight that does not fit fp16: the engine keeps the fp32 MFMA form for the encoder (bit-identical to option encoder=3)"""
     ts = tt.loads(weights_blob)
