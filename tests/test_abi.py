@@ -114,3 +114,24 @@ def test_layer1_kernel_layout_invariants():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "vadc_amd", "csrc"), os.path.join(ROOT, "tests", "c", "l1_layout_check.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_counted_wait_kernels_do_not_spill(tmp_path):
+    """k_layer1_regs / k_layer1_regs_v4 wait for their LDS-DMA pieces with COUNTED s_waitcnt vmcnt(N): the count assumes that the only vector-memory
+    operations a wave issues per iteration are its own 4 + 13 + 4, and an in-flight load's destination register must not be moved.  A register spill
+    (scratch traffic is vector-memory traffic) would break both silently -- so the hot instantiations must compile without any."""
+    import re, shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src_dir = os.path.join(ROOT, "vadc_amd", "csrc")
+    for src, kernel in (("kernels_layer1_regs.hip", "k_layer1_regsILi8ELi0"), ("kernels_layer1_regs_v4.hip", "k_layer1_regs_v4ILi8")):
+        out = str(tmp_path / (src + ".s"))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                            "-o", out, os.path.join(src_dir, src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txt = open(out).read()
+        m = re.search(r"\.name:\s+_ZN4vadc\d+" + kernel + r".*?\.vgpr_spill_count:\s+(\d+)", txt, re.S)
+        p = re.search(r"\.name:\s+_ZN4vadc\d+" + kernel + r".*?\.private_segment_fixed_size:\s+(\d+)", txt, re.S)
+        assert m and p, kernel
+        assert int(m.group(1)) == 0 and int(p.group(1)) == 0, (kernel, m.group(1), p.group(1))
