@@ -135,3 +135,11 @@ def test_counted_wait_kernels_do_not_spill(tmp_path):
         p = re.search(r"\.name:\s+_ZN4vadc\d+" + kernel + r".*?\.private_segment_fixed_size:\s+(\d+)", txt, re.S)
         assert m and p, kernel
         assert int(m.group(1)) == 0 and int(p.group(1)) == 0, (kernel, m.group(1), p.group(1))
+        # and the operations the waits count are the ones in the listing: per iteration 4 loads of partial sums, 13 DMA pieces, 4 stores (each once more in
+        # the prologue, except the stores); more stores than counted would only make the waits conservative, fewer would make them too lax
+        body = txt[txt.index("_ZN4vadc" + re.search(r"_ZN4vadc(\d+)" + kernel, txt).group(1) + kernel):]
+        body = body[body.index(":"):body.index(".Lfunc_end")]
+        assert len(re.findall(r"\sglobal_load_lds_dwordx4\s", body)) == 26, kernel
+        assert len(re.findall(r"\sglobal_load_dword\s", body)) == 8, kernel
+        assert len(re.findall(r"\sglobal_store_dword\s", body)) >= 4, kernel
+        assert not re.findall(r"\sscratch_", body), kernel
