@@ -123,6 +123,60 @@ def test_basis_without_dft_symmetries_runs_the_full_tree(weights_blob):
     assert float(np.abs(p[0, :, 1] - o.forward_stream((x * 32768).astype(np.int16))[:, 1]).max()) <= PROB_TOL
 
 
+def test_zero_im_row_of_bin0_is_skipped_bit_exactly(weights_blob):
+    """k_frontend_sym (fe_opt = 3, the default) runs bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis (-w[n] sin 0): magnitudes,
+    log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
+    pcm = synth.make_streams(5, 7, seed0=411)
+    x = f32(pcm[:3]).reshape(-1)
+    e = Engine(weights_blob, max_streams=8, max_chunks_per_call=8, device=0)
+    try:
+        assert e.get_option("zero_im0") == 1 and e.get_option("fe_opt") == 3
+        out = {}
+        for opt in (3, 0):
+            e.set_option("fe_opt", opt); e.reset_streams()
+            out[opt] = (e.stage_from_samples(x, "magnitude"), e.stage_from_samples(x, "normalized"), e.run(pcm))
+            assert e.get_option("frontend_kernel") == 0
+        for a, b in zip(out[0], out[3]):
+            assert np.array_equal(bits(a), bits(b))
+    finally:
+        e.close()
+    o = O.Oracle(weights_blob)
+    for i in range(4):
+        h, c = o.new_state()
+        _, taps = o.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(bits(out[3][0][i]), bits(taps["magnitude"])), i
+
+
+def test_nonzero_im_row_of_bin0_reenables_its_tree(weights_blob):
+    """a basis whose im row of bin 0 is NOT zero: one tap of row 129 set to 0.25.  (The DFT symmetries force that row to zero, so such a basis has none of
+    them: the engine reports zero_im0 = 0 and runs the full tree, whose magnitudes are the bits of the oracle built from the same weights -- bin 0 included.)"""
+    ts = tt.loads(weights_blob)
+    basis = ts[0][1].copy()
+    basis.reshape(-1)[129 * 256 + 40] = np.float32(0.25)
+    blob = _blob_with(weights_blob, {0: basis})
+    x = f32(synth.speech_like(4 * 1536, seed=77))
+    e = Engine(blob, max_streams=2, max_chunks_per_call=8, device=0)
+    try:
+        assert e.get_option("zero_im0") == 0
+        got = e.stage_from_samples(x, "magnitude")
+        p = e.run(x.reshape(1, -1))
+        assert e.get_option("frontend_kernel") == 1
+    finally:
+        e.close()
+    o = O.Oracle(blob)
+    base = O.Oracle(weights_blob)
+    differs = False
+    for i in range(4):
+        h, c = o.new_state()
+        _, taps = o.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert np.array_equal(bits(got[i]), bits(taps["magnitude"])), i
+        h, c = base.new_state()
+        _, t0 = base.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        differs = differs or not np.array_equal(bits(taps["magnitude"][0]), bits(t0["magnitude"][0]))
+    assert differs                                                 # the perturbed tap does reach bin 0's magnitude
+    assert float(np.abs(p[0, :, 1] - o.forward_stream((x * 32768).astype(np.int16))[:, 1]).max()) <= PROB_TOL
+
+
 def test_unaligned_device_input_takes_the_full_tree(eng):
     """k_frontend_sym stages the input with 16-byte loads; a device pointer that is not 16-byte aligned is served by k_frontend_fl: same bits"""
     import torch
@@ -758,6 +812,47 @@ def test_full_size_4096_streams_properties(weights_blob, orc, precision, tol):
         assert float(np.abs(a[idx, :, 1] - want).max()) <= tol
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("S", [10240, 16384])
+def test_north_star_shape_one_chunk_per_stream_and_call(weights_blob, orc, S):
+    """the north star's literal shape (BASELINE.json: ">= 10k concurrent 16 kHz streams at real-time"): S streams x ONE chunk per call -- a chunk per stream
+    every 96 ms, vadc.c:56-103 at --batch 1 -- 8 calls with the state carried on the device.  Device-resident with graph replay, device-resident eager and
+    through the asynchronous host-buffer entry point: the three are bit-identical, and EVERY stream is within 1e-4 of the CPU oracle on its audio (80 distinct
+    signals, so that each of the 16 positions of a stream tile meets five of them)."""
+    import torch
+    calls, nb = 8, 80
+    base = synth.make_streams(nb, calls, seed0=10240)
+    pcm = np.ascontiguousarray(base[np.arange(S) % nb])                            # [S, calls * 1536]
+    want = orc.forward_streams(base)                                               # [nb, calls]
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=1, device=0)
+    try:
+        e.set_option("defer_join", 1)
+        st = torch.cuda.Stream()
+        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * 1536:(k + 1) * 1536])).cuda() for k in range(calls)]
+        res = {}
+        for graph in (1, 0):
+            e.set_option("graph", graph); e.reset_streams()
+            d_out = [torch.empty((S, 1, 2), dtype=torch.float32, device="cuda:0") for _ in range(calls)]
+            for k in range(calls):
+                e.run_device(d_in[k].data_ptr(), np.int16, S, 1, d_out[k].data_ptr(), st.cuda_stream)
+            e.join(st.cuda_stream); st.synchronize()
+            res[graph] = np.concatenate([o.cpu().numpy() for o in d_out], axis=1)
+        e.set_option("defer_join", 0); e.set_option("graph", 1); e.reset_streams()
+        parts = [np.ascontiguousarray(pcm[:, k * 1536:(k + 1) * 1536]) for k in range(calls)]
+        outs = [np.full((S, 1, 2), np.nan, np.float32) for _ in range(calls)]
+        for p_, o_ in zip(parts, outs):
+            e.run_async(p_, o_)
+        e.wait_async()
+        host = np.concatenate(outs, axis=1)
+        h_last, c_last = e.get_state(S - 1)
+    finally:
+        e.close()
+    assert np.array_equal(bits(res[1]), bits(res[0])) and np.array_equal(bits(res[1]), bits(host))
+    d = np.abs(res[1][:, :, 1] - want[np.arange(S) % nb])
+    assert float(d.max()) <= PROB_TOL, (float(d.max()), np.unravel_index(d.argmax(), d.shape))
+    assert np.array_equal(bits(res[1][: nb]), bits(res[1][S - nb:])) or S % nb                # the same audio in another slot: the same bits
+    assert np.isfinite(h_last).all() and np.isfinite(c_last).all()
 
 
 # ---------------------------------------------------------------------------------------------- C host CLI

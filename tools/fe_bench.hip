@@ -10,6 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
+#include <functional>
+#include <atomic>
+#include <thread>
+#include <unistd.h>
 
 using namespace vadc;
 
@@ -175,6 +180,7 @@ int main(int argc, char **argv)
       // a windowed-DFT basis with the reference's symmetries BY CONSTRUCTION: cos / sin from one quadrant table
       double qc[65];
       for (int k = 0; k <= 64; ++k) qc[k] = cos(2.0 * M_PI * k / 256.0);
+      qc[64] = 0.0;                                      // sin(0) = 0 exactly: the im row of bin 0 is all zeros, as in the shipped tensor
       auto cosi = [&](int m) { m &= 255; if (m > 128) m = 256 - m; return m <= 64 ? qc[m] : -qc[128 - m]; };
       auto sini = [&](int m) { return cosi(m - 64); };
       std::vector<float> nat((size_t)kFilters * 256);
@@ -213,6 +219,72 @@ int main(int argc, char **argv)
       CK(hipMemset(Y1, 0, ref.size() * 4));
       time_it("sym nb2 w4, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
       check("sym nb2 w4", Y1);
+      // OPT variants of the NB = 2 kernel: 1 = split rotation, 2 = bin 0 alone without its zero im tree
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 OPT1, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+      check("sym nb2 OPT1", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 OPT2, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+      check("sym nb2 OPT2", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 OPT2 (zero_im0 = 0), magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 0); });
+      check("sym nb2 OPT2 z0", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 OPT3, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+      check("sym nb2 OPT3", Y1);
+      for (int rep = 0; rep < 2; ++rep) {
+         time_it("sym nb2 OPT0, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 0>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+         time_it("sym nb2 OPT1, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+         time_it("sym nb2 OPT2, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+         time_it("sym nb2 OPT3, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+      }
+      if (getenv("FE_POWER")) {
+         // 1 s of back-to-back launches per variant, 4 rounds in turn, with the shader clock and the socket power sampled every 5 ms from sysfs
+         // (whichever card's pp_dpm_sclk / hwmon power1_* is readable and above idle): is the kernel's rate set by its instruction count or by the power cap?
+         std::vector<std::string> sclk, pwr;
+         for (int c = 0; c < 16; ++c) {
+            char b[256];
+            snprintf(b, sizeof b, "/sys/class/drm/card%d/device/pp_dpm_sclk", c); if (FILE *f = fopen(b, "r")) { fclose(f); sclk.push_back(b); }
+            for (int h = 0; h < 12; ++h)
+               for (const char *leaf : {"power1_average", "power1_input"}) {
+                  snprintf(b, sizeof b, "/sys/class/drm/card%d/device/hwmon/hwmon%d/%s", c, h, leaf); if (FILE *f = fopen(b, "r")) { fclose(f); pwr.push_back(b); }
+               }
+         }
+         printf("sysfs: %zu sclk files, %zu power files\n", sclk.size(), pwr.size());
+         auto read_sclk = [&](const std::string &p) { double v = 0; if (FILE *f = fopen(p.c_str(), "r")) { char l[128]; while (fgets(l, sizeof l, f)) if (strchr(l, '*')) { const char *q = strchr(l, ':'); if (q) v = atof(q + 1); } fclose(f); } return v; };
+         auto read_num = [&](const std::string &p) { double v = 0; if (FILE *f = fopen(p.c_str(), "r")) { if (fscanf(f, "%lf", &v) != 1) v = 0; fclose(f); } return v; };
+         struct Var { const char *name; std::function<void()> launch; };
+         std::vector<Var> vars = {
+            {"OPT0", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 0>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+            {"OPT3", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+            {"OPT2", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+         };
+         for (int round = 0; round < 4; ++round)
+            for (auto &v : vars) {
+               hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+               std::atomic<bool> stop{false};
+               double s_clk = 0, s_pw = 0; int ns = 0; double max_pw = 0;
+               std::thread th([&] {
+                  while (!stop) {
+                     double c = 0, pw = 0;
+                     for (auto &p : sclk) c = fmax(c, read_sclk(p));
+                     for (auto &p : pwr) pw = fmax(pw, read_num(p));
+                     s_clk += c; s_pw += pw; ++ns; max_pw = fmax(max_pw, pw);
+                     usleep(5000);
+                  }
+               });
+               CK(hipEventRecord(a, g_st));
+               const int L = 2000;
+               for (int r = 0; r < L; ++r) v.launch();
+               CK(hipEventRecord(b, g_st)); CK(hipEventSynchronize(b));
+               stop = true; th.join();
+               float ms; CK(hipEventElapsedTime(&ms, a, b));
+               printf("round %d %-5s %8.4f ms/launch   sclk %6.0f MHz   power avg %6.1f W max %6.1f W  (%d samples)\n", round, v.name, ms / L, ns ? s_clk / ns : 0, ns ? s_pw / ns * 1e-6 : 0, max_pw * 1e-6, ns);
+               fflush(stdout);
+            }
+         return 0;
+      }
+      if (getenv("FE_OPT_ONLY")) return 0;
       time_it("fl nb3 (all 129 bins), log mode", [&] { hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y0, FM, n, map, fm_stride, nullptr); });
       time_it("sym nb3 w4, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 3, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });
       time_it("sym nb2 w4, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride); });

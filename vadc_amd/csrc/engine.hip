@@ -20,8 +20,8 @@
 namespace vadc {
 void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
+void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
+void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
@@ -30,6 +30,8 @@ void launch_normalize_tap(const float *, const float *, size_t, float *, int, hi
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
 void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
+void launch_lstm_duo(const float *, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
+void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, int, hipStream_t, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -156,6 +158,8 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
+   bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
+   int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree: kernels_frontend.hip)
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
    int encoder_variant = 0;                     // 0 = default (layers 2-4 fused in one launch when the weights allow), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4, 5 = one launch per layer (split-fp16)
@@ -197,6 +201,8 @@ struct vadc_amd_engine {
    // layer-major LSTM (k_lstm_layer, variant 7): layer 0 -> layer 1 hand-off of the h0 sequence (same tile layout and size as an encoder hand-off
    // buffer), double buffered over forked calls like it: layer 1 of call k reads pair [xpar] while layer 0 of call k+1 writes the other one
    float *d_h0pair[2] = {nullptr, nullptr};
+   // k_lstm_duo with layer 0's input half as throughput work (variant 9): GX0 = bias + W_x0 . x, fp32, 16 KB per (tile, step); double buffered like the hand-off
+   float *d_gx0pair[2] = {nullptr, nullptr};
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
    float *d_h = nullptr, *d_c = nullptr;
@@ -342,6 +348,8 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
    size_t off_afrag = 0, off_nyq = 0;
    e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // FAST_STFT precision mode
    e->sym_ok = basis_has_dft_symmetries(tmp);
+   e->zero_im0 = true;
+   for (int n = 0; n < 256; ++n) if (tmp[(size_t)kBins * 256 + n] != 0.0f) e->zero_im0 = false;      // (-0 == 0)
    pk.add(nullptr, 512);  // the tap pipelines' final prefetch reads up to 1 KB past the last im row (k_frontend_fl: one (group, l-pair) block of "filter 258"): keep slack
 
    struct LOff { size_t dw_w, dw_b, pwT, pw_b, pjT, pj_b, qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b, cv_w, cv_b;
@@ -829,7 +837,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx0pair[0], e->d_gx0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
@@ -941,6 +949,8 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       e->h_l1img.clear(); e->h_l1img.shrink_to_fit();
    }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
+   if (e->model != VADC_AMD_MODEL_V5)
+      for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_gx0pair[p], padded_streams * max_chunks * (size_t)1792 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
@@ -1066,7 +1076,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1087,8 +1097,9 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || (value >= 6 && value <= 9))) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
@@ -1120,6 +1131,8 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (!e || !key || !value) return fail(VADC_AMD_EINVAL, "get_option: NULL argument");
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
+   else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
+   else if (strcmp(key, "zero_im0") == 0) *value = e->zero_im0 ? 1 : 0;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "layer1") == 0) *value = e->layer1_variant;
    else if (strcmp(key, "encoder_batch") == 0) *value = e->enc_batch;
@@ -1237,8 +1250,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
       } else if (fk == 0) {
          // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
-         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
-         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
+         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0);
+         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0);
       } else {
          // any basis, any alignment: the full tree for all 129 bins
          if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
@@ -1250,7 +1263,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
 // one stream tile, and whole-chip front-end + encoder time per chunk.
-static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9); }
+static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk >= 8 ? 0.9 : (lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9)); }
 static double enc_us_per_chunk(const vadc_amd_engine *e)
 {
    if (e->model == VADC_AMD_MODEL_V4) return 0.022;
@@ -1401,7 +1414,14 @@ static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_str
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
+   if (lk >= 8) launch_lstm_duo(e->d_act[3], lk == 9 ? e->d_gx0pair[e->xpar] : nullptr, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
+   else         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
+}
+// variant 9: layer 0's input half of chunks [c0, c0 + cg) as a throughput GEMM behind the encoder (same stream: the hand-off tiles are its input)
+static void launch_xproj_on(vadc_amd_engine *e, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+{
+   KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
+   launch_lstm_xproj(e->d_act[3], e->d_gx0pair[e->xpar], e->lstm, n_streams, n_chunks, c0, cg, 8 * e->n_cus, st, e->lstm_steps);
 }
 
 // call-to-call ordering (see the engine's last_a / last_b / last_c): `st` continues after the last work of that kind, wherever it ran
@@ -1519,6 +1539,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       wait_last_all(e, st);
       rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
          run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
+         if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, 0, n_chunks, st);
          launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, 0, n_chunks, st);
       });
       if (rc) return rc;
@@ -1574,6 +1595,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          const ItemMap map{n_chunks, c0, cg};
          rc = launch_sequence(e, SeqKey{d_in, nullptr, n_streams, n_chunks, (int)sizeof(T), G, gi, xp, lk, e->last_frontend_kernel}, e->sA, [&] {
             run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA);
+            if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, c0, cg, e->sA);
          });
          if (rc) return rc;
          const bool last_group = c0 + cg >= n_chunks;
@@ -1894,7 +1916,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
                                e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
+   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt, e->zero_im0);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
@@ -1996,6 +2018,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
          HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       }
    }
+   if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, 0, n_chunks, st);
    launch_lstm_on(e, lk, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);

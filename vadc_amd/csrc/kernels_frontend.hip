@@ -30,6 +30,7 @@
 // lanes (l, l+1) two at a time with v_pk_add_f32 (component-wise the same IEEE operations in the same order): every VALU
 // instruction costs ~4.6 cycles per wave64 here whether packed or not (PMC), so instruction count is what matters.
 #include "common.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -639,7 +640,9 @@ __device__ __forceinline__ void sym_rows(SymState<NB> &st, int B, f2v vr, f2v vi
 }
 
 // Stage K of a batch = (step S = K / NB = 4 LP + I, base bin B = K % NB), pipelined exactly like FlStages
-template <int NB, int K>
+// ZI: the im row of the batch's (only) base bin is identically zero (bin 0 of a DFT basis: -w[n] sin(0)): its products are +-0, its tree sums +-0, and a
+// zero of either sign adds and squares to the same bits downstream -- the tree is skipped, not approximated
+template <int NB, int K, bool ZI = false>
 struct SymStages {
    static __device__ __forceinline__ void run(SymState<NB> &st, const float *kf, unsigned xaddr, f16v &ca, f16v &cb, f16v &na, f16v &nb,
                                               f4v (&xc)[4], f4v (&xn)[4])
@@ -654,7 +657,7 @@ struct SymStages {
          VADC_FL_LDS16(xn, xaddr, ((S1 % 4) * kFlBlockPitch + (S1 / 4) * 16) * 4);
       }
       VADC_FL_SLOAD2(na, nb, kf, noff, noff + kImOffB);
-      const f2v gr = fl_tree8<0>(xc, ca), gi = fl_tree8<0>(xc, cb);
+      const f2v gr = fl_tree8<0>(xc, ca), gi = ZI ? (f2v){0.0f, 0.0f} : fl_tree8<0>(xc, cb);
       if constexpr (I == 0) { st.ta[2 * B] = gr; st.ta[2 * B + 1] = gi; }
       else if constexpr (I == 1) { st.ta[2 * B] = st.ta[2 * B] + gr; st.ta[2 * B + 1] = st.ta[2 * B + 1] + gi; }       // g_0 + g_1   (stft.c:165)
       else if constexpr (I == 2) { st.tb[2 * B] = gr; st.tb[2 * B + 1] = gi; }
@@ -666,15 +669,15 @@ struct SymStages {
       if constexpr (B == NB - 1) {
          asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
          __builtin_amdgcn_sched_barrier(0);
-         SymStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
+         SymStages<NB, K + 1, ZI>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
       } else {
          __builtin_amdgcn_sched_barrier(0);
-         SymStages<NB, K + 1>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
+         SymStages<NB, K + 1, ZI>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
       }
    }
 };
-template <int NB>
-struct SymStages<NB, 16 * NB> {
+template <int NB, bool ZI>
+struct SymStages<NB, 16 * NB, ZI> {
    static __device__ __forceinline__ void run(SymState<NB> &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
 };
 
@@ -700,18 +703,24 @@ __device__ __forceinline__ void sym_load_octet(const float *p, float (&v)[8])
    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <typename T, int MODE, int NB = 3, int MINW = 4>
+// OPT (bit mask; NB = 2 only): 1 = the base-bin split a wave serves rotates with the workgroup -- the 9-bin split (17 - 18 trees against 16) then loads every
+// SIMD in turn instead of always the one wave 0 lands on; 2 = split 0 runs bin 0 as its batch of one and, when `zero_im0` (the loaded basis' im row of bin 0 is
+// all +-0, checked by the engine at create), without that row's tree and without the emit of the row pair that bin 0 does not have.  Both keep every bit
+// (magnitudes, Y, partial sums).  Measured (round 4, tools/fe_bench FE_POWER: 2,000 launches per variant, four rounds in turn, 24,576 chunks on 224 CUs, shader
+// clock 2.39 GHz throughout): OPT 0 0.4370 ms, OPT 3 0.4354 (-0.4 %) -- the tree is 1 of 66 and the kernel's time is set by the SIMDs' issue rate, not by one wave.
+// (Also measured and NOT kept: log1p without its Newton step -- 0.4316 ms, -1.2 %, but max |dp| over the 25,600-chunk parity sweep 3.3e-5 -> 6.3e-5.)
+template <typename T, int MODE, int NB = 3, int MINW = 4, int OPT = 0>
 __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict__ pcm,          // [n_chunks][1536], 16-byte aligned
                                                            const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
                                                            float *__restrict__ Y,              // [n_chunks][129][25]
                                                            float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
-                                                           int n_chunks, ItemMap map, size_t fm_stride)
+                                                           int n_chunks, ItemMap map, size_t fm_stride, int zero_im0 = 0)
 {
    static_assert(NB == 3 || NB == 2, "base-bin split tables exist for NB = 2, 3");
    constexpr int kFlChunks = fl_chunks(1);
    __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
    const int tid = threadIdx.x, lane = tid & 63;
-   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // base-bin split
+   const int wave = (OPT & 1) ? ((__builtin_amdgcn_readfirstlane(tid >> 6) + (int)blockIdx.x) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);   // base-bin split
    const long total_pos = (long)n_chunks * kFrames;
    const long p0 = (long)blockIdx.x * 64;
    const int item0 = (int)(p0 / kFrames);
@@ -762,26 +771,47 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
       __builtin_amdgcn_sched_barrier(0);
    }
    // rows of base bin b: (b, 128 - b, 64 - b, 64 + b); 64 -+ 0 coincide, and 64 -+ 32 are rows 32 and 96 again
+   auto emit_row = [&](int bin, bool counted, float re, float im) {
+      const float re2 = re * re, im2 = im * im;
+      const float p2 = re2 + im2;
+      float val;
+      if (MODE == 0) {
+         const float x = __builtin_amdgcn_sqrtf(p2) * 1048576.0f;
+         val = log1p_hw(x);                                                     // misc.c:42-45
+         if (counted) bin_sum += val;                                          // misc.c:55-59
+      } else {
+         val = sqrtf(p2);                                                      // stft.c:209
+      }
+      if (writer && counted) yout[bin * kFrames] = val;
+   };
    auto emit = [&](int b, const float *y8) {
       const int bins[4] = {b, 128 - b, 64 - b, 64 + b};
       const bool ok[4] = {true, true, b < 32, b > 0 && b < 32};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-         const float re = y8[2 * q], im = y8[2 * q + 1];
-         const float re2 = re * re, im2 = im * im;
-         const float p2 = re2 + im2;
-         float val;
-         if (MODE == 0) {
-            val = log1p_hw(__builtin_amdgcn_sqrtf(p2) * 1048576.0f);          // misc.c:42-45
-            if (ok[q]) bin_sum += val;                                         // misc.c:55-59
-         } else {
-            val = sqrtf(p2);                                                   // stft.c:209
-         }
-         if (writer && ok[q]) yout[bins[q] * kFrames] = val;
-      }
+      for (int q = 0; q < 4; ++q) emit_row(bins[q], ok[q], y8[2 * q], y8[2 * q + 1]);
    };
+   // a batch of one base bin from the current pipeline state (ca / cb / xc hold its first stage)
+   auto single = [&](int f, auto zi_tag, bool is_bin0) {
+      constexpr bool ZI = decltype(zi_tag)::value;
+      const float *kf = basis + (size_t)f * kFilterLen;
+      SymState<1> st;
+      SymStages<1, 0, ZI>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st.sa[k]));
+      if (is_bin0) {                                                           // rows 0, 128, 64 (64 - 0 and 64 + 0 coincide)
+         emit_row(0, true, st.sa[0], st.sa[1]); emit_row(128, true, st.sa[2], st.sa[3]); emit_row(64, true, st.sa[4], st.sa[5]);
+      } else emit(f, &st.sa[0]);
+   };
+   int f_loop = f_start;
+   if constexpr (NB == 2 && (OPT & 2)) {
+      if (wave == 0) {                                                         // split 0 = bin 0 alone, then bins 1..8 in pairs (same bin order: same partial sums)
+         if (zero_im0) single(0, std::integral_constant<bool, true>{}, true);
+         else          single(0, std::integral_constant<bool, false>{}, true);
+         f_loop = 1;
+      }
+   }
 #pragma unroll 1
-   for (int f = f_start; f + NB <= f_end; f += NB) {
+   for (int f = f_loop; f + NB <= f_end; f += NB) {
       const float *kf = basis + (size_t)f * kFilterLen;                        // wave-uniform
       SymState<NB> st;
       SymStages<NB, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
@@ -790,20 +820,16 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
 #pragma unroll
       for (int B = 0; B < NB; ++B) emit(f + B, &st.sa[8 * B]);
    }
-   if constexpr (NB == 2) {                                                    // NB = 2: wave 0 owns 9 base bins, the odd one as a batch of its own
+   if constexpr (NB == 2 && !(OPT & 2)) {                                      // NB = 2: wave 0 owns 9 base bins, the odd one as a batch of its own
       if (wave == 0) {
          const int f = f_end - 1;
          const float *kf = basis + (size_t)f * kFilterLen;
-         SymState<1> st;
          VADC_FL_LDS16(xc, xaddr, 0);
          VADC_FL_SLOAD2(ca, cb, kf, fl_tap_off(0, 0, 0), fl_tap_off(0, 0, 0) + kImOffB);
          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
          asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
          __builtin_amdgcn_sched_barrier(0);
-         SymStages<1, 0>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
-#pragma unroll
-         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st.sa[k]));
-         emit(f, &st.sa[0]);
+         single(f, std::integral_constant<bool, false>{}, false);
       }
    }
    if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
@@ -882,19 +908,23 @@ void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, fl
 }
 
 // k_frontend_sym: the default v3.1 front end (basis symmetries verified by the engine, pcm 16-byte aligned)
+// opt: the kernel's OPT mask (0 = round 3's kernel; 3 = rotating splits + bin 0 as a batch of one, its im tree skipped when zero_im0)
 constexpr int kSymNB = 2;   // tools/fe_bench sym, 16,384 chunks: NB = 2 0.300 ms, NB = 3 0.329 ms (k_frontend_fl: 1.07 ms)
-void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+template <typename T>
+static void launch_frontend_sym(const T *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0)
 {
    const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_sym<float, 0, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_sym<float, 1, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   if (mode != 0)     hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else if (opt == 3) hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else               hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
 }
-
-void launch_frontend_sym_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
+void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0)
 {
-   const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
-   else           hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, kSymNB>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride);
+   launch_frontend_sym<float>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, opt, zero_im0);
+}
+void launch_frontend_sym_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0)
+{
+   launch_frontend_sym<int16_t>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, opt, zero_im0);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24
