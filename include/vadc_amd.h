@@ -186,9 +186,16 @@ int  vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float *samples,
 int  vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *in, int n, int from_stage, int to_stage, float *out);
 /* LSTM + decoder only: x [n_streams][n_chunks][64][7] (encoder output layout), state from the engine. */
 int  vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, int n_streams, int n_chunks, float *probs);
-/* The first encoder layer's transformer block in isolation, for the reference's op-level fixtures (test.c:931, 1105, 1143): `y` [n][16][25] enters
- * the layer's own kernel behind its conv block; what = 1: dual_head_attention incl. the out projection (transformer.c:13-153), 2: transformer_block
- * (:160-234), 3: layer_norm with the block's norm1 parameters (misc.c:143-210).  out [n][16][25].  Silero v3.1 only. */
+/* The decoder alone (silero_v3.c:231-303: ReLU -> conv 64 -> 2 -> mean over the steps -> sigmoid; reference fixture test.c:170): x [n][64][steps] stands
+ * in for the second LSTM layer's output of n one-chunk streams inside the recurrence kernel, whose decoder then runs as in the product.  probs [n][2];
+ * the streams' state is neither read nor written. */
+int  vadc_amd_debug_decoder(vadc_amd_engine *e, const float *x, int n, float *probs);
+/* Parts of the first encoder layer in isolation, for the reference's op-level fixtures.  what = 1, 2, 3, 5: `y` [n][16][25] enters the layer's own kernel
+ * behind its conv block -- 1: dual_head_attention incl. the out projection (transformer.c:13-153; test.c:1105), 2: transformer_block (:160-234; test.c:1143),
+ * 3: layer_norm with the block's norm1 parameters (misc.c:143-210; test.c:931), 5: the layer's tail on `y` as the strided conv's input -- conv k = 1 with
+ * BatchNorm folded in, ReLU, every step (transformer.c:279-290, misc.c:98-141; test.c:966).  what = 4: `y` [n][129][25] runs through the product's input
+ * pipeline and conv block (depthwise k = 5 + ReLU, pointwise + projection, ReLU: conv.c:17-113, 532-589, 761-814; test.c:545, 581, 820) with a zero
+ * normalization offset and leaves behind the block's ReLU.  out [n][16][25].  Silero v3.1 only; 4 and 5 need the register-resident layer-1 kernel. */
 int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, int n, float *out);
 /* Switches (all int-valued; an unknown key or value is VADC_AMD_EINVAL):
  *   "graph"       1: kernel sequences (a whole small call; the front end + encoder of one chunk group of a forked call) are captured into hipGraphs on

@@ -295,6 +295,133 @@ def test_reference_fixture_layer_norm(weights_blob, fixture_path):              
     e.close()
 
 
+# ---- the six op-level fixtures of test.c that round 3 left to the oracle alone (test.c:170, 545, 581, 820, 900, 966) ------------------------------
+def _windows_25(x64):
+    """a [129, 64] fixture input as three overlapping [129, 25] chunks (columns 0..24, 21..45, 39..63) and, per chunk, the columns whose depthwise-conv
+    neighbourhood (+-2) lies inside it or at a true end of the sequence: the product's layer-1 kernel is built for the product's 25 steps"""
+    starts, keep = (0, 21, 39), ((0, 23), (23, 43), (43, 64))
+    return np.stack([x64[:, s_:s_ + 25] for s_ in starts]), starts, keep
+
+
+def _stitch(chunks, starts, keep, rows):
+    out = np.zeros((rows, 64), np.float32)
+    for ch, s_, (a, b) in zip(chunks, starts, keep):
+        out[:, a:b] = ch[:, a - s_:b - s_]
+    return out
+
+
+def _conv_block_engine(weights_blob, dw_w, dw_b, pw_w, pw_b, pj_w, pj_b):
+    rep = {1: dw_w.reshape(129, 1, 5), 2: dw_b, 3: pw_w.reshape(16, 129, 1), 4: pw_b, 5: pj_w.reshape(16, 129, 1), 6: pj_b}
+    return Engine(_blob_with(weights_blob, {k: np.ascontiguousarray(v, np.float32) for k, v in rep.items()}), max_streams=1, max_chunks_per_call=4, device=0)
+
+
+def test_reference_fixture_first_layer_conv_block(weights_blob, fixture_path):            # test.c:820
+    """first_layer_conv_block (relu(pw(relu(dw(x))) + proj(x)), conv.c:761-814) through the PRODUCT's layer-1 kernel -- its LDS-DMA input pipeline, its DPP
+    depthwise taps, its 258 -> 16 split-fp16 GEMM -- left behind the conv block (vadc_amd_debug_layer1_block what = 4)"""
+    dw_w, dw_b, pw_w, pw_b, pj_w, pj_b, x, ref = [a for _, a in tt.load(fixture_path("first_layer_conv_block"))]
+    chunks, starts, keep = _windows_25(x)
+    e = _conv_block_engine(weights_blob, dw_w, dw_b, pw_w, pw_b, pj_w, pj_b)
+    try:
+        got = _stitch(e.layer1_block(chunks, "conv_block"), starts, keep, 16)
+    finally:
+        e.close()
+    assert float(np.abs(got - ref).max()) < 1e-4
+
+
+def test_reference_fixture_pw_conv_129_16(weights_blob, fixture_path):                    # test.c:581
+    """pw_conv_129_16 (conv k = 1, 129 -> 16, conv.c:532-589): the fixture's weights as the conv block's projection, the depthwise / pointwise half zeroed;
+    the block ends in a ReLU, so W and -W give the positive and the negative part of W x + b"""
+    x, w, b, ref = [a for _, a in tt.load(fixture_path("pw_conv_129_16"))]
+    chunks, starts, keep = _windows_25(x)
+    z5, z1, zw, z16 = np.zeros((129, 5), np.float32), np.zeros(129, np.float32), np.zeros((16, 129), np.float32), np.zeros(16, np.float32)
+    parts = []
+    for sign in (1.0, -1.0):
+        e = _conv_block_engine(weights_blob, z5, z1, zw, z16, sign * w.reshape(16, 129), sign * b)
+        try:
+            parts.append(_stitch(e.layer1_block(chunks, "conv_block"), starts, keep, 16))
+        finally:
+            e.close()
+    assert float(np.abs((parts[0] - parts[1]) - ref).max()) < 1e-4
+
+
+def test_reference_fixture_dw_conv_129(weights_blob, fixture_path):                       # test.c:545
+    """dw_conv_129 (depthwise k = 5, zero pad 2, conv.c:17-113) as the product's conv block computes it -- relu(dw(x)) feeding a pointwise conv --
+    observed 16 channels at a time through a pointwise weight that selects them (exact: 1.0 x (hi + lo)); dw and -dw give the two signs"""
+    x, w, b, ref = [a for _, a in tt.load(fixture_path("dw_conv_129"))]
+    chunks, starts, keep = _windows_25(x)
+    zw, z16 = np.zeros((16, 129), np.float32), np.zeros(16, np.float32)
+    got = np.zeros((129, 64), np.float32)
+    for g in range(9):
+        sel = np.zeros((16, 129), np.float32)
+        ch = np.arange(16 * g, min(16 * g + 16, 129))
+        sel[ch - 16 * g, ch] = 1.0
+        parts = []
+        for sign in (1.0, -1.0):
+            e = _conv_block_engine(weights_blob, sign * w.reshape(129, 5), sign * b, sel, z16, zw, z16)
+            try:
+                parts.append(_stitch(e.layer1_block(chunks, "conv_block"), starts, keep, 16))
+            finally:
+                e.close()
+        got[ch] = (parts[0] - parts[1])[: ch.size]
+    assert float(np.abs(got - ref).max()) < 1e-4
+
+
+def test_reference_fixture_batch_norm(weights_blob, fixture_path):                        # test.c:966
+    """batchnorm_test [50, 16, 13] (misc.c:98-141 / 221-258) through the first layer's tail -- the strided conv's GEMM with BatchNorm folded in by the host,
+    ReLU -- with an identity conv (vadc_amd_debug_layer1_block what = 5); the fixture's 13 steps are the chunk's even steps; (w, b) and (-w, -b) give the signs"""
+    x, mean, var, w, b, ref = [a for _, a in tt.load(fixture_path("batchnorm_test"))]
+    y = np.zeros((x.shape[0], 16, 25), np.float32)
+    y[:, :, ::2] = x
+    one, zero = np.ones(16, np.float32), np.zeros(16, np.float32)
+    parts = []
+    for sign in (1.0, -1.0):
+        rep = {17: one, 18: zero, 19: np.eye(16, dtype=np.float32).reshape(16, 16, 1), 20: zero, 21: sign * w, 22: sign * b, 23: mean, 24: var}
+        e = Engine(_blob_with(weights_blob, rep), max_streams=1, max_chunks_per_call=64, device=0)
+        try:
+            parts.append(e.layer1_block(y, "tail")[:, :, ::2])
+        finally:
+            e.close()
+    assert float(np.abs((parts[0] - parts[1]) - ref).max()) < 1e-4
+
+
+def test_reference_fixture_decoder(weights_blob, fixture_path):                           # test.c:170
+    """decoder_test (silero_v3.c:231-303) through the decoder of the recurrence kernel (k_lstm_layer, the second layer's launch) with the fixture's input in
+    place of that layer's output.  test.c asks its own CPU decoder for 1e-10; the device decoder sums the 64 channels in the kernel's lane tree and takes the
+    hardware's expf / division for the sigmoid: fp32 rounding level, 2e-7 here."""
+    x, w, b, ref = [a for _, a in tt.load(fixture_path("decoder_test"))]
+    ts = tt.loads(weights_blob)
+    idx = next(i for i, (n, a) in enumerate(ts) if a.shape == (2, 64, 1))
+    assert ts[idx + 1][1].shape == (2,)
+    e = Engine(_blob_with(weights_blob, {idx: w, idx + 1: b}), max_streams=20, max_chunks_per_call=4, device=0)
+    try:
+        got = e.decoder(np.concatenate([x, 0.5 * x, np.repeat(x, 18, axis=0)]))              # 20 items: a full stream tile and a ragged one
+        h0, c0 = e.get_state(0)
+    finally:
+        e.close()
+    assert float(np.abs(got[0] - ref.reshape(-1)).max()) < 2e-7
+    assert np.array_equal(bits(got[0]), bits(got[2])) and np.array_equal(bits(got[0]), bits(got[19]))      # any slot of any tile: the same bits
+    assert not np.any(h0) and not np.any(c0)                                                      # the streams' state is untouched
+
+
+def test_reference_fixture_softmax(fixture_path, tmp_path):                               # test.c:900
+    """softmax_test [100, 100] (tensor.h:751-784) through the softmax PRIMITIVES of the product's attention (enc_regs_prims.h: the accumulator layout, the
+    lane-quad reductions over the LDS crossbar, exp2 of log2(e)-scaled scores, v_rcp_f32 of the row sum) in a test kernel that lets a row span seven
+    16-column tiles (tests/c/softmax_fixture.hip) -- the product instantiates them for the 25 / 13 / 7 steps of its layers, which no 100-wide row fits"""
+    import shutil, subprocess
+    from conftest import ROOT
+    x, ref = [a for _, a in tt.load(fixture_path("softmax_test"))]
+    exe = os.path.join(ROOT, "tests", "c", "softmax_fixture")
+    if not os.path.exists(exe):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(ROOT, "tests", "c", "softmax_fixture.hip"), "-o", exe])
+    fin, fout = str(tmp_path / "in.f32"), str(tmp_path / "out.f32")
+    np.ascontiguousarray(x, np.float32).tofile(fin)
+    subprocess.check_call([exe, fin, str(x.shape[0]), str(x.shape[1]), fout], timeout=120)
+    got = np.fromfile(fout, np.float32).reshape(x.shape)
+    assert float(np.abs(got - ref).max()) < 1e-4
+    assert float(np.abs(got.sum(axis=1) - 1.0).max()) < 1e-5
+
+
 def test_reference_fixture_adaptive_audio_normalization(eng, fixture_path):               # test.c:1071
     x, ref = [a for _, a in tt.load(fixture_path("adaptive_audio_normalization_test"))]
     got = eng.stage_from_stage(x, "magnitude", "normalized")

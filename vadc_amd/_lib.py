@@ -18,7 +18,7 @@ SYMBOLS = [
     "vadc_amd_run_s16_async", "vadc_amd_run_f32_async", "vadc_amd_wait_async",
     "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
     "vadc_amd_get_context", "vadc_amd_set_context",
-    "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder", "vadc_amd_debug_layer1_block",
+    "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder", "vadc_amd_debug_layer1_block", "vadc_amd_debug_decoder",
     "vadc_amd_set_option", "vadc_amd_get_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
     "vadc_amd_kernel_name",
 ]
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     L.vadc_amd_debug_stage_from_stage.argtypes = [vp, vp, i32, i32, i32, vp]
     L.vadc_amd_debug_lstm_decoder.argtypes = [vp, vp, i32, i32, vp]
     L.vadc_amd_debug_layer1_block.argtypes = [vp, i32, vp, i32, vp]
+    L.vadc_amd_debug_decoder.argtypes = [vp, vp, i32, vp]
     L.vadc_amd_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vadc_amd_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
     L.vadc_amd_set_profiling.argtypes = [vp, i32]

@@ -30,8 +30,7 @@ void launch_normalize_tap(const float *, const float *, size_t, float *, int, hi
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
 void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
-void launch_lstm_duo(const float *, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
-void launch_lstm_xproj(const float *, float *, const LstmWeights &, int, int, int, int, int, hipStream_t, int);
+void launch_lstm_decoder_tap(const float *, const LstmWeights &, float *, int, hipStream_t, int, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
       *n2_w, *n2_b, *cv_f, *cv_b, *pwj_k1;
@@ -201,8 +200,6 @@ struct vadc_amd_engine {
    // layer-major LSTM (k_lstm_layer, variant 7): layer 0 -> layer 1 hand-off of the h0 sequence (same tile layout and size as an encoder hand-off
    // buffer), double buffered over forked calls like it: layer 1 of call k reads pair [xpar] while layer 0 of call k+1 writes the other one
    float *d_h0pair[2] = {nullptr, nullptr};
-   // k_lstm_duo with layer 0's input half as throughput work (variant 9): GX0 = bias + W_x0 . x, fp32, 16 KB per (tile, step); double buffered like the hand-off
-   float *d_gx0pair[2] = {nullptr, nullptr};
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
    float *d_h = nullptr, *d_c = nullptr;
@@ -837,7 +834,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx0pair[0], e->d_gx0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
@@ -949,8 +946,6 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       e->h_l1img.clear(); e->h_l1img.shrink_to_fit();
    }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
-   if (e->model != VADC_AMD_MODEL_V5)
-      for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_gx0pair[p], padded_streams * max_chunks * (size_t)1792 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
@@ -1097,7 +1092,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       e->frontend_variant = value;
       return VADC_AMD_OK;
    }
-   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || (value >= 6 && value <= 9))) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
@@ -1263,7 +1258,7 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
 // one stream tile, and whole-chip front-end + encoder time per chunk.
-static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk >= 8 ? 0.9 : (lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9)); }
+static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9); }
 static double enc_us_per_chunk(const vadc_amd_engine *e)
 {
    if (e->model == VADC_AMD_MODEL_V4) return 0.022;
@@ -1278,7 +1273,7 @@ static double enc_us_per_chunk(const vadc_amd_engine *e)
 // 6 and 7 are BIT-identical (same MFMAs in the same k order per gate row, pinned contraction in the cell update, the same decoder summation tree:
 // tests/test_gpu_parity.py::test_lstm_variants_agree), so the choice may depend on the call's shape without a stream's bits depending on how its
 // chunks are cut into calls.  A small call that stays on the caller's stream takes 6: there the two layer launches would run one after the other.
-static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = true)
+static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = true, int n_chunks = 1 << 20)
 {
    if (e->lstm_variant == 3 || !e->lstm_h3_ok) return 3;
    if (e->lstm_variant >= 6) return e->lstm_variant;
@@ -1286,7 +1281,10 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
    const int tiles = (n_streams + kLstmTile - 1) / kLstmTile;
    // Tree front end (Silero v3.1), round-3 sweep: the layer-major pair on a small partition of its own is the best or within 1 % of it
    // up to half a chip of tiles (2048 streams), whether or not the chain is the critical path; beyond, one workgroup per tile beside the next call's front end
-   if (!e->use_gemm_frontend()) return tiles <= e->n_cus / 2 ? 7 : 6;
+   // (round 4: calls of one or two chunks per stream over more tiles than that -- the north star's serving shape, 10,240 streams x 1 chunk -- take the pair as well: a
+   // workgroup of k_lstm_wavefront_h3 loads and splits both layers' weights (128 KB) for 7 slots of work and holds half a CU's registers meanwhile; 4096 x 1 2.18 -> 2.22 M,
+   // 10,240 x 1 2.82 -> 2.92 M, 16,384 x 1 2.90 -> 3.15 M audio-s/s, tools/lstm_variant_sweep.py; at 4096 x 16 the single kernel stays ahead, 3.55 against 3.52 M)
+   if (!e->use_gemm_frontend()) return (tiles <= e->n_cus / 2 || n_chunks <= 2) ? 7 : 6;
    if (tiles >= 20 && tiles <= e->n_cus / 2) return 6;      // GEMM front end (Silero v4), same sweep: one workgroup per tile on the small partition is 1 % ahead of the pair
    const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
    return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
@@ -1414,14 +1412,7 @@ static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_str
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
-   if (lk >= 8) launch_lstm_duo(e->d_act[3], lk == 9 ? e->d_gx0pair[e->xpar] : nullptr, e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
-   else         launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
-}
-// variant 9: layer 0's input half of chunks [c0, c0 + cg) as a throughput GEMM behind the encoder (same stream: the hand-off tiles are its input)
-static void launch_xproj_on(vadc_amd_engine *e, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
-{
-   KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-   launch_lstm_xproj(e->d_act[3], e->d_gx0pair[e->xpar], e->lstm, n_streams, n_chunks, c0, cg, 8 * e->n_cus, st, e->lstm_steps);
+   launch_lstm(lk, e->d_act[3], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
 }
 
 // call-to-call ordering (see the engine's last_a / last_b / last_c): `st` continues after the last work of that kind, wherever it ran
@@ -1526,7 +1517,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
    // small calls stay on the caller's stream -- unless the caller pipelines calls (defer_join) and the recurrence is long: then the layer-major pair on the
    // internal streams runs layer 1 of one call beside layer 0 of the next (16 x 96: 0.13 -> 0.27 M audio-s/s)
    const bool forked = !(G == 1 && (long)n_streams * n_chunks < 2048 && !(e->defer_join && n_chunks >= 32));
-   const int lk = resolve_lstm(e, n_streams, forked);
+   const int lk = resolve_lstm(e, n_streams, forked, n_chunks);
    e->last_lstm_kernel = lk;
    e->last_frontend_kernel = pick_frontend(e, d_in);
    int rc = VADC_AMD_OK;
@@ -1539,7 +1530,6 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       wait_last_all(e, st);
       rc = launch_sequence(e, SeqKey{d_in, d_probs, n_streams, n_chunks, (int)sizeof(T), 1, -1, e->xpar, lk, e->last_frontend_kernel}, st, [&] {
          run_front_and_encoder<T>(e, d_in, n_streams * n_chunks, map, lk, st);
-         if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, 0, n_chunks, st);
          launch_lstm_on(e, lk, d_probs, n_streams, n_chunks, 0, n_chunks, st);
       });
       if (rc) return rc;
@@ -1595,7 +1585,6 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          const ItemMap map{n_chunks, c0, cg};
          rc = launch_sequence(e, SeqKey{d_in, nullptr, n_streams, n_chunks, (int)sizeof(T), G, gi, xp, lk, e->last_frontend_kernel}, e->sA, [&] {
             run_front_and_encoder<T>(e, d_in, n_streams * cg, map, lk, e->sA);
-            if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, c0, cg, e->sA);
          });
          if (rc) return rc;
          const bool last_group = c0 + cg >= n_chunks;
@@ -1960,13 +1949,26 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
 
 extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, int n, float *out)
 {
-   if (!e || !y || !out || what < 1 || what > 3) return fail(VADC_AMD_EINVAL, "debug_layer1_block: bad argument");
+   if (!e || !y || !out || what < 1 || what > 5) return fail(VADC_AMD_EINVAL, "debug_layer1_block: bad argument");
    if (e->model != VADC_AMD_MODEL_V31) return fail(VADC_AMD_EINVAL, "debug_layer1_block: Silero v3.1 only (the other models carry no transformer block)");
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_layer1_block: n=%d out of range", n);
+   if (what >= 4 && !e->use_l1_regs()) return fail(VADC_AMD_EINVAL, "debug_layer1_block: what=%d (conv block / tail) is a tap of k_layer1_regs, which this engine does not run (option layer1, or a weight outside fp16's range)", what);
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
    const size_t bytes = (size_t)n * 16 * 25 * sizeof(float);
+   if (what == 4) {
+      // the conv block (conv.c:761-814) exactly as the product runs it: the chunk's [129][25] through the LDS-DMA pipeline, partial sums of zero (offset 0)
+      HIP_TRY(hipMemcpyAsync(e->d_Y, y, (size_t)n * kBins * kFrames * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(hipMemsetAsync(e->d_FM, 0, kBinSplit * e->max_items * kFrames * sizeof(float), st), VADC_AMD_EHIP);
+      L1RegsArgs a;
+      a.y = e->d_Y; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_tap; a.n_chunks = n; a.map = ItemMap{n, 0, n};
+      launch_layer1_regs_tap(what, a, st);
+      HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+      HIP_TRY(hipMemcpyAsync(out, e->d_tap, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+      return VADC_AMD_OK;
+   }
    HIP_TRY(hipMemcpyAsync(e->d_tap, y, bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
    if (e->use_l1_regs()) {
       L1RegsArgs a;
@@ -1976,6 +1978,23 @@ extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const f
    launch_layer1_tap(what, e->d_tap, e->lwm[0], e->d_Y, n, ItemMap{n, 0, n}, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(out, e->d_Y, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   return VADC_AMD_OK;
+}
+
+extern "C" int vadc_amd_debug_decoder(vadc_amd_engine *e, const float *x, int n, float *probs)
+{
+   if (!e || !x || !probs) return fail(VADC_AMD_EINVAL, "debug_decoder: NULL argument");
+   if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_decoder: no stage taps for the Silero v5 path");
+   if (n <= 0 || (size_t)n > e->max_items || n > e->max_streams) return fail(VADC_AMD_EINVAL, "debug_decoder: n=%d out of range (one item per stream slot)", n);
+   if (!e->lstm_h3_ok) return fail(VADC_AMD_EINVAL, "debug_decoder: a tap of k_lstm_layer, which this engine does not run (an LSTM weight outside fp16's range)");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
+   hipStream_t st = e->stream;
+   HIP_TRY(hipMemcpyAsync(e->d_tap, x, (size_t)n * 64 * e->lstm_steps * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   launch_lstm_decoder_tap(e->d_tap, e->lstm, e->d_probs, n, st, e->model, e->lstm_steps);
+   HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -2018,7 +2037,6 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
          HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       }
    }
-   if (lk == 9) launch_xproj_on(e, n_streams, n_chunks, 0, n_chunks, st);
    launch_lstm_on(e, lk, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);

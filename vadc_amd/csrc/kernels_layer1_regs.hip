@@ -69,11 +69,22 @@ __device__ __forceinline__ bool l1_owns(int t, int lc) { return t == 0 ? lc <= 1
 // ---- transformer block + 1x1 conv (BatchNorm and LayerNorm 2 folded) + ReLU on the chunk's two tiles -------------------------------------------
 // y: the conv block's output (residual stream) on entry, relu(conv(LN2(...))) on return.  TAP (stage taps for the reference's op-level fixtures):
 // 1 = y becomes the attention's result through the out projection (transformer.c:13-153) and the function returns, 2 = the transformer block's result
-// (:160-234, LayerNorm 2 with its own scale and shift).
+// (:160-234, LayerNorm 2 with its own scale and shift), 5 = only the tail runs: y is what the strided conv consumes (transformer.c:279-290; batch_norm misc.c:98-141).
 template <int TAP>
 __device__ __forceinline__ void l1_block(f4 (&y)[2], const char *img, const float *vec, int lane)
 {
    const int q = lane >> 4;
+   if constexpr (TAP == 5) {                                    // the layer's tail alone: conv k = 1 with BatchNorm (and LayerNorm 2's affine) folded in, ReLU
+      const AOp wc = lds_aop(img + LL::f_cv, lane);
+      const f4 bc = lds_vec4(vec, LL::v_cv_b + 4 * q);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+         const f4 z = mm(wc, split4_hl(y[b]), bc);
+#pragma unroll
+         for (int r = 0; r < 4; ++r) y[b][r] = relu(z[r]);
+      }
+      return;
+   }
    const AOp wq = lds_aop(img + LL::f_qkv, lane), wk = lds_aop(img + LL::f_qkv + kFrag4Bytes, lane), wv = lds_aop(img + LL::f_qkv + 2 * kFrag4Bytes, lane);
    const f4 bq = lds_vec4(vec, LL::v_q_b + 4 * q), bk = lds_vec4(vec, LL::v_k_b + 4 * q);
    AOp qf[2], vf[2];
@@ -167,18 +178,21 @@ __device__ __forceinline__ void l1_block(f4 (&y)[2], const char *img, const floa
    }
 }
 
-// NW waves per workgroup, one workgroup per CU (persistent: waves take chunks round-robin); TAP != 0: entered behind the conv block (see l1_block)
+// NW waves per workgroup, one workgroup per CU (persistent: waves take chunks round-robin); TAP 1, 2, 3, 5: entered behind the conv block (see l1_block) with
+// a.y = [n][16][25]; TAP 4: the whole input path and the conv block as in the product (a.y = the chunk's [129][25], a.fm its partial sums), left behind the
+// conv block's ReLU (conv.c:761-814) with every step of the chunk written as [n][16][25]
 template <int NW, int TAP>
 __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
 {
-   __shared__ __attribute__((aligned(16))) char lds[kL1ImgBytes + (TAP ? 16 : NW * kL1BufBytes)];
+   constexpr bool ENTER = TAP != 0 && TAP != 4;                 // the chunk enters behind the conv block: no input pipeline
+   __shared__ __attribute__((aligned(16))) char lds[kL1ImgBytes + (ENTER ? 16 : NW * kL1BufBytes)];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, lc = lane & 15;
    const int slot = blockIdx.x * NW + wave, nslots = gridDim.x * NW;
    const char *img = lds;
    const float *vec = reinterpret_cast<const float *>(lds + LL::f_end);
-   char *buf = lds + kL1ImgBytes + (TAP ? 0 : wave * kL1BufBytes);
+   char *buf = lds + kL1ImgBytes + (ENTER ? 0 : wave * kL1BufBytes);
 
    // ---- the input pipeline -----------------------------------------------------------------------------------------------------------------
    // A chunk's bytes travel from the 16-byte boundary below its first one into this wave's buffer as 13 LDS-DMA pieces of 1 KB in four GROUPS --
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
    };
 // wait until at most N of the wave's vector-memory operations are outstanding; `more`: whether this iteration issues for a next chunk
 #define L1R_WAIT(more, n_more, n_last) do { if (more) asm volatile("s_waitcnt vmcnt(" #n_more ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n_last ")" ::: "memory"); } while (0)
-   if (!TAP && slot < a.n_chunks) {
+   if (!ENTER && slot < a.n_chunks) {
       const int n0 = a.map(slot);
       issue_sums(n0);
 #pragma unroll
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
    for (int item = slot; item < a.n_chunks; item += nslots) {
       f4 y[2];
       const int n = a.map(item);
-      if constexpr (TAP != 0) {
+      if constexpr (ENTER) {
 #pragma unroll
          for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -398,6 +412,14 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
       asm volatile("" :: "v"(y[0][0]), "v"(y[1][3]));
 #endif
       L1R_PH(3);
+      if constexpr (TAP == 4) {                                // the conv block's result, every step (at least four store instructions per iteration, as the waits count)
+#pragma unroll
+         for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+               if (l1_owns(t, lc)) a.out[(size_t)n * (16 * kFrames) + (4 * q + r) * kFrames + l1_step(t, lc)] = y[t][r];
+         continue;
+      }
 #ifndef VADC_L1R_ABL_NOBLOCK
       l1_block<0>(y, img, vec, lane);
 #endif
@@ -440,14 +462,16 @@ void launch_layer1_regs(const L1RegsArgs &a, int max_wgs, hipStream_t st)
    hipLaunchKernelGGL((k_layer1_regs<8, 0>), dim3(g), dim3(512), 0, st, a);
 }
 
-// stage taps for the op-level fixtures (vadc_amd_debug_layer1_block): a.y = [n][16][25], a.out = [n][16][25]
+// stage taps for the op-level fixtures (vadc_amd_debug_layer1_block): a.y = [n][16][25] (what = 4: [n][129][25] + a.fm), a.out = [n][16][25]
 void launch_layer1_regs_tap(int what, const L1RegsArgs &a, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
    const int g = std::min(256, (a.n_chunks + 3) / 4);
    if (what == 1)      hipLaunchKernelGGL((k_layer1_regs<4, 1>), dim3(g), dim3(256), 0, st, a);
    else if (what == 2) hipLaunchKernelGGL((k_layer1_regs<4, 2>), dim3(g), dim3(256), 0, st, a);
-   else                hipLaunchKernelGGL((k_layer1_regs<4, 3>), dim3(g), dim3(256), 0, st, a);
+   else if (what == 3) hipLaunchKernelGGL((k_layer1_regs<4, 3>), dim3(g), dim3(256), 0, st, a);
+   else if (what == 4) hipLaunchKernelGGL((k_layer1_regs<8, 4>), dim3(std::min(256, (a.n_chunks + 7) / 8)), dim3(512), 0, st, a);      // the product's shape: 8 waves, the input pipeline
+   else                hipLaunchKernelGGL((k_layer1_regs<4, 5>), dim3(g), dim3(256), 0, st, a);
 }
 
 }  // namespace vadc

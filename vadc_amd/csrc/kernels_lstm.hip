@@ -426,13 +426,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 // All 8 waves of a workgroup work on one layer: a wave owns 8 hidden units x 4 gates = 2 MFMA row tiles (rows ordered [unit][gate], so that
 // i, f, g, o of a unit are the 4 accumulator registers of one lane), 24 MFMAs and 2 cells per lane and slot -- half of the two-layer kernel's.
 // Measured slot: 1.0 us against 1.54 us (tools: bench.py --opt lstm=6 / 7).
-template <int TS, int DEC, int L>
+// TAPDEC (L = 1 only; stage tap for the reference's decoder fixture, test.c:170): the recurrence is bypassed -- h1 of step k is read from `tap_h`
+// [stream][64][TS] fp32 -- and everything behind it (ReLU, the sum over the chunk's steps, the partial dots and their tree, mean, bias, sigmoid:
+// silero_v3.c:231-303) runs as in the product; one chunk per stream, the streams' state is neither read nor written.
+template <int TS, int DEC, int L, bool TAPDEC = false>
 __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
                                                        _Float16 *__restrict__ h0seq,            // L = 0: the h0 sequence, same layout
                                                        LstmWeights w,
                                                        float *__restrict__ hs, float *__restrict__ cs,
                                                        float *__restrict__ probs,               // L = 1
-                                                       int n_streams, int n_chunks, int c0, int cg)
+                                                       int n_streams, int n_chunks, int c0, int cg, const float *__restrict__ tap_h = nullptr)
 {
    // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
@@ -480,8 +483,8 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       for (int m = 0; m < 2; ++m) {
          dw[0][m] = w.dec_w[u0 + m];
          dw[1][m] = w.dec_w[64 + u0 + m];
-         c[m] = cs[(size_t)s_col * 128 + L * 64 + u0 + m];
-         hlast[m] = hs[(size_t)s_col * 128 + L * 64 + u0 + m];
+         c[m] = TAPDEC ? 0.0f : cs[(size_t)s_col * 128 + L * 64 + u0 + m];
+         hlast[m] = TAPDEC ? 0.0f : hs[(size_t)s_col * 128 + L * 64 + u0 + m];
          hi2[m] = (_Float16)hlast[m];
          lo2[m] = (_Float16)(hlast[m] - (float)hi2[m]);
       }
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
    };
    auto xfrag = [&](int slot, int part, int kb) -> h8v { return *reinterpret_cast<const h8v *>(&xr[slot & 3][part][((4 * kb + quad) * 16 + col) * 8]); };
-   if (wave < 4) {
+   if (!TAPDEC && wave < 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_x(i, i);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       f4v acc[2];
       acc[0] = accx[0]; acc[1] = accx[1];
 #ifndef VADC_LSTM_ABL_NOXLOAD     // (timing-only ablation: the slot without its input fetch)
-      if (wave < 4) issue_x(k + 4, k);                        // step k + 4 into the ring slot step k was read from (one slot ago)
+      if (!TAPDEC && wave < 4) issue_x(k + 4, k);             // step k + 4 into the ring slot step k was read from (one slot ago)
 #endif
       // layer 0: write the h tile of slot k - 1 (LDS parity `par`, complete since the last barrier) to the h0 sequence while this slot computes.
       // Issued AFTER the input loads: vector-memory operations retire in order, so a store in front of them would put its completion on the
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          __builtin_amdgcn_sched_barrier(0);
       }
 #ifndef VADC_LSTM_ABL_NOMFMA
+      if constexpr (!TAPDEC) {
 #pragma unroll
       for (int kb = 2; kb < 4; ++kb) {                        // the layer's own h (k-blocks 2, 3)
          const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
             accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], xbh[kb], accx[m], 0, 0, 0);
          }
       }
+      }
 #else
       { const int off = col * kHPitch + 8 * quad; const h8v bh = *reinterpret_cast<const h8v *>(&hb[par][0][off]); acc[0][0] += (float)bh[0] + (float)xfrag(k + 1, 0, 0)[0]; }
 #endif
@@ -587,10 +592,14 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
 #ifndef VADC_LSTM_ABL_NOGATES
+         float hn;
+         if constexpr (TAPDEC) hn = tap_h[((size_t)s_col * 64 + u0 + m) * TS + k];
+         else {
          const float ig = fast_sigmoid(acc[m][0]), fg = fast_sigmoid(acc[m][1]);
          const float gg = fast_tanh(acc[m][2]), og = fast_sigmoid(acc[m][3]);
          c[m] = fmaf(fg, c[m], ig * gg);                       // as k_lstm_wavefront_h3
-         const float hn = og * fast_tanh(c[m]);
+         hn = og * fast_tanh(c[m]);
+         }
 #else
          const float hn = (acc[m][0] + acc[m][1]) * 0.01f + (acc[m][2] + acc[m][3]) * 0.01f;
 #endif
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       }
       // waves 0-3: the piece of step k + 2 (issued two slots ago; read in the next slot) has landed -- newer operations may stay in flight: two
       // pieces (layer 1), plus layer 0's h0-tile stores (counted together, retired in order)
-      if (wave < 4) { if (L == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      if (!TAPDEC && wave < 4) { if (L == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
       __syncthreads();                                        // one barrier per slot
       par ^= 1;
       if (L == 1) {
@@ -656,366 +665,13 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       *reinterpret_cast<uint4 *>(out_seq + (size_t)(total - 1) * kStepHalves + rowi * 64 + seg * 8) =
          *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
    }
-   if (col_ok) {
+   if (!TAPDEC && col_ok) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
          cs[(size_t)s_col * 128 + L * 64 + u0 + m] = c[m];
          hs[(size_t)s_col * 128 + L * 64 + u0 + m] = hlast[m];
       }
    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_lstm_duo: BOTH layers of a 16-stream tile in one 16-wave workgroup, layer 1 two slots behind layer 0 (engine variant 8)
-// ------------------------------------------------------------------------------------------------
-// k_lstm_layer made the two layers two launches on two CU sets: 32 of the chip's 256 CUs at 256 streams, each at a tenth of its capacity,
-// and a call's two chains drain one after the other.  Here waves 0-7 are k_lstm_layer<0>'s waves and waves 8-15 k_lstm_layer<1>'s (a wave owns 8
-// units x 4 gates = 2 MFMA row tiles, 2 cells per lane), on ONE CU with one barrier per slot, and h0 never leaves the LDS:
-//   slot k, layer 0:  finishes step k      = (bias + W_x0 . x_k)      + W_h0 . h0_{k-1}   -> gates -> h0_k
-//   slot k, layer 1:  finishes step k - 2  = (bias + W_x1 . h0_{k-2}) + W_h1 . h1_{k-3}   -> gates -> h1_{k-2}
-//                     and starts step k - 1:  bias + W_x1 . h0_{k-1}  (its input half: nothing recurrent in it, used in the next slot)
-// so that every wave has 12 MFMAs between the barrier and its gates and at most 12 more in the shadow of the gate arithmetic.  The MFMA sequence on
-// an accumulator is k_lstm_layer's / k_lstm_wavefront_h3's (bias; k-blocks 0, 1, 2, 3, each al.bh, ah.bl, ah.bh), the cell update and the decoder's
-// summation tree are theirs: the three kernels are bit-identical.  ONE copy of the slot body serves both layers (LDS addresses selected per wave).
-// XIN = 0: layer 0's input half is computed here, one slot ahead, from the encoder's split-fp16 tiles (LDS-DMA ring as in k_lstm_layer).
-// XIN = 1: it arrives as fp32 gate pre-activations GX0 = bias + W_x0 . x_t -- computed by the same three-term MFMA sequence as a throughput GEMM on
-//          the rest of the chip (k_lstm_xproj) -- [tile][chunk][step][wave 8][row tile 2][lane 64][gate 4]; a wave copies ITS OWN 2 KB per step by LDS-DMA
-//          into a ring kGxDepth steps deep (no other wave reads them: a counted vmcnt, no barrier).  The workgroup's matrix pipes then issue 72
-//          instead of 96 MFMAs per SIMD and slot.
-constexpr int kGxDepth = 6;
-template <int TS, int DEC, int XIN>
-__global__ __launch_bounds__(1024, 1) void k_lstm_duo(const _Float16 *__restrict__ in_tiles,   // XIN 0: split-fp16 encoder tiles [tile][n_chunks][TS][hi|lo][16][64]
-                                                      const float *__restrict__ gx,            // XIN 1: GX0 [tile][n_chunks][TS][8][2][64][4]
-                                                      LstmWeights w,
-                                                      float *__restrict__ hs, float *__restrict__ cs,
-                                                      float *__restrict__ probs,
-                                                      int n_streams, int n_chunks, int c0, int cg)
-{
-   __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][2][kTileS * kHPitch];             // [layer][parity][hi / lo][stream][unit]
-   __shared__ __attribute__((aligned(16))) _Float16 xr[XIN ? 1 : 4][2][kTileS * 64];           // XIN 0: input ring [step & 3][hi / lo][segment][stream]
-   __shared__ __attribute__((aligned(16))) float gxr[XIN ? kGxDepth : 1][8][2][64 * 4];        // XIN 1: GX0 ring [step % depth][wave][row tile][lane][gate]
-   __shared__ float pd[2][8][2][kTileS];
-   __shared__ __attribute__((aligned(16))) float bias_s[16][2][4][4];                         // [wave][row tile][quad][gate]: the accumulators' initial values
-
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int L = wave >> 3;                                // layer of this wave
-   const int wv = wave & 7;
-   const int tile = blockIdx.x;
-   const int col = lane & 15;
-   const int quad = lane >> 4;
-   const int s0 = tile * kTileS;
-   const int s_col = min(s0 + col, n_streams - 1);
-   const bool col_ok = (s0 + col) < n_streams;
-   const int u0 = 8 * wv + 2 * quad;
-
-   h8v ah[2][4], al[2][4];
-   {
-      const int q = (lane & 15) >> 2, r = lane & 3;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-         const float *row = w.w + ((size_t)L * 256 + r * 64 + 8 * wv + 2 * q + m) * 128 + 8 * quad;
-#pragma unroll
-         for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-               const float v = row[32 * kb + e];
-               const _Float16 hi = (_Float16)v;
-               ah[m][kb][e] = hi;
-               al[m][kb][e] = (_Float16)(v - (float)hi);
-            }
-      }
-   }
-   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-   float c[2], hlast[2], dw[2][2];
-   if (col == 0) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-         for (int r = 0; r < 4; ++r) bias_s[wave][m][quad][r] = w.b[L * 256 + r * 64 + u0 + m];
-   }
-   {
-      _Float16 hi2[2], lo2[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-         dw[0][m] = w.dec_w[u0 + m];
-         dw[1][m] = w.dec_w[64 + u0 + m];
-         c[m] = cs[(size_t)s_col * 128 + L * 64 + u0 + m];
-         hlast[m] = hs[(size_t)s_col * 128 + L * 64 + u0 + m];
-         hi2[m] = (_Float16)hlast[m];
-         lo2[m] = (_Float16)(hlast[m] - (float)hi2[m]);
-      }
-      *reinterpret_cast<h2v *>(&hb[L][0][0][col * kHPitch + u0]) = (h2v){hi2[0], hi2[1]};
-      *reinterpret_cast<h2v *>(&hb[L][0][1][col * kHPitch + u0]) = (h2v){lo2[0], lo2[1]};
-   }
-   constexpr int kStepHalves = 2 * kTileS * 64;
-   constexpr int kStepGx = kTileS * 64 * 4;                 // floats of one (tile, step) block of GX0
-   const int total = TS * cg;
-   const _Float16 *in_seq = in_tiles + ((size_t)tile * n_chunks + c0) * TS * kStepHalves;
-   const float *gx_lane = gx + ((size_t)tile * n_chunks + c0) * TS * kStepGx + (size_t)(2 * wv) * 256 + lane * 4;     // [wave][row tile][lane][gate] (k_lstm_xproj)
-   auto issue_x = [&](int step, int slot) {                 // XIN 0, waves 0-3: one 1 KB piece each (see k_lstm_layer)
-      const int tl = wave >> 1, hf = wave & 1;
-      const _Float16 *g = in_seq + (size_t)min(step, total - 1) * kStepHalves + tl * (kTileS * 64) + (lane & 15) * 64 + (4 * hf + (lane >> 4)) * 8;
-      const unsigned dst = (unsigned)(uintptr_t)(lds_void_t *)&xr[XIN ? 0 : (slot & 3)][tl][hf * 512];
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
-   };
-   auto issue_gx = [&](int step, int rs) {                  // XIN 1, waves 0-7: this wave's own two 1 KB pieces of GX0[step] into ring slot rs
-      const float *g = gx_lane + (size_t)min(step, total - 1) * kStepGx;
-      const unsigned dst = (unsigned)(uintptr_t)(lds_void_t *)&gxr[XIN ? rs : 0][wv][0][0];
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"
-                   :: "s"(dst), "s"(dst + 1024u), "v"(g), "v"(g + 256) : "memory");
-   };
-   // a lane's B fragment (16 bytes) of k-block kb of the input half: layer 0 from the ring image [segment][stream], layer 1 = h0 from its LDS tile
-   f4v accx[2];
-   __syncthreads();
-   accx[0] = *reinterpret_cast<const f4v *>(&bias_s[wave][0][quad][0]);
-   accx[1] = *reinterpret_cast<const f4v *>(&bias_s[wave][1][quad][0]);
-   if (XIN == 0) {
-      if (wave < 4) {
-#pragma unroll
-         for (int i = 0; i < 4; ++i) issue_x(i, i);
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      if (L == 0) {
-#pragma unroll
-         for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-               const h8v bh = *reinterpret_cast<const h8v *>(&xr[0][0][((4 * kb + quad) * 16 + col) * 8]);
-               const h8v bl = *reinterpret_cast<const h8v *>(&xr[0][1][((4 * kb + quad) * 16 + col) * 8]);
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], bh, accx[m], 0, 0, 0);
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bl, accx[m], 0, 0, 0);
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bh, accx[m], 0, 0, 0);
-            }
-      }
-   } else if (L == 0) {
-#pragma unroll
-      for (int i = 0; i < kGxDepth - 1; ++i) issue_gx(i, i);
-   }
-   __syncthreads();
-
-   int p0 = 0, p1 = 0;                                      // LDS parity holding the CURRENT h0 / h1
-   int rs = 0;                                              // XIN 1: ring slot of step k
-   float rsum[2] = {0.0f, 0.0f};
-   float psum = 0.0f;
-#pragma unroll 1      // one copy of the slot body (see k_lstm_layer)
-   for (int k = 0; k < total + 2; ++k) {
-      const bool on = (L == 0) ? (k < total) : (k >= 2);                       // this wave finishes a step in this slot
-      const bool ahead = (L == 0) ? (XIN == 0) : (k >= 1 && k <= total);       // ... and starts the input half of the next one
-      const int step = (L == 0) ? k : k - 2;
-      const int chi = step / TS, t = step - chi * TS;
-      f4v acc[2];
-      if (XIN == 1 && L == 0) {
-         // GX0[k]: this wave's own pieces, issued kGxDepth - 1 slots ago; newer ones (steps k + 1 .. k + depth - 2) may stay in flight
-         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (kGxDepth - 2)) : "memory");
-         acc[0] = *reinterpret_cast<const f4v *>(&gxr[XIN ? rs : 0][wv][0][lane * 4]);
-         acc[1] = *reinterpret_cast<const f4v *>(&gxr[XIN ? rs : 0][wv][1][lane * 4]);
-         const int prev = rs == 0 ? kGxDepth - 1 : rs - 1;                      // the slot read in the previous iteration
-         issue_gx(k + kGxDepth - 1, prev);
-         rs = rs == kGxDepth - 1 ? 0 : rs + 1;
-      } else {
-         acc[0] = accx[0]; acc[1] = accx[1];
-         if (XIN == 0 && wave < 4) issue_x(k + 4, k);
-      }
-      const _Float16 *hown = &hb[L][L == 0 ? p0 : p1][0][0];
-      if (on) {
-#pragma unroll
-         for (int kb = 2; kb < 4; ++kb) {                    // the layer's own h (k-blocks 2, 3)
-            const int off = col * kHPitch + 32 * (kb & 1) + 8 * quad;
-            const h8v bh = *reinterpret_cast<const h8v *>(hown + off);
-            const h8v bl = *reinterpret_cast<const h8v *>(hown + kTileS * kHPitch + off);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-               acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], bh, acc[m], 0, 0, 0);
-               acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bl, acc[m], 0, 0, 0);
-               acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bh, acc[m], 0, 0, 0);
-            }
-         }
-      }
-      if (ahead) {
-         // bias + W_x . (input of the step this wave finishes in the NEXT slot): layer 0 x_{k+1} from the ring, layer 1 h0_{k-1} from its tile
-         accx[0] = *reinterpret_cast<const f4v *>(&bias_s[wave][0][quad][0]);
-         accx[1] = *reinterpret_cast<const f4v *>(&bias_s[wave][1][quad][0]);
-#pragma unroll
-         for (int kb = 0; kb < 2; ++kb) {
-            const _Float16 *ph = (L == 0) ? &xr[XIN ? 0 : ((k + 1) & 3)][0][((4 * kb + quad) * 16 + col) * 8] : &hb[0][p0][0][col * kHPitch + 32 * kb + 8 * quad];
-            const int lo_off = (L == 0) ? kTileS * 64 : kTileS * kHPitch;
-            const h8v xbh = *reinterpret_cast<const h8v *>(ph);
-            const h8v xbl = *reinterpret_cast<const h8v *>(ph + lo_off);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], xbh, accx[m], 0, 0, 0);
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], xbl, accx[m], 0, 0, 0);
-               accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], xbh, accx[m], 0, 0, 0);
-            }
-         }
-      }
-      const bool chunk_done = (L == 1) && on && (t == TS - 1);
-      if (on) {
-         _Float16 hi2[2], lo2[2];
-#pragma unroll
-         for (int m = 0; m < 2; ++m) {
-            const float ig = fast_sigmoid(acc[m][0]), fg = fast_sigmoid(acc[m][1]);
-            const float gg = fast_tanh(acc[m][2]), og = fast_sigmoid(acc[m][3]);
-            c[m] = fmaf(fg, c[m], ig * gg);                    // as k_lstm_wavefront_h3 / k_lstm_layer
-            const float hn = og * fast_tanh(c[m]);
-            hlast[m] = hn;
-            hi2[m] = (_Float16)hn;
-            lo2[m] = (_Float16)(hn - (float)hi2[m]);
-            if (L == 1) rsum[m] = (DEC == 0 ? rsum[m] : 0.0f) + fmaxf(hn, 0.0f);
-         }
-         _Float16 *hnew = &hb[L][(L == 0 ? p0 : p1) ^ 1][0][0];
-         *reinterpret_cast<h2v *>(hnew + col * kHPitch + u0) = (h2v){hi2[0], hi2[1]};
-         *reinterpret_cast<h2v *>(hnew + kTileS * kHPitch + col * kHPitch + u0) = (h2v){lo2[0], lo2[1]};
-         if (L == 1 && (DEC == 1 || chunk_done)) {
-            // decoder partial dots of this wave's 8 units, in k_lstm_wavefront_h3's summation tree (see k_lstm_layer)
-            float d0, d1 = 0.0f;
-            {
-               const float pe0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], 0.0f));
-               const float up0 = __shfl_up(pe0, 16);
-               d0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], up0));
-               d0 += __shfl_xor(d0, 32);
-               if (DEC == 0) {
-                  const float pe1 = fmaf(dw[1][1], rsum[1], fmaf(dw[1][0], rsum[0], 0.0f));
-                  const float up1 = __shfl_up(pe1, 16);
-                  d1 = fmaf(dw[1][1], rsum[1], fmaf(dw[1][0], rsum[0], up1));
-                  d1 += __shfl_xor(d1, 32);
-                  rsum[0] = rsum[1] = 0.0f;
-               }
-            }
-            if (quad == 1) { pd[k & 1][wv][0][col] = d0; if (DEC == 0) pd[k & 1][wv][1][col] = d1; }
-         }
-      }
-      if (XIN == 0 && wave < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the piece of step k + 2 has landed (read in the next slot)
-      __syncthreads();                                        // one barrier per slot
-      if (k < total) p0 ^= 1;
-      if (k >= 2) p1 ^= 1;
-      if (wave == 8 && on) {
-         if (DEC == 0 && chunk_done && lane < 2 * kTileS) {
-            const int sc = lane & 15, f = lane >> 4, q = k & 1;
-            float m = ((pd[q][0][f][sc] + pd[q][1][f][sc]) + (pd[q][2][f][sc] + pd[q][3][f][sc])) + ((pd[q][4][f][sc] + pd[q][5][f][sc]) + (pd[q][6][f][sc] + pd[q][7][f][sc]));
-            m = m / (float)TS + w.dec_b[f];
-            if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
-         }
-         if (DEC == 1 && lane < kTileS) {
-            const int q = k & 1;
-            const float m = ((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + ((pd[q][4][0][lane] + pd[q][5][0][lane]) + (pd[q][6][0][lane] + pd[q][7][0][lane]));
-            psum += sigmoidf_(m + w.dec_b[0]);
-            if (t == TS - 1) {
-               const float pr = psum / (float)TS;
-               if (s0 + lane < n_streams) {
-                  probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 0] = pr;
-                  probs[((size_t)(s0 + lane) * n_chunks + (c0 + chi)) * 2 + 1] = pr;
-               }
-               psum = 0.0f;
-            }
-         }
-      }
-   }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // no LDS-DMA piece may land after the workgroup has gone
-   if (col_ok) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-         cs[(size_t)s_col * 128 + L * 64 + u0 + m] = c[m];
-         hs[(size_t)s_col * 128 + L * 64 + u0 + m] = hlast[m];
-      }
-   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_lstm_xproj: GX0 = bias + W_x0 . x_t for every (tile, step) of a call -- layer 0's input half as throughput work
-// ------------------------------------------------------------------------------------------------
-// Nothing in it is recurrent (lstm.c:52-61 computes W . [x ; h] as one product; the x columns of W meet the encoder's output only), so it
-// needs no place in the latency chain.  The MFMA sequence per accumulator is the recurrence kernels' (bias; k-blocks 0, 1, each al.bh, ah.bl, ah.bh)
-// and the fp32 accumulators are stored as they are: k_lstm_duo<XIN = 1> continues from them with k-blocks 2, 3 -- the same bits as computing all four
-// in place.  Layout = the consumer's accumulator layout: [tile][chunk][step][wave 8][row tile 2][lane 64][gate 4] fp32, 16 KB per (tile, step): a
-// producer store and a consumer LDS-DMA piece are each 1 KB contiguous.  A workgroup = 4 waves x 4 row tiles of one (tile, step) at a time.
-template <int TS>
-__global__ __launch_bounds__(256) void k_lstm_xproj(const _Float16 *__restrict__ in_tiles, float *__restrict__ gx, LstmWeights w,
-                                                    int n_tiles, int n_chunks, int c0, int cg)
-{
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int col = lane & 15;
-   const int quad = lane >> 4;
-   h8v ah[4][2], al[4][2];
-   f4v bias[4];
-#pragma unroll
-   for (int rt = 0; rt < 4; ++rt) {
-      const int wv = 2 * wave + (rt >> 1), m = rt & 1;
-      const int q = (lane & 15) >> 2, r = lane & 3;
-      const float *row = w.w + ((size_t)r * 64 + 8 * wv + 2 * q + m) * 128 + 8 * quad;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-         for (int e = 0; e < 8; ++e) {
-            const float v = row[32 * kb + e];
-            const _Float16 hi = (_Float16)v;
-            ah[rt][kb][e] = hi;
-            al[rt][kb][e] = (_Float16)(v - (float)hi);
-         }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bias[rt][g] = w.b[g * 64 + 8 * wv + 2 * quad + m];
-   }
-   constexpr int kStepHalves = 2 * kTileS * 64;
-   constexpr int kStepGx = kTileS * 64 * 4;
-   const int per_tile = cg * TS, total = n_tiles * per_tile;
-   for (int i = blockIdx.x; i < total; i += gridDim.x) {
-      const int tile = i / per_tile, s = i - tile * per_tile;
-      const size_t blk = ((size_t)tile * n_chunks + c0) * TS + s;
-      const _Float16 *src = in_tiles + blk * kStepHalves + col * 64 + 8 * quad;
-      h8v bh[2], bl[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-         bh[kb] = *reinterpret_cast<const h8v *>(src + 32 * kb);
-         bl[kb] = *reinterpret_cast<const h8v *>(src + kTileS * 64 + 32 * kb);
-      }
-      float *dst = gx + blk * kStepGx + (size_t)(4 * wave) * 256 + lane * 4;
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-         f4v acc = bias[rt];
-#pragma unroll
-         for (int kb = 0; kb < 2; ++kb) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][kb], bh[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][kb], bl[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][kb], bh[kb], acc, 0, 0, 0);
-         }
-         __builtin_nontemporal_store(acc, reinterpret_cast<f4v *>(dst + rt * 256));
-      }
-   }
-}
-void launch_lstm_xproj(const float *enc, float *gx, const LstmWeights &w, int n_streams, int n_chunks, int c0, int cg, int grid_wgs, hipStream_t st, int steps)
-{
-   const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
-   const int n_tiles = (n_streams + kTileS - 1) / kTileS;
-   const long total = (long)n_tiles * cg * steps;
-   const dim3 grid((unsigned)(total < grid_wgs ? total : grid_wgs)), block(256);
-   if (steps == 7)      hipLaunchKernelGGL((k_lstm_xproj<7>), grid, block, 0, st, x, gx, w, n_tiles, n_chunks, c0, cg);
-   else if (steps == 3) hipLaunchKernelGGL((k_lstm_xproj<3>), grid, block, 0, st, x, gx, w, n_tiles, n_chunks, c0, cg);
-   else if (steps == 2) hipLaunchKernelGGL((k_lstm_xproj<2>), grid, block, 0, st, x, gx, w, n_tiles, n_chunks, c0, cg);
-   else                 hipLaunchKernelGGL((k_lstm_xproj<1>), grid, block, 0, st, x, gx, w, n_tiles, n_chunks, c0, cg);
-}
-
-// variant 8: both layers in one 16-wave workgroup per tile.  gx == nullptr: layer 0's input half is computed in the kernel from the encoder's tiles
-template <int TS, int DEC>
-static void launch_duo_ts(const _Float16 *x, const float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
-                          int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
-{
-   const dim3 grid((n_streams + kTileS - 1) / kTileS), block(1024);
-   if (gx) hipLaunchKernelGGL((k_lstm_duo<TS, DEC, 1>), grid, block, 0, st, x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else    hipLaunchKernelGGL((k_lstm_duo<TS, DEC, 0>), grid, block, 0, st, x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-}
-void launch_lstm_duo(const float *enc, const float *gx, const LstmWeights &w, float *hs, float *cs, float *probs,
-                     int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps)
-{
-   const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
-   if (model == 0)      launch_duo_ts<7, 0>(x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else if (steps == 3) launch_duo_ts<3, 1>(x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else if (steps == 2) launch_duo_ts<2, 1>(x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else                 launch_duo_ts<1, 1>(x, gx, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
 }
 
 // one layer of the layer-major form (engine variant 7): layer 0 reads the encoder's split-fp16 tiles and writes h0seq, layer 1 reads h0seq
@@ -1037,6 +693,17 @@ void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeig
    else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
    else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
    else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+}
+
+// stage tap: the decoder of k_lstm_layer<.., 1> on n items of [64][steps] (one chunk each), probs [n][2]
+void launch_lstm_decoder_tap(const float *tap_h, const LstmWeights &w, float *probs, int n, hipStream_t st, int model, int steps)
+{
+   const dim3 grid((n + kTileS - 1) / kTileS), block(512);
+   const _Float16 *none = nullptr;
+   if (model == 0)      hipLaunchKernelGGL((k_lstm_layer<7, 0, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
+   else if (steps == 3) hipLaunchKernelGGL((k_lstm_layer<3, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
+   else if (steps == 2) hipLaunchKernelGGL((k_lstm_layer<2, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
+   else                 hipLaunchKernelGGL((k_lstm_layer<1, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
 }
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)

@@ -191,10 +191,19 @@ class Engine:
         return out
 
     def layer1_block(self, y: np.ndarray, what: str) -> np.ndarray:
-        """the first layer's transformer block in isolation: y [n, 16, 25] -> [n, 16, 25]; what = "attention" | "transformer_block" | "layer_norm" """
-        y = np.ascontiguousarray(y, dtype=np.float32).reshape(-1, 16, 25)
-        out = np.empty_like(y)
-        self._check(self._L.vadc_amd_debug_layer1_block(self._h, {"attention": 1, "transformer_block": 2, "layer_norm": 3}[what], _ptr(y), y.shape[0], _ptr(out)))
+        """parts of the first encoder layer in isolation: y [n, 16, 25] -> [n, 16, 25]; what = "attention" | "transformer_block" | "layer_norm" |
+        "tail" (strided conv's arithmetic + folded BatchNorm + ReLU, every step); what = "conv_block": y [n, 129, 25] -> [n, 16, 25] (the product's input pipeline)"""
+        code = {"attention": 1, "transformer_block": 2, "layer_norm": 3, "conv_block": 4, "tail": 5}[what]
+        y = np.ascontiguousarray(y, dtype=np.float32).reshape((-1, 129, 25) if code == 4 else (-1, 16, 25))
+        out = np.empty((y.shape[0], 16, 25), np.float32)
+        self._check(self._L.vadc_amd_debug_layer1_block(self._h, code, _ptr(y), y.shape[0], _ptr(out)))
+        return out
+
+    def decoder(self, x: np.ndarray) -> np.ndarray:
+        """the decoder alone: x [n, 64, steps] -> [n, 2] (the recurrence kernel's decoder with x in place of the second LSTM layer's output; state untouched)"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((x.shape[0], 2), np.float32)
+        self._check(self._L.vadc_amd_debug_decoder(self._h, _ptr(x), x.shape[0], _ptr(out)))
         return out
 
     def lstm_decoder(self, enc: np.ndarray) -> np.ndarray:
