@@ -41,6 +41,23 @@ typedef struct {
 } Options;
 
 static double g_total_speech = 0.0;
+/* --stats: the reference reports after EVERY emitted segment (print_speech_stats inside emit_speech_segment, vadc.c:259, :1040-1076): a progress line on
+ * stderr ending in '\r'.  Same fields in the same order; the wall clock is CLOCK_MONOTONIC instead of QueryPerformanceCounter. */
+static int64_t g_total_samples = 0;
+static int g_sample_rate = 16000;
+static struct timespec g_t0;
+static void print_speech_stats(void)
+{
+   struct timespec t1;
+   clock_gettime(CLOCK_MONOTONIC, &t1);
+   const double wall = (t1.tv_sec - g_t0.tv_sec) + 1e-9 * (t1.tv_nsec - g_t0.tv_nsec);
+   const double dur = (double)g_total_samples / g_sample_rate;
+   const int hours = (int)(dur / 3600.0), minutes = (int)((dur - hours * 3600.0) / 60.0);
+   const int seconds = (int)(dur - hours * 3600.0 - minutes * 60.0);
+   const int ms = (int)((dur - hours * 3600.0 - minutes * 60.0 - seconds) * 1000.0);
+   fprintf(stderr, "time=%02d:%02d:%02d.%04d", hours, minutes, seconds, ms);
+   fprintf(stderr, " %7.2f speech (%5.1f%%), %5.1f / %5.1f (%5.1fx)\r", g_total_speech, dur > 0 ? g_total_speech / dur * 100.0 : 0.0, dur, wall, wall > 0 ? dur / wall : 0.0);
+}
 
 static void emit_segment(Segment s, const Options *o, float spc)
 {
@@ -56,6 +73,7 @@ static void emit_segment(Segment s, const Options *o, float spc)
       fprintf(stdout, "%.2f,%.2f\n", start_p, end_p);
    }
    fflush(stdout);
+   if (o->stats) print_speech_stats();                              /* vadc.c:259 */
 }
 
 static Segment combine_or_emit(Segment buffered, Segment cur, const Options *o, float spc)
@@ -211,6 +229,7 @@ int main(int argc, char **argv)
    int64_t total_samples = 0;
    struct timespec t0, t1;
    clock_gettime(CLOCK_MONOTONIC, &t0);
+   g_t0 = t0; g_sample_rate = sample_rate;
 
    const size_t window_bytes = (size_t)WINDOW_CHUNKS * chunk * sizeof(int16_t);      /* vadc.c:799-805: chunks_count = 96 chunks of input_count samples */
    for (;;) {
@@ -218,6 +237,7 @@ int main(int argc, char **argv)
       size_t values = bytes / sizeof(int16_t);
       if (values == 0) break;
       total_samples += (int64_t)values;
+      g_total_samples = total_samples;
       int n_chunks = (int)(values / chunk);                        /* vadc.c:964: a partial tail chunk is dropped */
       for (int c0 = 0; c0 < n_chunks; c0 += o.batch) {
          int n = n_chunks - c0 < o.batch ? n_chunks - c0 : o.batch;

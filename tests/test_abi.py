@@ -108,6 +108,16 @@ def test_adapter_runner_compiles_over_the_mirrors():
     assert r.returncode == 0, r.stderr
 
 
+def test_multi_gpu_c_host_compiles():
+    """host/vadc_hip_multi.c (one engine per GPU, ncclGather of the probabilities: the north star's multi-GPU host in C) must compile as C against the
+    HIP runtime's and RCCL's C APIs wherever the ROCm headers are (it RUNS in tests/test_gpu_multi_host.py)"""
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no ROCm headers")
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "host", "vadc_hip_multi.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_layer1_kernel_layout_invariants():
     """what k_layer1_regs relies on, as static_asserts over the header the kernel and the engine's image packer share (tests/c/l1_layout_check.cpp): the
     channel -> operand-slot map is a bijection and bank-conflict free, the DMA groups overwrite consumed bytes only, image + wave buffers fit the LDS"""
