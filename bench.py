@@ -26,8 +26,15 @@ The JSON line is kept short (the driver reads the tail of stdout); its verbose f
   cpu_baseline -- the reference C backend (oracle/_ref, kind "reference") or the CPU oracle (kind "port") on this box's host cores: all
                   cores (one process per core, value = aggregate), one core at batch 96 and at batch 1 (BASELINE config 1)
   host_fed     -- the same step through vadc_amd_run_s16 (pageable host buffers in and out: PCIe-inclusive); never `value`
-  configs      -- {"4096x16": ...}: the largest single-GPU configuration (BASELINE config 3: 4096 streams x 16 chunks, SPLIT16 precision, graph replay)
-                  timed in the same run after the headline's timed region: value, ms_per_step, the dominant kernel's roofline fraction
+  stage_fracs  -- {kernel: [fraction of its binding pipe's peak, pipe]} for every kernel of the step (STFT against the non-FMA vector
+                  peak, the GEMM stages against the matrix peak)
+  configs      -- timed in the same run after the headline's timed region, each with value, ms_per_step and the dominant kernel's roofline fraction:
+                  "4096x16"  the largest single-GPU configuration (BASELINE config 3: 4096 streams x 16 chunks, SPLIT16 precision, graph replay);
+                  "10240x1"  the north star's literal shape (>= 10 k concurrent streams at real time: 10,240 streams x ONE chunk per call), with the
+                             latency a chunk sees (`latency_ms`: one isolated call, issue -> probabilities complete; the budget is the 96 ms until the
+                             stream's next chunk) and the rate through the asynchronous host-buffer entry point (`host_fed`);
+                  "256x96_fp32_mfma"  the headline workload with every GEMM as literal fp32 MFMA (options encoder = 3, lstm = 3, layer1 = 1): what the
+                             split-fp16 x 3 arithmetic of `dtype` buys
 """
 import argparse
 import json
@@ -249,13 +256,16 @@ def dry_run(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------- the largest single-GPU configuration, beside the headline
-def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20, warmup=5):
-    """BASELINE config 3 (4096 streams x 16 chunks per step, SPLIT16 precision, graph replay) timed in the same run, after the headline's timed
-    region: same step discipline (deferred joins, one issuing stream, three input buffers), device time from torch's synchronize on both sides.
-    Reported beside `value`, never instead of it."""
+def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20, warmup=5, opts=None, latency=False, host_fed=False):
+    """Another configuration timed in the same run, after the headline's timed region: same step discipline (deferred joins, one issuing stream, three
+    input buffers, graph replay), device time from torch's synchronize on both sides.  Reported beside `value`, never instead of it.
+    latency: also the time of ONE isolated call from its issue to its probabilities being complete (median of 20); host_fed: also the rate through
+    vadc_amd_run_s16_async (page-locked host buffers in and out)."""
     from vadc_amd import synth
     from vadc_amd.engine import Engine
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=precision)
+    for k_, v_ in (opts or {}).items():
+        eng.set_option(k_, v_)
     NB = 3
     base = synth.make_streams(16, NB * Cn, seed0=777)
     pcm = np.ascontiguousarray(np.tile(base, (S // 16 + 1, 1))[:S])
@@ -285,12 +295,38 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
     fe_kernel = eng.get_option("frontend_kernel")
     dom = max(kt, key=kt.get)
-    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, eng.get_option("layer1") == 0)
+    _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, eng.get_option("layer1_kernel") == 0)
     pipe = max(exe, key=lambda p_: exe[p_] / PEAKS[p_])
     out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
            "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
            "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
+    if opts:
+        out["options"] = dict(opts)
+    if latency:
+        lat = []
+        for i in range(20):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(i)
+            eng.join(st.cuda_stream)
+            st.synchronize()
+            lat.append(time.perf_counter() - t1)
+        out["latency_ms"] = round(float(np.median(lat)) * 1e3, 3)
+        out["latency_budget_ms"] = 96.0
+    if host_fed:
+        host = [np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(NB)]
+        outs = [np.empty((S, Cn, 2), np.float32) for _ in range(NB)]
+        for i in range(2 * NB):
+            eng.run_async(host[i % NB], outs[i % NB])
+        eng.wait_async()
+        n_host = 30
+        t1 = time.perf_counter()
+        for i in range(n_host):
+            eng.run_async(host[i % NB], outs[i % NB])
+        eng.wait_async()
+        dta = time.perf_counter() - t1
+        out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dta, 1), "ms_per_step": round(dta / n_host * 1e3, 3), "pcie_gb_per_s": round(S * Cn * 3072 * n_host / dta / 1e9, 1)}
     eng.close()
     return out
 
@@ -442,13 +478,19 @@ def run_rank(args, world, rank, local_rank):
         gv = [shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev) for _ in range(K)]
         if world > 1:
             dist.barrier()
+        single = []                            # one GPU: no gather keeps a step's probabilities, and steps i, i + NB share d_probs[i % NB] -- a copy per step, behind its join
         for i in range(K):
             step(i, gv[i])
+            if world == 1:
+                if args.defer_join:
+                    eng.join(streams[0].cuda_stream)
+                with torch.cuda.stream(streams[0] if args.defer_join else streams[i % NB]):
+                    single.append(d_probs[i % NB].clone())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         if rank == 0:
-            res = np.stack([(g.result() if world > 1 else d_probs[i % NB]).detach().cpu().numpy().copy() for i, g in enumerate(gv)])
+            res = np.stack([(g.result() if world > 1 else single[i]).detach().cpu().numpy().copy() for i, g in enumerate(gv)])
             np.savez(args.verify_dump, probs=res, total_streams=total_streams, world=world, chunks=Cn, buffers=NB, steps=K)
 
     if rank == 0:
@@ -469,7 +511,7 @@ def run_rank(args, world, rank, local_rank):
         for k, (n_l, ms) in kt.items():
             if not n_l:
                 continue
-            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major, eng.get_option("layer1") == 0)
+            alg, exe = kernel_cost(args.model, k, fe_kernel, layer_major, eng.get_option("layer1_kernel") == 0)
             per_launch = S * Cn * n_prof / n_l                    # chunks one launch processes (a step may be split into chunk groups)
             sec = ms / n_l / 1e3
             # binding pipe = the one whose executed FLOP take longest at its peak (the pipes can overlap: this is the LOWER bound on the kernel's time)
@@ -482,6 +524,7 @@ def run_rank(args, world, rank, local_rank):
         dom = max(per_kernel, key=lambda k: kt[k][1] * cu_share[k])
         d = per_kernel[dom]
         traffic = None
+        traffic_source = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB -> B): only a pass collected
             # on exactly this workload AND this front-end kernel counts (tools/rocprof_reduce.py writes both into the file), else null
             default_workload = args.model == "v31" and mode == 0 and S == 256 and Cn == 96
@@ -491,6 +534,7 @@ def run_rank(args, world, rank, local_rank):
                     and prof.get("precision", "fp32") == args.precision and prof.get("frontend_kernel") == FRONTEND_KERNELS.get(fe_kernel)
                     and dom in prof.get("kernels", {})):
                 traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_source = f"profiles/{name} (rocprofv3 --pmc pass of this workload, committed; not measured in this run)"
         except (OSError, ValueError):
             pass
         out = {
@@ -501,11 +545,11 @@ def run_rank(args, world, rank, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32 STFT + split-f16x3 GEMMs (f32 accumulate)", 1: "f32 STFT + split-f16x3 GEMMs (f32 accumulate), f32-MFMA fallbacks refused",
                                                      2: "split-f16x3 GEMM STFT + split-f16x3 GEMMs (f32 accumulate)"}[mode], "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
-                                   f"{ {0: 'fp32', 1: 'SPLIT16 precision mode (BASELINE config 3)', 2: 'FAST_STFT throughput mode (outside the 1e-4 bar)'}[mode]}, s16le input resident in HBM",
+                                   f"{ {0: 'parity mode: exact fp32 STFT tree + split-fp16 x 3 GEMMs with fp32 accumulation (22-bit operands; BASELINE config 2 says fp32: the literal fp32-MFMA engine is configs[256x96_fp32_mfma])', 1: 'SPLIT16 precision mode (BASELINE config 3)', 2: 'FAST_STFT throughput mode (outside the 1e-4 bar)'}[mode]}, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
                        "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
-                         "unit": "TFLOP/s", "frac": d["frac_of_pipe_peak"], "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": d["frac_of_pipe_peak"], "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": d["ms_per_launch"], "chunks_per_launch": d["chunks_per_launch"], "pipe": d["pipe"],
                          # the same rate against the fp32 FMA peak (what the vector ALU could do if the reference's tree allowed contraction), and the
                          # measured HBM bytes of the launch over its algorithmic bytes (the front end: 3,072 B of s16 samples per chunk; others: the whole path's 3.1 KB)
@@ -523,6 +567,7 @@ def run_rank(args, world, rank, local_rank):
                                  "the 129 bins (the rest follow from the basis' DFT symmetries, bit-exactly), so it EXECUTES 27 % of the dense-basis FLOP that "
                                  "algorithmic_* counts (SURVEY.md 8(d))"},
             "kernels": per_kernel,
+            "stage_fracs": {k: [v["frac_of_pipe_peak"], v["pipe"]] for k, v in per_kernel.items()},
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph
         }
@@ -558,7 +603,9 @@ def run_rank(args, world, rank, local_rank):
         if world == 1 and not args.no_side_config and not args.verify_dump and args.model == "v31" and not (S == 4096 and Cn == 16):
             eng.close()
             eng = None
-            out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1)}
+            out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1),
+                              "10240x1": side_config(torch, blob, dev, local_rank, args.model, 10240, 1, 0, steps=200, warmup=20, latency=True, host_fed=True),
+                              "256x96_fp32_mfma": side_config(torch, blob, dev, local_rank, args.model, 256, 96, 0, opts={"encoder": 3, "lstm": 3, "layer1": 1})}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         # The line the driver parses stays SHORT (it reads the tail of stdout): the per-kernel accounting and the long notes go to a details file

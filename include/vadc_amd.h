@@ -67,13 +67,15 @@ enum {
    VADC_AMD_PRECISION_FP32 = 0,   /* the parity mode (BASELINE config 2).  STFT with the reference's exact fp32 reduction tree (stft.c:115-184): bit-identical
                                      magnitudes.  After the normalization every dense contraction runs at fp32 ACCURACY on whichever pipe is fastest:
                                      split-fp16 operands (a = hi + lo, 22 significant bits, exact products, fp32 accumulation: 3 fp16 MFMAs per fp32 one) for
-                                     the LSTM gate GEMMs and the GEMMs of layers 2-4, fp32 MFMA for layer 1; options "encoder"=3 / "lstm"=3 force fp32 MFMA. */
+                                     the LSTM gate GEMMs and every GEMM of the encoder (layer 1 included: k_layer1_regs); a weight outside fp16's range
+                                     selects the fp32-MFMA form of the kernel it belongs to by itself, options "encoder"=3 / "lstm"=3 / "layer1"=1 force it. */
    VADC_AMD_PRECISION_SPLIT16 = 1,/* BASELINE config 3 ("reduced-precision compute + fp32 LSTM state"), as SURVEY.md section 0 prescribes it: the STFT keeps the
                                      reference's exact tree -- any other summation order moves near-silent bins, log1p(2^20 x) amplifies that, and single chunks
                                      leave the 1e-4 bar (measured: up to 7e-4 with the STFT as a GEMM) -- and everything behind the normalization is
                                      split-precision 16-bit MFMA with fp32 accumulation.  Since k_frontend_sym made the exact tree as cheap as a GEMM this is
-                                     what mode 0 runs by default too; mode 1 additionally refuses the fp32-MFMA fallbacks (create fails with EWEIGHTS if a
-                                     weight does not fit fp16's range). */
+                                     what mode 0 runs by default too; mode 1 additionally refuses EVERY fp32-MFMA fallback: create fails with EWEIGHTS if a
+                                     weight of the LSTM, of layers 2-4 or of the first layer does not fit fp16's range, and "encoder"=3 / "lstm"=3 /
+                                     "layer1"=1 are rejected. */
    VADC_AMD_PRECISION_FAST_STFT = 2 /* throughput mode, NOT within the 1e-4 bar: the STFT as a folded real-input GEMM on the fp16 matrix pipe (split-fp16
                                      operands, any summation order): front end 2x faster than the exact tree; probabilities deviate from the C backend by up
                                      to ~7e-4 on single chunks (p99.9 3e-4; distribution in DESIGN.md).  Silero v4 (whose parity target is a framework
@@ -102,6 +104,8 @@ typedef struct vadc_amd_caps {
    int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1024 / 512 (option "window"); v4 8 kHz: 768 / 512 / 256 */
    int32_t sample_rate;                   /* 16000; 8000 for the container of the v4 graph's 8 kHz branch               */
    int32_t context_size;                  /* 0; 64 for Silero v5 (vadc.c:697-701): kept per stream on the device, callers pass windows only */
+   int32_t cu_partition_ok;               /* 1: the device has the CU-mask layout the LSTM partition rules were measured on (256 CUs, mask bit i -> XCD i % 8: checked at
+                                             create) and the partition may be used; 0: any other layout (CPX / DPX mode, another part): no CU partition, plain streams */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -150,13 +154,19 @@ int  vadc_amd_join(vadc_amd_engine *e, void *hip_stream);
 /* Host buffers, ASYNCHRONOUS: what a real backend_run caller holds -- host samples in, host probabilities out (vadc.c:873-909: the stream reader fills
  * host memory; silero.h:53-74 hands it to the backend) -- without the copy -> run -> copy serialisation of vadc_amd_run_*.  A call returns as soon as its
  * work is enqueued: the H2D copy on a copy stream of its own, the kernels behind it, the 8 bytes per chunk of probabilities back on a third stream
- * behind the call's completion; up to three calls are in flight (the fourth waits, on the host, for the first).  Both host buffers are page-locked on
- * first sight (hipHostRegister; ranges that are page-locked already are taken as they are) and must stay valid and unmodified until
- * vadc_amd_wait_async.  Results are bit-identical to vadc_amd_run_device_* on the same inputs.  host_probs: [n_streams][n_chunks][2]. */
+ * behind the call's completion; up to three calls are in flight (the fourth waits, on the host, for the first).  Both host buffers must stay valid and
+ * unmodified until vadc_amd_wait_async.  Results are bit-identical to vadc_amd_run_device_* on the same inputs.  host_probs: [n_streams][n_chunks][2].
+ * Page-locking: both buffers are page-locked on first sight (hipHostRegister; ranges that are page-locked already are taken as they are) and REMEMBERED --
+ * up to 16 ranges, the least recently used one unregistered when a 17th arrives; a range that overlaps remembered ones without lying inside one replaces
+ * them by their union.  Buffer lifetime rule: before freeing (or unmapping) a buffer that was ever passed here, call vadc_amd_unpin on it -- as for
+ * any hipHostRegister'ed memory -- or run with option "pin_host" = 0 (no page-locking: pageable copies, about a third of the link rate). */
 int  vadc_amd_run_s16_async(vadc_amd_engine *e, const int16_t *host_pcm, int n_streams, int n_chunks, float *host_probs);
 int  vadc_amd_run_f32_async(vadc_amd_engine *e, const float *host_samples, int n_streams, int n_chunks, float *host_probs);
 /* Host-synchronous: every asynchronous call issued so far has delivered its probabilities. */
 int  vadc_amd_wait_async(vadc_amd_engine *e);
+/* The caller is about to free the host buffer that contains `host_ptr`: waits for the asynchronous calls in flight and drops (unregisters) every
+ * remembered range that contains it.  A pointer the engine never saw is not an error. */
+int  vadc_amd_unpin(vadc_amd_engine *e, const void *host_ptr);
 
 /* ---- per-stream state (the reference has one implicit stream; silero.h:36-37) ---------------- */
 /* Zero the state of the listed streams (stream_ids == NULL: all max_streams). */
@@ -209,9 +219,9 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "groups"      number of chunk groups a call is pipelined in: the LSTM of group g overlaps the front end + encoder of group g+1.  0 = auto (default): up
  *                 to 4 for calls the caller waits for, 1 with "defer_join" (consecutive calls overlap instead)
  *   "lstm"        0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy -- 7 = layer-major (k_lstm_layer: layer 0 and
- *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls while the recurrence would otherwise be
- *                 the longer of the concurrent streams, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both layers); 6 and 7 produce
- *                 the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
+ *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls up to half a chip of stream tiles and
+ *                 for calls of one or two chunks per stream, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both layers); 6 and 7
+ *                 produce the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
  *   "frontend"    Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins 0..32, the other 96 bins from the basis'
  *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
  *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = k_frontend_gemm (default), 1 = the tree kernel with the v4 geometry
@@ -223,14 +233,23 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "layer1"      the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4 (Silero v4, default window): input by LDS-DMA,
  *                 split-fp16 MFMAs, activations in registers -- when its weights fit fp16's range; 1 = the K = 1 fp32-MFMA form of k_layer_mfma (rounds 1 - 2)
  *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
+ *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
+ *   "fe_opt"      k_frontend_sym: 3 (default) = bin 0 without the tree of its all-zero im row, the 9-bin split rotating over the waves; 0 = round 3's kernel
+ *                 (same bits)
+ *   "cu_mask_check" 1 (default): the LSTM's CU partition is used only on a device whose CU-mask layout passed the check at create (caps.cu_partition_ok);
+ *                 0: trust the rules anyway; 2: behave as if the check had failed (tests)
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
  *                 1: magnitudes are written by the front end and read by the first stage
  *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream
  *                 when the chain has slack, disjoint otherwise; 2: always shared; 0: never mask.  "lstm_cus": size of that partition (multiple of 8; 0 =
  *                 sized by the engine) */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
-/* Reads a switch back, plus read-only facts about the last call: "lstm_cus" = CUs reserved for the LSTM (0 = no partition), "lstm_kernel" = the
- * LSTM variant it ran (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 k_frontend_gemm, 3 k_frontend v4 tree). */
+/* Reads a switch back, plus read-only facts: "lstm_cus" = CUs reserved for the LSTM by the last call (0 = no partition), "lstm_kernel" = the LSTM variant it ran
+ * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 k_frontend_gemm, 3 k_frontend v4 tree), "layer1_kernel" = the first
+ * layer's form that runs (0 register-resident, 1 per-layer: option "layer1" is the request), "layer1_selfcheck" (1: the register-resident first layer agreed
+ * with the per-layer form on the probe chunks at create; 0: it did not and the per-layer form serves; -1: not applicable), "zero_im0" (the basis' im row of
+ * bin 0 is all zeros: k_frontend_sym skips its tree), "cu_layout_ok" (the device has the CU-mask layout the partition rules assume), "pinned_ranges" (host
+ * ranges the asynchronous entry points currently keep page-locked). */
 int  vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *value);
 
 /* ---- measurement: per-kernel HIP-event timing on the launch stream --------------------------- */

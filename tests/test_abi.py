@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -127,29 +128,38 @@ def test_layer1_kernel_layout_invariants():
 
 
 def test_counted_wait_kernels_do_not_spill(tmp_path):
-    """k_layer1_regs / k_layer1_regs_v4 wait for their LDS-DMA pieces with COUNTED s_waitcnt vmcnt(N): the count assumes that the only vector-memory
-    operations a wave issues per iteration are its own 4 + 13 + 4, and an in-flight load's destination register must not be moved.  A register spill
-    (scratch traffic is vector-memory traffic) would break both silently -- so the hot instantiations must compile without any."""
-    import re, shutil
+    """k_layer1_regs / k_layer1_regs_v4 / k_lstm_layer wait for their LDS-DMA pieces with COUNTED s_waitcnt vmcnt(N): the count assumes that the only
+    vector-memory operations a wave issues per iteration are the ones the source lists, and an in-flight load's destination register must not be moved.  A
+    register spill (scratch traffic is vector-memory traffic), another operation count or a compiler-made write of M0 would break that silently -- the same
+    checker the Makefile runs on every build (tools/check_counted_waits.py), here on fresh listings; and the checker itself must catch a doctored listing."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_counted_waits as ccw
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     src_dir = os.path.join(ROOT, "vadc_amd", "csrc")
-    for src, kernel in (("kernels_layer1_regs.hip", "k_layer1_regsILi8ELi0"), ("kernels_layer1_regs_v4.hip", "k_layer1_regs_v4ILi8")):
+    outs = []
+    for src in ("kernels_layer1_regs.hip", "kernels_layer1_regs_v4.hip", "kernels_lstm.hip"):
         out = str(tmp_path / (src + ".s"))
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
-                            "-o", out, os.path.join(src_dir, src)], capture_output=True, text=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+                            "-I", os.path.join(ROOT, "include"), "-o", out, os.path.join(src_dir, src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-        txt = open(out).read()
-        m = re.search(r"\.name:\s+_ZN4vadc\d+" + kernel + r".*?\.vgpr_spill_count:\s+(\d+)", txt, re.S)
-        p = re.search(r"\.name:\s+_ZN4vadc\d+" + kernel + r".*?\.private_segment_fixed_size:\s+(\d+)", txt, re.S)
-        assert m and p, kernel
-        assert int(m.group(1)) == 0 and int(p.group(1)) == 0, (kernel, m.group(1), p.group(1))
-        # and the operations the waits count are the ones in the listing: per iteration 4 loads of partial sums, 13 DMA pieces, 4 stores (each once more in
-        # the prologue, except the stores); more stores than counted would only make the waits conservative, fewer would make them too lax
-        body = txt[txt.index("_ZN4vadc" + re.search(r"_ZN4vadc(\d+)" + kernel, txt).group(1) + kernel):]
-        body = body[body.index(":"):body.index(".Lfunc_end")]
-        assert len(re.findall(r"\sglobal_load_lds_dwordx4\s", body)) == 26, kernel
-        assert len(re.findall(r"\sglobal_load_dword\s", body)) == 8, kernel
-        assert len(re.findall(r"\sglobal_store_dword\s", body)) >= 4, kernel
-        assert not re.findall(r"\sscratch_", body), kernel
+        outs.append(out)
+    seen = set()
+    for o in outs:
+        errors, s_ = ccw.check(o)
+        assert not errors, errors
+        seen |= s_
+    assert seen == set(ccw.RULES)                                   # every kernel the rules name was found in a listing
+    # a listing with one DMA piece missing, and one with a spill inside the layer-1 kernel, must be rejected
+    txt = open(outs[0]).read()
+    bad1 = str(tmp_path / "missing_piece.s")
+    i = txt.index("_ZN4vadc13k_layer1_regsILi8ELi0")
+    j = txt.index("global_load_lds_dwordx4", txt.index(":", i))
+    open(bad1, "w").write(txt[:j] + "s_nop 0 ;" + txt[j + len("global_load_lds_dwordx4"):])
+    assert ccw.check(bad1)[0]
+    bad2 = str(tmp_path / "spill.s")
+    open(bad2, "w").write(txt[:j] + "scratch_store_dword off, v1, off\n\tglobal_load_lds_dwordx4" + txt[j + len("global_load_lds_dwordx4"):])
+    assert ccw.check(bad2)[0]
+

@@ -1271,6 +1271,147 @@ def test_async_host_entry_points_bit_identical_to_the_device_path(weights_blob, 
     assert np.array_equal(bits(want), bits(got))
 
 
+def test_async_calls_through_fresh_host_buffers(weights_blob):
+    """a caller that allocates a NEW pair of host buffers for every asynchronous call and frees them afterwards (telling the engine first: vadc_amd_unpin): 200
+    calls deliver the bits of the device path, the engine's list of page-locked ranges stays bounded, and with "pin_host" = 0 (no page-locking, nothing to
+    forget) the same holds without the unpin"""
+    S, Cn, calls = 64, 4, 200
+    base = synth.make_streams(S, 8 * Cn, seed0=6161)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        parts = [np.ascontiguousarray(base[:, (k % 8) * Cn * 1536:((k % 8) + 1) * Cn * 1536]) for k in range(calls)]
+        want = [e.run(p_) for p_ in parts]                                           # state carried through all 200 calls
+        for pin in (1, 0):
+            e.set_option("pin_host", pin); e.reset_streams()
+            live, worst = [], 0
+            for k in range(calls):
+                buf_in = np.empty((S, Cn * 1536 + 4096), np.int16)[:, : Cn * 1536].copy()    # a fresh allocation of a size the allocator has not just freed
+                buf_in[...] = parts[k]
+                buf_out = np.full((S, Cn, 2), np.nan, np.float32)
+                e.run_async(buf_in, buf_out)
+                live.append((k, buf_in, buf_out))
+                if len(live) > 3:                                                     # three calls in flight: the oldest one is complete after wait_async
+                    e.wait_async()
+                    for kk, bi, bo in live:
+                        assert np.array_equal(bits(bo), bits(want[kk])), (pin, kk)
+                        if pin:
+                            e.unpin(bi); e.unpin(bo)
+                    live = []
+                worst = max(worst, e.get_option("pinned_ranges"))
+            e.wait_async()
+            for kk, bi, bo in live:
+                assert np.array_equal(bits(bo), bits(want[kk])), (pin, kk)
+                if pin:
+                    e.unpin(bi); e.unpin(bo)
+            assert e.get_option("pinned_ranges") == 0 and worst <= (8 if pin else 0), (pin, worst)
+    finally:
+        e.close()
+
+
+def test_async_pinned_ranges_are_bounded_and_overlaps_merge(weights_blob):
+    """40 live buffer pairs used in turn: at most 16 remembered ranges (least recently used evicted), results unchanged; a call whose buffer overlaps a
+    remembered range without lying inside it replaces that range by the union"""
+    S, Cn = 16, 2
+    pcm = synth.make_streams(S, Cn, seed0=77)
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        want = e.run(pcm)
+        ins = [pcm.copy() for _ in range(40)]
+        outs = [np.empty((S, Cn, 2), np.float32) for _ in range(40)]
+        for rep in range(2):
+            for i in range(40):
+                e.reset_streams()
+                e.run_async(ins[i], outs[i]); e.wait_async()
+                assert np.array_equal(bits(outs[i]), bits(want))
+                assert e.get_option("pinned_ranges") <= 16
+        for a in ins + outs:
+            e.unpin(a)
+        assert e.get_option("pinned_ranges") == 0
+        big = np.zeros((3 * S, Cn * 1536), np.int16)
+        big[:S] = pcm; big[S:2 * S] = pcm; big[2 * S:] = pcm
+        out = np.empty((S, Cn, 2), np.float32)
+        e.reset_streams(); e.run_async(big[:S], out); e.wait_async()                 # rows [0, S)
+        n1 = e.get_option("pinned_ranges")
+        e.reset_streams(); e.run_async(big[S // 2: S // 2 + S], out); e.wait_async()  # rows [S/2, 3S/2): overlaps the first range -> one union range + `out`
+        assert e.get_option("pinned_ranges") == n1
+        assert np.array_equal(bits(out[S // 2:]), bits(want[: S - S // 2]))
+        e.unpin(big); e.unpin(out)
+    finally:
+        e.close()
+
+
+def test_cu_mask_layout_is_checked_and_the_fallback_runs_without_a_partition(weights_blob, orc):
+    """the LSTM partition's rules assume 256 CUs and CU-mask bit i -> XCD i % 8; the engine verifies that on the device at create (caps.cu_partition_ok) and,
+    where it does not hold -- forced here with option "cu_mask_check" = 2 --, runs a forked call with no partition (plain streams): the same bits"""
+    S, Cn = 256, 8                                                                    # 2048 chunk items: the call forks
+    pcm = synth.make_streams(16, Cn, seed0=909)
+    pcm = np.ascontiguousarray(np.tile(pcm, (S // 16, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        assert e.caps()["cu_partition_ok"] == 1 and e.get_option("cu_layout_ok") == 1      # an MI355X in SPX mode
+        a = e.run(pcm)
+        assert e.get_option("lstm_cus") == 32
+        e.set_option("cu_mask_check", 2); e.reset_streams()
+        assert e.caps()["cu_partition_ok"] == 0
+        b = e.run(pcm)
+        assert e.get_option("lstm_cus") == 0
+        e.set_option("cu_mask_check", 1); e.reset_streams()
+        c = e.run(pcm)
+        assert e.get_option("lstm_cus") == 32
+    finally:
+        e.close()
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
+    assert float(np.abs(a[:16, :, 1] - orc.forward_streams(pcm[:16])).max()) <= PROB_TOL
+
+
+def test_layer1_selfcheck_and_its_fallback(weights_blob, orc, tmp_path):
+    """every engine checks its register-resident first layer (hand-counted waits over LDS-DMA the compiler cannot see) against the per-layer form on three
+    probe chunks at create: it passes; forced to fail (a child process with VADC_AMD_FORCE_L1_SELFCHECK_FAIL), the engine warns, runs the per-layer form and
+    still answers like the oracle"""
+    import subprocess, sys
+    from conftest import ROOT
+    e = Engine(weights_blob, max_streams=4, max_chunks_per_call=4, device=0)
+    try:
+        assert e.get_option("layer1_selfcheck") == 1 and e.get_option("layer1_kernel") == 0
+    finally:
+        e.close()
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from vadc_amd import synth; from vadc_amd.engine import Engine\n"
+        "blob = open(%r, 'rb').read(); pcm = synth.make_streams(3, 5, seed0=333)\n"
+        "e = Engine(blob, max_streams=3, max_chunks_per_call=5, device=0)\n"
+        "print(e.get_option('layer1_selfcheck'), e.get_option('layer1_kernel')); np.save(%r, e.run(pcm)); e.close()\n"
+    ) % (ROOT, os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), str(tmp_path / "p.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VADC_AMD_FORCE_L1_SELFCHECK_FAIL="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[:2] == ["0", "1"] and "per-layer form serves" in r.stderr
+    got = np.load(str(tmp_path / "p.npy"))
+    assert float(np.abs(got[:, :, 1] - orc.forward_streams(synth.make_streams(3, 5, seed0=333))).max()) <= PROB_TOL
+
+
+def test_split16_refuses_every_fp32_fallback(weights_blob):
+    """precision SPLIT16 (BASELINE config 3): no fp32-MFMA form anywhere -- options encoder = 3, lstm = 3 and layer1 = 1 are rejected, and a container with a
+    first-layer weight outside fp16's range does not create (in the parity mode the same container runs, on the per-layer form)"""
+    e = Engine(weights_blob, max_streams=2, max_chunks_per_call=2, device=0, precision=1)
+    try:
+        for key, val in (("encoder", 3), ("lstm", 3), ("layer1", 1)):
+            with pytest.raises(VadcAmdError):
+                e.set_option(key, val)
+        assert e.get_option("layer1_kernel") == 0
+    finally:
+        e.close()
+    ts = tt.loads(weights_blob)
+    w = ts[3][1].copy(); w.reshape(-1)[11] = 7.0e4                              # a pointwise weight of the first layer
+    blob = _blob_with(weights_blob, {3: w})
+    with pytest.raises(VadcAmdError):
+        Engine(blob, max_streams=2, max_chunks_per_call=2, device=0, precision=1)
+    e = Engine(blob, max_streams=2, max_chunks_per_call=2, device=0, precision=0)
+    try:
+        assert e.get_option("layer1_kernel") == 1 and e.get_option("layer1_selfcheck") == -1
+    finally:
+        e.close()
+
+
 def test_three_engines_alive_in_one_process(weights_blob, orc):
     """a long-lived host with several engines: three engines (different workspace sizes, forked and small calls, deferred joins on one of them) are
     created, used interleaved, destroyed in another order than they were created, and a fourth one is created afterwards -- every result is the

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""The kernels that wait for their LDS-DMA pieces with COUNTED `s_waitcnt vmcnt(N)` (k_layer1_regs, k_layer1_regs_v4, k_lstm_layer) issue those pieces from
+inline asm the compiler cannot see: the counts hold only if the compiled kernel issues exactly the vector-memory operations the source assumes, spills nothing
+(scratch traffic is vector-memory traffic; an in-flight load's destination register must not move) and if nothing but those asm statements writes M0 between
+an `s_mov_b32 m0` and the DMA that reads it.  (hipcc rejects "m0" in an asm clobber list -- a reserved register -- so the listing is where this is checked.)
+Run by vadc_amd/csrc/Makefile on every build of these files and by tests/test_abi.py:
+    python tools/check_counted_waits.py <listing.s> [<listing.s> ...]        # exit code 1 and a message on the first violation
+"""
+import re
+import sys
+
+# kernel name fragment (Itanium-mangled, after _ZN4vadc<len>) -> expectations on its listing
+RULES = {
+    "k_layer1_regsILi8ELi0": {"dma": 26, "load_dword": 8, "min_store_dword": 4},          # per iteration: 4 partial sums, 13 pieces, 4 stores; pieces and sums once more in the prologue
+    "k_layer1_regs_v4ILi8": {"dma": 26, "load_dword": 8, "min_store_dword": 4},
+    # ring prologue 4 + one per slot.  hipcc keeps the state write-back's addresses in scratch across the slot loop (two stores in the prologue, two loads in the
+    # epilogue: older than every piece the loop waits for, so the counts stand); INSIDE the loop there must be none
+    "k_lstm_layerILi7ELi0ELi0ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
+    "k_lstm_layerILi7ELi0ELi1ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
+}
+
+
+def inner_loop(body):
+    """the text of the kernel's (single) innermost loop: from the label marked 'Inner Loop Header' to the first label behind its last 'in Loop' block"""
+    lines = body.split("\n")
+    start = next((i for i, l in enumerate(lines) if "Inner Loop Header" in l), None)
+    if start is None:
+        return ""
+    last_in = max(i for i, l in enumerate(lines) if "in Loop: Header" in l or i == start)
+    end = next((i for i in range(last_in + 1, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i])), len(lines))
+    return "\n".join(lines[start:end])
+
+
+def kernels(txt):
+    for m in re.finditer(r"^(_ZN4vadc\d+\S+):", txt, re.M):
+        name = m.group(1)
+        end = txt.find(".Lfunc_end", m.end())
+        yield name, txt[m.end():end if end > 0 else len(txt)]
+
+
+def check(path):
+    txt = open(path).read()
+    errors, seen = [], set()
+    meta = {}
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[nm] = (int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    for name, body in kernels(txt):
+        for frag, rule in RULES.items():
+            if frag not in name:
+                continue
+            seen.add(frag)
+            spill, scratch = meta.get(name, (None, None))
+            if rule.get("scratch_outside_loop_ok"):
+                if re.search(r"\sscratch_", inner_loop(body)) or not inner_loop(body):
+                    errors.append(f"{name}: scratch instructions inside the slot loop (or no loop found)")
+            else:
+                if spill != 0 or scratch != 0:
+                    errors.append(f"{name}: {spill} spilled registers, {scratch} bytes of scratch (must be 0 / 0)")
+                if re.search(r"\sscratch_", body):
+                    errors.append(f"{name}: scratch instructions in the listing")
+            dma = len(re.findall(r"\sglobal_load_lds_dwordx4\s", body))
+            if dma != rule["dma"]:
+                errors.append(f"{name}: {dma} global_load_lds_dwordx4, the waits count {rule['dma']}")
+            if "load_dword" in rule:
+                n = len(re.findall(r"\sglobal_load_dword\s", body))
+                if n != rule["load_dword"]:
+                    errors.append(f"{name}: {n} global_load_dword, the waits count {rule['load_dword']}")
+            if "min_store_dword" in rule:
+                n = len(re.findall(r"\sglobal_store_dword\s", body))
+                if n < rule["min_store_dword"]:
+                    errors.append(f"{name}: {n} global_store_dword, the waits count at least {rule['min_store_dword']}")
+            # every write of M0 is one of ours (s_mov_b32 m0 directly in front of its DMA); the compiler's own uses of M0 would sit between them unseen
+            m0_writes = len(re.findall(r"\ss_mov_b32\s+m0,", body))
+            other_m0 = len(re.findall(r"\s(?!s_mov_b32)\S+\s+m0,", body))
+            if m0_writes != dma or other_m0:
+                errors.append(f"{name}: {m0_writes} s_mov_b32 m0 for {dma} DMA pieces, {other_m0} other writes of m0")
+    return errors, seen
+
+
+def main(paths):
+    bad = []
+    seen = set()
+    for p in paths:
+        e, s = check(p)
+        bad += [f"{p}: {x}" for x in e]
+        seen |= s
+    for b in bad:
+        print("check_counted_waits:", b, file=sys.stderr)
+    if not bad:
+        print(f"check_counted_waits: {len(seen)} kernel(s) in {len(paths)} listing(s): vector-memory operation counts match their waits, no spills, M0 written by the DMA statements only")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

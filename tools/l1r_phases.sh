@@ -1,9 +1,8 @@
 #!/bin/bash
 # cycle stamps inside k_layer1_regs (one wave per workgroup): share of a chunk's time spent waiting for its DMA, in the normalization offset, the conv
-# block, the transformer block and the store.  gpurun -- 'bash tools/l1r_phases.sh'   (rebuilds the library with -DVADC_L1R_PHASE_PROF, then restores it)
+# block, the transformer block and the store.  gpurun -- 'bash tools/l1r_phases.sh'   (a variant of the library with -DVADC_L1R_PHASE_PROF beside the product: tools/abl_build.sh)
 cd "$(dirname "$0")/.." || exit 1
-build() { (cd vadc_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c kernels_layer1_regs.hip -o build/kernels_layer1_regs.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libvadc_amd.so build/engine.o build/kernels_frontend.o build/kernels_frontend_gemm.o build/kernels_encoder_mfma.o build/kernels_encoder_fused.o build/kernels_layer1_regs.o build/kernels_lstm.o build/kernels_v5.o); }
-build -DVADC_L1R_PHASE_PROF
+export VADC_AMD_LIB=$(bash tools/abl_build.sh kernels_layer1_regs.hip -DVADC_L1R_PHASE_PROF | tail -1)
 python - <<'PY'
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
@@ -14,7 +13,7 @@ blob = open("tests/golden/reference_fixtures/silero_v31_16k.testtensor", "rb").r
 n = 24576
 e = Engine(blob, max_streams=256, max_chunks_per_call=96, device=0)
 x = (np.random.default_rng(1).standard_normal((n, 129, 25)) * 2.0).astype(np.float32)
-L = C.CDLL(os.path.join("vadc_amd", "libvadc_amd.so"))
+L = C.CDLL(os.environ["VADC_AMD_LIB"])
 out = (C.c_ulonglong * 8)()
 e.stage_from_stage(x, "normalized", "layer1")
 L.vadc_amd_debug_l1r_phases(out, 1)
@@ -25,4 +24,3 @@ names = ["loop top (store drain)", "wait for the DMA", "normalization offset", "
 for nm, c in zip(names, v): print(f"{nm:28s} {c / v.sum() * 100:5.1f} %   {c / (3 * 256 * 12):9.0f} cycles per chunk")
 e.close()
 PY
-build

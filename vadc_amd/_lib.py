@@ -18,7 +18,7 @@ SYMBOLS = [
     "vadc_amd_run_s16_async", "vadc_amd_run_f32_async", "vadc_amd_wait_async",
     "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
     "vadc_amd_get_context", "vadc_amd_set_context",
-    "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder", "vadc_amd_debug_layer1_block", "vadc_amd_debug_decoder",
+    "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder", "vadc_amd_debug_layer1_block", "vadc_amd_debug_decoder", "vadc_amd_unpin",
     "vadc_amd_set_option", "vadc_amd_get_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
     "vadc_amd_kernel_name",
 ]
@@ -28,7 +28,7 @@ class Caps(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch_size_restriction", "is_silero_v5", "input_size_min", "input_size_max", "output_dims",
         "output_stride", "silero_probability_out_index", "lstm_hidden_size", "max_streams",
-        "max_chunks_per_call", "device", "precision", "model_kind", "lstm_steps_per_chunk", "window_samples", "sample_rate", "context_size")]
+        "max_chunks_per_call", "device", "precision", "model_kind", "lstm_steps_per_chunk", "window_samples", "sample_rate", "context_size", "cu_partition_ok")]
 
 
 _lib = None
@@ -55,9 +55,12 @@ def _preload_hip_runtime() -> None:
 
 
 def load() -> C.CDLL:
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    # experiments only (tools/abl_build.sh): a variant of the library built beside the product, never in its place
+    if os.environ.get("VADC_AMD_LIB"):
+        LIB_PATH = os.environ["VADC_AMD_LIB"]
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
@@ -89,6 +92,7 @@ def load() -> C.CDLL:
     L.vadc_amd_debug_lstm_decoder.argtypes = [vp, vp, i32, i32, vp]
     L.vadc_amd_debug_layer1_block.argtypes = [vp, i32, vp, i32, vp]
     L.vadc_amd_debug_decoder.argtypes = [vp, vp, i32, vp]
+    L.vadc_amd_unpin.argtypes = [vp, vp]
     L.vadc_amd_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vadc_amd_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32)]
     L.vadc_amd_set_profiling.argtypes = [vp, i32]

@@ -157,6 +157,9 @@ struct vadc_amd_engine {
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
+   bool cu_layout_ok = false;                   // 256 CUs and CU-mask bit i -> XCD i % 8 (cu_mask_layout_ok): what the LSTM partition rules assume
+   int cu_mask_check = 1;                       // option "cu_mask_check": 1 = the partition needs cu_layout_ok (default), 0 = trust the rules anyway, 2 = behave as if the check had failed (tests)
+   bool cu_partition_usable() const { return cu_mask_check == 0 || (cu_mask_check == 1 && cu_layout_ok); }
    bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
    int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree: kernels_frontend.hip)
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
@@ -169,10 +172,11 @@ struct vadc_amd_engine {
    // k_layer1_regs (kernels_layer1_regs.hip): its LDS image
    void *d_l1img = nullptr;
    std::vector<unsigned char> h_l1img;
+   int layer1_selfcheck = -1;                   // -1: not run (no register-resident first layer in this engine), 1: it agrees with the per-layer form on the probe chunks, 0: it does not (the per-layer form serves)
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
-   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2; }
+   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2 && layer1_selfcheck != 0; }
    // Silero v4: k_layer1_regs_v4 serves the default window (24 frames) with the magnitude half of the input recovered from Y ("v4_mag" = 0)
-   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && v4_mag == 0; }   // ("encoder" = 2: the first stage as the LDS slab path)
+   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && v4_mag == 0 && layer1_selfcheck != 0; }   // ("encoder" = 2: the first stage as the LDS slab path)
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
@@ -182,8 +186,13 @@ struct vadc_amd_engine {
    hipEvent_t ev_h2dx[3] = {nullptr, nullptr, nullptr};
    int h2d_parts = 1;                            // option "h2d_streams": pieces (= copy streams) of an asynchronous call's H2D copy
    unsigned anext = 0;
-   struct HostRange { const char *p; size_t n; bool ours; };
-   std::vector<HostRange> pinned;                // host ranges already seen by the async entry points (ours: registered here, unregistered at destroy)
+   struct HostRange { const char *p; size_t n; bool ours; unsigned long long last; };
+   // host ranges the async entry points have seen: at most kMaxPinned, least recently used one evicted (and unregistered); ours: registered here.  A caller
+   // that frees a buffer it has passed tells the engine first (vadc_amd_unpin); option "pin_host" = 0 turns the page-locking off altogether
+   static constexpr size_t kMaxPinned = 16;
+   std::vector<HostRange> pinned;
+   unsigned long long pin_clock = 0;
+   int pin_host = 1;
    int enc_batch = 0;                           // option "encoder_batch": form of k_enc_fused (0 / 1: 12 waves x one pair tile per batch, 2: 8 waves x two)
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
    LstmWeights lstm;
@@ -857,6 +866,8 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    delete e;
 }
 
+static bool cu_mask_layout_ok(int device, int n_cus);
+static int layer1_selfcheck(vadc_amd_engine *e);
 extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max_streams, int max_chunks,
                                int precision, vadc_amd_engine **out)
 {
@@ -914,6 +925,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
+   e->cu_layout_ok = cu_mask_layout_ok(device, e->n_cus);
    for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
@@ -961,6 +973,14 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       vadc_amd_destroy(e);
       return rc;
    }
+   if (precision == VADC_AMD_PRECISION_SPLIT16 && e->model != VADC_AMD_MODEL_V5 && !e->d_l1img) {
+      vadc_amd_destroy(e);
+      return fail(VADC_AMD_EWEIGHTS, "create: SPLIT16 precision runs every GEMM with split-fp16 operands, but a first-layer weight of this container does not fit fp16's range; use VADC_AMD_PRECISION_FP32");
+   }
+   rc = layer1_selfcheck(e);
+   if (rc == VADC_AMD_OK && e->layer1_selfcheck == 0 && precision == VADC_AMD_PRECISION_SPLIT16)
+      rc = fail(VADC_AMD_EHIP, "create: the register-resident first layer failed its self-check and SPLIT16 refuses the fp32-MFMA fallback");
+   if (rc) { vadc_amd_destroy(e); return rc; }
    *out = e;
    return VADC_AMD_OK;
 }
@@ -977,6 +997,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    caps->context_size = e->model == VADC_AMD_MODEL_V5 ? 64 : 0;
    caps->window_samples = e->window;
    caps->sample_rate = e->sample_rate;
+   caps->cu_partition_ok = e->cu_partition_usable() ? 1 : 0;
    caps->output_dims = 3;                      // silero.h:43
    caps->output_stride = 2;                    // vadc.c:704-708
    caps->silero_probability_out_index = 1;
@@ -1068,10 +1089,12 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       return fail(VADC_AMD_EINVAL, "set_option: %s=%d exists for Silero v3.1 only (the v4 stages carry no split-fp16 GEMMs)", key, value);
    if (e->precision == VADC_AMD_PRECISION_SPLIT16 && value == 3 && (strcmp(key, "encoder") == 0 || strcmp(key, "lstm") == 0))
       return fail(VADC_AMD_EINVAL, "set_option: %s=3 selects fp32 MFMA; the SPLIT16 precision mode runs split-fp16 GEMMs only", key);
+   if (e->precision == VADC_AMD_PRECISION_SPLIT16 && value == 1 && strcmp(key, "layer1") == 0)
+      return fail(VADC_AMD_EINVAL, "set_option: layer1=1 selects the fp32-MFMA form of the first layer; the SPLIT16 precision mode runs split-fp16 GEMMs only");
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "cu_mask_check"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1095,6 +1118,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
+   if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
+   if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
@@ -1127,6 +1152,12 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
+   else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
+   else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
+   else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
+   else if (strcmp(key, "cu_mask_check") == 0) *value = e->cu_mask_check;
+   else if (strcmp(key, "cu_layout_ok") == 0) *value = e->cu_layout_ok ? 1 : 0;
+   else if (strcmp(key, "pinned_ranges") == 0) *value = (int)e->pinned.size();
    else if (strcmp(key, "zero_im0") == 0) *value = e->zero_im0 ? 1 : 0;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "layer1") == 0) *value = e->layer1_variant;
@@ -1147,6 +1178,100 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
 // ---------------------------------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// The register-resident first layer (k_layer1_regs, k_layer1_regs_v4) waits for its LDS-DMA pieces with hand-counted s_waitcnt vmcnt(N) over operations the
+// compiler cannot see.  The build checks the listing (tools/check_counted_waits.py); every engine also checks the RESULT once, on the device it runs on: three
+// probe chunks through that kernel and through the per-layer form (k_layer_mfma, compiler-managed waits).  More than 5e-5 apart: the per-layer form serves
+// from then on, with a warning on stderr (get_option "layer1_selfcheck" = 0).
+// ---------------------------------------------------------------------------------------------------
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st, const float *in_stage);
+static int layer1_selfcheck(vadc_amd_engine *e)
+{
+   if (!(e->use_l1_regs() || e->use_l1_regs_v4())) return VADC_AMD_OK;
+   const int n = (int)std::min<size_t>(3, e->max_items), T = e->frames;
+   const size_t fms = e->max_items * (size_t)kFrames;
+   std::vector<float> y((size_t)n * kBins * T), fm(kBinSplit * fms, 0.0f);
+   for (int c = 0; c < n; ++c)
+      for (int b = 0; b < kBins; ++b)
+         for (int t = 0; t < T; ++t) {
+            const float v = 5.0f + 4.0f * sinf(0.37f * b + 0.61f * t + 1.3f * c) + (b % 7 == 0 ? 3.0f : 0.0f);      // log-magnitude-like values in 0 .. 13
+            y[((size_t)c * kBins + b) * T + t] = v;
+            fm[(size_t)(b / kBinsPerSplit) * fms + (size_t)c * T + t] += v;
+         }
+   hipStream_t st = e->stream;
+   HIP_TRY(hipMemcpyAsync(e->d_Y, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(hipMemcpyAsync(e->d_FM, fm.data(), fm.size() * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   const size_t elems = (size_t)n * e->stage_elems[VADC_AMD_STAGE_LAYER1];
+   std::vector<float> a(elems), b(elems);
+   for (int form = 0; form < 2; ++form) {
+      e->layer1_variant = form;
+      run_encoder_layers(e, 0, 0, n, ItemMap{n, 0, n}, 0, st, nullptr);
+      HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
+      HIP_TRY(hipMemcpyAsync((form == 0 ? a : b).data(), e->d_act[0], elems * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+      HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+   }
+   e->layer1_variant = 0;
+   float worst = 0.0f, scale = 1.0f;
+   bool finite = true;
+   for (size_t i = 0; i < elems; ++i) { worst = std::max(worst, fabsf(a[i] - b[i])); scale = std::max(scale, fabsf(b[i])); finite = finite && std::isfinite(a[i]); }
+   if (getenv("VADC_AMD_FORCE_L1_SELFCHECK_FAIL")) worst = 1.0f;      // tests: the fallback path
+   e->layer1_selfcheck = (finite && worst <= 5e-5f * scale) ? 1 : 0;
+   if (!e->layer1_selfcheck)
+      fprintf(stderr, "vadc_amd: the register-resident first encoder layer disagrees with the per-layer form on the probe chunks (max |d| %.3e): the per-layer form serves this engine\n", worst);
+   return VADC_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The CU partition's premise, checked on the device (once per process and device): the rules below (lstm_partition_cus, encoder_cus) were measured on an
+// MI355X in SPX mode -- 256 CUs, and a hipExtStreamCreateWithCUMask mask deals its bits to the 8 XCDs in turn: the first 8 k bits are k CUs of EVERY XCD
+// (tools/cumask_probe.hip).  On a partitioned
+// (CPX / DPX) or differently built part they would be silently wrong -- slow, not incorrect -- so on any other layout the engine runs WITHOUT a
+// partition (plain prioritised streams) and says so: caps.cu_partition_ok = 0.
+// ---------------------------------------------------------------------------------------------------
+// a workgroup that fills a CU's LDS (only one fits per CU) and stays for a while: a grid of these lands one per CU of the stream's mask
+__global__ __launch_bounds__(64) void k_probe_hold(unsigned *out, int spin)
+{
+   __shared__ char big[140 * 1024];
+   unsigned xcc;
+   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+   big[threadIdx.x] = (char)xcc;
+   const unsigned long long t0 = __builtin_readcyclecounter();
+   while (__builtin_readcyclecounter() - t0 < (unsigned long long)spin) { }
+   if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xf) + (big[7] & 0);
+}
+// (a one-bit mask is no probe: every bit then reports XCC 0 -- the id is relative to the XCDs the queue may use; tools/cumask_probe.hip)
+static bool cu_mask_layout_ok(int device, int n_cus)
+{
+   static int cache[64];                                    // 0 = unknown, 1 = ok, 2 = not ok
+   if (device >= 0 && device < 64 && cache[device]) return cache[device] == 1;
+   bool ok = n_cus == 256;
+   unsigned *d = nullptr;
+   if (ok && hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+   const int words = (n_cus + 31) / 32;
+   // the two shapes the engine uses: the first 16 / 32 mask bits for the recurrence (2 / 4 CUs of every XCD), all the others for the front end + encoder
+   for (int taken : {16, 32}) {
+      for (int side = 0; side < 2 && ok; ++side) {
+         std::vector<uint32_t> m(words, 0u);
+         for (int cu = 0; cu < n_cus; ++cu) if ((cu < taken) == (side == 0)) m[cu / 32] |= 1u << (cu % 32);
+         const int grid = side == 0 ? taken : n_cus - taken;
+         hipStream_t st = nullptr;
+         std::vector<unsigned> got(256, 99u);
+         if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+         hipLaunchKernelGGL(k_probe_hold, dim3(grid), dim3(64), 0, st, d, 60000);
+         if (hipMemcpyAsync(got.data(), d, grid * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+         (void)hipStreamDestroy(st);
+         int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+         for (int i = 0; i < grid; ++i) if (got[i] < 8) ++per[got[i]];
+         for (int x = 0; x < 8; ++x) if (per[x] != grid / 8) ok = false;
+         if (getenv("VADC_AMD_DEBUG_CUMASK")) fprintf(stderr, "cu_mask_layout_ok: %d bits %s: workgroups per XCD %d %d %d %d %d %d %d %d (expected %d each)\n", taken, side == 0 ? "alone" : "excluded",
+                                                      per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], grid / 8);
+      }
+   }
+   if (d) (void)hipFree(d);
+   if (device >= 0 && device < 64) cache[device] = ok ? 1 : 2;
+   return ok;
+}
+
 static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const char *who)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "%s: NULL engine", who);
@@ -1183,7 +1308,8 @@ static int encoder_cus(const vadc_amd_engine *e, hipStream_t st)
 
 // lstm_layout: the last layer writes the LSTM-native tile layout (hot path) instead of [n][64][7] (stage taps)
 // `in_stage`: input of layer `first` when it is not the engine's own buffer (stage taps fed from the host)
-static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st, const float *in_stage = nullptr)
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st) { run_encoder_layers(e, first, last, n, map, lstm_layout, st, nullptr); }
+static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, ItemMap map, int lstm_layout, hipStream_t st, const float *in_stage)
 {
    for (int l = first; l <= last; ++l) {
       const float *in = (l == first && in_stage) ? in_stage : ((l == 0) ? e->d_Y : e->d_act[l - 1]);
@@ -1297,7 +1423,7 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
 static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *shared)
 {
    *shared = e->cu_partition == 2;
-   if (!e->cu_partition) return 0;
+   if (!e->cu_partition || !e->cu_partition_usable()) return 0;
    if (e->lstm_cus_forced > 0) return e->lstm_cus_forced;      // option "lstm_cus" (experiments)
    const int lk = resolve_lstm(e, n_streams);
    const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
@@ -1706,14 +1832,69 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
 // ---- asynchronous host-buffer entry points: the shape a real backend_run caller has (host buffers in and out, vadc.c:873-909) without the
 // synchronous copy -> run -> copy of vadc_amd_run_*.  A call returns once its work is enqueued; vadc_amd_wait_async returns when the probabilities of
 // every call issued so far are in their host buffers.
+// every copy the async entry points have issued has finished (a registration may only go away under no copy)
+static void drain_copy_streams(vadc_amd_engine *e)
+{
+   for (hipStream_t cs : {e->s_h2d, e->s_d2h, e->s_h2dx[0], e->s_h2dx[1], e->s_h2dx[2]}) if (cs) (void)hipStreamSynchronize(cs);
+}
+static void forget_range(vadc_amd_engine *e, size_t i)
+{
+   if (e->pinned[i].ours && hipHostUnregister(const_cast<char *>(e->pinned[i].p)) != hipSuccess) (void)hipGetLastError();
+   e->pinned.erase(e->pinned.begin() + (long)i);
+}
 static void pin_host_range(vadc_amd_engine *e, const void *ptr, size_t bytes)
 {
+   if (!e->pin_host || bytes == 0) return;
    const char *p = static_cast<const char *>(ptr);
-   for (auto &r : e->pinned) if (p >= r.p && p + bytes <= r.p + r.n) return;
+   const char *lo = p, *hi = p + bytes;
+   for (auto &r : e->pinned) if (p >= r.p && hi <= r.p + r.n) { r.last = ++e->pin_clock; return; }
+   // A range that OVERLAPS remembered ones without lying inside one (a caller's buffer grew, or an allocator handed out an address inside an older,
+   // freed range): the old registrations go -- after every copy in flight has finished -- and the union is registered in their place
+   bool drained = false;
+   for (size_t i = 0; i < e->pinned.size();) {
+      const auto &r = e->pinned[i];
+      if (lo < r.p + r.n && r.p < hi) {
+         if (!drained) { drain_copy_streams(e); drained = true; }
+         if (r.p < lo) lo = r.p;
+         if (r.p + r.n > hi) hi = r.p + r.n;
+         forget_range(e, i);
+      } else ++i;
+   }
    // page-locked memory lets the copy engine read / write the caller's buffer directly (pageable memory goes through a staging copy: 3x slower)
-   hipError_t he = hipHostRegister(const_cast<char *>(p), bytes, hipHostRegisterDefault);
+   hipError_t he = hipHostRegister(const_cast<char *>(lo), (size_t)(hi - lo), hipHostRegisterDefault);
+   if (he != hipSuccess && (lo != p || hi != p + bytes)) {       // the union was not registrable (part of it is gone): this call's range alone
+      (void)hipGetLastError();
+      lo = p; hi = p + bytes;
+      he = hipHostRegister(const_cast<char *>(lo), bytes, hipHostRegisterDefault);
+   }
    if (he != hipSuccess) (void)hipGetLastError();          // already page-locked by the caller (hipHostMalloc, a pinned torch tensor), or not registrable: copy as is
-   e->pinned.push_back({p, bytes, he == hipSuccess});
+   e->pinned.push_back({lo, (size_t)(hi - lo), he == hipSuccess, ++e->pin_clock});
+   if (e->pinned.size() > vadc_amd_engine::kMaxPinned) {   // the least recently used range: at most 3 calls x 2 ranges are in flight, all of them more recent
+      size_t victim = 0;
+      for (size_t i = 1; i + 1 < e->pinned.size(); ++i) if (e->pinned[i].last < e->pinned[victim].last) victim = i;
+      if (!drained) drain_copy_streams(e);
+      forget_range(e, victim);
+   }
+}
+
+extern "C" int vadc_amd_unpin(vadc_amd_engine *e, const void *host_ptr)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "unpin: NULL engine");
+   if (!host_ptr) return VADC_AMD_OK;
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   const char *p = static_cast<const char *>(host_ptr);
+   bool drained = false;
+   for (size_t i = 0; i < e->pinned.size();) {
+      if (p >= e->pinned[i].p && p < e->pinned[i].p + e->pinned[i].n) {
+         if (!drained) {                                     // the asynchronous calls that may still copy from / into it
+            for (auto &sl : e->aslot) if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP); sl.busy = false; }
+            drain_copy_streams(e);
+            drained = true;
+         }
+         forget_range(e, i);
+      } else ++i;
+   }
+   return VADC_AMD_OK;
 }
 
 template <typename T>
@@ -1737,13 +1918,25 @@ static int run_async(vadc_amd_engine *e, const T *host_in, int n_streams, int n_
          HIP_TRY(hipEventCreateWithFlags(&e->ev_h2dx[i], hipEventDisableTiming), VADC_AMD_EHIP);
       }
    }
-   vadc_amd_engine::AsyncSlot &sl = e->aslot[e->anext++ % vadc_amd_engine::kAsyncSlots];
+   vadc_amd_engine::AsyncSlot &sl = e->aslot[e->anext % vadc_amd_engine::kAsyncSlots];
    if (!sl.d_in) {
-      HIP_TRY(hipMalloc(&sl.d_in, e->max_items * kChunk * sizeof(float)), VADC_AMD_ENOMEM);
-      HIP_TRY(hipMalloc(&sl.d_probs, e->max_items * 2 * sizeof(float)), VADC_AMD_ENOMEM);
-      HIP_TRY(hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming), VADC_AMD_EHIP);
-      HIP_TRY(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming), VADC_AMD_EHIP);
+      // all four or none: a slot left half made by a failed allocation would be taken for complete by the next call
+      void *d_in = nullptr; float *d_pr = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+      hipError_t he = hipMalloc(&d_in, e->max_items * kChunk * sizeof(float));
+      if (he == hipSuccess) he = hipMalloc(&d_pr, e->max_items * 2 * sizeof(float));
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_in, hipEventDisableTiming);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_out, hipEventDisableTiming);
+      if (he != hipSuccess) {
+         (void)hipGetLastError();
+         if (d_in) (void)hipFree(d_in);
+         if (d_pr) (void)hipFree(d_pr);
+         if (ev_in) (void)hipEventDestroy(ev_in);
+         if (ev_out) (void)hipEventDestroy(ev_out);
+         return fail(VADC_AMD_ENOMEM, "%s: staging slot: %s", who, hipGetErrorString(he));
+      }
+      sl.d_in = d_in; sl.d_probs = d_pr; sl.in_done = ev_in; sl.out_done = ev_out;
    }
+   ++e->anext;
    if (sl.busy) HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP);      // the call that used this slot three calls ago: back-pressure
    const size_t n = (size_t)n_streams * n_chunks;
    pin_host_range(e, host_in, n * e->window * sizeof(T));

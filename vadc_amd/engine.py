@@ -133,6 +133,10 @@ class Engine:
     def wait_async(self):
         self._check(self._L.vadc_amd_wait_async(self._h))
 
+    def unpin(self, buf: np.ndarray):
+        """before a host buffer that was passed to run_async is freed: the engine forgets (and un-page-locks) it"""
+        self._check(self._L.vadc_amd_unpin(self._h, _ptr(buf)))
+
     def run_device(self, d_in_ptr: int, dtype, n_streams: int, n_chunks: int, d_probs_ptr: int, hip_stream: int = 0):
         fn = self._L.vadc_amd_run_device_s16 if np.dtype(dtype) == np.int16 else self._L.vadc_amd_run_device_f32
         self._check(fn(self._h, C.c_void_p(d_in_ptr), n_streams, n_chunks, C.c_void_p(d_probs_ptr),
