@@ -68,6 +68,26 @@ def test_largest_single_gpu_config_rides_along():
     assert h["value"] > 0 and h["synchronous"] > 0 and h["pcie_gb_per_s"] > 0
 
 
+def test_round4_fields_of_the_line():
+    """round 4: the workload string names the arithmetic that runs, every kernel's fraction of its pipe rides in the line, the source of `traffic` is said, and two more
+    configurations are timed beside the headline -- the north star's literal shape (10,240 streams x 1 chunk per call, with the latency a chunk sees and the host-fed
+    rate) and the literal-fp32-MFMA engine on the headline workload"""
+    d = _latest_default()
+    assert "split-fp16" in d["config"]["workload"] and "STFT" in d["config"]["workload"]
+    sf = d["stage_fracs"]
+    for k in ("k_frontend", "k_layer1", "k_enc234", "k_lstm"):
+        assert k in sf and 0 < sf[k][0] <= 1.0 and sf[k][1] in ("valu_nofma", "fp16", "fp32"), k
+    assert sf["k_frontend"][1] == "valu_nofma" and abs(sf["k_frontend"][0] - d["roofline"]["frac"]) < 1e-3
+    assert d["roofline"]["traffic"] is None or "profiles/" in d["roofline"]["traffic_source"]
+    ns = d["configs"]["10240x1"]
+    want = 10240 * 1 * 0.096 / (ns["ms_per_step"] * 1e-3)
+    assert abs(ns["value"] - want) / want < 1e-3 and ns["value"] > 10240                      # >= 10 k concurrent real-time streams, with room
+    assert 0 < ns["latency_ms"] < ns["latency_budget_ms"] == 96.0 and ns["host_fed"]["value"] > 10240
+    lit = d["configs"]["256x96_fp32_mfma"]
+    assert lit["options"] == {"encoder": 3, "lstm": 3, "layer1": 1} and 0 < lit["value"] < d["value"]
+    assert len(json.dumps(d, separators=(",", ":"))) < 6000                                      # the driver reads the tail of stdout: the line stays short
+
+
 def test_kernel_stats_list_every_kernel_of_the_step():
     """the tracked rocprofv3 summary carries all five kernels of the step, the two k_lstm_layer launches (whose names rocprofv3 leaves mangled) included"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_256x96_kernel_stats.csv")))

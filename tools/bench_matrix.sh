@@ -12,3 +12,5 @@ python bench.py --model v4 --no-cpu-baseline --no-side-config --details $O/bench
 python bench.py --model v4 --streams 4096 --chunks-per-step 16 --no-cpu-baseline --details $O/bench_v4_4096x16_details.json 2>/dev/null | tail -1 > $O/bench_v4_4096x16.json
 python tests/reports/parity_report.py > $O/parity_report.log 2>&1
 tail -1 $O/parity_report.log
+python bench.py --streams 10240 --chunks-per-step 1 --no-cpu-baseline --no-side-config --details $O/bench_10240x1_details.json 2>/dev/null | tail -1 > $O/bench_10240x1.json
+python tools/sweep_streams.py > $O/sweep_streams.log 2>&1

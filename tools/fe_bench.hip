@@ -238,6 +238,8 @@ int main(int argc, char **argv)
          time_it("sym nb2 OPT2, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
          time_it("sym nb2 OPT3, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
       }
+      float *Y32 = nullptr;
+      if (getenv("FE_POWER")) CK(hipMalloc(&Y32, (size_t)n * kBins * 32 * 4));
       if (getenv("FE_POWER")) {
          // 1 s of back-to-back launches per variant, 4 rounds in turn, with the shader clock and the socket power sampled every 5 ms from sysfs
          // (whichever card's pp_dpm_sclk / hwmon power1_* is readable and above idle): is the kernel's rate set by its instruction count or by the power cap?
@@ -258,7 +260,13 @@ int main(int argc, char **argv)
             {"OPT0", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 0>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
             {"OPT3", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
             {"OPT2", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+            // rows of Y on 128-byte boundaries (pitch 32 floats instead of 25: + 28 % bytes, no row straddles a 128-byte line)
+            {"YP32", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3, 32>), grid, dim3(256), 0, g_st, pcm, basis, Y32, FM1, n, map, fm_stride, 1); }},
          };
+         if (getenv("FE_ONLY")) {                      // one variant, 200 launches: for a rocprofv3 --pmc pass (WRITE_SIZE per launch)
+            for (auto &v : vars) if (!strcmp(v.name, getenv("FE_ONLY"))) { for (int r = 0; r < 200; ++r) v.launch(); CK(hipDeviceSynchronize()); printf("%s x 200\n", v.name); }
+            return 0;
+         }
          for (int round = 0; round < 4; ++round)
             for (auto &v : vars) {
                hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));

@@ -27,3 +27,8 @@ for w in "v4 fp32" "v31 split16"; do
    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt_$1_$2 -- python3 bench.py $NB $W > $O/prof_kt_$1_$2.log 2>&1
    echo "$w done"
 done
+# the driver's form (20 timed steps after 5 warm-up steps): kernel trace for tools/trace_timeline.py
+rm -rf $O/prof_kt_driver
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_kt_driver -- python3 bench.py --steps 20 --warmup 5 $NB > $O/prof_kt_driver.log 2>&1
+python3 tools/trace_timeline.py $O/prof_kt_driver 20 > $O/driver_form_timeline.txt 2>&1
+echo "driver-form trace done"

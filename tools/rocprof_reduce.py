@@ -22,7 +22,7 @@ def short_name(full):
         return "k_enc234"
     if "k_layer1_regs" in full:
         return "k_layer1"
-    m = re.search(r"k_lstm_layer<\d+, \d+, (\d)>", full) or re.search(r"k_lstm_layerILi\d+ELi\d+ELi(\d)E", full)     # rocprofv3 leaves some names mangled
+    m = re.search(r"k_lstm_layer<\d+, \d+, (\d)[,>]", full) or re.search(r"k_lstm_layerILi\d+ELi\d+ELi(\d)E", full)     # rocprofv3 leaves some names mangled
     if m:
         return "k_lstm" if m.group(1) == "0" else "k_lstm_l1"
     m = re.search(r"k_layer_mfma<(\d+), (\d+), (\d+)", full) or re.search(r"k_layer<(\d+), (\d+), (\d+)", full)

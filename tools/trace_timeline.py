@@ -9,7 +9,10 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 def kind(n):
     if "k_frontend" in n: return "fe"
     if "k_enc_fused" in n: return "enc"
-    if "k_lstm_layer" in n: return "l0" if "ELi0EEE" in n or ", 0>" in n else "l1"
+    if "k_lstm_layer" in n:      # layer = the third template argument (mangled: k_lstm_layerILi7ELi0ELi<L>ELb0E...; demangled: k_lstm_layer<7, 0, <L>, false>)
+        import re
+        m = re.search(r"k_lstm_layerILi\d+ELi\d+ELi(\d)E", n) or re.search(r"k_lstm_layer<\d+, \d+, (\d)", n)
+        return "l0" if m and m.group(1) == "0" else "l1"
     if "k_layer_mfma" in n or "k_layer1_regs" in n: return "l1k"
     return "other"
 fe = [e for e in ev if kind(e[2]) == "fe"][-K:]

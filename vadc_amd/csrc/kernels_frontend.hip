@@ -709,7 +709,8 @@ __device__ __forceinline__ void sym_load_octet(const float *p, float (&v)[8])
 // (magnitudes, Y, partial sums).  Measured (round 4, tools/fe_bench FE_POWER: 2,000 launches per variant, four rounds in turn, 24,576 chunks on 224 CUs, shader
 // clock 2.39 GHz throughout): OPT 0 0.4370 ms, OPT 3 0.4354 (-0.4 %) -- the tree is 1 of 66 and the kernel's time is set by the SIMDs' issue rate, not by one wave.
 // (Also measured and NOT kept: log1p without its Newton step -- 0.4316 ms, -1.2 %, but max |dp| over the 25,600-chunk parity sweep 3.3e-5 -> 6.3e-5.)
-template <typename T, int MODE, int NB = 3, int MINW = 4, int OPT = 0>
+// YP (tools/fe_bench.hip only; the product keeps kFrames): row pitch of Y in floats -- 32 = rows on 128-byte boundaries (round 4's measurement of VERDICT r03 item 8)
+template <typename T, int MODE, int NB = 3, int MINW = 4, int OPT = 0, int YP = kFrames>
 __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict__ pcm,          // [n_chunks][1536], 16-byte aligned
                                                            const float *__restrict__ basis,    // [258][256] permuted (k_frontend's)
                                                            float *__restrict__ Y,              // [n_chunks][129][25]
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
    const unsigned xaddr = (unsigned)(uintptr_t)(lds_f *)(xs + (item - item0) * kSymChunkPitch + kFlBlockPitch * n);
 
    const int f_start = sym_first_bin(wave, NB), f_end = sym_end_bin(wave, NB);
-   float *yout = Y + (size_t)chunk * (kBins * kFrames) + n;
+   float *yout = Y + (size_t)chunk * (kBins * YP) + n;
    float bin_sum = 0.0f;
    constexpr int kImOffB = kBins * kFilterLen * 4;
 
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
       } else {
          val = sqrtf(p2);                                                      // stft.c:209
       }
-      if (writer && counted) yout[bin * kFrames] = val;
+      if (writer && counted) yout[bin * YP] = val;
    };
    auto emit = [&](int b, const float *y8) {
       const int bins[4] = {b, 128 - b, 64 - b, 64 + b};
