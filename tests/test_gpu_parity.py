@@ -441,6 +441,36 @@ def test_reference_fixture_lstm(weights_blob, fixture_path, variant):           
     assert float(np.abs(h[1] - ref[6]).max()) < 1e-4     # last output row == top-layer h
 
 
+@pytest.mark.parametrize("variant", [6, 7])
+def test_lstm_gate_tails_and_tiny_activations(weights_blob, variant):
+    """the recurrence's hardware transcendentals (v_exp_f32 / v_rcp_f32 sigmoid and tanh) and its split-fp16 operands at the ends of their ranges: inputs
+    scaled from 1e-6 (the lo halves are fp16 denormals, the hi halves too below 6e-5) to 100 (gate pre-activations of +-100s: exp overflows to inf and
+    must come back as an exact 0 / 1 / -1), signed.  State and probabilities against the CPU oracle's lstm + decoder on the same inputs."""
+    ts = tt.loads(weights_blob)
+    w, b, dw, db = ts[95][1], ts[96][1], ts[97][1], ts[98][1]
+    scales = [1e-6, 1e-4, 1e-3, 3e-2, 1.0, 10.0, 30.0, 100.0]
+    Cn = 3
+    rng = np.random.default_rng(2024)
+    x = np.stack([(rng.standard_normal((Cn, 64, 7)) * sc).astype(np.float32) for sc in scales])      # [S, C, 64, 7]
+    e = Engine(weights_blob, max_streams=len(scales), max_chunks_per_call=Cn, device=0)
+    try:
+        e.set_option("lstm", variant)
+        got = e.lstm_decoder(x)
+        states = [e.get_state(s_) for s_ in range(len(scales))]
+    finally:
+        e.close()
+    assert np.isfinite(got).all()
+    for s_, sc in enumerate(scales):
+        h, c = np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32)
+        for ch in range(Cn):
+            out, h, c = O.lstm_seq(np.ascontiguousarray(x[s_, ch].T), w, b, h, c)                      # [7, 64] top-layer outputs
+            want = O.decoder(np.ascontiguousarray(out.T), dw, db)
+            assert float(np.abs(got[s_, ch] - want).max()) <= 2e-5, (sc, ch, got[s_, ch], want)
+        hg, cg = states[s_]
+        # the cell state is unbounded (|c| grows by up to 1 per step while the gates saturate): compare relative to its size
+        assert float(np.abs(hg - h).max()) <= 2e-5 and float(np.abs(cg - c).max()) <= 2e-5 * max(1.0, float(np.abs(c).max())), (sc, float(np.abs(hg - h).max()), float(np.abs(cg - c).max()))
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("name", STREAMS)
 @pytest.mark.parametrize("dtype", ["s16", "f32"])
