@@ -22,7 +22,8 @@ The JSON line is kept short (the driver reads the tail of stdout); its verbose f
   roofline     -- dominant kernel (by CU-time): EXECUTED FLOP per launch / HIP-event duration against the peak of the pipe that executes them
                   (events recorded inside the timed region, on the kernel's own stream, on every 8th step); the algorithmic (dense-basis,
                   SURVEY.md 8(d)) figure rides along
-  kernels_ms   -- HIP-event average launch duration of every kernel of the step
+  kernels_ms   -- HIP-event average launch duration of every kernel of the step (k_lstm_l1, the recurrence's second layer, is launched BESIDE the first layer of
+                  the same call and follows its progress -- engine option "lstm_trail" --, so its event pair includes its wait for that layer to start)
   cpu_baseline -- the reference C backend (oracle/_ref, kind "reference") or the CPU oracle (kind "port") on this box's host cores: all
                   cores (one process per core, value = aggregate), one core at batch 96 and at batch 1 (BASELINE config 1)
   host_fed     -- the same step through vadc_amd_run_s16 (pageable host buffers in and out: PCIe-inclusive); never `value`
@@ -567,6 +568,7 @@ def run_rank(args, world, rank, local_rank):
                                  "the 129 bins (the rest follow from the basis' DFT symmetries, bit-exactly), so it EXECUTES 27 % of the dense-basis FLOP that "
                                  "algorithmic_* counts (SURVEY.md 8(d))"},
             "kernels": per_kernel,
+            "lstm_trail": bool(eng.get_option("lstm_trail")) and layer_major,      # layer 1 of the recurrence beside layer 0 of the same call
             "stage_fracs": {k: [v["frac_of_pipe_peak"], v["pipe"]] for k, v in per_kernel.items()},
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph

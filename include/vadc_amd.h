@@ -233,6 +233,9 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "layer1"      the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4 (Silero v4, default window): input by LDS-DMA,
  *                 split-fp16 MFMAs, activations in registers -- when its weights fit fp16's range; 1 = the K = 1 fp32-MFMA form of k_layer_mfma (rounds 1 - 2)
  *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
+ *   "lstm_trail"  1 (default): with the layer-major LSTM on its CU partition, layer 1 of a call is launched BESIDE layer 0 of the same call and follows its published
+ *                 progress a few steps behind (same XCD, same L2: no cache maintenance) -- a call's recurrence takes one chain instead of two (the last call
+ *                 of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves); 0: layer 1 starts when layer 0 has finished.  Same bits
  *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
  *   "fe_opt"      k_frontend_sym: 3 (default) = bin 0 without the tree of its all-zero im row, the 9-bin split rotating over the waves; 0 = round 3's kernel
  *                 (same bits)

@@ -441,6 +441,32 @@ def test_reference_fixture_lstm(weights_blob, fixture_path, variant):           
     assert float(np.abs(h[1] - ref[6]).max()) < 1e-4     # last output row == top-layer h
 
 
+@pytest.mark.parametrize("S,Cn,calls,groups", [(256, 8, 3, 1), (100, 24, 2, 1), (256, 16, 2, 4), (33, 40, 2, 2), (512, 4, 2, 1), (1024, 4, 2, 1)])
+def test_lstm_layer1_beside_layer0_of_the_same_call(weights_blob, orc, S, Cn, calls, groups):
+    """option "lstm_trail" (default on): layer 1 of the recurrence is launched beside layer 0 of the SAME call and follows its published progress a few steps
+    behind, each tile's two workgroups on one XCD (tickets per XCD), the hand-over through that XCD's L2 with no cache maintenance.  Bit-identical to the
+    sequential form -- one workgroup per CU (16 tiles), ragged tile counts (7 and 3 tiles: grids padded to 8), more tiles than CUs (32 and 64 tiles taken in
+    turn), chunk groups, carried state, twice in a row -- and the oracle's answers"""
+    base = synth.make_streams(min(S, 24), Cn * calls, seed0=77 + S)
+    pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    out = []
+    try:
+        for trail in (0, 1, 1):
+            e.set_option("lstm_trail", trail); e.set_option("groups", groups); e.set_option("lstm", 7); e.reset_streams()
+            res = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+            assert e.get_option("lstm_cus") > 0                                    # the CU partition is what lets the two launches overlap
+            out.append((res, [e.get_state(s_) for s_ in (0, S // 2, S - 1)]))
+    finally:
+        e.close()
+    for res, st in out[1:]:
+        assert np.array_equal(bits(out[0][0]), bits(res))
+        for a, b in zip(out[0][1], st):
+            assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    want = orc.forward_streams(base[:3])
+    assert float(np.abs(out[1][0][:3, :, 1] - want).max()) <= PROB_TOL
+
+
 @pytest.mark.parametrize("variant", [6, 7])
 def test_lstm_gate_tails_and_tiny_activations(weights_blob, variant):
     """the recurrence's hardware transcendentals (v_exp_f32 / v_rcp_f32 sigmoid and tanh) and its split-fp16 operands at the ends of their ranges: inputs

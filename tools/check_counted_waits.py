@@ -15,20 +15,33 @@ RULES = {
     "k_layer1_regs_v4ILi8": {"dma": 26, "load_dword": 8, "min_store_dword": 4},
     # ring prologue 4 + one per slot.  hipcc keeps the state write-back's addresses in scratch across the slot loop (two stores in the prologue, two loads in the
     # epilogue: older than every piece the loop waits for, so the counts stand); INSIDE the loop there must be none
-    "k_lstm_layerILi7ELi0ELi0ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
-    "k_lstm_layerILi7ELi0ELi1ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
+    "k_lstm_layerILi7ELi0ELi0ELb0ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
+    "k_lstm_layerILi7ELi0ELi1ELb0ELb0": {"dma": 5, "scratch_outside_loop_ok": True},
+    # the TRAIL forms (layer 1 beside layer 0 of the same call): the published tile count travels through the scalar cache, no vector-memory operation is added
+    "k_lstm_layerILi7ELi0ELi0ELb0ELb1": {"dma": 5, "scratch_outside_loop_ok": True},
+    "k_lstm_layerILi7ELi0ELi1ELb0ELb1": {"dma": 5, "scratch_outside_loop_ok": True},
 }
 
 
 def inner_loop(body):
-    """the text of the kernel's (single) innermost loop: from the label marked 'Inner Loop Header' to the first label behind its last 'in Loop' block"""
+    """the text of the kernel's SLOT loop: the depth-1 loop that holds the MFMAs and the barrier (the TRAIL kernels also have polling loops in front of and
+    inside it) -- from its header label to the first label behind the last block that names it as its header"""
     lines = body.split("\n")
-    start = next((i for i, l in enumerate(lines) if "Inner Loop Header" in l), None)
-    if start is None:
-        return ""
-    last_in = max(i for i, l in enumerate(lines) if "in Loop: Header" in l or i == start)
-    end = next((i for i in range(last_in + 1, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[i])), len(lines))
-    return "\n".join(lines[start:end])
+    best = ""
+    for i, l in enumerate(lines):
+        if "Loop Header: Depth=1" not in l:
+            continue
+        m = re.match(r"\.L(BB\d+_\d+):", l) or (i > 0 and re.match(r"\.L(BB\d+_\d+):", lines[i - 1]))      # (the header's comment may sit on the line behind its label)
+        if not m:
+            continue
+        tag = "Header=" + m.group(1) + " "
+        members = [j for j, x in enumerate(lines) if tag in x + " "]
+        last = max(members) if members else i
+        end = next((j for j in range(last + 1, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[j]) and tag not in lines[j] + " " and "Parent Loop " + m.group(1) not in lines[j]), len(lines))
+        text = "\n".join(lines[min([i] + members):end])             # (a rotated loop's first block may sit in front of its header label)
+        if "v_mfma" in text and "s_barrier" in text and len(text) > len(best):
+            best = text
+    return best
 
 
 def kernels(txt):
@@ -54,6 +67,9 @@ def check(path):
             if rule.get("scratch_outside_loop_ok"):
                 if re.search(r"\sscratch_", inner_loop(body)) or not inner_loop(body):
                     errors.append(f"{name}: scratch instructions inside the slot loop (or no loop found)")
+                # a compiler-made full drain in the slot loop (it waited there for the carried state's loads until round 4) also drains the pieces the counted waits leave in flight
+                if re.search(r"s_waitcnt\s+vmcnt\(0\)", inner_loop(body)):
+                    errors.append(f"{name}: s_waitcnt vmcnt(0) inside the slot loop")
             else:
                 if spill != 0 or scratch != 0:
                     errors.append(f"{name}: {spill} spilled registers, {scratch} bytes of scratch (must be 0 / 0)")
@@ -73,8 +89,12 @@ def check(path):
             # every write of M0 is one of ours (s_mov_b32 m0 directly in front of its DMA); the compiler's own uses of M0 would sit between them unseen
             m0_writes = len(re.findall(r"\ss_mov_b32\s+m0,", body))
             other_m0 = len(re.findall(r"\s(?!s_mov_b32)\S+\s+m0,", body))
-            if m0_writes != dma or other_m0:
-                errors.append(f"{name}: {m0_writes} s_mov_b32 m0 for {dma} DMA pieces, {other_m0} other writes of m0")
+            if m0_writes != dma + rule.get("extra_m0", 0) or other_m0:
+                errors.append(f"{name}: {m0_writes} s_mov_b32 m0 for {dma} + {rule.get('extra_m0', 0)} DMA pieces, {other_m0} other writes of m0")
+            if "dword_dma" in rule:
+                n = len(re.findall(r"\sglobal_load_lds_dword\s", body))
+                if n != rule["dword_dma"]:
+                    errors.append(f"{name}: {n} global_load_lds_dword, expected {rule['dword_dma']}")
     return errors, seen
 
 

@@ -29,7 +29,7 @@ void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, flo
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
-void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
+void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int, int *, int, int *, int);
 void launch_lstm_decoder_tap(const float *, const LstmWeights &, float *, int, hipStream_t, int, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
@@ -209,6 +209,14 @@ struct vadc_amd_engine {
    // layer-major LSTM (k_lstm_layer, variant 7): layer 0 -> layer 1 hand-off of the h0 sequence (same tile layout and size as an encoder hand-off
    // buffer), double buffered over forked calls like it: layer 1 of call k reads pair [xpar] while layer 0 of call k+1 writes the other one
    float *d_h0pair[2] = {nullptr, nullptr};
+   // layer 1 beside layer 0 of the SAME call (k_lstm_layer's TRAIL form, option "lstm_trail"): per hand-off buffer and chunk group, one word per stream tile that
+   // layer 0 publishes its progress in; the epoch (one per launch pair, 1 .. 2047) makes a value left by an earlier launch read as zero
+   int *d_lstm_progress[2] = {nullptr, nullptr};
+   size_t progress_tiles = 0;
+   int lstm_epoch = 0;
+   int lstm_trail = 1;
+   int *d_lstm_tickets = nullptr;               // [2 layers][8 XCDs]: the counters a TRAIL workgroup draws its tile from (L2-local atomics); ticket_base = what earlier launches drew per XCD
+   unsigned ticket_base = 0;
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
    int xpar = 0;
    float *d_h = nullptr, *d_c = nullptr;
@@ -843,7 +851,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
@@ -866,7 +874,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    delete e;
 }
 
-static bool cu_mask_layout_ok(int device, int n_cus);
+static int cu_mask_layout_flags(int device, int n_cus);
 static int layer1_selfcheck(vadc_amd_engine *e);
 extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max_streams, int max_chunks,
                                int precision, vadc_amd_engine **out)
@@ -925,7 +933,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
-   e->cu_layout_ok = cu_mask_layout_ok(device, e->n_cus);
+   e->cu_layout_ok = (cu_mask_layout_flags(device, e->n_cus) & 1) != 0;
    for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
@@ -958,6 +966,13 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       e->h_l1img.clear(); e->h_l1img.shrink_to_fit();
    }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
+   e->progress_tiles = (padded_streams / kLstmTile + 7) / 8 * 8;
+   if (he == hipSuccess) he = hipMalloc(&e->d_lstm_tickets, 16 * sizeof(int));
+   if (he == hipSuccess) he = hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));
+   for (int p = 0; p < 2 && he == hipSuccess; ++p) {
+      he = hipMalloc(&e->d_lstm_progress[p], vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));      // per group: [tiles] counts, [tiles] XCC ids
+      if (he == hipSuccess) he = hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));
+   }
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
@@ -1119,6 +1134,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
@@ -1155,6 +1171,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
+   else if (strcmp(key, "lstm_trail") == 0) *value = e->lstm_trail;
    else if (strcmp(key, "cu_mask_check") == 0) *value = e->cu_mask_check;
    else if (strcmp(key, "cu_layout_ok") == 0) *value = e->cu_layout_ok ? 1 : 0;
    else if (strcmp(key, "pinned_ranges") == 0) *value = (int)e->pinned.size();
@@ -1240,36 +1257,46 @@ __global__ __launch_bounds__(64) void k_probe_hold(unsigned *out, int spin)
    if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xf) + (big[7] & 0);
 }
 // (a one-bit mask is no probe: every bit then reports XCC 0 -- the id is relative to the XCDs the queue may use; tools/cumask_probe.hip)
-static bool cu_mask_layout_ok(int device, int n_cus)
+// bit 0: the layout holds.  (Which XCD workgroup i of a launch lands on is NOT a property of the layout: it is (start + i) % 8 with a start that differs between
+// queues and over time -- tools/xcd_map_probe.hip -- which is why k_lstm_layer's TRAIL form lets every XCD hand out its own tiles.)
+static int cu_mask_layout_flags(int device, int n_cus)
 {
-   static int cache[64];                                    // 0 = unknown, 1 = ok, 2 = not ok
-   if (device >= 0 && device < 64 && cache[device]) return cache[device] == 1;
+   static int cache[64];                                    // 0 = unknown, else flags + 4
+   if (device >= 0 && device < 64 && cache[device]) return cache[device] - 4;
    bool ok = n_cus == 256;
    unsigned *d = nullptr;
    if (ok && hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
    const int words = (n_cus + 31) / 32;
+   // grid workgroups on the mask bits [lo, hi); their XCDs into got[]
+   auto run = [&](int lo, int hi, int grid, std::vector<unsigned> &got) -> bool {
+      std::vector<uint32_t> m(words, 0u);
+      for (int cu = lo; cu < hi; ++cu) m[cu / 32] |= 1u << (cu % 32);
+      hipStream_t st = nullptr;
+      got.assign(256, 99u);
+      if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
+      hipLaunchKernelGGL(k_probe_hold, dim3(grid), dim3(64), 0, st, d, 60000);
+      bool good = hipMemcpyAsync(got.data(), d, grid * sizeof(unsigned), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      if (!good) (void)hipGetLastError();
+      (void)hipStreamDestroy(st);
+      return good;
+   };
+   std::vector<unsigned> got;
    // the two shapes the engine uses: the first 16 / 32 mask bits for the recurrence (2 / 4 CUs of every XCD), all the others for the front end + encoder
    for (int taken : {16, 32}) {
       for (int side = 0; side < 2 && ok; ++side) {
-         std::vector<uint32_t> m(words, 0u);
-         for (int cu = 0; cu < n_cus; ++cu) if ((cu < taken) == (side == 0)) m[cu / 32] |= 1u << (cu % 32);
          const int grid = side == 0 ? taken : n_cus - taken;
-         hipStream_t st = nullptr;
-         std::vector<unsigned> got(256, 99u);
-         if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-         hipLaunchKernelGGL(k_probe_hold, dim3(grid), dim3(64), 0, st, d, 60000);
-         if (hipMemcpyAsync(got.data(), d, grid * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); ok = false; }
-         (void)hipStreamDestroy(st);
+         if (!run(side == 0 ? 0 : taken, side == 0 ? taken : n_cus, grid, got)) { ok = false; break; }
          int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
          for (int i = 0; i < grid; ++i) if (got[i] < 8) ++per[got[i]];
          for (int x = 0; x < 8; ++x) if (per[x] != grid / 8) ok = false;
-         if (getenv("VADC_AMD_DEBUG_CUMASK")) fprintf(stderr, "cu_mask_layout_ok: %d bits %s: workgroups per XCD %d %d %d %d %d %d %d %d (expected %d each)\n", taken, side == 0 ? "alone" : "excluded",
+         if (getenv("VADC_AMD_DEBUG_CUMASK")) fprintf(stderr, "cu_mask_layout: %d bits %s: workgroups per XCD %d %d %d %d %d %d %d %d (expected %d each)\n", taken, side == 0 ? "alone" : "excluded",
                                                       per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], grid / 8);
       }
    }
    if (d) (void)hipFree(d);
-   if (device >= 0 && device < 64) cache[device] = ok ? 1 : 2;
-   return ok;
+   const int flags = ok ? 1 : 0;
+   if (device >= 0 && device < 64) cache[device] = flags + 4;
+   return flags;
 }
 
 static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const char *who)
@@ -1532,9 +1559,9 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (lk == 7) {
-      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps); }
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0); }
       KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps);
+      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0);
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
@@ -1722,15 +1749,29 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             // (Cutting a group's recurrence into several launches per layer, layer 1 of a part beside layer 0 of the next, was measured: the
             // call's last probability is ready earlier, but 256 x 96 loses 1.5 % in steady state -- 2.49 M -> 2.45 M -- to the extra launches,
             // records and cross-queue waits, and a 20-step run gains nothing measurable.)
+            // TRAIL: layer 1 is launched beside layer 0 and follows its published progress a few slots behind (kernels_lstm.hip) -- only on the CU partition: there the
+            // two launches have queues and CUs of their own, so a layer-1 workgroup that polls can never stand in the way of the layer-0 workgroup it waits for
+            // (with per-kernel profiling on, layer 1's event pair includes its wait for layer 0's progress: the two launches overlap by design)
+            const bool trail = e->lstm_trail && e->lstm_cus > 0 && e->cu_partition_usable();
+            int *progress = nullptr;
+            if (trail) {
+               if (++e->lstm_epoch > 2047) {                    // the 11-bit epoch wraps: once in 2,047 launches the words are cleared behind everything that may read them
+                  for (hipEvent_t ev : {e->last_b, e->last_c}) if (e->ev_last_valid && ev) (void)hipEventSynchronize(ev);
+                  for (int p = 0; p < 2; ++p) (void)hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));
+                  e->lstm_epoch = 1;
+               }
+               progress = e->d_lstm_progress[xp] + (size_t)gi * 2 * e->progress_tiles;
+            }
             {
                KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
             }
             hipEvent_t l0_done = last_group ? e->ev_b[xp] : e->ev_l0[gi];   // the call's last record on this stream is also this hand-off pair's "layer 0 done"
             (void)hipEventRecord(l0_done, e->sB);
-            (void)hipStreamWaitEvent(e->sC, l0_done, 0);
+            if (!trail) (void)hipStreamWaitEvent(e->sC, l0_done, 0);
             KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
-            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps);
+            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
+            if (trail) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);      // every XCD's counter of either layer has advanced by grid / 8
          }
          c0 += cg;
       }

@@ -38,6 +38,7 @@ __device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __bui
 
 // ------------------------------------------------------------------------------------------------
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // LDS-DMA: 64 lanes x 16 B land at (wave-uniform LDS base) + lane*16 without touching VGPRs
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -429,23 +430,58 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 // TAPDEC (L = 1 only; stage tap for the reference's decoder fixture, test.c:170): the recurrence is bypassed -- h1 of step k is read from `tap_h`
 // [stream][64][TS] fp32 -- and everything behind it (ReLU, the sum over the chunk's steps, the partial dots and their tree, mean, bias, sigmoid:
 // silero_v3.c:231-303) runs as in the product; one chunk per stream, the streams' state is neither read nor written.
-template <int TS, int DEC, int L, bool TAPDEC = false>
+// TRAIL (round 4): the two layer launches of a call run AT THE SAME TIME, layer 1 a few slots behind layer 0, instead of one after the other -- a call's recurrence
+// then takes one chain, not two (the last call of a run: 0.5 ms earlier; a single call's latency halves), with nothing but kernel boundaries BETWEEN calls as
+// before.  Workgroup t of BOTH launches runs on XCD t % 8 (workgroups are dealt to the XCDs by their index; the engine verifies it on the device at create and
+// the kernels check it again: layer 0 publishes its XCC id, layer 1 traps on a mismatch), so the pair shares ONE L2 and the hand-over needs no cache maintenance
+// at all: layer 0's tile stores go through its write-through vector L1 into that L2 as always, and behind each slot's barrier one lane publishes how many tiles
+// are complete -- the counted vmcnt(4) of waves 0-3 in front of that barrier is exactly the guarantee: everything older than the four newest vector-memory
+// operations of a wave (store k-1, piece k+4, store k-2, piece k+3) has been acknowledged by the L2, i.e. tiles <= k-3.  Layer 1 fetches tiles (LDS-DMA, as
+// always: its vector L1 was invalidated when the kernel started and sees every tile address for the first time) only below the published count, which wave 7
+// reads through the SCALAR cache -- s_dcache_inv + s_load_dword at the top of a slot, consumed at its end: no vector-memory operation, nothing on the slot's
+// path -- and hands to the other waves through the LDS.  When the count is not there yet the workgroup polls (bounded: after ~2 s the kernel traps instead of
+// hanging the device).  `progress[tile]` = epoch << 20 | tiles complete; the epoch (one per launch pair) makes a value left by an earlier call read as zero.
+// (Measured on the way: the same hand-over with device-scope accesses -- sc0 sc1 on the tile stores, the tile loads and the count -- is correct on any XCD
+// placement but takes every access to the fabric: both chains 0.5 -> 1.0 ms.  An earlier attempt with agent-scope FENCES wrote back and invalidated the whole
+// L2 at every hand-over and cost the front end 2 %: DESIGN.md 4.4.)
+template <int TS, int DEC, int L, bool TAPDEC = false, bool TRAIL = false>
 __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
                                                        _Float16 *__restrict__ h0seq,            // L = 0: the h0 sequence, same layout
                                                        LstmWeights w,
                                                        float *__restrict__ hs, float *__restrict__ cs,
                                                        float *__restrict__ probs,               // L = 1
-                                                       int n_streams, int n_chunks, int c0, int cg, const float *__restrict__ tap_h = nullptr)
+                                                       int n_streams, int n_chunks, int c0, int cg, const float *__restrict__ tap_h = nullptr,
+                                                       int *__restrict__ progress = nullptr, int epoch = 0, int *__restrict__ tickets = nullptr, int ticket_base = 0)
 {
    // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
    __shared__ __attribute__((aligned(16))) _Float16 xr[4][2][kTileS * 64];   // input ring: [step & 3][hi / lo][16-byte segment 0..7][stream] (LDS-DMA, see below)
    __shared__ float pd[2][8][2][kTileS];
+   __shared__ __attribute__((aligned(8))) float dws[2][64];  // layer 1: the decoder's weights (read once per chunk: not worth four registers across the slot loop)
+   __shared__ __attribute__((aligned(16))) float bias_s[8][2][4][4];   // TRAIL layer 1: the accumulators' initial values [wave][row tile][quad][gate] (eight registers less across the slot loop)
+   __shared__ int avail_raw[2];                              // TRAIL, layer 1: the published word as read in slot k, at [k & 1]
+   __shared__ int avail_sync;                                // TRAIL, layer 1: the count a synchronous poll found
 
    const int tid = threadIdx.x;
    const int lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int tile = blockIdx.x;
+   int tile = blockIdx.x;
+   if (TRAIL) {
+      // Which XCD workgroup i of a launch lands on is (start + i) % 8 with a start that differs between queues and over time (tools/xcd_map_probe.hip), so the
+      // pair of a tile is made by the XCD itself: the grid is a multiple of 8 (every XCD gets grid / 8 workgroups whatever the start), and a workgroup takes
+      // tile xcc + 8 j with j its ticket from ITS XCD's counter of this layer (an L2-local atomic; `ticket_base` = what earlier launches have drawn) -- the
+      // same rule in both launches, so tile t runs on XCD t % 8 in both.  Workgroups beyond the last tile leave.
+      __shared__ int tile_s;
+      if (tid == 0) {
+         unsigned xcc;
+         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+         xcc &= 7u;
+         tile_s = (int)xcc + 8 * (int)((unsigned)atomicAdd(tickets + L * 8 + (int)xcc, 1) - (unsigned)ticket_base);      // (both counts wrap together)
+      }
+      __syncthreads();
+      tile = tile_s;
+      if (tile >= (n_streams + kTileS - 1) / kTileS) return;
+   }
    const int col = lane & 15;
    const int quad = lane >> 4;
    const int s0 = tile * kTileS;
@@ -472,17 +508,20 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       }
    }
    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-   float c[2], hlast[2], dw[2][2], bias_r[2][4];
+   constexpr bool BIAS_LDS = TRAIL && L == 1;
+   float c[2], hlast[2], bias_r[2][4];
+   if (L == 1 && tid < 128) dws[tid >> 6][tid & 63] = w.dec_w[tid];
 #pragma unroll
    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bias_r[m][r] = w.b[L * 256 + r * 64 + u0 + m];
+      for (int r = 0; r < 4; ++r) {
+         bias_r[m][r] = w.b[L * 256 + r * 64 + u0 + m];
+         if (BIAS_LDS && col == 0) bias_s[wave][m][quad][r] = bias_r[m][r];
+      }
    {
       _Float16 hi2[2], lo2[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-         dw[0][m] = w.dec_w[u0 + m];
-         dw[1][m] = w.dec_w[64 + u0 + m];
          c[m] = TAPDEC ? 0.0f : cs[(size_t)s_col * 128 + L * 64 + u0 + m];
          hlast[m] = TAPDEC ? 0.0f : hs[(size_t)s_col * 128 + L * 64 + u0 + m];
          hi2[m] = (_Float16)hlast[m];
@@ -511,6 +550,48 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
    };
    auto xfrag = [&](int slot, int part, int kb) -> h8v { return *reinterpret_cast<const h8v *>(&xr[slot & 3][part][((4 * kb + quad) * 16 + col) * 8]); };
+   // TRAIL, layer 1: tiles of layer 0 that may be fetched
+   int avail = 0;
+   auto decode = [&](int raw) { return ((raw >> 20) == epoch) ? (raw & 0xFFFFF) : 0; };
+   // a plain store through the write-through vector L1 into the XCD's L2, and nothing behind it: a `volatile` store becomes a system-scope flat_store + s_waitcnt
+   // vmcnt(0), which put a fabric round trip into wave 7's slot -- every slot (layer 0: 0.74 -> 1.13 us)
+   auto publish = [&](int *p, int v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); };
+   const int *flag = progress + (TRAIL ? tile : 0);            // wave-uniform
+   auto read_flag_now = [&]() -> int {                         // through the scalar cache, invalidated first: what the L2 holds now
+      int v;
+      asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flag) : "memory");
+      return v;
+   };
+   auto wait_for = [&](int need) {                             // workgroup-uniform: every wave calls it with the same `need` and the same `avail`
+      unsigned spins = 0;
+      while (avail < need) {
+         if (wave == 7) { const int v = read_flag_now(); if (lane == 0) avail_sync = decode(v); }
+         __syncthreads();
+         avail = max(avail, avail_sync);
+         __syncthreads();
+         if (avail < need) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > 4000000u) __builtin_trap();          // ~2 s: layer 0 is not coming (never a hang)
+         }
+      }
+   };
+   if (TRAIL && L == 1) {
+      if (tid < 2) avail_raw[tid] = 0;
+      __syncthreads();
+      wait_for(min(4, TS * cg));
+      // the pair must share an L2: layer 0 publishes the XCC it runs on beside its count
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      int other = 0;
+      for (int tries = 0; tries < 1000 && (other >> 20) != epoch; ++tries)       // (stored before the first count by the same lane; a few more looks cost nothing)
+         asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(other) : "s"(progress + gridDim.x + tile) : "memory");
+      if ((other >> 20) != epoch || (unsigned)(other & 0xf) != (xcc & 0xf)) __builtin_trap();
+   }
+   if (TRAIL && L == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      if (tid == 448) publish(progress + gridDim.x + tile, (epoch << 20) | (int)(xcc & 0xf));
+   }
    if (!TAPDEC && wave < 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) issue_x(i, i);
@@ -521,7 +602,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 #pragma unroll
    for (int m = 0; m < 2; ++m) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
+      for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];             // (the prologue: bias_s is complete behind the next barrier only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
          const h8v bh = xfrag(0, 0, kb), bl = xfrag(0, 1, kb);
@@ -535,6 +616,12 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    int par = 0;
    float rsum[2] = {0.0f, 0.0f};
    float psum = 0.0f;
+   // the decoder's bias of this lane's output (wave 0 finishes the decoder): fetched once -- as a load inside the loop it drained wave 0's LDS-DMA pieces
+   // (the compiler's s_waitcnt vmcnt(0) for it) once per chunk
+   const float dec_bias = (L == 1) ? w.dec_b[DEC == 0 ? ((lane >> 4) & 1) : 0] : 0.0f;
+   // every value loaded before the loop is consumed HERE: hipcc otherwise waits for the carried state's loads at their first use inside the loop -- an
+   // s_waitcnt vmcnt(0) in every slot, which also drains the LDS-DMA pieces and the tile store the counted waits leave in flight
+   asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(hlast[0]), "+v"(hlast[1]));
    // one copy of the slot body: an unrolled loop may round its copies differently (fma contraction is decided per copy), and then a step's
    // bits would depend on its position in the call
 #pragma unroll 1
@@ -542,6 +629,14 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       const int chi = k / TS, t = k - chi * TS;
       f4v acc[2];
       acc[0] = accx[0]; acc[1] = accx[1];
+      int flag_v = 0;
+      if (TRAIL && L == 1) {
+         // the word read in the previous slot (in the LDS since its barrier); the piece issued below is tile min(k + 4, total - 1)
+         if (k >= 1) avail = max(avail, decode(avail_raw[(k - 1) & 1]));
+         const int need = min(k + 4, total - 1) + 1;
+         if (avail < need) wait_for(need);
+         if (wave == 7) asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0" : "=s"(flag_v) : "s"(flag) : "memory");      // consumed at the end of the slot
+      }
 #ifndef VADC_LSTM_ABL_NOXLOAD     // (timing-only ablation: the slot without its input fetch)
       if (!TAPDEC && wave < 4) issue_x(k + 4, k);             // step k + 4 into the ring slot step k was read from (one slot ago)
 #endif
@@ -551,8 +646,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       if (L == 0 && k >= 1 && tid < 256) {
          __builtin_amdgcn_sched_barrier(0);
          const int rowi = tid >> 3, seg = tid & 7;           // 32 rows (16 hi + 16 lo) of 64 halves = 8 x 16 bytes
-         *reinterpret_cast<uint4 *>(out_seq + (size_t)(k - 1) * kStepHalves + rowi * 64 + seg * 8) =
-            *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
+         const u4v tv = *reinterpret_cast<const u4v *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
+         u4v *tp = reinterpret_cast<u4v *>(out_seq + (size_t)(k - 1) * kStepHalves + rowi * 64 + seg * 8);
+         *tp = tv;
          __builtin_amdgcn_sched_barrier(0);
       }
 #ifndef VADC_LSTM_ABL_NOMFMA
@@ -575,8 +671,11 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       for (int kb = 0; kb < 2; ++kb) { xbh[kb] = xfrag(k + 1, 0, kb); xbl[kb] = xfrag(k + 1, 1, kb); }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
+         if constexpr (BIAS_LDS) accx[m] = *reinterpret_cast<const f4v *>(&bias_s[wave][m][quad][0]);
+         else {
 #pragma unroll
-         for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
+            for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
+         }
 #pragma unroll
          for (int kb = 0; kb < 2; ++kb) {
             accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], xbh[kb], accx[m], 0, 0, 0);
@@ -619,6 +718,8 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          // Here those 4 units are this lane's 2 (even quad) followed by the 2 of the lane 16 above (odd quad): the odd quad continues the chain.
          float d0, d1 = 0.0f;
          {
+            const float2 w0 = *reinterpret_cast<const float2 *>(&dws[0][u0]), w1 = *reinterpret_cast<const float2 *>(&dws[1][u0]);
+            const float dw[2][2] = {{w0.x, w0.y}, {w1.x, w1.y}};
             const float pe0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], 0.0f));
             const float up0 = __shfl_up(pe0, 16);
             d0 = fmaf(dw[0][1], rsum[1], fmaf(dw[0][0], rsum[0], up0));         // odd quads: the 4-unit chain of h3's lane
@@ -636,19 +737,25 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       // waves 0-3: the piece of step k + 2 (issued two slots ago; read in the next slot) has landed -- newer operations may stay in flight: two
       // pieces (layer 1), plus layer 0's h0-tile stores (counted together, retired in order)
       if (!TAPDEC && wave < 4) { if (L == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      if (TRAIL && L == 1 && wave == 7) {                     // the word requested at the top of the slot: into the LDS for the next slot
+         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(flag_v) :: "memory");
+         if (lane == 0) avail_raw[k & 1] = flag_v;
+      }
       __syncthreads();                                        // one barrier per slot
       par ^= 1;
+      // tiles <= k - 3 are complete (every wave of 0-3 has passed its vmcnt(4): see TRAIL above)
+      if (TRAIL && L == 0 && tid == 448 && k >= 3) publish(progress + tile, (epoch << 20) | (k - 2));
       if (L == 1) {
          if (DEC == 0 && chunk_done && wave == 0 && lane < 2 * kTileS) {
             const int sc = lane & 15, f = lane >> 4, q = k & 1;
             float m = ((pd[q][0][f][sc] + pd[q][1][f][sc]) + (pd[q][2][f][sc] + pd[q][3][f][sc])) + ((pd[q][4][f][sc] + pd[q][5][f][sc]) + (pd[q][6][f][sc] + pd[q][7][f][sc]));
-            m = m / (float)TS + w.dec_b[f];
+            m = m / (float)TS + dec_bias;
             if (s0 + sc < n_streams) probs[((size_t)(s0 + sc) * n_chunks + (c0 + chi)) * 2 + f] = sigmoidf_(m);
          }
          if (DEC == 1 && wave == 0 && lane < kTileS) {
             const int q = k & 1;
             const float m = ((pd[q][0][0][lane] + pd[q][1][0][lane]) + (pd[q][2][0][lane] + pd[q][3][0][lane])) + ((pd[q][4][0][lane] + pd[q][5][0][lane]) + (pd[q][6][0][lane] + pd[q][7][0][lane]));
-            psum += sigmoidf_(m + w.dec_b[0]);
+            psum += sigmoidf_(m + dec_bias);
             if (t == TS - 1) {
                const float pr = psum / (float)TS;
                if (s0 + lane < n_streams) {
@@ -662,8 +769,14 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    }
    if (L == 0 && tid < 256) {                                 // the last step's tile
       const int rowi = tid >> 3, seg = tid & 7;
-      *reinterpret_cast<uint4 *>(out_seq + (size_t)(total - 1) * kStepHalves + rowi * 64 + seg * 8) =
-         *reinterpret_cast<const uint4 *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
+      const u4v tv = *reinterpret_cast<const u4v *>(&hb[par][rowi >> 4][(rowi & 15) * kHPitch + seg * 8]);
+      u4v *tp = reinterpret_cast<u4v *>(out_seq + (size_t)(total - 1) * kStepHalves + rowi * 64 + seg * 8);
+      *tp = tv;
+   }
+   if (TRAIL && L == 0) {                                     // every tile of the call is out: the final count
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 448) publish(progress + tile, (epoch << 20) | total);
    }
    if (!TAPDEC && col_ok) {
 #pragma unroll
@@ -676,23 +789,32 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 
 // one layer of the layer-major form (engine variant 7): layer 0 reads the encoder's split-fp16 tiles and writes h0seq, layer 1 reads h0seq
 // steps = LSTM steps per chunk: 7 (Silero v3.1); 3 / 2 / 1 (Silero v4 with 1536- / 1024- / 512-sample windows)
+// progress != nullptr: the TRAIL form (layer 1 may run beside layer 0 of the same call); epoch in [1, 2048); tickets / ticket_base: see the kernel
 template <int TS, int DEC>
 static void launch_layer_ts(int layer, const _Float16 *x, _Float16 *h, const LstmWeights &w, float *hs, float *cs, float *probs,
-                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
+                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int *progress, int epoch, int *tickets, int ticket_base)
 {
-   const dim3 grid((n_streams + kTileS - 1) / kTileS), block(512);
-   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
-   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg);
+   const int tiles = (n_streams + kTileS - 1) / kTileS;
+   const float *no_tap = nullptr;
+   if (progress) {
+      const dim3 grid((tiles + 7) / 8 * 8), block(512);          // a multiple of 8: every XCD gets the same number of workgroups
+      if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0, false, true>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
+      else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, true>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
+      return;
+   }
+   const dim3 grid(tiles), block(512);
+   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
+   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
 }
 void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
-                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps)
+                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps, int *progress, int epoch, int *tickets, int ticket_base)
 {
    const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
    _Float16 *h = reinterpret_cast<_Float16 *>(h0seq);
-   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
-   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st);
+   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
+   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
+   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
+   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
 }
 
 // stage tap: the decoder of k_lstm_layer<.., 1> on n items of [64][steps] (one chunk each), probs [n][2]
@@ -700,10 +822,10 @@ void launch_lstm_decoder_tap(const float *tap_h, const LstmWeights &w, float *pr
 {
    const dim3 grid((n + kTileS - 1) / kTileS), block(512);
    const _Float16 *none = nullptr;
-   if (model == 0)      hipLaunchKernelGGL((k_lstm_layer<7, 0, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
-   else if (steps == 3) hipLaunchKernelGGL((k_lstm_layer<3, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
-   else if (steps == 2) hipLaunchKernelGGL((k_lstm_layer<2, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
-   else                 hipLaunchKernelGGL((k_lstm_layer<1, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h);
+   if (model == 0)      hipLaunchKernelGGL((k_lstm_layer<7, 0, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h, (int *)nullptr, 0, (int *)nullptr, 0);
+   else if (steps == 3) hipLaunchKernelGGL((k_lstm_layer<3, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h, (int *)nullptr, 0, (int *)nullptr, 0);
+   else if (steps == 2) hipLaunchKernelGGL((k_lstm_layer<2, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h, (int *)nullptr, 0, (int *)nullptr, 0);
+   else                 hipLaunchKernelGGL((k_lstm_layer<1, 1, 1, true>), grid, block, 0, st, none, (_Float16 *)nullptr, w, (float *)nullptr, (float *)nullptr, probs, n, 1, 0, 1, tap_h, (int *)nullptr, 0, (int *)nullptr, 0);
 }
 
 // processes chunks [c0, c0 + cg) of every stream (n_chunks = chunks per stream in the buffers' layout)
