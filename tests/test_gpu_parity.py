@@ -467,6 +467,27 @@ def test_lstm_layer1_beside_layer0_of_the_same_call(weights_blob, orc, S, Cn, ca
     assert float(np.abs(out[1][0][:3, :, 1] - want).max()) <= PROB_TOL
 
 
+def test_lstm_trail_epoch_wrap_and_forced_small_partition(weights_blob):
+    """the progress words carry an 11-bit epoch (one per launch pair): across its wrap the engine clears them behind everything that may read them; and a partition
+    whose halves do not reach every XCD (option "lstm_cus" = 8) runs the sequential form.  Same bits throughout"""
+    S, Cn, calls = 128, 16, 6
+    base = synth.make_streams(16, Cn * calls, seed0=2047)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        e.set_option("lstm", 7); e.set_option("lstm_trail", 0)
+        want = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+        e.set_option("lstm_trail", 1); e.set_option("lstm_epoch", 2044); e.reset_streams()
+        got = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+        assert 1 <= e.get_option("lstm_epoch") <= 24                             # wrapped (a synchronous call pipelines up to 4 chunk groups: up to 4 launch pairs per call)
+        e.set_option("lstm_cus", 8); e.reset_streams()
+        small = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+        assert e.get_option("lstm_cus") == 8
+    finally:
+        e.close()
+    assert np.array_equal(bits(want), bits(got)) and np.array_equal(bits(want), bits(small))
+
+
 @pytest.mark.parametrize("variant", [6, 7])
 def test_lstm_gate_tails_and_tiny_activations(weights_blob, variant):
     """the recurrence's hardware transcendentals (v_exp_f32 / v_rcp_f32 sigmoid and tanh) and its split-fp16 operands at the ends of their ranges: inputs

@@ -1135,6 +1135,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
@@ -1172,6 +1173,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
    else if (strcmp(key, "lstm_trail") == 0) *value = e->lstm_trail;
+   else if (strcmp(key, "lstm_epoch") == 0) *value = e->lstm_epoch;
    else if (strcmp(key, "cu_mask_check") == 0) *value = e->cu_mask_check;
    else if (strcmp(key, "cu_layout_ok") == 0) *value = e->cu_layout_ok ? 1 : 0;
    else if (strcmp(key, "pinned_ranges") == 0) *value = (int)e->pinned.size();
@@ -1282,8 +1284,8 @@ static int cu_mask_layout_flags(int device, int n_cus)
    };
    std::vector<unsigned> got;
    // the two shapes the engine uses: the first 16 / 32 mask bits for the recurrence (2 / 4 CUs of every XCD), all the others for the front end + encoder
-   for (int taken : {16, 32}) {
-      for (int side = 0; side < 2 && ok; ++side) {
+   for (int taken : {8, 16, 32}) {                          // (8: one half of the smallest partition, see the TRAIL form of k_lstm_layer)
+      for (int side = 0; side < (taken == 8 ? 1 : 2) && ok; ++side) {
          const int grid = side == 0 ? taken : n_cus - taken;
          if (!run(side == 0 ? 0 : taken, side == 0 ? taken : n_cus, grid, got)) { ok = false; break; }
          int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1752,7 +1754,10 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             // TRAIL: layer 1 is launched beside layer 0 and follows its published progress a few slots behind (kernels_lstm.hip) -- only on the CU partition: there the
             // two launches have queues and CUs of their own, so a layer-1 workgroup that polls can never stand in the way of the layer-0 workgroup it waits for
             // (with per-kernel profiling on, layer 1's event pair includes its wait for layer 0's progress: the two launches overlap by design)
-            const bool trail = e->lstm_trail && e->lstm_cus > 0 && e->cu_partition_usable();
+            // and only while either half of the partition has CUs on all 8 XCDs (a forced "lstm_cus" of 8 would not)
+            // and not on a SHARED partition: a layer-1 workgroup that waits for its layer 0 holds its CU, which the front end + encoder could otherwise use
+            // between two chains (Silero v4 at 256 streams: 4.72 -> 4.36 M with it)
+            const bool trail = e->lstm_trail && e->lstm_cus >= 16 && (e->lstm_cus / 2) % 8 == 0 && !e->lstm_shared && e->cu_partition_usable();
             int *progress = nullptr;
             if (trail) {
                if (++e->lstm_epoch > 2047) {                    // the 11-bit epoch wraps: once in 2,047 launches the words are cleared behind everything that may read them

@@ -476,7 +476,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          unsigned xcc;
          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
          xcc &= 7u;
-         tile_s = (int)xcc + 8 * (int)((unsigned)atomicAdd(tickets + L * 8 + (int)xcc, 1) - (unsigned)ticket_base);      // (both counts wrap together)
+         const unsigned j = (unsigned)atomicAdd(tickets + L * 8 + (int)xcc, 1) - (unsigned)ticket_base;      // (both counts wrap together)
+         if (j >= gridDim.x / 8) __builtin_trap();          // an XCD that got more than its share of the grid: another would leave tiles undone -- fail loudly
+         tile_s = (int)xcc + 8 * (int)j;
       }
       __syncthreads();
       tile = tile_s;
