@@ -24,22 +24,22 @@ RULES = {
 
 
 def inner_loop(body):
-    """the text of the kernel's SLOT loop: the depth-1 loop that holds the MFMAs and the barrier (the TRAIL kernels also have polling loops in front of and
-    inside it) -- from its header label to the first label behind the last block that names it as its header"""
+    """the text of the kernel's SLOT loop: the innermost loop that holds the MFMAs and the barrier (the TRAIL kernels wrap it in a loop over blocks and have
+    polling loops around it) -- from its first block to the first label behind the last block that names it as its header"""
     lines = body.split("\n")
     best = ""
     for i, l in enumerate(lines):
-        if "Loop Header: Depth=1" not in l:
+        if not re.search(r"Loop Header: Depth=\d", l):
             continue
-        m = re.match(r"\.L(BB\d+_\d+):", l) or (i > 0 and re.match(r"\.L(BB\d+_\d+):", lines[i - 1]))      # (the header's comment may sit on the line behind its label)
+        m = next((mm for mm in (re.match(r"\.L(BB\d+_\d+):", lines[j]) for j in range(i, max(i - 4, -1), -1)) if mm), None)      # (the header's comments may sit on the lines behind its label)
         if not m:
             continue
         tag = "Header=" + m.group(1) + " "
         members = [j for j, x in enumerate(lines) if tag in x + " "]
         last = max(members) if members else i
         end = next((j for j in range(last + 1, len(lines)) if re.match(r"\.LBB\d+_\d+:", lines[j]) and tag not in lines[j] + " " and "Parent Loop " + m.group(1) not in lines[j]), len(lines))
-        text = "\n".join(lines[min([i] + members):end])             # (a rotated loop's first block may sit in front of its header label)
-        if "v_mfma" in text and "s_barrier" in text and len(text) > len(best):
+        text = "\n".join(lines[min([i - 3] + members):end])         # (a rotated loop's first block may sit in front of its header label)
+        if "v_mfma" in text and "s_barrier" in text and (not best or len(text) < len(best)):
             best = text
     return best
 

@@ -11,13 +11,13 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 e = Engine(blob, max_streams=S, max_chunks_per_call=C, device=0)
 rng = np.random.default_rng(1)
 x = np.abs(rng.standard_normal((S, C, 64, 7)).astype(np.float32))
-for lk in (7, 6):
-    e.set_option("lstm", lk)
+for lk, trail in ((7, 2), (7, 0), (6, 0)):      # (7, 2): the TRAIL kernels of the layer-major form, one after the other: what their bookkeeping costs
+    e.set_option("lstm", lk); e.set_option("lstm_trail", trail)
     e.lstm_decoder(x)
     e.reset_kernel_times(); e.set_profiling(True)
     for _ in range(reps):
         e.lstm_decoder(x)
     e.set_profiling(False)
     kt = e.kernel_times()
-    print(f"lstm={lk}: " + "  ".join(f"{k} {ms / c:.4f} ms ({ms / c / (7 * C) * 1e3:.3f} us/slot)" for k, (c, ms) in kt.items() if c))
+    print(f"lstm={lk} trail={trail}: " + "  ".join(f"{k} {ms / c:.4f} ms ({ms / c / (7 * C) * 1e3:.3f} us/slot)" for k, (c, ms) in kt.items() if c))
 e.close()

@@ -1134,7 +1134,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
-   if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
@@ -1561,9 +1561,15 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (lk == 7) {
-      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0); }
-      KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-      launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0);
+      // ("lstm_trail" = 2, measurements only: the TRAIL kernels one after the other on this stream -- what their bookkeeping costs with nothing to wait for)
+      int *progress = nullptr;
+      if (e->lstm_trail == 2) { if (++e->lstm_epoch > 2047) e->lstm_epoch = 1; progress = e->d_lstm_progress[e->xpar]; }
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base); }
+      {
+         KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
+         launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
+      }
+      if (progress) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
@@ -1757,7 +1763,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             // and only while either half of the partition has CUs on all 8 XCDs (a forced "lstm_cus" of 8 would not)
             // and not on a SHARED partition: a layer-1 workgroup that waits for its layer 0 holds its CU, which the front end + encoder could otherwise use
             // between two chains (Silero v4 at 256 streams: 4.72 -> 4.36 M with it)
-            const bool trail = e->lstm_trail && e->lstm_cus >= 16 && (e->lstm_cus / 2) % 8 == 0 && !e->lstm_shared && e->cu_partition_usable();
+            const bool trail = e->lstm_trail == 1 && e->lstm_cus >= 16 && (e->lstm_cus / 2) % 8 == 0 && !e->lstm_shared && e->cu_partition_usable();
             int *progress = nullptr;
             if (trail) {
                if (++e->lstm_epoch > 2047) {                    // the 11-bit epoch wraps: once in 2,047 launches the words are cleared behind everything that may read them

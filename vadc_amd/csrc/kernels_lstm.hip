@@ -434,13 +434,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 // then takes one chain, not two (the last call of a run: 0.5 ms earlier; a single call's latency halves), with nothing but kernel boundaries BETWEEN calls as
 // before.  Workgroup t of BOTH launches runs on XCD t % 8 (workgroups are dealt to the XCDs by their index; the engine verifies it on the device at create and
 // the kernels check it again: layer 0 publishes its XCC id, layer 1 traps on a mismatch), so the pair shares ONE L2 and the hand-over needs no cache maintenance
-// at all: layer 0's tile stores go through its write-through vector L1 into that L2 as always, and behind each slot's barrier one lane publishes how many tiles
-// are complete -- the counted vmcnt(4) of waves 0-3 in front of that barrier is exactly the guarantee: everything older than the four newest vector-memory
-// operations of a wave (store k-1, piece k+4, store k-2, piece k+3) has been acknowledged by the L2, i.e. tiles <= k-3.  Layer 1 fetches tiles (LDS-DMA, as
-// always: its vector L1 was invalidated when the kernel started and sees every tile address for the first time) only below the published count, which wave 7
-// reads through the SCALAR cache -- s_dcache_inv + s_load_dword at the top of a slot, consumed at its end: no vector-memory operation, nothing on the slot's
-// path -- and hands to the other waves through the LDS.  When the count is not there yet the workgroup polls (bounded: after ~2 s the kernel traps instead of
-// hanging the device).  `progress[tile]` = epoch << 20 | tiles complete; the epoch (one per launch pair) makes a value left by an earlier call read as zero.
+// at all: layer 0's tile stores go through its write-through vector L1 into that L2 as always, and at the end of every BLOCK of 28 slots one lane publishes how
+// many tiles are complete -- the counted vmcnt(4) of waves 0-3 in front of a slot's barrier is exactly the guarantee: everything older than the four newest
+// vector-memory operations of a wave (store k-1, piece k+4, store k-2, piece k+3) has been acknowledged by the L2, i.e. tiles <= k-3.  Layer 1 fetches tiles
+// (LDS-DMA, as always: its vector L1 was invalidated when the kernel started and sees every tile address for the first time) only below the published count:
+// in front of a block it asks whether the block's pieces are there, and if not the workgroup polls -- wave 7 reads the word through the SCALAR cache
+// (s_dcache_inv + s_load_dword: what the L2 holds now), hands it to the others through the LDS, between two barriers -- bounded: after ~2 s the kernel traps
+// instead of hanging the device.  The slot loop's body is exactly the one without the hand-over (a check per slot, even every eighth, cost layer 1 0.11 - 0.16
+// us of its 0.76-us slot, mostly through what it did to hipcc's schedule of the body: tools/trail_ablate.sh in the history).  `progress[tile]` = epoch << 20 |
+// tiles complete; the epoch (one per launch pair) makes a value left by an earlier call read as zero.
 // (Measured on the way: the same hand-over with device-scope accesses -- sc0 sc1 on the tile stores, the tile loads and the count -- is correct on any XCD
 // placement but takes every access to the fabric: both chains 0.5 -> 1.0 ms.  An earlier attempt with agent-scope FENCES wrote back and invalidated the whole
 // L2 at every hand-over and cost the front end 2 %: DESIGN.md 4.4.)
@@ -458,8 +460,6 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    __shared__ __attribute__((aligned(16))) _Float16 xr[4][2][kTileS * 64];   // input ring: [step & 3][hi / lo][16-byte segment 0..7][stream] (LDS-DMA, see below)
    __shared__ float pd[2][8][2][kTileS];
    __shared__ __attribute__((aligned(8))) float dws[2][64];  // layer 1: the decoder's weights (read once per chunk: not worth four registers across the slot loop)
-   __shared__ __attribute__((aligned(16))) float bias_s[8][2][4][4];   // TRAIL layer 1: the accumulators' initial values [wave][row tile][quad][gate] (eight registers less across the slot loop)
-   __shared__ int avail_raw[2];                              // TRAIL, layer 1: the published word as read in slot k, at [k & 1]
    __shared__ int avail_sync;                                // TRAIL, layer 1: the count a synchronous poll found
 
    const int tid = threadIdx.x;
@@ -510,7 +510,6 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       }
    }
    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-   constexpr bool BIAS_LDS = TRAIL && L == 1;
    float c[2], hlast[2], bias_r[2][4];
    if (L == 1 && tid < 128) dws[tid >> 6][tid & 63] = w.dec_w[tid];
 #pragma unroll
@@ -518,7 +517,6 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
          bias_r[m][r] = w.b[L * 256 + r * 64 + u0 + m];
-         if (BIAS_LDS && col == 0) bias_s[wave][m][quad][r] = bias_r[m][r];
       }
    {
       _Float16 hi2[2], lo2[2];
@@ -578,9 +576,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       }
    };
    if (TRAIL && L == 1) {
-      if (tid < 2) avail_raw[tid] = 0;
-      __syncthreads();
-      wait_for(min(4, TS * cg));
+      wait_for(min(4, TS * cg));                             // the prologue's four pieces
       // the pair must share an L2: layer 0 publishes the XCC it runs on beside its count
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -604,7 +600,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 #pragma unroll
    for (int m = 0; m < 2; ++m) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];             // (the prologue: bias_s is complete behind the next barrier only)
+      for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
          const h8v bh = xfrag(0, 0, kb), bl = xfrag(0, 1, kb);
@@ -626,19 +622,23 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(hlast[0]), "+v"(hlast[1]));
    // one copy of the slot body: an unrolled loop may round its copies differently (fma contraction is decided per copy), and then a step's
    // bits would depend on its position in the call
+   // TRAIL: the hand-over is looked after between BLOCKS of kTrailBlock slots, outside the slot loop, whose body stays what it is without it (as a check per
+   // slot -- even every eighth -- the bookkeeping cost layer 1 0.11 - 0.16 us of its 0.76-us slot, most of it by what it did to the compiler's schedule of the
+   // body: tools/trail_ablate.sh).  Layer 0 publishes its count at the end of a block, layer 1 asks in front of one whether its pieces are there.
+   constexpr int kTrailBlock = 28;
+   int k = 0;
+   while (k < total) {
+   int kend = total;
+   if (TRAIL) kend = min(total, k + kTrailBlock);
+   if (TRAIL && L == 1) {
+      const int need = min(kend + 3, total - 1) + 1;          // the slots of this block issue the pieces of tiles up to kend + 3
+      if (avail < need) wait_for(need);
+   }
 #pragma unroll 1
-   for (int k = 0; k < total; ++k) {
+   for (; k < kend; ++k) {
       const int chi = k / TS, t = k - chi * TS;
       f4v acc[2];
       acc[0] = accx[0]; acc[1] = accx[1];
-      int flag_v = 0;
-      if (TRAIL && L == 1) {
-         // the word read in the previous slot (in the LDS since its barrier); the piece issued below is tile min(k + 4, total - 1)
-         if (k >= 1) avail = max(avail, decode(avail_raw[(k - 1) & 1]));
-         const int need = min(k + 4, total - 1) + 1;
-         if (avail < need) wait_for(need);
-         if (wave == 7) asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0" : "=s"(flag_v) : "s"(flag) : "memory");      // consumed at the end of the slot
-      }
 #ifndef VADC_LSTM_ABL_NOXLOAD     // (timing-only ablation: the slot without its input fetch)
       if (!TAPDEC && wave < 4) issue_x(k + 4, k);             // step k + 4 into the ring slot step k was read from (one slot ago)
 #endif
@@ -673,11 +673,8 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       for (int kb = 0; kb < 2; ++kb) { xbh[kb] = xfrag(k + 1, 0, kb); xbl[kb] = xfrag(k + 1, 1, kb); }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-         if constexpr (BIAS_LDS) accx[m] = *reinterpret_cast<const f4v *>(&bias_s[wave][m][quad][0]);
-         else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
-         }
+         for (int r = 0; r < 4; ++r) accx[m][r] = bias_r[m][r];
 #pragma unroll
          for (int kb = 0; kb < 2; ++kb) {
             accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], xbh[kb], accx[m], 0, 0, 0);
@@ -739,14 +736,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       // waves 0-3: the piece of step k + 2 (issued two slots ago; read in the next slot) has landed -- newer operations may stay in flight: two
       // pieces (layer 1), plus layer 0's h0-tile stores (counted together, retired in order)
       if (!TAPDEC && wave < 4) { if (L == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-      if (TRAIL && L == 1 && wave == 7) {                     // the word requested at the top of the slot: into the LDS for the next slot
-         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(flag_v) :: "memory");
-         if (lane == 0) avail_raw[k & 1] = flag_v;
-      }
       __syncthreads();                                        // one barrier per slot
       par ^= 1;
-      // tiles <= k - 3 are complete (every wave of 0-3 has passed its vmcnt(4): see TRAIL above)
-      if (TRAIL && L == 0 && tid == 448 && k >= 3) publish(progress + tile, (epoch << 20) | (k - 2));
+
       if (L == 1) {
          if (DEC == 0 && chunk_done && wave == 0 && lane < 2 * kTileS) {
             const int sc = lane & 15, f = lane >> 4, q = k & 1;
@@ -768,6 +760,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
             }
          }
       }
+   }
+   // the end of a block (its last slot was k - 1): every wave of 0-3 passed its vmcnt(4) in front of that slot's barrier, so tiles <= k - 4 are complete
+   if (TRAIL && L == 0 && tid == 448 && k >= 4) publish(progress + tile, (epoch << 20) | (k - 3));
    }
    if (L == 0 && tid < 256) {                                 // the last step's tile
       const int rowi = tid >> 3, seg = tid & 7;
