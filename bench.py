@@ -568,7 +568,8 @@ def run_rank(args, world, rank, local_rank):
                                  "the 129 bins (the rest follow from the basis' DFT symmetries, bit-exactly), so it EXECUTES 27 % of the dense-basis FLOP that "
                                  "algorithmic_* counts (SURVEY.md 8(d))"},
             "kernels": per_kernel,
-            "lstm_trail": bool(eng.get_option("lstm_trail")) and layer_major,      # layer 1 of the recurrence beside layer 0 of the same call
+            "lstm_trail": bool(eng.get_option("lstm_trail_used")) and layer_major,      # layer 1 of the recurrence beside layer 0 of the same call (what the last step did:
+                                                                                          # under a tool that serialises kernels the engine does not)
             "stage_fracs": {k: [v["frac_of_pipe_peak"], v["pipe"]] for k, v in per_kernel.items()},
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph

@@ -235,7 +235,10 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
  *   "lstm_trail"  1 (default): with the layer-major LSTM on its CU partition, layer 1 of a call is launched BESIDE layer 0 of the same call and follows its published
  *                 progress a few steps behind (same XCD, same L2: no cache maintenance) -- a call's recurrence takes one chain instead of two (the last call
- *                 of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves); 0: layer 1 starts when layer 0 has finished.  Same bits
+ *                 of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves); 0: layer 1 starts when layer 0 has finished.  Same bits.
+ *                 Used only in a process whose kernels were SEEN to overlap at create ("kernels_overlap"): a tool that lets one kernel onto the device at a
+ *                 time (rocprofv3 --pmc) would start layer 0 when layer 1 has ended -- there the engine launches the two one after the other by itself
+ *                 ("lstm_trail_used" says what the last call did).  "overlap_check" 2: behave as if that probe had failed (tests)
  *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
  *   "fe_opt"      k_frontend_sym: 3 (default) = bin 0 without the tree of its all-zero im row, the 9-bin split rotating over the waves; 0 = round 3's kernel
  *                 (same bits)

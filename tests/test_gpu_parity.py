@@ -456,6 +456,8 @@ def test_lstm_layer1_beside_layer0_of_the_same_call(weights_blob, orc, S, Cn, ca
             e.set_option("lstm_trail", trail); e.set_option("groups", groups); e.set_option("lstm", 7); e.reset_streams()
             res = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
             assert e.get_option("lstm_cus") > 0                                    # the CU partition is what lets the two launches overlap
+            if e.get_option("kernels_overlap"):                                    # (not under a tool that serialises kernels: there the engine launches them in turn)
+                assert e.get_option("lstm_trail_used") == trail
             out.append((res, [e.get_state(s_) for s_ in (0, S // 2, S - 1)]))
     finally:
         e.close()
@@ -482,10 +484,18 @@ def test_lstm_trail_epoch_wrap_and_forced_small_partition(weights_blob):
         assert 1 <= e.get_option("lstm_epoch") <= 24                             # wrapped (a synchronous call pipelines up to 4 chunk groups: up to 4 launch pairs per call)
         e.set_option("lstm_cus", 8); e.reset_streams()
         small = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
-        assert e.get_option("lstm_cus") == 8
+        assert e.get_option("lstm_cus") == 8 and e.get_option("lstm_trail_used") == 0
+        # a process whose kernels do not overlap (a counter-collecting profiler serialises them; here: the probe's answer overridden): in turn, by itself
+        e.set_option("lstm_cus", 0); e.set_option("overlap_check", 2); e.reset_streams()
+        serial = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+        assert e.get_option("lstm_trail") == 1 and e.get_option("lstm_trail_used") == 0
+        e.set_option("overlap_check", 1); e.reset_streams()
+        again = np.concatenate([e.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+        assert e.get_option("lstm_trail_used") == e.get_option("kernels_overlap")
     finally:
         e.close()
     assert np.array_equal(bits(want), bits(got)) and np.array_equal(bits(want), bits(small))
+    assert np.array_equal(bits(want), bits(serial)) and np.array_equal(bits(want), bits(again))
 
 
 @pytest.mark.parametrize("variant", [6, 7])

@@ -159,6 +159,9 @@ struct vadc_amd_engine {
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
    bool cu_layout_ok = false;                   // 256 CUs and CU-mask bit i -> XCD i % 8 (cu_mask_layout_ok): what the LSTM partition rules assume
    int cu_mask_check = 1;                       // option "cu_mask_check": 1 = the partition needs cu_layout_ok (default), 0 = trust the rules anyway, 2 = behave as if the check had failed (tests)
+   bool kernels_overlap = false;                // two kernels on two masked streams were seen to run at the same time (cu_mask_layout_flags bit 1): what "lstm_trail" needs
+   int overlap_check = 1;                       // option "overlap_check": 1 = "lstm_trail" needs kernels_overlap (default), 2 = behave as if the probe had failed (tests)
+   bool trail_possible() const { return overlap_check == 1 && kernels_overlap; }
    bool cu_partition_usable() const { return cu_mask_check == 0 || (cu_mask_check == 1 && cu_layout_ok); }
    bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
    int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree: kernels_frontend.hip)
@@ -215,6 +218,7 @@ struct vadc_amd_engine {
    size_t progress_tiles = 0;
    int lstm_epoch = 0;
    int lstm_trail = 1;
+   int lstm_trail_used = 0;                     // whether the last call's layer-major launches were a TRAIL pair (option "lstm_trail_used", read only)
    int *d_lstm_tickets = nullptr;               // [2 layers][8 XCDs]: the counters a TRAIL workgroup draws its tile from (L2-local atomics); ticket_base = what earlier launches drew per XCD
    unsigned ticket_base = 0;
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
@@ -934,6 +938,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
    e->cu_layout_ok = (cu_mask_layout_flags(device, e->n_cus) & 1) != 0;
+   e->kernels_overlap = (cu_mask_layout_flags(device, e->n_cus) & 2) != 0;
    for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
@@ -1135,6 +1140,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
+   if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
@@ -1173,6 +1179,8 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
    else if (strcmp(key, "lstm_trail") == 0) *value = e->lstm_trail;
+   else if (strcmp(key, "kernels_overlap") == 0) *value = e->kernels_overlap ? 1 : 0;
+   else if (strcmp(key, "lstm_trail_used") == 0) *value = e->lstm_trail_used;
    else if (strcmp(key, "lstm_epoch") == 0) *value = e->lstm_epoch;
    else if (strcmp(key, "cu_mask_check") == 0) *value = e->cu_mask_check;
    else if (strcmp(key, "cu_layout_ok") == 0) *value = e->cu_layout_ok ? 1 : 0;
@@ -1258,6 +1266,16 @@ __global__ __launch_bounds__(64) void k_probe_hold(unsigned *out, int spin)
    while (__builtin_readcyclecounter() - t0 < (unsigned long long)spin) { }
    if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xf) + (big[7] & 0);
 }
+// role 0: wait (bounded) for w[0] and note in w[1] whether it came; role 1: set w[0].  System scope: the two may sit on different XCDs.
+__global__ __launch_bounds__(64) void k_probe_overlap(unsigned *w, int role, long long ticks)
+{
+   if (threadIdx.x != 0) return;
+   if (role == 1) { __hip_atomic_store(w, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+   const long long t0 = wall_clock64();
+   unsigned seen = 0;
+   while (!seen && wall_clock64() - t0 < ticks) { seen = __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); __builtin_amdgcn_s_sleep(32); }
+   w[1] = seen;
+}
 // (a one-bit mask is no probe: every bit then reports XCC 0 -- the id is relative to the XCDs the queue may use; tools/cumask_probe.hip)
 // bit 0: the layout holds.  (Which XCD workgroup i of a launch lands on is NOT a property of the layout: it is (start + i) % 8 with a start that differs between
 // queues and over time -- tools/xcd_map_probe.hip -- which is why k_lstm_layer's TRAIL form lets every XCD hand out its own tiles.)
@@ -1295,8 +1313,29 @@ static int cu_mask_layout_flags(int device, int n_cus)
                                                       per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], grid / 8);
       }
    }
+   // bit 1: kernels on two streams run AT THE SAME TIME in this process.  Under a tool that serialises kernel dispatches (rocprofv3 --pmc: one kernel on the
+   // device at a time, so that its counters are its own) they do not, and a layer-1 launch that follows the progress of a layer-0 launch (k_lstm_layer's TRAIL
+   // form) would wait for a kernel the tool starts only when layer 1 has ended.  Asked of the device, not of the environment: a kernel on one masked stream
+   // waits -- for 20 ms at most -- for a word a kernel launched AFTER it on another stream sets.
+   bool overlap = false;
+   if (ok && d) {
+      std::vector<uint32_t> m0(words, 0u), m1(words, 0u);
+      m0[0] = 0xffu; m1[0] = 0xff00u;
+      hipStream_t s0 = nullptr, s1 = nullptr;
+      if (hipExtStreamCreateWithCUMask(&s0, (uint32_t)words, m0.data()) == hipSuccess && hipExtStreamCreateWithCUMask(&s1, (uint32_t)words, m1.data()) == hipSuccess &&
+          hipMemsetAsync(d, 0, 2 * sizeof(unsigned), s0) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess) {
+         hipLaunchKernelGGL(k_probe_overlap, dim3(1), dim3(64), 0, s0, d, 0, 2000000ll);      // wall_clock64: 100 MHz
+         hipLaunchKernelGGL(k_probe_overlap, dim3(1), dim3(64), 0, s1, d, 1, 0ll);
+         unsigned seen = 0;
+         if (hipStreamSynchronize(s1) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess && hipMemcpy(&seen, d + 1, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) overlap = seen == 1;
+      }
+      (void)hipGetLastError();
+      if (s0) (void)hipStreamDestroy(s0);
+      if (s1) (void)hipStreamDestroy(s1);
+      if (getenv("VADC_AMD_DEBUG_CUMASK")) fprintf(stderr, "cu_mask_layout: kernels on two streams %s\n", overlap ? "overlap" : "do NOT overlap (serialised by a tool?)");
+   }
    if (d) (void)hipFree(d);
-   const int flags = ok ? 1 : 0;
+   const int flags = (ok ? 1 : 0) | (overlap ? 2 : 0);
    if (device >= 0 && device < 64) cache[device] = flags + 4;
    return flags;
 }
@@ -1763,8 +1802,10 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             // and only while either half of the partition has CUs on all 8 XCDs (a forced "lstm_cus" of 8 would not)
             // and not on a SHARED partition: a layer-1 workgroup that waits for its layer 0 holds its CU, which the front end + encoder could otherwise use
             // between two chains (Silero v4 at 256 streams: 4.72 -> 4.36 M with it)
-            const bool trail = e->lstm_trail == 1 && e->lstm_cus >= 16 && (e->lstm_cus / 2) % 8 == 0 && !e->lstm_shared && e->cu_partition_usable();
+            // and only in a process whose kernels overlap at all: a tool that serialises dispatches (rocprofv3 --pmc) would start layer 0 when layer 1 has ended
+            const bool trail = e->lstm_trail == 1 && e->lstm_cus >= 16 && (e->lstm_cus / 2) % 8 == 0 && !e->lstm_shared && e->cu_partition_usable() && e->trail_possible();
             int *progress = nullptr;
+            e->lstm_trail_used = trail ? 1 : 0;
             if (trail) {
                if (++e->lstm_epoch > 2047) {                    // the 11-bit epoch wraps: once in 2,047 launches the words are cleared behind everything that may read them
                   for (hipEvent_t ev : {e->last_b, e->last_c}) if (e->ev_last_valid && ev) (void)hipEventSynchronize(ev);
