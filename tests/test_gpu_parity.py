@@ -1499,6 +1499,40 @@ def test_split16_refuses_every_fp32_fallback(weights_blob):
         e.close()
 
 
+def test_engines_with_trailing_layers_at_the_same_time(weights_blob):
+    """three engines of one process on one device, driven by three host threads at once, both with the layer-major recurrence and "lstm_trail": their CU partitions are the
+    SAME CUs (layer-1 workgroups of both wait on the half where the other's also wait; the layer-0 workgroups they wait for never wait for anything, so every
+    one of them gets its turn), with different tile counts (16 and 7 tiles) and more tiles than CUs (40).  Same bits as each engine alone"""
+    import threading
+    shapes = [(256, 12, 5), (100, 20, 4), (640, 4, 4)]
+    pcms = []
+    for S, Cn, calls in shapes:
+        base = synth.make_streams(min(S, 20), Cn * calls, seed0=900 + S)
+        pcms.append(np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S]))
+    engines = [Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0) for S, Cn, _ in shapes]
+    def drive(i, out):
+        S, Cn, calls = shapes[i]
+        e = engines[i]
+        e.set_option("lstm", 7); e.reset_streams()
+        out[i] = np.concatenate([e.run(pcms[i][:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(calls)], axis=1)
+    try:
+        alone, together = [None] * 3, [None] * 3
+        for i in range(3):
+            drive(i, alone)
+        for rep in range(3):
+            ths = [threading.Thread(target=drive, args=(i, together)) for i in range(3)]
+            for t in ths: t.start()
+            for t in ths: t.join(timeout=120)
+            assert not any(t.is_alive() for t in ths)
+            for i in range(3):
+                assert np.array_equal(bits(alone[i]), bits(together[i])), (rep, i)
+        if engines[0].get_option("kernels_overlap"):
+            assert engines[0].get_option("lstm_trail_used") == 1
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_three_engines_alive_in_one_process(weights_blob, orc):
     """a long-lived host with several engines: three engines (different workspace sizes, forked and small calls, deferred joins on one of them) are
     created, used interleaved, destroyed in another order than they were created, and a fourth one is created afterwards -- every result is the
