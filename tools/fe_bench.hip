@@ -197,6 +197,18 @@ int main(int argc, char **argv)
                   for (int b = 0; b < 2; ++b)
                      h_basis[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = nat[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
       CK(hipMemcpy(basis, h_basis.data(), h_basis.size() * 4, hipMemcpyHostToDevice));
+      // k_frontend_ri's copy: base bins 0..32, (re, im) of a tap side by side ([f][ii][lp][l % 2][j][re | im], engine.hip)
+      std::vector<float> h_ri((size_t)35 * 512 + 64, 0.0f);
+      for (int f = 0; f < 33; ++f)
+         for (int ii = 0; ii < 4; ++ii)
+            for (int lp = 0; lp < 4; ++lp)
+               for (int h = 0; h < 2; ++h)
+                  for (int j = 0; j < 8; ++j)
+                     for (int c = 0; c < 2; ++c)
+                        h_ri[(size_t)f * 512 + ii * 128 + lp * 32 + h * 16 + j * 2 + c] = nat[(size_t)(c ? kBins + f : f) * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + h)];
+      float *basis_ri;
+      CK(hipMalloc(&basis_ri, h_ri.size() * 4));
+      CK(hipMemcpy(basis_ri, h_ri.data(), h_ri.size() * 4, hipMemcpyHostToDevice));
       float *FM1;
       CK(hipMalloc(&FM1, (size_t)kBinSplit * n * kFrames * 4));
       const size_t fm_stride = (size_t)n * kFrames;
@@ -232,7 +244,53 @@ int main(int argc, char **argv)
       CK(hipMemset(Y1, 0, ref.size() * 4));
       time_it("sym nb2 OPT3, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
       check("sym nb2 OPT3", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("ri (re, im pairs), magnitude", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1); });
+      check("ri", Y1);
+      if (getenv("FE_RI_DEBUG")) {                        // mismatching words by bin
+         std::vector<long> by_bin(kBins, 0);
+         for (size_t i = 0; i < got.size(); ++i) if (memcmp(&got[i], &ref[i], 4)) ++by_bin[(i / kFrames) % kBins];
+         for (int b = 0; b < kBins; ++b) if (by_bin[b]) printf("      bin %3d: %ld\n", b, by_bin[b]);
+         printf("      first words of bin 1: got %g %g %g want %g %g %g\n", got[25], got[26], got[27], ref[25], ref[26], ref[27]);
+         return 0;
+      }
+      CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("ri (zero_im0 = 0), magnitude", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 0); });
+      check("ri z0", Y1);
+      {  // log mode: Y and the partial bin sums of k_frontend_ri against k_frontend_sym OPT 3, bit for bit
+         std::vector<float> ya(ref.size()), yb(ref.size()), fa((size_t)kBinSplit * n * kFrames), fb(fa.size());
+         float *FM2; CK(hipMalloc(&FM2, fa.size() * 4));
+         hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y0, FM1, n, map, fm_stride, 1);
+         hipLaunchKernelGGL((k_frontend_ri<int16_t, 0, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM2, n, map, fm_stride, 1);
+         CK(hipDeviceSynchronize());
+         CK(hipMemcpy(ya.data(), Y0, ya.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(yb.data(), Y1, yb.size() * 4, hipMemcpyDeviceToHost));
+         CK(hipMemcpy(fa.data(), FM1, fa.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fb.data(), FM2, fb.size() * 4, hipMemcpyDeviceToHost));
+         printf("   ri log mode against sym OPT3: Y %s, FM %s\n", memcmp(ya.data(), yb.data(), ya.size() * 4) ? "MISMATCH" : "bit-identical", memcmp(fa.data(), fb.data(), fa.size() * 4) ? "MISMATCH" : "bit-identical");
+         CK(hipFree(FM2));
+         CK(hipMemcpy(ref.data(), Y0, 0, hipMemcpyDeviceToHost));
+      }
+      if (getenv("FE_RI_REPEAT")) {                       // k_frontend_ri against ITSELF and against k_frontend_sym, launch after launch: a result that depends on timing shows here
+         const int R = atoi(getenv("FE_RI_REPEAT"));
+         std::vector<float> y0(ref.size()), y1(ref.size()), f0((size_t)kBinSplit * n * kFrames), f1(f0.size());
+         hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y0, FM, n, map, fm_stride, 1);
+         CK(hipDeviceSynchronize());
+         CK(hipMemcpy(y0.data(), Y0, y0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(f0.data(), FM, f0.size() * 4, hipMemcpyDeviceToHost));
+         long bad_runs = 0;
+         for (int r = 0; r < R; ++r) {
+            CK(hipMemsetAsync(Y1, 0xff, y1.size() * 4, g_st));
+            hipLaunchKernelGGL((k_frontend_ri<int16_t, 0, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(y1.data(), Y1, y1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(f1.data(), FM1, f1.size() * 4, hipMemcpyDeviceToHost));
+            size_t by = 0, bf = 0; long first = -1;
+            for (size_t i = 0; i < y1.size(); ++i) if (memcmp(&y1[i], &y0[i], 4)) { ++by; if (first < 0) first = (long)i; }
+            for (size_t i = 0; i < f1.size(); ++i) if (memcmp(&f1[i], &f0[i], 4)) ++bf;
+            if (by || bf) { ++bad_runs; printf("   run %d: %zu words of Y, %zu of FM differ; first: chunk %ld bin %ld frame %ld\n", r, by, bf, first / (kBins * kFrames), (first / kFrames) % kBins, first % kFrames); }
+         }
+         printf("ri x %d at %d chunks: %ld runs with differences\n", R, n, bad_runs);
+         return 0;
+      }
       for (int rep = 0; rep < 2; ++rep) {
+         time_it("ri, log mode", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 0, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1); });
          time_it("sym nb2 OPT0, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 0>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
          time_it("sym nb2 OPT1, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 1>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
          time_it("sym nb2 OPT2, log mode", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
@@ -259,7 +317,7 @@ int main(int argc, char **argv)
          std::vector<Var> vars = {
             {"OPT0", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 0>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
             {"OPT3", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
-            {"OPT2", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 2>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+            {"RI", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 0, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1); }},
             // rows of Y on 128-byte boundaries (pitch 32 floats instead of 25: + 28 % bytes, no row straddles a 128-byte line)
             {"YP32", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3, 32>), grid, dim3(256), 0, g_st, pcm, basis, Y32, FM1, n, map, fm_stride, 1); }},
          };
