@@ -124,21 +124,20 @@ def test_basis_without_dft_symmetries_runs_the_full_tree(weights_blob):
 
 
 def test_zero_im_row_of_bin0_is_skipped_bit_exactly(weights_blob):
-    """the three forms of the exact-tree front end: k_frontend_ri (fe_opt = 11, the default: packed pairs = (re, im) of one tree lane, the derived rows' sums and the
-    logarithm two values per instruction) and k_frontend_sym with fe_opt = 3 run bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis
-    (-w[n] sin 0): magnitudes, log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
+    """k_frontend_sym (fe_opt = 3, the default) runs bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis (-w[n] sin 0): magnitudes,
+    log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
     pcm = synth.make_streams(5, 7, seed0=411)
     x = f32(pcm[:3]).reshape(-1)
     e = Engine(weights_blob, max_streams=8, max_chunks_per_call=8, device=0)
     try:
         assert e.get_option("zero_im0") == 1 and e.get_option("fe_opt") == 3
         out = {}
-        for opt in (11, 3, 0):
+        for opt in (3, 0):
             e.set_option("fe_opt", opt); e.reset_streams()
             out[opt] = (e.stage_from_samples(x, "magnitude"), e.stage_from_samples(x, "normalized"), e.run(pcm))
             assert e.get_option("frontend_kernel") == 0
-        for a, b, c in zip(out[0], out[3], out[11]):
-            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
+        for a, b in zip(out[0], out[3]):
+            assert np.array_equal(bits(a), bits(b))
     finally:
         e.close()
     o = O.Oracle(weights_blob)

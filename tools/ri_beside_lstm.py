@@ -1,4 +1,5 @@
-"""engine A runs stage taps alone (front end; front end + first layers) again and again while engine B, from another thread, keeps the device busy with whole steps
+"""(needs the engine of commit b91f1ec, where option "fe_opt" = 11 selects k_frontend_ri: tools/study/k_frontend_ri.h)
+engine A runs stage taps alone (front end; front end + first layers) again and again while engine B, from another thread, keeps the device busy with whole steps
 (10,240 x 1, layer-major LSTM): does a stage of A ever change its bits?"""
 import sys, os, threading
 sys.path.insert(0, os.getcwd())
