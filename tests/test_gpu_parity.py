@@ -1533,6 +1533,21 @@ def test_engines_with_trailing_layers_at_the_same_time(weights_blob):
             e.close()
 
 
+def test_runs_repeat_bit_for_bit_beside_their_own_neighbours():
+    """run-to-run determinism under the engine's own concurrency (tools/soak_determinism.py, shortened: the full soak is profiles/r04/soak_determinism.jsonl): the same
+    calls from reset state, graph replay and eager launches in turn, again and again -- every run's probabilities are the first run's bits, at the north star's shape
+    (the recurrence's workgroups beside the front end's on the same CUs), with the recurrence on CUs of its own and layer 1 trailing layer 0, and with ragged tiles.
+    (Round 4 met a front-end variant whose bits changed beside k_lstm_layer once in 1.5e5 workgroups -- DESIGN.md 4.1 (d): this is the test that caught it.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("soak_determinism", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_determinism.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    soak.scale = 1.0
+    for shape in ((10240, 1, 8, 40), (256, 96, 3, 8), (100, 24, 4, 20), (640, 8, 6, 16)):
+        rec = soak.soak(*shape)
+        assert rec["runs_differing_from_the_first"] == 0, rec
+
+
 def test_three_engines_alive_in_one_process(weights_blob, orc):
     """a long-lived host with several engines: three engines (different workspace sizes, forked and small calls, deferred joins on one of them) are
     created, used interleaved, destroyed in another order than they were created, and a fourth one is created afterwards -- every result is the
