@@ -8,14 +8,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vadc_amd import synth
 from vadc_amd.engine import Engine
-blob = open("tests/golden/reference_fixtures/silero_v31_16k.testtensor", "rb").read()
+BLOBS = {"v31": "tests/golden/reference_fixtures/silero_v31_16k.testtensor", "v4": "tests/golden/silero_v4_16k.testtensor", "v5": "tests/golden/silero_v5_seeded.testtensor"}
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 scale = 1.0
-def soak(S, Cn, calls, reps, opts=None):
-    base = synth.make_streams(min(S, 48), calls * Cn, seed0=4000 + S)
-    pcm = np.ascontiguousarray(base[np.arange(S) % base.shape[0]])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536])).cuda() for k in range(calls)]
+def soak(S, Cn, calls, reps, opts=None, model="v31"):
+    blob = open(BLOBS[model], "rb").read()
     e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    W = e.window                                                   # samples per chunk (1536; Silero v5: 512)
+    base = synth.make_streams(min(S, 48), -(-calls * Cn * W // 1536), seed0=4000 + S)
+    pcm = np.ascontiguousarray(base[np.arange(S) % base.shape[0]])
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * W:(k + 1) * Cn * W])).cuda() for k in range(calls)]
     for k_, v_ in (opts or {}).items(): e.set_option(k_, v_)
     e.set_option("defer_join", 1)
     st = torch.cuda.Stream()
@@ -31,12 +33,14 @@ def soak(S, Cn, calls, reps, opts=None):
         if first is None: first = r
         elif not np.array_equal(bits(first), bits(r)):
             bad += 1; worst = max(worst, float(np.abs(first - r).max()))
-    rec = ({"streams": S, "chunks_per_call": Cn, "calls": calls, "runs": reps, "options": opts or {}, "lstm_kernel": e.get_option("lstm_kernel"), "lstm_cus": e.get_option("lstm_cus"),
+    rec = ({"model": model, "streams": S, "chunks_per_call": Cn, "calls": calls, "runs": reps, "options": opts or {}, "lstm_kernel": e.get_option("lstm_kernel"), "lstm_cus": e.get_option("lstm_cus"),
                       "lstm_trail_used": e.get_option("lstm_trail_used"), "runs_differing_from_the_first": bad, "max_abs_dp": worst})
     print(json.dumps(rec), flush=True)
     e.close()
     return rec
-SHAPES = [(10240, 1, 8, 600), (16384, 1, 4, 200), (4096, 1, 8, 300), (256, 96, 3, 120), (256, 8, 8, 300), (100, 24, 4, 300), (640, 8, 6, 200), (1024, 4, 8, 200), (4096, 16, 2, 60), (256, 96, 3, 60, {"lstm_trail": 0}), (10240, 1, 8, 200, {"lstm": 6})]
+SHAPES = [(10240, 1, 8, 600), (16384, 1, 4, 200), (4096, 1, 8, 300), (256, 96, 3, 120), (256, 8, 8, 300), (100, 24, 4, 300), (640, 8, 6, 200), (1024, 4, 8, 200), (4096, 16, 2, 60), (256, 96, 3, 60, {"lstm_trail": 0}), (10240, 1, 8, 200, {"lstm": 6}),
+          (256, 96, 3, 60, None, "v4"), (4096, 16, 2, 40, None, "v4"), (10240, 1, 6, 150, None, "v4"), (768, 32, 3, 60, None, "v4"),
+          (256, 96, 3, 60, None, "v5"), (4096, 16, 2, 40, None, "v5"), (64, 192, 2, 60, None, "v5")]
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     for a in SHAPES:
