@@ -322,8 +322,16 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_ri(const T *__restrict__
             }
          }
 #endif
+#if defined(VADC_RI_ABL) && (VADC_RI_ABL & 16)
+         emit_row(b, st.sa[4 * B].x, st.sa[4 * B].y); emit_row(128 - b, st.sa[4 * B + 1].x, st.sa[4 * B + 1].y);
+         if (b < 32) { emit_row(64 - b, st.sa[4 * B + 2].x, st.sa[4 * B + 2].y); emit_row(64 + b, st.sa[4 * B + 3].x, st.sa[4 * B + 3].y); }
+#elif defined(VADC_RI_ABL) && (VADC_RI_ABL & 32)
+         emit_pair(b, 128 - b, st.sa[4 * B], st.sa[4 * B + 1]);
+         emit_pair(min(64 - b, 63), max(64 + b, 65) > 96 ? 96 : max(64 + b, 65), st.sa[4 * B + 2], st.sa[4 * B + 3]);      // (timing probe: no branch around the second pair; b = 32 writes garbage rows)
+#else
          emit_pair(b, 128 - b, st.sa[4 * B], st.sa[4 * B + 1]);
          if (b < 32) emit_pair(64 - b, 64 + b, st.sa[4 * B + 2], st.sa[4 * B + 3]);
+#endif
       }
    }
    if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
