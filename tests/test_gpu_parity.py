@@ -124,20 +124,21 @@ def test_basis_without_dft_symmetries_runs_the_full_tree(weights_blob):
 
 
 def test_zero_im_row_of_bin0_is_skipped_bit_exactly(weights_blob):
-    """k_frontend_sym (fe_opt = 3, the default) runs bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis (-w[n] sin 0): magnitudes,
-    log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
+    """the three forms of the exact-tree front end: k_frontend_sym with fe_opt = 3 (the default) and k_frontend_ri (fe_opt = 11: packed pairs = (re, im) of one tree lane, the
+    derived rows' sums and the logarithm two values per instruction) run bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis
+    (-w[n] sin 0): magnitudes, log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
     pcm = synth.make_streams(5, 7, seed0=411)
     x = f32(pcm[:3]).reshape(-1)
     e = Engine(weights_blob, max_streams=8, max_chunks_per_call=8, device=0)
     try:
         assert e.get_option("zero_im0") == 1 and e.get_option("fe_opt") == 3
         out = {}
-        for opt in (3, 0):
+        for opt in (11, 3, 0):
             e.set_option("fe_opt", opt); e.reset_streams()
             out[opt] = (e.stage_from_samples(x, "magnitude"), e.stage_from_samples(x, "normalized"), e.run(pcm))
             assert e.get_option("frontend_kernel") == 0
-        for a, b in zip(out[0], out[3]):
-            assert np.array_equal(bits(a), bits(b))
+        for a, b, c in zip(out[0], out[3], out[11]):
+            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
     finally:
         e.close()
     o = O.Oracle(weights_blob)
@@ -1537,7 +1538,8 @@ def test_runs_repeat_bit_for_bit_beside_their_own_neighbours():
     """run-to-run determinism under the engine's own concurrency (tools/soak_determinism.py, shortened: the full soak is profiles/r04/soak_determinism.jsonl): the same
     calls from reset state, graph replay and eager launches in turn, again and again -- every run's probabilities are the first run's bits, at the north star's shape
     (the recurrence's workgroups beside the front end's on the same CUs), with the recurrence on CUs of its own and layer 1 trailing layer 0, and with ragged tiles.
-    (Round 4 met a front-end variant whose bits changed beside k_lstm_layer once in 1.5e5 workgroups -- DESIGN.md 4.1 (d): this is the test that caught it.)"""
+    (Round 4 met a packed-add form whose low result lost a term beside k_lstm_layer once in 8 million executions -- DESIGN.md 4.1 (d): the north star's shape,
+    graph against eager, is what caught it.)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("soak_determinism", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_determinism.py"))
     soak = importlib.util.module_from_spec(spec)

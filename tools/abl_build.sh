@@ -12,6 +12,7 @@ obj=${src%.hip}.o
 mkdir -p build/abl
 extra=""
 [ "$src" = kernels_frontend.hip ] && extra="-ffp-contract=off -fno-slp-vectorize"
+[ "$src" = kernels_encoder_fused.hip ] && extra="-fno-slp-vectorize"          # as the Makefile (tools/check_pk_opsel.py)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c "$src" -o "build/abl/$obj"
 objs=""
 for o in build/*.o; do

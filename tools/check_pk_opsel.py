@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Build-time check of a gfx950 ISA listing: no packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) may take the LOW result's second or third source
+from the HIGH dword of its register pair (op_sel:[x,1] / op_sel:[x,x,1]).
+
+Round 4 measured (tools/study/ri_repro.hip): `v_pk_add_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` -- low result = a.lo + b.HI -- returned a.lo alone
+(b.hi read as zero) in lanes 48 .. 63, about once in 8 million executions, while waves of another kernel shared the SIMD; the same sum written with the swapped pair
+as the FIRST source (op_sel:[1,0]) never did (0 of 12,000 launches against 164 of 6,000).  hipcc emits the risky form by itself when SLP vectorisation packs a
+horizontal pair sum (k_enc_fused had six), so the listing of EVERY kernel file is checked, not only hand-written asm.
+
+   python3 tools/check_pk_opsel.py build/*.s        exit status 1 and the offending lines when the form is present"""
+import re, sys
+
+PK = re.compile(r"^\s*(v_pk_(?:add|mul|fma)_f32)\s+(.*)$")
+SEL = re.compile(r"op_sel:\[([01](?:,[01])*)\]")
+
+
+def risky(line):
+    m = PK.match(line)
+    if not m:
+        return False
+    s = SEL.search(m.group(2))
+    if not s:
+        return False
+    bits = s.group(1).split(",")
+    return any(b == "1" for b in bits[1:])        # low result's src1 (or src2) taken from the high dword
+
+
+def check(path):
+    bad, kernel = [], None
+    for n, line in enumerate(open(path), 1):
+        k = re.match(r"^(_Z\w+):", line)
+        if k:
+            kernel = k.group(1)
+        if risky(line):
+            bad.append((n, kernel, line.strip()))
+    return bad
+
+
+def main(argv):
+    total, files = 0, 0
+    for path in argv:
+        files += 1
+        for n, kernel, line in check(path):
+            total += 1
+            print(f"check_pk_opsel: {path}:{n}: in {kernel}: {line}\n   the LOW result takes a later source's HIGH dword: write the swapped pair as the first source (or keep the sum unpacked)", file=sys.stderr)
+    if total:
+        return 1
+    print(f"check_pk_opsel: {files} listing(s): no packed-fp32 instruction takes its low result's second / third source from a high dword")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

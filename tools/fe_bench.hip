@@ -4,9 +4,6 @@
 // Times every variant with HIP events on random s16 input and checks that all variants produce the same
 // bits (magnitudes in MODE 1; MODE 0 outputs except the rotated-order mean of STAGGER variants).
 #include "../vadc_amd/csrc/kernels_frontend.hip"
-namespace vadc {
-#include "study/k_frontend_ri.h"      // the (re, im)-packed form studied in round 4 (not in the product)
-}
 
 #include <cmath>
 #include <cstdio>

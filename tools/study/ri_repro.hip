@@ -1,13 +1,16 @@
-// tools/study/ri_repro.hip -- NOT part of the product.  A standalone reproducer for DESIGN.md 4.1 (d): k_frontend_ri (the (re, im)-packed front end, study/k_frontend_ri.h)
-// launched again and again on one stream while the layer kernels of the recurrence (k_lstm_layer, the product's) run on two other streams over dummy data;
-// every launch's magnitudes are compared ON THE DEVICE with k_frontend_sym's (computed alone, before).  Timing-only ablations of the NEIGHBOUR through the
-// product's macros tell which of its instruction classes it takes:
+// tools/study/ri_repro.hip -- NOT part of the product.  The reproducer behind DESIGN.md 4.1 (d) and tools/check_pk_opsel.py: k_frontend_ri (the product's kernel)
+// launched again and again on one stream while the layer kernels of the recurrence (k_lstm_layer, the product's) run on two other streams over dummy data; every
+// launch's magnitudes are compared ON THE DEVICE with k_frontend_sym's (computed alone, before).
+//   victim "ri"      the shipped form: the half-swapped pair is the FIRST source of the two v_pk_add_f32 per l-pair            0 of 12,000 launches differ
+//   victim "ri_src1" the natural form: `v_pk_add_f32 d, P, Q op_sel:[0,1] op_sel_hi:[1,0]`, low result = P.lo + Q.HI         164 of 6,000: always 16 words, one
+//                    row 64 -+ b, lanes 48 .. 63 of one workgroup, the low result = P.lo alone (the values occur nowhere else in the output)
+//   victim "sym"     k_frontend_sym                                                                                             0 of 6,000
+//   neighbour "none" any victim alone on the chip                                                                               0 of 3,000
+// Timing-only ablations of the NEIGHBOUR through the product's macros (no MFMAs / no transcendentals / no LDS-DMA: 2,444 / 60 / 513 of 6,000) say that no instruction
+// class of it is needed -- only that its waves share the SIMDs:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize [-DVADC_LSTM_ABL_NOMFMA | -DVADC_LSTM_ABL_NOGATES | -DVADC_LSTM_ABL_NOXLOAD] tools/study/ri_repro.hip -o tools/study/ri_repro
-//   tools/study/ri_repro [launches = 6000] [victim: ri | sym] [neighbour: lstm | none]
+//   tools/study/ri_repro [launches = 6000] [victim: ri | ri_src1 | sym] [neighbour: lstm | none]
 #include "../../vadc_amd/csrc/kernels_frontend.hip"
-namespace vadc {
-#include "k_frontend_ri.h"
-}
 #include "../../vadc_amd/csrc/kernels_lstm.hip"
 #include <cmath>
 #include <cstdio>
@@ -27,7 +30,8 @@ __global__ void k_count_diff(const unsigned *a, const unsigned *b, size_t n, uns
 int main(int argc, char **argv)
 {
    const int R = argc > 1 ? atoi(argv[1]) : 6000;
-   const bool victim_ri = !(argc > 2 && !strcmp(argv[2], "sym"));
+   const char *victim = argc > 2 ? argv[2] : "ri";
+   const bool victim_ri = !strcmp(victim, "ri"), victim_src1 = !strcmp(victim, "ri_src1");
    const bool neighbour = !(argc > 3 && !strcmp(argv[3], "none"));
    const int n = 2048;                                      // chunks per front-end launch: 800 workgroups
    // basis with the DFT symmetries by construction (tools/fe_bench.hip), speech-like input
@@ -87,8 +91,9 @@ int main(int argc, char **argv)
    int bad = 0;
    for (int r = 0; r < R; ++r) {
       cnt[0] = 0; cnt[1] = 0;
-      if (victim_ri) hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4>), grid, dim3(256), 0, sv, pcm, basis, basis_ri, Y1, FM, n, map, fm_stride, 1);
-      else           hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 3>), grid, dim3(256), 0, sv, pcm, basis, Y1, FM, n, map, fm_stride, 1);
+      if (victim_ri)        hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4, false>), grid, dim3(256), 0, sv, pcm, basis, basis_ri, Y1, FM, n, map, fm_stride, 1);
+      else if (victim_src1) hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4, true>), grid, dim3(256), 0, sv, pcm, basis, basis_ri, Y1, FM, n, map, fm_stride, 1);
+      else                  hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 3>), grid, dim3(256), 0, sv, pcm, basis, Y1, FM, n, map, fm_stride, 1);
       hipLaunchKernelGGL(k_count_diff, dim3(256), dim3(256), 0, sv, (const unsigned *)Y0, (const unsigned *)Y1, ny, cnt, cnt + 1);
       CK(hipStreamSynchronize(sv));
       if (cnt[0] && bad < 4) {                              // where do the wrong values come from?  search k_frontend_sym's output for the same bits near by
@@ -112,6 +117,6 @@ int main(int argc, char **argv)
       if (cnt[0]) { ++bad; if (bad <= 6) { const size_t i = cnt[1]; printf("   launch %d: %u words differ; first: chunk %zu bin %zu frame %zu (position %zu -> lane %zu)\n", r, cnt[0], i / (kBins * kFrames), (i / kFrames) % kBins, i % kFrames, (i / (kBins * kFrames)) * kFrames + i % kFrames, ((i / (kBins * kFrames)) * kFrames + i % kFrames) % 64); } }
    }
    stop = true; th.join();
-   printf("%s beside %s: %d of %d launches differ from k_frontend_sym alone\n", victim_ri ? "k_frontend_ri" : "k_frontend_sym", neighbour ? "k_lstm_layer (both layers, 640 tiles)" : "nothing", bad, R);
+   printf("%s beside %s: %d of %d launches differ from k_frontend_sym alone\n", victim_ri ? "k_frontend_ri (swapped pair first)" : victim_src1 ? "k_frontend_ri<SRC1> (swapped pair second)" : "k_frontend_sym", neighbour ? "k_lstm_layer (both layers, 640 tiles)" : "nothing", bad, R);
    return 0;
 }

@@ -20,8 +20,8 @@
 namespace vadc {
 void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
-void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
+void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int, const float *);
+void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int, const float *);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
@@ -156,6 +156,7 @@ struct vadc_amd_engine {
    hipStream_t stream = nullptr;
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
+   const float *d_basis_ri = nullptr;           // base bins 0..32 with (re, im) interleaved per tap: k_frontend_ri's copy ([33][ii][lp][l % 2][j][re | im]), when sym_ok
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
    bool cu_layout_ok = false;                   // 256 CUs and CU-mask bit i -> XCD i % 8 (cu_mask_layout_ok): what the LSTM partition rules assume
    int cu_mask_check = 1;                       // option "cu_mask_check": 1 = the partition needs cu_layout_ok (default), 0 = trust the rules anyway, 2 = behave as if the check had failed (tests)
@@ -164,7 +165,7 @@ struct vadc_amd_engine {
    bool trail_possible() const { return overlap_check == 1 && kernels_overlap; }
    bool cu_partition_usable() const { return cu_mask_check == 0 || (cu_mask_check == 1 && cu_layout_ok); }
    bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
-   int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree: kernels_frontend.hip)
+   int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree), or 11 = k_frontend_ri ((re, im)-packed trees and epilogue: 8 % fewer instructions, the same time -- kernels_frontend.hip)
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
    int encoder_variant = 0;                     // 0 = default (layers 2-4 fused in one launch when the weights allow), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4, 5 = one launch per layer (split-fp16)
@@ -363,6 +364,17 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                for (int b = 0; b < 2; ++b)
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
+   // the same taps for k_frontend_ri: base bins 0..32, the re and the im tap of a position side by side (an SGPR pair = second operand of one v_pk_mul_f32 whose
+   // first is the sample, broadcast): [f][i = 3,2,1,0][l / 2][l % 2][j][re | im]; one (group, l-pair) block of slack for the pipeline's last prefetch
+   std::vector<float> ri((size_t)(33 + 2) * 512 + 64, 0.0f);
+   for (int f = 0; f < 33; ++f)
+      for (int ii = 0; ii < 4; ++ii)
+         for (int lp = 0; lp < 4; ++lp)
+            for (int h = 0; h < 2; ++h)
+               for (int j = 0; j < 8; ++j)
+                  for (int c = 0; c < 2; ++c)
+                     ri[(size_t)f * 512 + ii * 128 + lp * 32 + h * 16 + j * 2 + c] = tmp[(size_t)(c ? kBins + f : f) * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + h)];
+   const size_t off_basis_ri = pk.add(ri.data(), ri.size());
    size_t off_afrag = 0, off_nyq = 0;
    e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // FAST_STFT precision mode
    e->sym_ok = basis_has_dft_symmetries(tmp);
@@ -602,6 +614,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
+      e->d_basis_ri = base + off_basis_ri;
       if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
       for (int l = 0; l < 4; ++l) {
          LayerWeights w;
@@ -1137,7 +1150,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3)) { e->fe_opt = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3 || value == 11)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
@@ -1439,8 +1452,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
       } else if (fk == 0) {
          // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
-         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0);
-         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0);
+         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
+         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
       } else {
          // any basis, any alignment: the full tree for all 129 bins
          if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
@@ -2191,7 +2204,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
                                e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt, e->zero_im0);
+   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
