@@ -160,6 +160,7 @@ struct vadc_amd_engine {
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
    bool cu_layout_ok = false;                   // 256 CUs and CU-mask bit i -> XCD i % 8 (cu_mask_layout_ok): what the LSTM partition rules assume
    int cu_mask_check = 1;                       // option "cu_mask_check": 1 = the partition needs cu_layout_ok (default), 0 = trust the rules anyway, 2 = behave as if the check had failed (tests)
+   double clock_scale = 1.0;                    // 2.4 GHz / the device's peak shader clock: scales the partition rules' measured times (lstm_slot_us, enc_us_per_chunk)
    bool kernels_overlap = false;                // two kernels on two masked streams were seen to run at the same time (cu_mask_layout_flags bit 1): what "lstm_trail" needs
    int overlap_check = 1;                       // option "overlap_check": 1 = "lstm_trail" needs kernels_overlap (default), 2 = behave as if the probe had failed (tests)
    bool trail_possible() const { return overlap_check == 1 && kernels_overlap; }
@@ -950,6 +951,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    const size_t N = e->max_items;
    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
    e->n_cus = prop.multiProcessorCount;
+   if (prop.clockRate > 500000 && prop.clockRate < 5000000) e->clock_scale = 2400000.0 / prop.clockRate;      // kHz; MI355X reports 2,400,000
    e->cu_layout_ok = (cu_mask_layout_flags(device, e->n_cus) & 1) != 0;
    e->kernels_overlap = (cu_mask_layout_flags(device, e->n_cus) & 2) != 0;
    for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -1465,11 +1467,15 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
 
 // Cost model shared by the two scheduling decisions below (measured on MI355X): microseconds per recurrence slot of
 // one stream tile, and whole-chip front-end + encoder time per chunk.
-static double lstm_slot_us(const vadc_amd_engine *, int lk) { return lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9); }
+// The two measured constants of the partition rules, taken on an MI355X (256 CUs, 2.4 GHz peak): a slot of the recurrence is a latency (it scales with the clock),
+// the front end + encoder's time per chunk a throughput (clock x CUs) -- on a part that reports another clock both are scaled, so that the rules compare like with like
+// (the partition itself is only used on the CU layout the create-time check knows: cu_mask_layout_flags)
+static double lstm_slot_us(const vadc_amd_engine *e, int lk) { return (lk == 7 ? 0.75 : (lk == 6 ? 1.6 : 3.9)) * e->clock_scale; }
 static double enc_us_per_chunk(const vadc_amd_engine *e)
 {
-   if (e->model == VADC_AMD_MODEL_V4) return 0.022;
-   return e->use_gemm_frontend() ? 0.022 : (e->sym_ok && e->frontend_variant == 0 ? 0.033 : 0.075);      // round 3: layers 2-4 fused (0.010 -> 0.0046 us per chunk)
+   const double cu_scale = e->n_cus > 0 ? 256.0 / e->n_cus : 1.0;
+   if (e->model == VADC_AMD_MODEL_V4) return 0.022 * e->clock_scale * cu_scale;
+   return (e->use_gemm_frontend() ? 0.022 : (e->sym_ok && e->frontend_variant == 0 ? 0.033 : 0.075)) * e->clock_scale * cu_scale;      // round 3: layers 2-4 fused (0.010 -> 0.0046 us per chunk)
 }
 
 // LSTM kernel for this call: option "lstm" 0 = auto.  3 = k_lstm_wavefront_fused (fp32 MFMA) when an LSTM weight does not fit fp16's range, or when
