@@ -1,0 +1,101 @@
+// tools/study/pk_opsel_hazard.hip -- a synthetic probe of the behaviour behind tools/check_pk_opsel.py, without any kernel of the product:
+// a victim whose waves execute, again and again,   E = v_pk_add_f32(P, Q) op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]   (low result = P.lo - Q.HI)
+// on fresh P, Q and compare the low result with a scalar v_sub_f32 of the same registers -- alone, and beside a neighbour kernel on another stream whose waves
+// share the SIMDs (a barrier + LDS + vector-ALU loop).  Variant "src0": the same sum with the swapped pair as the first source (op_sel:[1,0]).
+//   hipcc --offload-arch=gfx950 -O2 -o tools/study/pk_opsel_hazard tools/study/pk_opsel_hazard.hip ;  tools/study/pk_opsel_hazard [launches = 2000]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <atomic>
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int SRC0>
+__global__ __launch_bounds__(256, 4) void k_victim(const float *seed, unsigned *bad, unsigned *bad_lane_hist, int iters)
+{
+   const int lane = threadIdx.x & 63;
+   float a = seed[threadIdx.x] + blockIdx.x * 1e-3f, b = seed[256 + threadIdx.x], c = seed[512 + threadIdx.x], d = seed[768 + threadIdx.x];
+   unsigned wrong = 0;
+   // the surroundings the instruction has in k_frontend_ri: taps arrive by scalar loads issued right behind it, products take an SGPR pair and a broadcast sample
+   f16v ta, tb;
+   asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ta), "=&s"(tb) : "s"(seed));
+   for (int i = 0; i < iters; ++i) {
+      // fresh operands as in a tree: eight products x * (re, im) of an SGPR pair with the sample broadcast, summed pairwise
+      f2v q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+         const f2v xp = {a + 0.03125f * j, b - 0.0625f * j}, kp = {(j & 1) ? tb[2 * (j >> 1)] : ta[2 * (j >> 1)], (j & 1) ? tb[2 * (j >> 1) + 1] : ta[2 * (j >> 1) + 1]};
+         if (j < 4) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=&v"(q[j]) : "v"(xp), "s"(kp));
+         else       asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=&v"(q[j]) : "v"(xp), "s"(kp));
+      }
+      f2v P = ((q[0] + q[1]) + (q[2] + q[3])) + (f2v){c, d};
+      f2v Q = ((q[4] + q[5]) + (q[6] + q[7])) - (f2v){d, c};
+      f2v E;
+      if (SRC0) asm volatile("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=&v"(E) : "v"(P), "v"(Q));
+      else      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(E) : "v"(P), "v"(Q));
+      // the next stage's taps are requested right behind it (different tuples in turn, as the kernel's double buffer)
+      if (i & 1) asm volatile("s_load_dwordx16 %0, %1, 0x80" : "=&s"(ta) : "s"(seed));
+      else       asm volatile("s_load_dwordx16 %0, %1, 0xc0" : "=&s"(tb) : "s"(seed));
+      float want_lo, want_hi;
+      asm volatile("v_sub_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5" : "=&v"(want_lo), "=&v"(want_hi) : "v"(P.x), "v"(Q.y), "v"(P.y), "v"(Q.x));
+      if (__float_as_uint(E.x) != __float_as_uint(want_lo) || __float_as_uint(E.y) != __float_as_uint(want_hi)) {
+         if (!wrong && atomicAdd(bad + 66, 1u) == 0) { float *dbg = reinterpret_cast<float *>(bad + 67); dbg[0] = P.x; dbg[1] = P.y; dbg[2] = Q.x; dbg[3] = Q.y; dbg[4] = E.x; dbg[5] = E.y; dbg[6] = want_lo; dbg[7] = want_hi; bad[75] = lane; bad[76] = i; }
+         ++wrong;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ta), "+s"(tb));
+      // next iteration's values depend on this one's (no hoisting), stay bounded
+      a = a * 0.75f + E.x * 0.125f + 0.01f; b = b * 0.75f - E.y * 0.125f; c = c * 0.5f + want_lo * 0.25f; d = d * 0.5f + 0.125f * want_hi + 0.02f;
+   }
+   if (wrong) { atomicAdd(bad, wrong); atomicAdd(bad_lane_hist + lane, 1u); }
+   if (a + b + c + d == 12345.678f) bad[1] = 1;       // keep the chain alive
+}
+
+// the neighbour: workgroups of 8 waves that take turns at a barrier, exchange through the LDS and do some vector arithmetic -- what a recurrence kernel looks like to its SIMD
+__global__ __launch_bounds__(512, 4) void k_neighbour(float *out, int iters)
+{
+   __shared__ float sh[512];
+   float v = threadIdx.x * 0.001f;
+   for (int i = 0; i < iters; ++i) {
+      sh[threadIdx.x] = v;
+      __syncthreads();
+      v = sh[(threadIdx.x + 37) & 511] * 0.5f + v * 0.25f + 0.1f;
+      v = __builtin_amdgcn_rcpf(1.0f + v * v) + v * 0.125f;
+      __syncthreads();
+   }
+   out[blockIdx.x * 512 + threadIdx.x] = v;
+}
+
+int main(int argc, char **argv)
+{
+   const int R = argc > 1 ? atoi(argv[1]) : 2000;
+   float h[1024]; srand(3); for (float &x : h) x = ((rand() % 2001) - 1000) / 997.0f;
+   float *seed, *nout; unsigned *bad;
+   CK(hipMalloc(&seed, sizeof h)); CK(hipMemcpy(seed, h, sizeof h, hipMemcpyHostToDevice));
+   CK(hipMalloc(&nout, 2048 * 512 * 4));
+   CK(hipHostMalloc(&bad, (2 + 64 + 16) * 4));
+   hipStream_t sv, sn;
+   CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sn, hipStreamNonBlocking));
+   for (int neighbour = 0; neighbour < 2; ++neighbour)
+      for (int src0 = 0; src0 < 2; ++src0) {
+         std::atomic<bool> stop{false};
+         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_neighbour, dim3(1024), dim3(512), 0, sn, nout, 40); (void)hipStreamSynchronize(sn); } });
+         for (int i = 0; i < 82; ++i) bad[i] = 0;
+         int bad_launches = 0; unsigned long long executions = 0;
+         for (int r = 0; r < R; ++r) {
+            const unsigned before = bad[0];
+            if (src0) hipLaunchKernelGGL(k_victim<1>, dim3(1024), dim3(256), 0, sv, seed, bad, bad + 2, 400);
+            else      hipLaunchKernelGGL(k_victim<0>, dim3(1024), dim3(256), 0, sv, seed, bad, bad + 2, 400);
+            CK(hipStreamSynchronize(sv));
+            executions += 1024ull * 4 * 400;
+            if (bad[0] != before) ++bad_launches;
+         }
+         stop = true; th.join();
+         if (bad[66]) { const float *dbg = reinterpret_cast<const float *>(bad + 67); printf("   first wrong result: lane %u iteration %u: P (%a, %a) Q (%a, %a) -> E (%a, %a), scalar (%a, %a)\n", bad[75], bad[76], dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]); }
+         unsigned lo = 0, hi = 0; for (int l = 0; l < 64; ++l) (l < 48 ? lo : hi) += bad[2 + l];
+         printf("swapped pair as the %s source, %s: %d of %d launches with a wrong result (%u wrong results in %.2e wave-executions; lanes 0..47: %u waves-lanes, lanes 48..63: %u)\n",
+                src0 ? "FIRST " : "SECOND", neighbour ? "beside the neighbour kernel" : "alone on the chip          ", bad_launches, R, bad[0], (double)executions, lo, hi);
+      }
+   return 0;
+}
