@@ -3,12 +3,21 @@
 // on fresh P, Q and compare the low result with a scalar v_sub_f32 of the same registers -- alone, and beside a neighbour kernel on another stream whose waves
 // share the SIMDs (a barrier + LDS + vector-ALU loop).  Variant "src0": the same sum with the swapped pair as the first source (op_sel:[1,0]).
 //   hipcc --offload-arch=gfx950 -O2 -o tools/study/pk_opsel_hazard tools/study/pk_opsel_hazard.hip ;  tools/study/pk_opsel_hazard [launches = 2000]
+#ifdef WITH_LSTM          // -DWITH_LSTM: the neighbour is the product's k_lstm_layer pair (as in ri_repro.hip) instead of the synthetic one
+#include "../../vadc_amd/csrc/kernels_lstm.hip"
+#include <vector>
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <atomic>
 typedef float f2v __attribute__((ext_vector_type(2)));
+#ifdef WITH_LSTM
+#define NEIGHBOUR_NAME "beside k_lstm_layer x 2      "
+#else
+#define NEIGHBOUR_NAME "beside the neighbour kernel"
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -53,23 +62,61 @@ __global__ __launch_bounds__(256, 4) void k_victim(const float *seed, unsigned *
 }
 
 // the neighbour: workgroups of 8 waves that take turns at a barrier, exchange through the LDS and do some vector arithmetic -- what a recurrence kernel looks like to its SIMD
+// NEIGHBOUR_FEATURE (compile-time bit mask): 1 = an LDS-DMA load per iteration (global_load_lds_dwordx4 with its M0 write), 2 = a plain vector load, 4 = a v_mfma,
+// 8 = only the M0 write, 16 = ~110 registers per lane, 32 = a 16-byte store per lane and iteration
+#ifndef NEIGHBOUR_FEATURE
+#define NEIGHBOUR_FEATURE 0
+#endif
 __global__ __launch_bounds__(512, 4) void k_neighbour(float *out, int iters)
 {
    __shared__ float sh[512];
+   __shared__ __attribute__((aligned(16))) float dma[8 * 256];      // 8 waves x 1 KB
    float v = threadIdx.x * 0.001f;
+   float big[104];                                        // NEIGHBOUR_FEATURE 5: ~128 registers per lane, as k_lstm_layer
+   if (NEIGHBOUR_FEATURE & 16) { for (int e = 0; e < 104; ++e) big[e] = v + e; for (int e = 0; e < 104; ++e) asm volatile("" : "+v"(big[e])); }
+   typedef __attribute__((address_space(3))) void lds_void;
    for (int i = 0; i < iters; ++i) {
+      if (NEIGHBOUR_FEATURE & 1) {
+         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void *)&dma[(threadIdx.x >> 6) * 256]);
+         const float *g = out + ((size_t)blockIdx.x * 512 + threadIdx.x) * 4 % (2048 * 512 - 4);
+         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
+      }
+      if (NEIGHBOUR_FEATURE & 2) { float t; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(out + threadIdx.x) : "memory"); v += t * 1e-30f; }
+      if (NEIGHBOUR_FEATURE & 8) { const unsigned dst = __builtin_amdgcn_readfirstlane(64u * (threadIdx.x >> 6)); asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory"); }
+      if (NEIGHBOUR_FEATURE & 32) { typedef unsigned u4v __attribute__((ext_vector_type(4))); u4v t4 = {__float_as_uint(v), 1u, 2u, 3u}; *reinterpret_cast<u4v *>(out + ((size_t)blockIdx.x * 512 + threadIdx.x) * 4 % (2048 * 512 - 4)) = t4; }
       sh[threadIdx.x] = v;
       __syncthreads();
+      if (NEIGHBOUR_FEATURE & 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); v += dma[threadIdx.x & 255] * 1e-30f; }
+      if (NEIGHBOUR_FEATURE & 4) {
+         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+         typedef float f4v __attribute__((ext_vector_type(4)));
+         h8v a8, b8; for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(v + e); b8[e] = (_Float16)(v - e); }
+#ifdef NEIGHBOUR_DENORM            // fp16 DENORMAL operands (the lo halves of split-fp16 weights are mostly denormals)
+         for (int e = 0; e < 8; ++e) a8[e] = (_Float16)(1.0e-6f * (float)(e + 1) + v * 1.0e-9f);
+#endif
+         f4v acc = {v, v, v, v}, acc2 = {v, -v, v, -v};
+#ifndef NEIGHBOUR_MFMAS
+#define NEIGHBOUR_MFMAS 1            // dependent MFMAs per accumulator and iteration (k_lstm_layer: 6 on each of two accumulators, back to back)
+#endif
+#pragma unroll
+         for (int r = 0; r < NEIGHBOUR_MFMAS; ++r) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc, 0, 0, 0);
+            if (NEIGHBOUR_MFMAS > 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b8, a8, acc2, 0, 0, 0);
+         }
+         v += (acc[0] + acc2[1]) * 1e-30f;
+      }
       v = sh[(threadIdx.x + 37) & 511] * 0.5f + v * 0.25f + 0.1f;
       v = __builtin_amdgcn_rcpf(1.0f + v * v) + v * 0.125f;
       __syncthreads();
    }
+   if (NEIGHBOUR_FEATURE & 16) { for (int e = 0; e < 104; ++e) asm volatile("" : "+v"(big[e])); for (int e = 0; e < 104; ++e) v += big[e] * 1e-30f; }
    out[blockIdx.x * 512 + threadIdx.x] = v;
 }
 
 int main(int argc, char **argv)
 {
    const int R = argc > 1 ? atoi(argv[1]) : 2000;
+   const int n_iters = getenv("NEIGHBOUR_ITERS") ? atoi(getenv("NEIGHBOUR_ITERS")) : 40;      // length of a neighbour workgroup's life
    float h[1024]; srand(3); for (float &x : h) x = ((rand() % 2001) - 1000) / 997.0f;
    float *seed, *nout; unsigned *bad;
    CK(hipMalloc(&seed, sizeof h)); CK(hipMemcpy(seed, h, sizeof h, hipMemcpyHostToDevice));
@@ -77,10 +124,29 @@ int main(int argc, char **argv)
    CK(hipHostMalloc(&bad, (2 + 64 + 16) * 4));
    hipStream_t sv, sn;
    CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sn, hipStreamNonBlocking));
+#ifdef WITH_LSTM
+   const int LS = 10240, ltiles = LS / 16, layers = getenv("LSTM_LAYERS") ? atoi(getenv("LSTM_LAYERS")) : 3;      // bit 0: layer 0's kernel, bit 1: layer 1's
+   hipStream_t sn2; CK(hipStreamCreateWithFlags(&sn2, hipStreamNonBlocking));
+   _Float16 *lx, *lh0; float *lwb, *lhs, *lcs, *lprobs;
+   const size_t tile_halves = (size_t)ltiles * 7 * 2 * 16 * 64;
+   CK(hipMalloc(&lx, tile_halves * 2)); CK(hipMalloc(&lh0, tile_halves * 2));
+   { std::vector<_Float16> hx(tile_halves); for (auto &v : hx) v = (_Float16)(((rand() % 2001) - 1000) / 4000.0f); CK(hipMemcpy(lx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(lh0, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
+   { std::vector<float> hw((size_t)2 * 256 * 128 + 2 * 256 + 128 + 2); for (auto &v : hw) v = ((rand() % 2001) - 1000) / 8000.0f; CK(hipMalloc(&lwb, hw.size() * 4)); CK(hipMemcpy(lwb, hw.data(), hw.size() * 4, hipMemcpyHostToDevice)); }
+   CK(hipMalloc(&lhs, (size_t)LS * 128 * 4)); CK(hipMalloc(&lcs, (size_t)LS * 128 * 4)); CK(hipMalloc(&lprobs, (size_t)LS * 2 * 4));
+   CK(hipMemset(lhs, 0, (size_t)LS * 128 * 4)); CK(hipMemset(lcs, 0, (size_t)LS * 128 * 4));
+   vadc::LstmWeights lw; lw.w = lwb; lw.wT = lwb; lw.b = lwb + 2 * 256 * 128; lw.dec_w = lw.b + 2 * 256; lw.dec_b = lw.dec_w + 128;
+#endif
    for (int neighbour = 0; neighbour < 2; ++neighbour)
       for (int src0 = 0; src0 < 2; ++src0) {
          std::atomic<bool> stop{false};
-         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_neighbour, dim3(1024), dim3(512), 0, sn, nout, 40); (void)hipStreamSynchronize(sn); } });
+#ifdef WITH_LSTM
+         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) {
+               if (layers & 1) vadc::launch_lstm_layer(0, reinterpret_cast<const float *>(lx), reinterpret_cast<float *>(lh0), lw, lhs, lcs, lprobs, LS, 1, 0, 1, sn, 0, 7, nullptr, 0, nullptr, 0);
+               if (layers & 2) vadc::launch_lstm_layer(1, reinterpret_cast<const float *>(lx), reinterpret_cast<float *>(lh0), lw, lhs, lcs, lprobs, LS, 1, 0, 1, sn2, 0, 7, nullptr, 0, nullptr, 0); }
+            (void)hipStreamSynchronize(sn); (void)hipStreamSynchronize(sn2); } });
+#else
+         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_neighbour, dim3(1024), dim3(512), 0, sn, nout, n_iters); (void)hipStreamSynchronize(sn); } });
+#endif
          for (int i = 0; i < 82; ++i) bad[i] = 0;
          int bad_launches = 0; unsigned long long executions = 0;
          for (int r = 0; r < R; ++r) {
@@ -95,7 +161,7 @@ int main(int argc, char **argv)
          if (bad[66]) { const float *dbg = reinterpret_cast<const float *>(bad + 67); printf("   first wrong result: lane %u iteration %u: P (%a, %a) Q (%a, %a) -> E (%a, %a), scalar (%a, %a)\n", bad[75], bad[76], dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]); }
          unsigned lo = 0, hi = 0; for (int l = 0; l < 64; ++l) (l < 48 ? lo : hi) += bad[2 + l];
          printf("swapped pair as the %s source, %s: %d of %d launches with a wrong result (%u wrong results in %.2e wave-executions; lanes 0..47: %u waves-lanes, lanes 48..63: %u)\n",
-                src0 ? "FIRST " : "SECOND", neighbour ? "beside the neighbour kernel" : "alone on the chip          ", bad_launches, R, bad[0], (double)executions, lo, hi);
+                src0 ? "FIRST " : "SECOND", neighbour ? NEIGHBOUR_NAME : "alone on the chip          ", bad_launches, R, bad[0], (double)executions, lo, hi);
       }
    return 0;
 }

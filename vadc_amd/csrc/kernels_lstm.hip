@@ -490,6 +490,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = (s0 + col) < n_streams;
    const int u0 = 8 * wave + 2 * quad;                    // this lane's cells: units u0 (row tile 0) and u0 + 1 (row tile 1), stream col
+#ifdef VADC_LSTM_ABL_STOP          // (study of tools/study/pk_opsel_hazard.hip: the kernel ends after phase N -- results are garbage)
+   if (VADC_LSTM_ABL_STOP == 1) return;
+#endif
 
    // A fragments, split.  Row tile m, row 4 q + r of it = gate r of unit 8 wave + 2 q + m; lane holds row (lane & 15), k = 32 kb + 8 quad + e.
    h8v ah[2][4], al[2][4];
@@ -511,6 +514,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
    }
    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
    float c[2], hlast[2], bias_r[2][4];
+#ifdef VADC_LSTM_ABL_STOP
+   if (VADC_LSTM_ABL_STOP == 2) { if (ah[0][0][0] == (_Float16)123.0f && al[1][3][7] == (_Float16)77.0f) probs[0] = 1.0f; return; }      // behind the weight fragments
+#endif
    if (L == 1 && tid < 128) dws[tid >> 6][tid & 63] = w.dec_w[tid];
 #pragma unroll
    for (int m = 0; m < 2; ++m)
@@ -596,6 +602,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    }
    __syncthreads();
+#ifdef VADC_LSTM_ABL_STOP
+   if (VADC_LSTM_ABL_STOP == 3) { if (ah[0][0][0] == (_Float16)123.0f && c[0] == 5.0f) probs[0] = 1.0f; return; }      // behind the state loads, the LDS h tile and the prologue's four DMA pieces
+#endif
    f4v accx[2];
 #pragma unroll
    for (int m = 0; m < 2; ++m) {
@@ -604,12 +613,19 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
          const h8v bh = xfrag(0, 0, kb), bl = xfrag(0, 1, kb);
+#if defined(VADC_LSTM_ABL_STOP) && defined(VADC_LSTM_ABL_PROLOGUE_NOMFMA)
+         accx[m][0] += (float)bh[0] + (float)bl[1] + (float)ah[m][kb][2] + (float)al[m][kb][3];
+#else
          accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kb], bh, accx[m], 0, 0, 0);
          accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bl, accx[m], 0, 0, 0);
          accx[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kb], bh, accx[m], 0, 0, 0);
+#endif
       }
    }
    __syncthreads();                                           // ring slot 0 is free for step 4
+#ifdef VADC_LSTM_ABL_STOP
+   if (VADC_LSTM_ABL_STOP == 4) { if (accx[0][0] == 123.0f && accx[1][3] == 5.0f) probs[0] = 1.0f; return; }      // behind the twelve MFMAs of the first slot's input half
+#endif
 
    int par = 0;
    float rsum[2] = {0.0f, 0.0f};
