@@ -1,8 +1,19 @@
-// tools/study/pk_opsel_hazard.hip -- a synthetic probe of the behaviour behind tools/check_pk_opsel.py, without any kernel of the product:
-// a victim whose waves execute, again and again,   E = v_pk_add_f32(P, Q) op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]   (low result = P.lo - Q.HI)
-// on fresh P, Q and compare the low result with a scalar v_sub_f32 of the same registers -- alone, and beside a neighbour kernel on another stream whose waves
-// share the SIMDs (a barrier + LDS + vector-ALU loop).  Variant "src0": the same sum with the swapped pair as the first source (op_sel:[1,0]).
-//   hipcc --offload-arch=gfx950 -O2 -o tools/study/pk_opsel_hazard tools/study/pk_opsel_hazard.hip ;  tools/study/pk_opsel_hazard [launches = 2000]
+// tools/study/pk_opsel_hazard.hip -- a fully synthetic reproducer of the gfx950 behaviour behind tools/check_pk_opsel.py; no kernel of the product is needed.
+//
+//   VICTIM     waves that execute, again and again,   E = v_pk_add_f32(P, Q) op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]   (low result = P.lo - Q.HI: the low result takes the
+//              SECOND source's HIGH dword) on fresh P, Q and compare both results with scalar v_sub_f32 / v_add_f32 of the same registers.
+//   NEIGHBOUR  a kernel on another stream whose waves share the SIMDs: barrier + LDS + vector ALU, plus (kind 1) MFMAs on two accumulators in turn or (kind 2) six
+//              BACK-TO-BACK DEPENDENT v_mfma_f32_16x16x32_f16 on ONE accumulator (each takes the previous one's result as its SrcC) -- what the inner loop of any GEMM is.
+//
+//   measured (MI355X, ROCm 7.2; 1.6e9 executions of the instruction per line):
+//      alone on the chip                                   0 wrong results
+//      beside kind 0 / kind 1                               0 / 0
+//      beside kind 2                                        7,351,488 wrong results (1 in 220), ALL in lanes 48 .. 63, low result = P.lo alone (Q.hi read as zero), high result right
+//      the same sum with the swapped pair as the FIRST source (v_pk_add_f32 E, Q, P op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]), beside kind 2:   0
+//
+//   hipcc --offload-arch=gfx950 -O2 -o tools/study/pk_opsel_hazard tools/study/pk_opsel_hazard.hip ;  tools/study/pk_opsel_hazard [launches = 1000]
+//   (-DWITH_LSTM: the neighbour is the product's k_lstm_layer pair instead -- 137,920 wrong results in 2.5e9; its first block of twelve MFMAs, six dependent per accumulator,
+//    is what it takes: -DVADC_LSTM_ABL_STOP=1..4, -DVADC_LSTM_ABL_PROLOGUE_NOMFMA)
 #ifdef WITH_LSTM          // -DWITH_LSTM: the neighbour is the product's k_lstm_layer pair (as in ri_repro.hip) instead of the synthetic one
 #include "../../vadc_amd/csrc/kernels_lstm.hip"
 #include <vector>
@@ -13,11 +24,6 @@
 #include <thread>
 #include <atomic>
 typedef float f2v __attribute__((ext_vector_type(2)));
-#ifdef WITH_LSTM
-#define NEIGHBOUR_NAME "beside k_lstm_layer x 2      "
-#else
-#define NEIGHBOUR_NAME "beside the neighbour kernel"
-#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -61,47 +67,25 @@ __global__ __launch_bounds__(256, 4) void k_victim(const float *seed, unsigned *
    if (a + b + c + d == 12345.678f) bad[1] = 1;       // keep the chain alive
 }
 
-// the neighbour: workgroups of 8 waves that take turns at a barrier, exchange through the LDS and do some vector arithmetic -- what a recurrence kernel looks like to its SIMD
-// NEIGHBOUR_FEATURE (compile-time bit mask): 1 = an LDS-DMA load per iteration (global_load_lds_dwordx4 with its M0 write), 2 = a plain vector load, 4 = a v_mfma,
-// 8 = only the M0 write, 16 = ~110 registers per lane, 32 = a 16-byte store per lane and iteration
-#ifndef NEIGHBOUR_FEATURE
-#define NEIGHBOUR_FEATURE 0
-#endif
+// the neighbour: workgroups of 8 waves that take turns at a barrier, exchange through the LDS and do some vector arithmetic -- what a recurrence kernel looks like to its SIMD.
+// KIND 0: that alone; 1: + six MFMAs on each of two accumulators, the two chains in turn; 2: + six MFMAs BACK TO BACK on ONE accumulator, each taking the previous one's result
+template <int KIND>
 __global__ __launch_bounds__(512, 4) void k_neighbour(float *out, int iters)
 {
    __shared__ float sh[512];
-   __shared__ __attribute__((aligned(16))) float dma[8 * 256];      // 8 waves x 1 KB
    float v = threadIdx.x * 0.001f;
-   float big[104];                                        // NEIGHBOUR_FEATURE 5: ~128 registers per lane, as k_lstm_layer
-   if (NEIGHBOUR_FEATURE & 16) { for (int e = 0; e < 104; ++e) big[e] = v + e; for (int e = 0; e < 104; ++e) asm volatile("" : "+v"(big[e])); }
-   typedef __attribute__((address_space(3))) void lds_void;
+   typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+   typedef float f4v __attribute__((ext_vector_type(4)));
    for (int i = 0; i < iters; ++i) {
-      if (NEIGHBOUR_FEATURE & 1) {
-         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void *)&dma[(threadIdx.x >> 6) * 256]);
-         const float *g = out + ((size_t)blockIdx.x * 512 + threadIdx.x) * 4 % (2048 * 512 - 4);
-         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(g) : "memory");
-      }
-      if (NEIGHBOUR_FEATURE & 2) { float t; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(out + threadIdx.x) : "memory"); v += t * 1e-30f; }
-      if (NEIGHBOUR_FEATURE & 8) { const unsigned dst = __builtin_amdgcn_readfirstlane(64u * (threadIdx.x >> 6)); asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory"); }
-      if (NEIGHBOUR_FEATURE & 32) { typedef unsigned u4v __attribute__((ext_vector_type(4))); u4v t4 = {__float_as_uint(v), 1u, 2u, 3u}; *reinterpret_cast<u4v *>(out + ((size_t)blockIdx.x * 512 + threadIdx.x) * 4 % (2048 * 512 - 4)) = t4; }
       sh[threadIdx.x] = v;
       __syncthreads();
-      if (NEIGHBOUR_FEATURE & 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); v += dma[threadIdx.x & 255] * 1e-30f; }
-      if (NEIGHBOUR_FEATURE & 4) {
-         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-         typedef float f4v __attribute__((ext_vector_type(4)));
+      if (KIND) {
          h8v a8, b8; for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(v + e); b8[e] = (_Float16)(v - e); }
-#ifdef NEIGHBOUR_DENORM            // fp16 DENORMAL operands (the lo halves of split-fp16 weights are mostly denormals)
-         for (int e = 0; e < 8; ++e) a8[e] = (_Float16)(1.0e-6f * (float)(e + 1) + v * 1.0e-9f);
-#endif
          f4v acc = {v, v, v, v}, acc2 = {v, -v, v, -v};
-#ifndef NEIGHBOUR_MFMAS
-#define NEIGHBOUR_MFMAS 1            // dependent MFMAs per accumulator and iteration (k_lstm_layer: 6 on each of two accumulators, back to back)
-#endif
 #pragma unroll
-         for (int r = 0; r < NEIGHBOUR_MFMAS; ++r) {
+         for (int r = 0; r < 6; ++r) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc, 0, 0, 0);
-            if (NEIGHBOUR_MFMAS > 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b8, a8, acc2, 0, 0, 0);
+            if (KIND == 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b8, a8, acc2, 0, 0, 0);
          }
          v += (acc[0] + acc2[1]) * 1e-30f;
       }
@@ -109,14 +93,13 @@ __global__ __launch_bounds__(512, 4) void k_neighbour(float *out, int iters)
       v = __builtin_amdgcn_rcpf(1.0f + v * v) + v * 0.125f;
       __syncthreads();
    }
-   if (NEIGHBOUR_FEATURE & 16) { for (int e = 0; e < 104; ++e) asm volatile("" : "+v"(big[e])); for (int e = 0; e < 104; ++e) v += big[e] * 1e-30f; }
    out[blockIdx.x * 512 + threadIdx.x] = v;
 }
 
 int main(int argc, char **argv)
 {
-   const int R = argc > 1 ? atoi(argv[1]) : 2000;
-   const int n_iters = getenv("NEIGHBOUR_ITERS") ? atoi(getenv("NEIGHBOUR_ITERS")) : 40;      // length of a neighbour workgroup's life
+   const int R = argc > 1 ? atoi(argv[1]) : 1000;
+   const int n_iters = getenv("NEIGHBOUR_ITERS") ? atoi(getenv("NEIGHBOUR_ITERS")) : 400;     // length of a neighbour workgroup's life
    float h[1024]; srand(3); for (float &x : h) x = ((rand() % 2001) - 1000) / 997.0f;
    float *seed, *nout; unsigned *bad;
    CK(hipMalloc(&seed, sizeof h)); CK(hipMemcpy(seed, h, sizeof h, hipMemcpyHostToDevice));
@@ -136,7 +119,18 @@ int main(int argc, char **argv)
    CK(hipMemset(lhs, 0, (size_t)LS * 128 * 4)); CK(hipMemset(lcs, 0, (size_t)LS * 128 * 4));
    vadc::LstmWeights lw; lw.w = lwb; lw.wT = lwb; lw.b = lwb + 2 * 256 * 128; lw.dec_w = lw.b + 2 * 256; lw.dec_b = lw.dec_w + 128;
 #endif
-   for (int neighbour = 0; neighbour < 2; ++neighbour)
+#ifdef WITH_LSTM
+   const int kinds = 2;      // 0 = alone, 1 = beside k_lstm_layer x 2
+#else
+   const int kinds = 4;      // 0 = alone, 1 .. 3 = beside k_neighbour<0 .. 2>
+#endif
+   static const char *names[4] = {"alone on the chip                                      ",
+#ifdef WITH_LSTM
+                                  "beside the product's k_lstm_layer pair                  ", "", ""};
+#else
+                                  "beside a neighbour without MFMAs                        ", "beside a neighbour with MFMAs on two accumulators in turn", "beside a neighbour with DEPENDENT back-to-back MFMAs    "};
+#endif
+   for (int neighbour = 0; neighbour < kinds; ++neighbour)
       for (int src0 = 0; src0 < 2; ++src0) {
          std::atomic<bool> stop{false};
 #ifdef WITH_LSTM
@@ -145,7 +139,11 @@ int main(int argc, char **argv)
                if (layers & 2) vadc::launch_lstm_layer(1, reinterpret_cast<const float *>(lx), reinterpret_cast<float *>(lh0), lw, lhs, lcs, lprobs, LS, 1, 0, 1, sn2, 0, 7, nullptr, 0, nullptr, 0); }
             (void)hipStreamSynchronize(sn); (void)hipStreamSynchronize(sn2); } });
 #else
-         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_neighbour, dim3(1024), dim3(512), 0, sn, nout, n_iters); (void)hipStreamSynchronize(sn); } });
+         std::thread th([&] { if (!neighbour) return; (void)hipSetDevice(0); while (!stop) { for (int k = 0; k < 8; ++k) {
+               if (neighbour == 1) hipLaunchKernelGGL(k_neighbour<0>, dim3(1024), dim3(512), 0, sn, nout, n_iters);
+               if (neighbour == 2) hipLaunchKernelGGL(k_neighbour<1>, dim3(1024), dim3(512), 0, sn, nout, n_iters);
+               if (neighbour == 3) hipLaunchKernelGGL(k_neighbour<2>, dim3(1024), dim3(512), 0, sn, nout, n_iters); }
+            (void)hipStreamSynchronize(sn); } });
 #endif
          for (int i = 0; i < 82; ++i) bad[i] = 0;
          int bad_launches = 0; unsigned long long executions = 0;
@@ -160,8 +158,8 @@ int main(int argc, char **argv)
          stop = true; th.join();
          if (bad[66]) { const float *dbg = reinterpret_cast<const float *>(bad + 67); printf("   first wrong result: lane %u iteration %u: P (%a, %a) Q (%a, %a) -> E (%a, %a), scalar (%a, %a)\n", bad[75], bad[76], dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]); }
          unsigned lo = 0, hi = 0; for (int l = 0; l < 64; ++l) (l < 48 ? lo : hi) += bad[2 + l];
-         printf("swapped pair as the %s source, %s: %d of %d launches with a wrong result (%u wrong results in %.2e wave-executions; lanes 0..47: %u waves-lanes, lanes 48..63: %u)\n",
-                src0 ? "FIRST " : "SECOND", neighbour ? NEIGHBOUR_NAME : "alone on the chip          ", bad_launches, R, bad[0], (double)executions, lo, hi);
+         printf("swapped pair as the %s source, %s: %u wrong results in %.2e executions (%d of %d launches; waves with a wrong lane 0..47: %u, lane 48..63: %u)\n",
+                src0 ? "FIRST " : "SECOND", names[neighbour], bad[0], (double)executions, bad_launches, R, lo, hi);
       }
    return 0;
 }
