@@ -5,7 +5,8 @@ from the HIGH dword of its register pair (op_sel:[x,1] / op_sel:[x,x,1]).
 Round 4 measured (tools/study/pk_opsel_hazard.hip -- fully synthetic --, tools/study/ri_repro.hip): `v_pk_add_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` -- low
 result = a.lo + b.HI -- returns a.lo alone (b.hi read as zero) in lanes 48 .. 63 while a wave of ANOTHER kernel on the same SIMD issues back-to-back dependent MFMAs (one
 accumulator, each taking the previous result as its SrcC: any GEMM's inner loop): up to once in 220 executions; never alone on the chip, never beside MFMAs on alternating
-accumulators; the same sum written with the swapped pair as the FIRST source (op_sel:[1,0]) never (0 in 1.6e9 against 7.3 M).  hipcc emits the risky form by itself when SLP
+accumulators; the same sum written with the swapped pair as the FIRST source (op_sel:[1,0]) never (0 in 1.6e9 against 7.3 M).  v_pk_mul_f32 with op_sel:[0,1] and
+v_pk_fma_f32 with the swap on its third source (op_sel:[0,0,1]) behave the same (-DVICTIM_OP=1 / 2 of the probe).  hipcc emits the risky form by itself when SLP
 vectorisation packs a horizontal pair sum (k_enc_fused had six), so the listing of EVERY kernel file is checked, not only hand-written asm.
 
    python3 tools/check_pk_opsel.py build/*.s        exit status 1 and the offending lines when the form is present"""

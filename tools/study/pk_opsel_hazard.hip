@@ -48,13 +48,26 @@ __global__ __launch_bounds__(256, 4) void k_victim(const float *seed, unsigned *
       f2v P = ((q[0] + q[1]) + (q[2] + q[3])) + (f2v){c, d};
       f2v Q = ((q[4] + q[5]) + (q[6] + q[7])) - (f2v){d, c};
       f2v E;
+#if defined(VICTIM_OP) && VICTIM_OP == 1       // v_pk_mul_f32: low = P.lo * Q.hi, high = P.hi * Q.lo
+      if (SRC0) asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(E) : "v"(P), "v"(Q));
+      else      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(E) : "v"(P), "v"(Q));
+#elif defined(VICTIM_OP) && VICTIM_OP == 2     // v_pk_fma_f32 with the swap on the THIRD source: low = P.lo * P.lo + Q.hi, high = P.hi * P.hi + Q.lo
+      asm volatile("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=&v"(E) : "v"(P), "v"(Q));
+#else
       if (SRC0) asm volatile("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=&v"(E) : "v"(P), "v"(Q));
       else      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(E) : "v"(P), "v"(Q));
+#endif
       // the next stage's taps are requested right behind it (different tuples in turn, as the kernel's double buffer)
       if (i & 1) asm volatile("s_load_dwordx16 %0, %1, 0x80" : "=&s"(ta) : "s"(seed));
       else       asm volatile("s_load_dwordx16 %0, %1, 0xc0" : "=&s"(tb) : "s"(seed));
       float want_lo, want_hi;
+#if defined(VICTIM_OP) && VICTIM_OP == 1
+      asm volatile("v_mul_f32 %0, %2, %3\n\tv_mul_f32 %1, %4, %5" : "=&v"(want_lo), "=&v"(want_hi) : "v"(P.x), "v"(Q.y), "v"(P.y), "v"(Q.x));
+#elif defined(VICTIM_OP) && VICTIM_OP == 2
+      asm volatile("v_fma_f32 %0, %2, %2, %3\n\tv_fma_f32 %1, %4, %4, %5" : "=&v"(want_lo), "=&v"(want_hi) : "v"(P.x), "v"(Q.y), "v"(P.y), "v"(Q.x));
+#else
       asm volatile("v_sub_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5" : "=&v"(want_lo), "=&v"(want_hi) : "v"(P.x), "v"(Q.y), "v"(P.y), "v"(Q.x));
+#endif
       if (__float_as_uint(E.x) != __float_as_uint(want_lo) || __float_as_uint(E.y) != __float_as_uint(want_hi)) {
          if (!wrong && atomicAdd(bad + 66, 1u) == 0) { float *dbg = reinterpret_cast<float *>(bad + 67); dbg[0] = P.x; dbg[1] = P.y; dbg[2] = Q.x; dbg[3] = Q.y; dbg[4] = E.x; dbg[5] = E.y; dbg[6] = want_lo; dbg[7] = want_hi; bad[75] = lane; bad[76] = i; }
          ++wrong;
