@@ -1,4 +1,5 @@
-"""(needs the engine of commit b91f1ec, where option "fe_opt" = 11 selects k_frontend_ri: tools/study/k_frontend_ri.h)
+"""(the harness that first showed DESIGN.md 4.1 (d): with the engine of commit b91f1ec, whose k_frontend_ri -- option "fe_opt" = 11 -- had the swapped pair as the SECOND source of its
+packed additions, 37 - 50 of 6,000 runs differ; at HEAD the same option is the fixed form and no run does)
 engine A runs stage taps alone (front end; front end + first layers) again and again while engine B, from another thread, keeps the device busy with whole steps
 (10,240 x 1, layer-major LSTM): does a stage of A ever change its bits?"""
 import sys, os, threading
