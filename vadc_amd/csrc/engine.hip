@@ -5,6 +5,7 @@
 // silero_run_one_batch_with_context (silero_v3.c:72-215).  No arithmetic of the path happens on the host
 // except the load-time weight repacking (transposes, basis permutation, BatchNorm folding).
 #include "../../include/vadc_amd.h"
+#include "gemm2_pack.h"
 #include "common.h"
 #include "enc_fused_layout.h"
 
@@ -26,6 +27,7 @@ void launch_frontend_v4_f32(const float *, const float *, float *, float *, floa
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
+void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
@@ -148,6 +150,8 @@ struct vadc_amd_engine {
    }
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
+   const float *d_afrag2 = nullptr, *d_nyq2 = nullptr; // ... the same for its second form (k_frontend_gemm2: 32x32x16 MFMAs, s16 input)
+   int fe_gemm = 2;                             // option "fe_gemm": 2 = k_frontend_gemm2 for s16 input (default), 1 = the first form for everything
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
    bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_FAST_STFT)); }
    float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
@@ -317,7 +321,7 @@ static bool basis_has_dft_symmetries(const std::vector<float> &basis)
 
 // GEMM front end (kernels_frontend_gemm.hip): needs re rows even about tap 128, im rows odd, tap 0 zero, im rows of bins 0
 // and 128 zero -- verified bit for bit on the loaded basis [258][256]; otherwise the tree kernel stays in charge.
-static bool build_gemm_frontend(const std::vector<float> &basis, Packer &pk, size_t &off_afrag, size_t &off_nyq)
+static bool build_gemm_frontend(const std::vector<float> &basis, Packer &pk, size_t &off_afrag, size_t &off_nyq, size_t &off_afrag2, size_t &off_nyq2)
 {
    auto B = [&](int row, int n) { return basis[(size_t)row * 256 + n]; };
    for (int k = 0; k < kBins; ++k) {
@@ -342,6 +346,10 @@ static bool build_gemm_frontend(const std::vector<float> &basis, Packer &pk, siz
    for (int n = 0; n < 128; ++n) ny[n] = (n == 0) ? B(128, 128) : B(128, n);
    off_afrag = pk.add(af.data(), af.size());
    off_nyq = pk.add(ny.data(), ny.size());
+   std::vector<float> af2, ny2;                 // the second form's operands (gemm2_pack.h)
+   pack_gemm2_frontend(basis, af2, ny2);
+   off_afrag2 = pk.add(af2.data(), af2.size());
+   off_nyq2 = pk.add(ny2.data(), ny2.size());
    return true;
 }
 
@@ -376,8 +384,8 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                   for (int c = 0; c < 2; ++c)
                      ri[(size_t)f * 512 + ii * 128 + lp * 32 + h * 16 + j * 2 + c] = tmp[(size_t)(c ? kBins + f : f) * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + h)];
    const size_t off_basis_ri = pk.add(ri.data(), ri.size());
-   size_t off_afrag = 0, off_nyq = 0;
-   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);   // FAST_STFT precision mode
+   size_t off_afrag = 0, off_nyq = 0, off_afrag2 = 0, off_nyq2 = 0;
+   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq, off_afrag2, off_nyq2);   // FAST_STFT precision mode
    e->sym_ok = basis_has_dft_symmetries(tmp);
    e->zero_im0 = true;
    for (int n = 0; n < 256; ++n) if (tmp[(size_t)kBins * 256 + n] != 0.0f) e->zero_im0 = false;      // (-0 == 0)
@@ -616,7 +624,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
       e->d_basis_ri = base + off_basis_ri;
-      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
+      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; e->d_afrag2 = base + off_afrag2; e->d_nyq2 = base + off_nyq2; }
       for (int l = 0; l < 4; ++l) {
          LayerWeights w;
          w.dw_w = base + lo[l].dw_w; w.dw_b = base + lo[l].dw_b; w.pwT = base + lo[l].pwT; w.pw_b = base + lo[l].pw_b;
@@ -664,8 +672,8 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
    pk.add(nullptr, 64);
-   size_t off_afrag = 0, off_nyq = 0;
-   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq);
+   size_t off_afrag = 0, off_nyq = 0, off_afrag2 = 0, off_nyq2 = 0;
+   e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq, off_afrag2, off_nyq2);
    auto frag = [](const std::vector<float> &W, int M, int K) {
       const int KKW = (K + 3) / 4;
       std::vector<float> f((size_t)(M / 16) * KKW * 64, 0.0f);
@@ -763,7 +771,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
-      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; }
+      if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; e->d_afrag2 = base + off_afrag2; e->d_nyq2 = base + off_nyq2; }
       for (int l = 0; l < 4; ++l) {
          LayerWeightsM &m = e->lwm[l];
          m = LayerWeightsM{};
@@ -1129,7 +1137,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "cu_mask_check"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1153,6 +1161,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3 || value == 11)) { e->fe_opt = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
@@ -1190,6 +1199,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
+   else if (strcmp(key, "fe_gemm") == 0) *value = e->fe_gemm;
    else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
@@ -1447,7 +1457,9 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       if (fk == 2) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0;
          float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
-         if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
+         // s16 input: the second form (32x32x16 MFMAs, one persistent workgroup per CU the stream may count on, pipelined across column tiles); f32 input: the first form
+         if (sizeof(T) == 2 && e->fe_gemm == 2) launch_frontend_gemm2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag2, e->d_nyq2, e->d_Y, mag, e->d_FM, fms, n, map, encoder_cus(e, st), st, geo);
+         else if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
          else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
       } else if (fk == 3) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
