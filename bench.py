@@ -59,7 +59,8 @@ MAC_V31 = {"k_frontend": (1_651_200, 0), "k_layer1": (181_053, 0), "k_layer2": (
            "k_layer4": (236_768, 229_376), "k_lstm": (458_752 + 896, 458_752),
            "k_enc234": (112_208 + 61_600 + 236_768, 0)}      # layers 2-4 in one launch (k_enc_fused): executed work counted in kernel_cost
 MAC_V4 = {"k_frontend": (1_585_152, 0), "k_layer1": (232_176, 0), "k_layer2": (19_392, 0), "k_layer3": (10_176, 0), "k_layer4": (25_056, 0),
-          "k_lstm": (196_608 + 192, 196_608)}
+          "k_lstm": (196_608 + 192, 196_608),
+          "k_enc234": (19_392 + 10_176 + 25_056, 0)}       # stages 2-4 in one launch (k_enc_fused_v4): executed work counted in kernel_cost
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)", 4: "k_frontend_ri"}
 
@@ -88,6 +89,10 @@ def kernel_cost(model, name, fe_kernel, layer_major=False, layer1_regs=False):
         # 48 for the 258 -> 16 conv block (8 k blocks x 3 split terms x 2 tiles), 4 for the Nyquist channel, 60 for the D = 16 transformer block and the
         # strided conv (two instructions per K = 16 product); depthwise conv, operand splits, softmax and LayerNorm are vector work
         return alg, {"fp16": (48 + 4 + 60) * 16384}
+    if name == "k_enc234" and model == "v4":
+        # k_enc_fused_v4 issues v_mfma_f32_16x16x32_f16 only (16,384 FLOP each, idle columns included), per chunk: stage 2 six for the conv block + six for the strided
+        # conv (one 16-column tile per chunk), stages 3 and 4 on one tile per two chunks: (6 + 6) / 2 and (12 + 12 + 24) / 2
+        return alg, {"fp16": (12 + 6 + 24) * 16384}
     if name == "k_enc234":
         # k_enc_fused issues v_mfma_f32_16x16x32_f16 only (16,384 FLOP each, zero-padded k and idle columns included): per chunk 60 in layer 2 (one
         # 16-column tile per chunk), 30 in layer 3 and 105 in layer 4 (one tile per two chunks); depthwise conv, softmax and LayerNorm are vector work

@@ -72,6 +72,41 @@ struct EncFusedArgs {
    ItemMap map;
 };
 
+// ---- Silero v4, stages 2-4 (k_enc_fused_v4, kernels_encoder_fused_v4.hip): ONE image -----------------------------------------------------
+// conv block + strided 1x1 conv per stage, no transformer block; the same fragment form and k orders as above (stage 2: stacked [pointwise | projection], hardware k order)
+template <int CIN, int D, bool PROJ>
+struct EncV4LayerLayout {
+   static constexpr int MT = D / 16, KB = D / 32;
+   static constexpr int f_pw  = 0;
+   static constexpr int f_pj  = f_pw + MT * kFragBytes;                     // stage 4 only (PROJ with 32 input channels)
+   static constexpr int f_cv  = (PROJ && CIN == 32) ? f_pj + MT * kFragBytes : f_pj;
+   static constexpr int f_end = f_cv + MT * KB * kFragBytes;
+   static constexpr int v_dw   = 0;                    // [6][CIN]: taps 0..4, bias
+   static constexpr int v_cb_b = v_dw + 6 * CIN;       // pointwise bias (+ projection bias)
+   static constexpr int v_cv_b = v_cb_b + D;
+   static constexpr int v_end  = (v_cv_b + D + 3) / 4 * 4;
+};
+typedef EncV4LayerLayout<16, 32, true>  EncV4L2;
+typedef EncV4LayerLayout<32, 32, false> EncV4L3;
+typedef EncV4LayerLayout<32, 64, true>  EncV4L4;
+constexpr int kEncV4_L2F = 0;
+constexpr int kEncV4_L3F = kEncV4_L2F + EncV4L2::f_end;
+constexpr int kEncV4_L4F = kEncV4_L3F + EncV4L3::f_end;
+constexpr int kEncV4_V2  = kEncV4_L4F + EncV4L4::f_end;              // bytes
+constexpr int kEncV4_V3  = kEncV4_V2 + EncV4L2::v_end * 4;
+constexpr int kEncV4_V4  = kEncV4_V3 + EncV4L3::v_end * 4;
+constexpr int kEncV4Bytes = kEncV4_V4 + EncV4L4::v_end * 4;
+static_assert(EncV4L2::f_end == 4 * kFragBytes && EncV4L3::f_end == 4 * kFragBytes && EncV4L4::f_end == 16 * kFragBytes, "fragment sizes");
+static_assert(kEncV4Bytes % 16 == 0, "the image is copied in 16-byte pieces");
+
+struct EncV4Args {
+   const float *in;          // first stage's output [n][16][12]
+   const void *img;          // device copy of the LDS image
+   void *out;                // split-fp16 LSTM-native tiles, 3 steps per chunk (common.h lstm_xh_index)
+   int n_chunks;
+   ItemMap map;
+};
+
 // ---- layer 1 (k_layer1_regs, kernels_layer1_regs.hip): ONE image ------------------------------------------------------------------------
 // conv block 129 -> 16: the [pointwise | projection] weights as K = 32 split-fp16 A fragments (2 KB each) over k blocks
 //   0..3: relu(dw(x)) of channels 32 kb + ..,   4..7: x of channels 32 (kb - 4) + ..

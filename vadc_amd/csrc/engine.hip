@@ -41,6 +41,7 @@ struct LayerWeightsM {
 };
 void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
 void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
+void launch_enc_fused_v4(const EncV4Args &, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
 void launch_layer1_regs(const L1RegsArgs &, int, hipStream_t);
 void launch_layer1_regs_tap(int, const L1RegsArgs &, hipStream_t);
@@ -181,6 +182,8 @@ struct vadc_amd_engine {
    // k_layer1_regs (kernels_layer1_regs.hip): its LDS image
    void *d_l1img = nullptr;
    std::vector<unsigned char> h_l1img;
+   void *d_encv4 = nullptr;                     // Silero v4: LDS image of k_enc_fused_v4 (stages 2-4 in one launch; enc_fused_layout.h)
+   std::vector<unsigned char> h_encv4;
    int layer1_selfcheck = -1;                   // -1: not run (no register-resident first layer in this engine), 1: it agrees with the per-layer form on the probe chunks, 0: it does not (the per-layer form serves)
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
    bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2 && layer1_selfcheck != 0; }
@@ -203,6 +206,8 @@ struct vadc_amd_engine {
    unsigned long long pin_clock = 0;
    int pin_host = 1;
    int enc_batch = 0;                           // option "encoder_batch": form of k_enc_fused (0 / 1: 12 waves x one pair tile per batch, 2: 8 waves x two)
+   // Silero v4, default window: stages 2-4 in one launch (hot path only: LSTM tiles out, no stage taps); option "encoder" = 5 keeps the per-stage launches
+   bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames == 24 && sample_rate == 16000; }
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
    LstmWeights lstm;
    // workspace
@@ -686,30 +691,33 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       return f;
    };
    struct LOff { size_t dw_w, dw_b, pw_f, pj_f, cb_b, cv_f, cv_b, pwj_k1; } lo[4];
-   struct { std::vector<float> dw_w, dw_b, pw, pj, cb_b, cv_w, cv_b; } r0;      // the first stage's weights as they come, for k_layer1_regs_v4's LDS image
+   struct RawV4 { std::vector<float> dw_w, dw_b, pw, pj, cb_b, cv_w, cv_b; } r0, rl[4];      // the stages' weights as they come, for the LDS images of k_layer1_regs_v4 (r0) and k_enc_fused_v4 (rl[1..3])
    for (int l = 0; l < 4; ++l) {
       const LayerShape &s = kLayersV4[l];
       const int D = s.d, C = s.cin;
       auto take = [&](int n, std::vector<float> &v) -> bool { if (!need(idx, n)) return false; copy_unaligned(v, ts[idx++]); return true; };
       std::vector<float> v, cbb;
-      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size()); if (l == 0) r0.dw_w = v;
-      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size()); if (l == 0) r0.dw_b = v;
+      if (!take(C * 5, v)) goto bad; lo[l].dw_w = pk.add(v.data(), v.size()); if (l == 0) r0.dw_w = v; rl[l].dw_w = v;
+      if (!take(C, v)) goto bad;     lo[l].dw_b = pk.add(v.data(), v.size()); if (l == 0) r0.dw_b = v; rl[l].dw_b = v;
       std::vector<float> pwm;
-      if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; }
+      if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pw_f = pk.add(f.data(), f.size()); pwm = v; rl[l].pw = v; }
       if (!take(D, v)) goto bad;     cbb = v;
       lo[l].pj_f = (size_t)-1;
       if (s.proj) {
-         if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); }
+         if (!take(D * C, v)) goto bad; { auto f = frag(v, D, C); lo[l].pj_f = pk.add(f.data(), f.size()); rl[l].pj = v; }
          if (l == 0) { auto k1 = k1_pack(pwm, v, D, C); lo[l].pwj_k1 = pk.add(k1.data(), k1.size()); r0.pw = pwm; r0.pj = v; }
          if (!take(D, v)) goto bad;
          for (int o = 0; o < D; ++o) cbb[o] += v[o];
       }
       lo[l].cb_b = pk.add(cbb.data(), cbb.size());
       if (l == 0) r0.cb_b = cbb;
+      rl[l].cb_b = cbb;
       if (!take(D * D, v)) goto bad; { auto f = frag(v, D, D); lo[l].cv_f = pk.add(f.data(), f.size()); }   // BatchNorm folded by the exporter
       if (l == 0) r0.cv_w = v;
+      rl[l].cv_w = v;
       if (!take(D, v)) goto bad;     lo[l].cv_b = pk.add(v.data(), v.size());
       if (l == 0) r0.cv_b = v;
+      rl[l].cv_b = v;
    }
    if (kLayersV4[0].cin == 2 * kBins && kLayersV4[0].d == 16 && r0.pj.size() == (size_t)16 * 2 * kBins) {
       // ---- LDS image of k_layer1_regs_v4 (enc_fused_layout.h: L1V4Layout) ----
@@ -754,6 +762,50 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       put_taps(v + L1V4Layout::v_tail + 8, kBins + 128);
       for (int o = 0; o < D; ++o) { v[L1V4Layout::v_cb_b + o] = r0.cb_b[o]; v[L1V4Layout::v_cv_b + o] = r0.cv_b[o]; }
       if (!ok) e->h_l1img.clear();                            // a weight outside fp16's range: k_layer_mfma's fp32 form serves
+   }
+   if (kLayersV4[1].cin == 16 && kLayersV4[1].d == 32 && kLayersV4[2].cin == 32 && kLayersV4[2].d == 32 && !kLayersV4[2].proj && kLayersV4[3].cin == 32 && kLayersV4[3].d == 64) {
+      // ---- LDS image of k_enc_fused_v4 (enc_fused_layout.h: EncV4LayerLayout): split-fp16 A fragments [hi 64 x 8 | lo 64 x 8] per (M tile, k block) ----
+      bool ok = true;
+      auto put_frags = [&ok](unsigned char *dst, const std::vector<float> &W, int M, int K, bool sigma) {
+         _Float16 *h = reinterpret_cast<_Float16 *>(dst);
+         const int KB = K / 32;
+         for (int mt = 0; mt < M / 16; ++mt)
+            for (int kb = 0; kb < KB; ++kb)
+               for (int l = 0; l < 64; ++l)
+                  for (int el = 0; el < 8; ++el) {
+                     const int q = l >> 4, k = sigma ? enc_sigma(kb, q, el) : 32 * kb + 8 * q + el;
+                     const float v = W[(size_t)(16 * mt + (l & 15)) * K + k];
+                     if (!(fabsf(v) < 60000.0f)) ok = false;
+                     const _Float16 hi = (_Float16)v;
+                     const size_t base = ((size_t)mt * KB + kb) * 1024;
+                     h[base + l * 8 + el] = hi;
+                     h[base + 512 + l * 8 + el] = (_Float16)(v - (float)hi);
+                  }
+      };
+      e->h_encv4.assign(kEncV4Bytes, 0);
+      auto build = [&](int l, unsigned char *fbase, float *vbase, auto L) {
+         typedef decltype(L) LL;
+         const RawV4 &r = rl[l];
+         const int D = kLayersV4[l].d, C = kLayersV4[l].cin;
+         if (C == 16) {                                        // stage 2: [pointwise | projection] stacked over K = 16 + 16, hardware k order
+            std::vector<float> st((size_t)D * 32);
+            for (int o = 0; o < D; ++o)
+               for (int c = 0; c < 16; ++c) { st[(size_t)o * 32 + c] = r.pw[(size_t)o * 16 + c]; st[(size_t)o * 32 + 16 + c] = r.pj[(size_t)o * 16 + c]; }
+            put_frags(fbase + LL::f_pw, st, D, 32, false);
+         } else {
+            put_frags(fbase + LL::f_pw, r.pw, D, 32, true);
+            if (kLayersV4[l].proj) put_frags(fbase + LL::f_pj, r.pj, D, 32, true);
+         }
+         put_frags(fbase + LL::f_cv, r.cv_w, D, D, true);
+         for (int t = 0; t < 5; ++t) for (int c = 0; c < C; ++c) vbase[LL::v_dw + t * C + c] = r.dw_w[(size_t)c * 5 + t];
+         for (int c = 0; c < C; ++c) vbase[LL::v_dw + 5 * C + c] = r.dw_b[c];
+         for (int o = 0; o < D; ++o) { vbase[LL::v_cb_b + o] = r.cb_b[o]; vbase[LL::v_cv_b + o] = r.cv_b[o]; }
+      };
+      unsigned char *img = e->h_encv4.data();
+      build(1, img + kEncV4_L2F, reinterpret_cast<float *>(img + kEncV4_V2), EncV4L2());
+      build(2, img + kEncV4_L3F, reinterpret_cast<float *>(img + kEncV4_V3), EncV4L3());
+      build(3, img + kEncV4_L4F, reinterpret_cast<float *>(img + kEncV4_V4), EncV4L4());
+      if (!ok) e->h_encv4.clear();                           // a weight outside fp16's range: the per-stage fp32 kernels serve
    }
    {
       if (!need(idx, 2 * 256 * 128) || !need(idx + 1, 2 * 256) || !need(idx + 2, 64) || !need(idx + 3, 1) || !need(idx + 4, 7)) goto bad;
@@ -877,7 +929,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
@@ -987,6 +1039,11 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       if (he == hipSuccess) he = hipMemcpy(e->d_encB, e->h_encB.data(), e->h_encB.size(), hipMemcpyHostToDevice);
       if (he == hipSuccess) he = hipMalloc(&e->d_enc_scratch, (N + 4) * kEncScratchPerChunk * sizeof(float));   // batches of up to 4 chunks: the last one may be partial
       e->h_encA.clear(); e->h_encA.shrink_to_fit(); e->h_encB.clear(); e->h_encB.shrink_to_fit();
+   }
+   if (he == hipSuccess && !e->h_encv4.empty()) {
+      he = hipMalloc(&e->d_encv4, e->h_encv4.size());
+      if (he == hipSuccess) he = hipMemcpy(e->d_encv4, e->h_encv4.data(), e->h_encv4.size(), hipMemcpyHostToDevice);
+      e->h_encv4.clear(); e->h_encv4.shrink_to_fit();
    }
    if (he == hipSuccess && !e->h_l1img.empty()) {
       he = hipMalloc(&e->d_l1img, e->h_l1img.size());
@@ -1417,6 +1474,13 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          a.tap4 = (last == 3 && lstm_layout == 0) ? e->d_act[3] : nullptr;
          a.n_chunks = n; a.first = l + 1; a.last = last + 1; a.map = map;
          launch_enc_fused(a, encoder_cus(e, st), e->enc_batch, st);
+         return;
+      }
+      if (l == 1 && last == 3 && lstm_layout == 2 && !in_stage && e->use_enc_fused_v4()) {      // Silero v4: stages 2-4 in one launch
+         KernelTimer t(e, VADC_AMD_KERNEL_ENC234, st);
+         EncV4Args a;
+         a.in = in; a.img = e->d_encv4; a.out = e->d_act[3]; a.n_chunks = n; a.map = map;
+         launch_enc_fused_v4(a, encoder_cus(e, st), st);
          return;
       }
       KernelTimer t(e, VADC_AMD_KERNEL_LAYER1 + l, st);
