@@ -34,6 +34,7 @@ The JSON line is kept short (the driver reads the tail of stdout); its verbose f
                   "10240x1"  the north star's literal shape (>= 10 k concurrent streams at real time: 10,240 streams x ONE chunk per call), with the
                              latency a chunk sees (`latency_ms`: one isolated call, issue -> probabilities complete; the budget is the 96 ms until the
                              stream's next chunk) and the rate through the asynchronous host-buffer entry point (`host_fed`);
+                  "v4_4096x16"  BASELINE config 4: Silero v4 16k at 4096 streams x 16 chunks (GEMM STFT on the fp16 matrix pipe, hipGraph replay);
                   "256x96_fp32_mfma"  the headline workload with every GEMM as literal fp32 MFMA (options encoder = 3, lstm = 3, layer1 = 1): what the
                              split-fp16 x 3 arithmetic of `dtype` buys
 """
@@ -63,6 +64,23 @@ MAC_V4 = {"k_frontend": (1_585_152, 0), "k_layer1": (232_176, 0), "k_layer2": (1
           "k_enc234": (19_392 + 10_176 + 25_056, 0)}       # stages 2-4 in one launch (k_enc_fused_v4): executed work counted in kernel_cost
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)", 4: "k_frontend_ri"}
+
+
+def dtype_label(mode, fe_kernel):
+    """what the arithmetic runs in -- by the front-end kernel that ran, not by the precision mode alone (Silero v4's STFT is the GEMM form in every mode)"""
+    gemms = "split-f16x3 GEMMs (f32 accumulate)"
+    if fe_kernel == 2:
+        return f"split-f16x3 GEMM STFT (f32 accumulate) + {gemms}"
+    return f"f32 STFT + {gemms}" + (", f32-MFMA fallbacks refused" if mode == 1 else "")
+
+
+def workload_label(model, mode, fe_kernel):
+    if model == "v4":
+        stft = ("STFT as a folded real-input GEMM on the fp16 matrix pipe (split-fp16 x 3, fp32 accumulation: the v4 parity target is a framework convolution in any fp32 order)"
+                if fe_kernel == 2 else "STFT by the fp32 tree kernel")
+        return f"BASELINE config 4: {stft} + split-fp16 x 3 GEMMs with fp32 accumulation (22-bit operands)"
+    return {0: "parity mode: exact fp32 STFT tree + split-fp16 x 3 GEMMs with fp32 accumulation (22-bit operands; BASELINE config 2 says fp32: the literal fp32-MFMA engine is configs[256x96_fp32_mfma])",
+            1: "SPLIT16 precision mode (BASELINE config 3)", 2: "FAST_STFT throughput mode (GEMM STFT: outside the 1e-4 bar)"}[mode]
 
 
 def kernel_cost(model, name, fe_kernel, layer_major=False, layer1_regs=False):
@@ -306,6 +324,7 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
            "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
+           "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
            "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
     if opts:
         out["options"] = dict(opts)
@@ -550,10 +569,9 @@ def run_rank(args, world, rank, local_rank):
                       "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32 STFT + split-f16x3 GEMMs (f32 accumulate)", 1: "f32 STFT + split-f16x3 GEMMs (f32 accumulate), f32-MFMA fallbacks refused",
-                                                     2: "split-f16x3 GEMM STFT + split-f16x3 GEMMs (f32 accumulate)"}[mode], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(mode, fe_kernel), "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
-                                   f"{ {0: 'parity mode: exact fp32 STFT tree + split-fp16 x 3 GEMMs with fp32 accumulation (22-bit operands; BASELINE config 2 says fp32: the literal fp32-MFMA engine is configs[256x96_fp32_mfma])', 1: 'SPLIT16 precision mode (BASELINE config 3)', 2: 'FAST_STFT throughput mode (outside the 1e-4 bar)'}[mode]}, s16le input resident in HBM",
+                                   f"{workload_label(args.model, mode, fe_kernel)}, s16le input resident in HBM",
                        "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
                        "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
@@ -613,9 +631,13 @@ def run_rank(args, world, rank, local_rank):
         if world == 1 and not args.no_side_config and not args.verify_dump and args.model == "v31" and not (S == 4096 and Cn == 16):
             eng.close()
             eng = None
+            blob_v4 = open(os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor"), "rb").read()
             out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1),
                               "10240x1": side_config(torch, blob, dev, local_rank, args.model, 10240, 1, 0, steps=200, warmup=20, latency=True, host_fed=True),
-                              "256x96_fp32_mfma": side_config(torch, blob, dev, local_rank, args.model, 256, 96, 0, opts={"encoder": 3, "lstm": 3, "layer1": 1})}
+                              "256x96_fp32_mfma": side_config(torch, blob, dev, local_rank, args.model, 256, 96, 0, opts={"encoder": 3, "lstm": 3, "layer1": 1}),
+                              # BASELINE config 4: Silero v4 at 4096 streams.  Last: an engine created in front of the 10,240 x 1 configuration moved that one's internal
+                              # streams onto other hardware queues and cost it 40 % (1.80 against 2.94 M alone and in this order: DESIGN.md section 6)
+                              "v4_4096x16": side_config(torch, blob_v4, dev, local_rank, "v4", 4096, 16, 0, steps=100, warmup=10)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         # The line the driver parses stays SHORT (it reads the tail of stdout): the per-kernel accounting and the long notes go to a details file

@@ -1029,6 +1029,70 @@ def test_full_size_4096_streams_properties(weights_blob, orc, precision, tol):
         e.close()
 
 
+@pytest.mark.parametrize("S,Cn,precision", [(256, 96, 0), (4096, 16, 1)])
+def test_oracle_at_the_bench_shapes_as_bench_drives_them(weights_blob, orc, S, Cn, precision):
+    """The configurations the metric is quoted on, driven EXACTLY as bench.py drives them -- graph replay, deferred joins, three input buffers used in turn, every step
+    issued from one stream with no host synchronisation in between, the state carried on the device -- and checked against the CPU ORACLE, not against the engine's own
+    eager path: 24 distinct signals sit in the first, a middle and the last stream tile (8 per tile, at both ends of the tile), three steps each, every one of those
+    streams within 1e-4 of silero_v3.c:72-215's restatement on its audio (the other streams carry copies)."""
+    import torch
+    NB, steps = 3, 3
+    nsig = 24
+    sig = synth.make_streams(nsig, steps * Cn, seed0=8800 + S)
+    tiles = [0, (S // 16) // 2, S // 16 - 1]
+    where = [16 * t + o for t in tiles for o in (0, 1, 2, 7, 8, 13, 14, 15)]
+    fill = synth.make_streams(16, steps * Cn, seed0=8900)
+    pcm = np.ascontiguousarray(np.tile(fill, (S // 16, 1)))
+    for k, s_ in enumerate(where):
+        pcm[s_] = sig[k]
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0, precision=precision)
+    try:
+        e.set_option("defer_join", 1)
+        e.set_option("groups", 1)
+        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(NB)]
+        d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(NB)]
+        st = torch.cuda.Stream()
+
+        def step(i):
+            e.run_device(d_in[i % NB].data_ptr(), np.int16, S, Cn, d_out[i % NB].data_ptr(), st.cuda_stream)
+        for i in range(2 * NB):                 # as bench.py: setup calls, then capture + instantiate every (input buffer, hand-off buffer) pairing
+            step(i)
+        torch.cuda.synchronize()
+        e.set_option("graph", 1)
+        for i in range(2 * NB):
+            step(i)
+        torch.cuda.synchronize()
+        e.reset_streams()
+        for i in range(steps):                  # the measured form: pure replays, back to back, one issuing stream
+            step(i)
+        e.join(st.cuda_stream)
+        st.synchronize()
+        got = np.concatenate([d_out[i % NB].cpu().numpy() for i in range(steps)], axis=1)      # steps <= NB: every step's buffer is still its own
+    finally:
+        e.close()
+    want = orc.forward_streams(sig)
+    d = np.abs(got[where][:, :, 1] - want)
+    assert float(d.max()) <= PROB_TOL, (float(d.max()), np.unravel_index(d.argmax(), d.shape))
+    assert np.isfinite(got).all()
+
+
+def test_soak_long_run_of_calls_vs_oracle(weights_blob, orc):
+    """tests/reports/soak_report.py as a test (shorter): 272 streams (17 tiles: a ragged last one) x 96 chunks x 24 synchronous calls with the state carried on the
+    device; the first, a middle and the last stream are recomputed by the oracle over all 2,304 chunks"""
+    S, Cn, calls = 272, 96, 24
+    pcm = synth.make_streams(S, Cn * 4, seed0=99)            # 4 distinct windows per stream, cycled
+    pick = [0, 137, 271]
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        got = np.concatenate([e.run(pcm[:, (k % 4) * Cn * 1536:((k % 4) + 1) * Cn * 1536])[pick] for k in range(calls)], axis=1)
+    finally:
+        e.close()
+    for j, s_ in enumerate(pick):
+        seq = np.concatenate([pcm[s_, (k % 4) * Cn * 1536:((k % 4) + 1) * Cn * 1536] for k in range(calls)])
+        want = orc.forward_stream(seq)
+        assert float(np.abs(got[j] - want).max()) <= PROB_TOL, (s_, float(np.abs(got[j] - want).max()))
+
+
 @pytest.mark.parametrize("S", [10240, 16384])
 def test_north_star_shape_one_chunk_per_stream_and_call(weights_blob, orc, S):
     """the north star's literal shape (BASELINE.json: ">= 10k concurrent 16 kHz streams at real-time"): S streams x ONE chunk per call -- a chunk per stream
