@@ -121,6 +121,9 @@ int  vadc_amd_create(const void *weights_blob, size_t weights_len, int device,
 void vadc_amd_destroy(vadc_amd_engine *e);
 const char *vadc_amd_last_error(void);
 int  vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps);
+/* The same for a caller compiled against another revision of this header: vadc_amd_caps only ever grows at its end, and this entry point writes
+ * min(caps_size, sizeof(vadc_amd_caps)) bytes -- pass sizeof of the struct you were compiled with. */
+int  vadc_amd_get_caps_sized(const vadc_amd_engine *e, void *caps, size_t caps_size);
 
 /* ---- the hot path: replaces backend_run (silero.h:53-74) ------------------------------------ */
 

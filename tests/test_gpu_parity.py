@@ -470,6 +470,37 @@ def test_lstm_layer1_beside_layer0_of_the_same_call(weights_blob, orc, S, Cn, ca
     assert float(np.abs(out[1][0][:3, :, 1] - want).max()) <= PROB_TOL
 
 
+def test_lstm_trail_failure_is_reported_not_trapped(weights_blob, orc):
+    """A layer 1 whose layer 0 never comes (test hook "trail_fault": the pair launched without its layer 0) runs out its bounded wait (~2 s), REPORTS it through the
+    engine's error word and ends -- no trap (which would take the HIP context, every engine and stream of the process, with it): the call fails with VADC_AMD_EHIP,
+    "lstm_trail" turns itself off, and the same engine and a fresh one in the same process go on to give the oracle's answers"""
+    S, Cn = 256, 8
+    base = synth.make_streams(16, Cn, seed0=4242)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        e.set_option("lstm", 7)
+        e.run(pcm)
+        if not e.get_option("lstm_trail_used"):
+            pytest.skip("the TRAIL pair is not in use here (kernels do not overlap in this process, or no CU partition)")
+        e.set_option("trail_fault", 1)
+        with pytest.raises(VadcAmdError):
+            e.run(pcm)
+        assert e.get_option("lstm_trail") == 0
+        e.reset_streams()
+        got = e.run(pcm)
+        assert e.get_option("lstm_trail_used") == 0
+    finally:
+        e.close()
+    want = orc.forward_streams(base)
+    assert float(np.abs(got[:16, :, 1] - want).max()) <= PROB_TOL
+    e2 = Engine(weights_blob, max_streams=16, max_chunks_per_call=Cn, device=0)      # the context survived
+    try:
+        assert float(np.abs(e2.run(base)[:, :, 1] - want).max()) <= PROB_TOL
+    finally:
+        e2.close()
+
+
 def test_lstm_trail_epoch_wrap_and_forced_small_partition(weights_blob):
     """the progress words carry an 11-bit epoch (one per launch pair): across its wrap the engine clears them behind everything that may read them; and a partition
     whose halves do not reach every XCD (option "lstm_cus" = 8) runs the sequential form.  Same bits throughout"""

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libvadc_amd.so")
 
 # every symbol include/vadc_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
-    "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps",
+    "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps", "vadc_amd_get_caps_sized",
     "vadc_amd_run_f32", "vadc_amd_run_s16", "vadc_amd_run_device_f32", "vadc_amd_run_device_s16",
     "vadc_amd_run_s16_async", "vadc_amd_run_f32_async", "vadc_amd_wait_async",
     "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",

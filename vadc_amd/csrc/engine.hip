@@ -31,7 +31,7 @@ void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, fl
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
-void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int, int *, int, int *, int);
+void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int, int *, int, int *, int, int *);
 void launch_lstm_decoder_tap(const float *, const LstmWeights &, float *, int, hipStream_t, int, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
@@ -230,6 +230,9 @@ struct vadc_amd_engine {
    int lstm_epoch = 0;
    int lstm_trail = 1;
    int lstm_trail_used = 0;                     // whether the last call's layer-major launches were a TRAIL pair (option "lstm_trail_used", read only)
+   int trail_fault = 0;                         // option "trail_fault" (tests): the next TRAIL pair is launched WITHOUT its layer 0, so that layer 1's bounded wait runs out
+   volatile int *h_trail_err = nullptr;         // the TRAIL kernels OR error bits in here instead of trapping (1 ticket imbalance, 2 layer 0 did not come, 4 a tile's pair on two XCDs)
+   int *d_trail_err = nullptr;                  // ... its device address
    int *d_lstm_tickets = nullptr;               // [2 layers][8 XCDs]: the counters a TRAIL workgroup draws its tile from (L2-local atomics); ticket_base = what earlier launches drew per XCD
    unsigned ticket_base = 0;
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
@@ -259,7 +262,7 @@ struct vadc_amd_engine {
    struct GraphEntry { const void *in; float *out; int S, C, elem, G, gi, xp, lk, fe; hipGraph_t g; hipGraphExec_t x; };
    std::vector<GraphEntry> graphs;
    hipEvent_t ev_in = nullptr, ev_b[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr}, ev_fe[kMaxGroups] = {nullptr},
-              ev_l0[kMaxGroups] = {nullptr};
+              ev_l0[kMaxGroups] = {nullptr}, ev_wrap[2] = {nullptr, nullptr};
    // Call-to-call ordering that does not depend on which stream the caller used: last_a = the last work that touched the
    // front-end / encoder buffers, last_b / last_c = the last LSTM (per-stream state, hand-off buffers).  Every call makes the
    // stream(s) that touch these wait for them first and re-points them.
@@ -931,6 +934,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
    for (void *p : ptrs) if (p) (void)hipFree(p);
+   if (e->h_trail_err) (void)hipHostFree(const_cast<int *>(e->h_trail_err));
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
       if (sl.d_probs) (void)hipFree(sl.d_probs);
@@ -948,6 +952,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    if (e->sC) (void)hipStreamDestroy(e->sC);
    for (hipEvent_t ev : {e->ev_in, e->ev_b[0], e->ev_b[1], e->ev_c[0], e->ev_c[1], e->ev_last}) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_l0) if (ev) (void)hipEventDestroy(ev);
+   for (hipEvent_t ev : e->ev_wrap) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
 }
@@ -1016,6 +1021,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->kernels_overlap = (cu_mask_layout_flags(device, e->n_cus) & 2) != 0;
    for (hipEvent_t *ev : {&e->ev_in, &e->ev_b[0], &e->ev_b[1], &e->ev_c[0], &e->ev_c[1], &e->ev_last}) if (he == hipSuccess) he = hipEventCreateWithFlags(ev, hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_l0[g], hipEventDisableTiming);
+   for (int g = 0; g < 2 && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_wrap[g], hipEventDisableTiming);
    for (int g = 0; g < vadc_amd_engine::kMaxGroups && he == hipSuccess; ++g) he = hipEventCreateWithFlags(&e->ev_fe[g], hipEventDisableTiming);
    if (he == hipSuccess) he = hipMalloc(&e->d_in_f32, N * kChunk * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_in_s16, N * kChunk * sizeof(int16_t));
@@ -1054,6 +1060,11 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->progress_tiles = (padded_streams / kLstmTile + 7) / 8 * 8;
    if (he == hipSuccess) he = hipMalloc(&e->d_lstm_tickets, 16 * sizeof(int));
    if (he == hipSuccess) he = hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));
+   // the TRAIL kernels' error word: host memory mapped into the device, so that the host reads it at its synchronisation points without a copy
+   { void *hp = nullptr, *dp = nullptr;
+     if (he == hipSuccess) he = hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped);
+     if (he == hipSuccess) { *static_cast<int *>(hp) = 0; he = hipHostGetDevicePointer(&dp, hp, 0); }
+     e->h_trail_err = static_cast<volatile int *>(hp); e->d_trail_err = static_cast<int *>(dp); }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) {
       he = hipMalloc(&e->d_lstm_progress[p], vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));      // per group: [tiles] counts, [tiles] XCC ids
       if (he == hipSuccess) he = hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));
@@ -1082,6 +1093,17 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
       rc = fail(VADC_AMD_EHIP, "create: the register-resident first layer failed its self-check and SPLIT16 refuses the fp32-MFMA fallback");
    if (rc) { vadc_amd_destroy(e); return rc; }
    *out = e;
+   return VADC_AMD_OK;
+}
+
+// caller's struct may be an older, shorter vadc_amd_caps: never write past what it has room for
+extern "C" int vadc_amd_get_caps_sized(const vadc_amd_engine *e, void *caps, size_t caps_size)
+{
+   if (!e || !caps || caps_size < sizeof(int32_t)) return fail(VADC_AMD_EINVAL, "get_caps_sized: NULL argument or no room for a field");
+   vadc_amd_caps full;
+   const int rc = vadc_amd_get_caps(e, &full);
+   if (rc) return rc;
+   memcpy(caps, &full, caps_size < sizeof(full) ? caps_size : sizeof(full));
    return VADC_AMD_OK;
 }
 
@@ -1194,7 +1216,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1221,6 +1243,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
+   if (strcmp(key, "trail_fault") == 0 && (value == 0 || value == 1)) { e->trail_fault = value; return VADC_AMD_OK; }
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -1583,12 +1606,12 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
 // costs the same whether a CU hosts one workgroup or takes several in turn -- while the front end + encoder scale with the CUs they are given:
 // the chain must never wait for a CU behind a front-end grid that fills the machine, so while it needs few CUs it gets CUs of its own.
 // *shared = true: the chain's CUs stay in the other stream's mask too (see ensure_pipeline_streams)
-static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *shared)
+// lk = the LSTM kernel run_device resolved for THIS call (its chunk count and forked-ness included: one decision, not two)
+static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *shared, int lk)
 {
    *shared = e->cu_partition == 2;
    if (!e->cu_partition || !e->cu_partition_usable()) return 0;
    if (e->lstm_cus_forced > 0) return e->lstm_cus_forced;      // option "lstm_cus" (experiments)
-   const int lk = resolve_lstm(e, n_streams);
    const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/2 tiles the chain is throughput work and gets the whole chip
@@ -1633,7 +1656,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
 static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
 {
    bool shared = false;
-   int want = lstm_partition_cus(e, n_streams, &shared);
+   int want = lstm_partition_cus(e, n_streams, &shared, lk);
    const bool split = lk == 7;                                  // layer-major LSTM: stream B = layer 0 on one half of the partition, stream C = layer 1 on the other
    if (e->lstm_cus == want && e->lstm_shared == shared && e->streams_split == split && e->sA && e->sB && e->sC) return VADC_AMD_OK;
    // drain the old streams through the events their last work is marked with (every call ends each stream it used with a record that one of
@@ -1698,10 +1721,10 @@ static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_str
       // ("lstm_trail" = 2, measurements only: the TRAIL kernels one after the other on this stream -- what their bookkeeping costs with nothing to wait for)
       int *progress = nullptr;
       if (e->lstm_trail == 2) { if (++e->lstm_epoch > 2047) e->lstm_epoch = 1; progress = e->d_lstm_progress[e->xpar]; }
-      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base); }
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err); }
       {
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-         launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
+         launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
       }
       if (progress) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);
       return;
@@ -1903,21 +1926,29 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
             e->lstm_trail_used = trail ? 1 : 0;
             if (trail) {
                if (++e->lstm_epoch > 2047) {                    // the 11-bit epoch wraps: once in 2,047 launches the words are cleared behind everything that may read them
-                  for (hipEvent_t ev : {e->last_b, e->last_c}) if (e->ev_last_valid && ev) (void)hipEventSynchronize(ev);
-                  for (int p = 0; p < 2; ++p) (void)hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));
+                  // ordered by the streams themselves, not by what kind of streams they happen to be: the clear runs on the layer-0 stream behind everything
+                  // issued so far on BOTH layer streams (earlier calls and this call's earlier chunk groups, whose layer-1 workgroups poll these words), and
+                  // the layer-1 stream goes on behind the clear
+                  (void)hipEventRecord(e->ev_wrap[0], e->sC);
+                  (void)hipStreamWaitEvent(e->sB, e->ev_wrap[0], 0);
+                  for (int p = 0; p < 2; ++p) (void)hipMemsetAsync(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int), e->sB);
+                  (void)hipEventRecord(e->ev_wrap[1], e->sB);
+                  (void)hipStreamWaitEvent(e->sC, e->ev_wrap[1], 0);
                   e->lstm_epoch = 1;
                }
                progress = e->d_lstm_progress[xp] + (size_t)gi * 2 * e->progress_tiles;
             }
-            {
+            if (trail && e->trail_fault) e->trail_fault = 0;      // (tests: layer 1 alone -- its tickets still advance, as they would beside a layer 0 that never started)
+            else {
                KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
             }
+            const bool l0_failed = trail && hipGetLastError() != hipSuccess;      // a layer 0 that was never launched must not be polled for: the pair in turn then
             hipEvent_t l0_done = last_group ? e->ev_b[xp] : e->ev_l0[gi];   // the call's last record on this stream is also this hand-off pair's "layer 0 done"
             (void)hipEventRecord(l0_done, e->sB);
-            if (!trail) (void)hipStreamWaitEvent(e->sC, l0_done, 0);
+            if (!trail || l0_failed) (void)hipStreamWaitEvent(e->sC, l0_done, 0);
             KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
-            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base);
+            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
             if (trail) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);      // every XCD's counter of either layer has advanced by grid / 8
          }
          c0 += cg;
@@ -1960,6 +1991,20 @@ extern "C" int vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm,
    return run_device<int16_t>(e, d_pcm, n_streams, n_chunks, d_probs, (hipStream_t)hip_stream);
 }
 
+// The TRAIL kernels report instead of trapping (kernels_lstm.hip): read their error word behind a synchronisation point.  A set word = layer 1 left without its
+// probabilities: the call's results are invalid -> VADC_AMD_EHIP, and the engine launches the pair in turn from now on.
+static int check_trail_error(vadc_amd_engine *e, const char *where)
+{
+   if (!e->h_trail_err || !*e->h_trail_err) return VADC_AMD_OK;
+   const int word = *e->h_trail_err;
+   *e->h_trail_err = 0;
+   e->lstm_trail = 0;
+   if (e->d_lstm_tickets) (void)hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));      // the pair's ticket counters may be out of step: start over
+   e->ticket_base = 0;
+   return fail(VADC_AMD_EHIP, "%s: the recurrence's second layer gave up on its first (bits %d: 1 ticket imbalance, 2 layer 0 did not come within 2 s, 4 XCD mismatch); "
+                              "this call's probabilities are invalid, lstm_trail is now off", where, word);
+}
+
 extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "synchronize: NULL engine");
@@ -1970,7 +2015,7 @@ extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
       HIP_TRY(hipEventSynchronize(e->last_c), VADC_AMD_EHIP);
    }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
-   return VADC_AMD_OK;
+   return check_trail_error(e, "synchronize");
 }
 
 extern "C" int vadc_amd_join(vadc_amd_engine *e, void *hip_stream)
@@ -1998,7 +2043,7 @@ extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
-   return VADC_AMD_OK;
+   return check_trail_error(e, "run_f32");
 }
 
 extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs)
@@ -2014,7 +2059,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
-   return VADC_AMD_OK;
+   return check_trail_error(e, "run_s16");
 }
 
 // ---- asynchronous host-buffer entry points: the shape a real backend_run caller has (host buffers in and out, vadc.c:873-909) without the
@@ -2175,7 +2220,7 @@ extern "C" int vadc_amd_wait_async(vadc_amd_engine *e)
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    for (auto &sl : e->aslot)
       if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP); sl.busy = false; }
-   return VADC_AMD_OK;
+   return check_trail_error(e, "wait_async");
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
                                                        float *__restrict__ hs, float *__restrict__ cs,
                                                        float *__restrict__ probs,               // L = 1
                                                        int n_streams, int n_chunks, int c0, int cg, const float *__restrict__ tap_h = nullptr,
-                                                       int *__restrict__ progress = nullptr, int epoch = 0, int *__restrict__ tickets = nullptr, int ticket_base = 0)
+                                                       int *__restrict__ progress = nullptr, int epoch = 0, int *__restrict__ tickets = nullptr, int ticket_base = 0, int *__restrict__ err = nullptr)
 {
    // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
@@ -477,12 +477,14 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
          xcc &= 7u;
          const unsigned j = (unsigned)atomicAdd(tickets + L * 8 + (int)xcc, 1) - (unsigned)ticket_base;      // (both counts wrap together)
-         if (j >= gridDim.x / 8) __builtin_trap();          // an XCD that got more than its share of the grid: another would leave tiles undone -- fail loudly
          tile_s = (int)xcc + 8 * (int)j;
+         // an XCD that got more than its share of the grid (another would leave tiles undone): reported, not trapped -- a trap takes the whole HIP context, every engine
+         // and stream of the process, with it.  The error word (`err`: host memory mapped into the device) is read by the host at its next synchronisation point: VADC_AMD_EHIP, TRAIL off.
+         if (j >= gridDim.x / 8) { atomicOr(err, 1); tile_s = -1; }
       }
       __syncthreads();
       tile = tile_s;
-      if (tile >= (n_streams + kTileS - 1) / kTileS) return;
+      if (tile < 0 || tile >= (n_streams + kTileS - 1) / kTileS) return;
    }
    const int col = lane & 15;
    const int quad = lane >> 4;
@@ -568,6 +570,10 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flag) : "memory");
       return v;
    };
+   // Layer 0 did not come within ~2 s (a time-sliced GPU, a tool that started serialising kernels after the create-time probe, a failed layer-0 launch): the
+   // workgroup REPORTS it (error word) and stops waiting -- it runs on over whatever the hand-off buffer holds (memory-safe: the engine's own allocation) and ends;
+   // the host sees the word at its next synchronisation point and fails the call.  Never a hang, and no trap (see the ticket above).  No early return either: a
+   // second exit from the block loop made hipcc put an s_waitcnt vmcnt(0) at the head of the slot loop.
    auto wait_for = [&](int need) {                             // workgroup-uniform: every wave calls it with the same `need` and the same `avail`
       unsigned spins = 0;
       while (avail < need) {
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          __syncthreads();
          if (avail < need) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > 4000000u) __builtin_trap();          // ~2 s: layer 0 is not coming (never a hang)
+            if (++spins > 4000000u) { if (tid == 0) publish(err, 2); avail = 1 << 30; }
          }
       }
    };
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       int other = 0;
       for (int tries = 0; tries < 1000 && (other >> 20) != epoch; ++tries)       // (stored before the first count by the same lane; a few more looks cost nothing)
          asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(other) : "s"(progress + gridDim.x + tile) : "memory");
-      if ((other >> 20) != epoch || (unsigned)(other & 0xf) != (xcc & 0xf)) __builtin_trap();
+      if (((other >> 20) != epoch || (unsigned)(other & 0xf) != (xcc & 0xf)) && avail < (1 << 30) && tid == 0) publish(err, 4);      // reported; the tiles may then be stale
    }
    if (TRAIL && L == 0) {
       unsigned xcc;
@@ -805,29 +811,29 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 // progress != nullptr: the TRAIL form (layer 1 may run beside layer 0 of the same call); epoch in [1, 2048); tickets / ticket_base: see the kernel
 template <int TS, int DEC>
 static void launch_layer_ts(int layer, const _Float16 *x, _Float16 *h, const LstmWeights &w, float *hs, float *cs, float *probs,
-                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int *progress, int epoch, int *tickets, int ticket_base)
+                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int *progress, int epoch, int *tickets, int ticket_base, int *err)
 {
    const int tiles = (n_streams + kTileS - 1) / kTileS;
    const float *no_tap = nullptr;
    if (progress) {
       const dim3 grid((tiles + 7) / 8 * 8), block(512);          // a multiple of 8: every XCD gets the same number of workgroups
-      if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0, false, true>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
-      else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, true>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
+      if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0, false, true>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
+      else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, true>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
       return;
    }
    const dim3 grid(tiles), block(512);
-   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
-   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base);
+   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
+   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
 }
 void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
-                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps, int *progress, int epoch, int *tickets, int ticket_base)
+                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps, int *progress, int epoch, int *tickets, int ticket_base, int *err)
 {
    const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
    _Float16 *h = reinterpret_cast<_Float16 *>(h0seq);
-   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
-   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
-   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
-   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base);
+   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
+   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
+   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
+   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
 }
 
 // stage tap: the decoder of k_lstm_layer<.., 1> on n items of [64][steps] (one chunk each), probs [n][2]
