@@ -193,6 +193,22 @@ def cpu_baseline(model, weights_path, seconds=10.0):
                       f"({sum(r['seconds'] for r in allc):.0f} core-seconds); single-core points: {one96['chunks']} chunks at batch 96, {one1['chunks']} at batch 1 (BASELINE config 1)"}
 
 
+def pin_rank_to_its_cpus(local_rank, local_world):
+    """N ranks of one node share the CPUs this job may use (a GPU box hands a job a slice of its hardware threads): each rank keeps to its own
+    share of the affinity mask, so that eight issuing threads do not migrate over -- and evict each other from -- the same few cores.
+    Returns the CPUs the rank ended up with (for the line / the tests); leaves the mask alone when there are fewer CPUs than ranks."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // max(local_world, 1)
+        if local_world > 1 and per >= 1:
+            mine = cpus[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            return mine
+        return cpus
+    except (AttributeError, OSError):
+        return []
+
+
 # ------------------------------------------------------------------------------------------------- rank spawning
 def free_port():
     s = socket.socket()
@@ -272,7 +288,7 @@ def dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU): rank skeleton over gloo", "value": None, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "dry_run": True, "gather_verified": ok, "total_streams": total,
+                          "dry_run": True, "gather_verified": ok, "total_streams": total, "rank_cpus": args.rank_cpus_n,
                           "config": {"workload": f"stand-in engine, {S} streams/rank x {Cn} chunks/step", "parallelism": f"streams sharded over {world} rank(s), gloo gather"}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -373,7 +389,11 @@ def run_rank(args, world, rank, local_rank):
     rehearsal = args.one_gpu_rehearsal        # N ranks on ONE GPU with gloo (a single-GPU box cannot form an RCCL group): exercises this rank code, not RCCL
     if rehearsal:
         local_rank = 0
+    # one process per GPU, bound by LOCAL_RANK before this process makes any HIP call (device_count() does not initialise the runtime on this image)
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} is bound to device {local_rank} (LOCAL_RANK), but {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local_rank)
+    assert torch.cuda.current_device() == local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
@@ -392,6 +412,7 @@ def run_rank(args, world, rank, local_rank):
         lo_, hi_ = shard.stream_block(rank, world, total_streams)
         S = hi_ - lo_
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision={"fp32": 0, "split16": 1, "fast_stft": 2}[args.precision])
+    assert eng.caps()["device"] == local_rank, (eng.caps()["device"], local_rank)      # the engine's kernels run on this rank's own GPU
     mode = eng.caps()["precision"]
     eng.set_option("groups", args.groups)
     for kv in args.opt:
@@ -730,6 +751,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    args.rank_cpus_n = len(pin_rank_to_its_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
     if args.dry_run:
         return dry_run(args, world, rank)
     return run_rank(args, world, rank, local_rank)

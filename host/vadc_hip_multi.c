@@ -7,8 +7,9 @@
  * vadc_amd_join (a device-side wait), so that step k's gather runs beside step k + 1's kernels.  Counterpart of the reference's single-engine
  * main (vadc.c:1127-1276) for N engines; the per-engine calls are the ones vadc.c:56-103 makes (backend_run on a window of chunks).
  *
- *   vadc_hip_multi --model weights.testtensor [--gpus N] [--streams-per-gpu S] [--chunks C] [--steps K] [--warmup W]
+ *   vadc_hip_multi --model weights.testtensor [--gpus N | --devices a,b,...] [--streams-per-gpu S] [--chunks C] [--steps K] [--warmup W]
  *                  [--pcm in.s16 --dump out.f32]
+ *   --devices  the HIP devices to use, in rank order (rank r = the r-th entry; the gather lands on the first); default: devices 0 .. N - 1
  *   --pcm   s16le [N * S][K * C * 1536]: step k feeds every stream its k-th window of C chunks, from reset state (warm-up steps are not run)
  *   --dump  the gathered probabilities of every step as float32 [K][N * S][C][2]  (what the tests compare with the CPU oracle)
  *   without --pcm: synthetic tones + noise, resident in HBM before the timed region
@@ -21,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -30,9 +32,12 @@
 #define CHUNK VADC_AMD_CHUNK_SAMPLES
 #define NBUF 3                         /* step buffers used in turn */
 
-#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, hipGetErrorString(e_)); w->rc = 2; goto out; } } while (0)
-#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, ncclGetErrorString(r_)); w->rc = 3; goto out; } } while (0)
-#define ENG_OK(x) do { if ((x) != VADC_AMD_OK) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, vadc_amd_last_error()); w->rc = 4; goto out; } } while (0)
+/* A rank that fails raises the shared flag: the others stop issuing gathers (a gather whose peer never comes would never complete), abort their communicator
+ * instead of waiting for what they have already enqueued, and the process exits non-zero instead of hanging. */
+#define FAIL(code) do { w->rc = (code); __atomic_store_n(w->failed, 1, __ATOMIC_RELEASE); goto out; } while (0)
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, hipGetErrorString(e_)); FAIL(2); } } while (0)
+#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, ncclGetErrorString(r_)); FAIL(3); } } while (0)
+#define ENG_OK(x) do { if ((x) != VADC_AMD_OK) { fprintf(stderr, "rank %d: %s failed: %s\n", w->rank, #x, vadc_amd_last_error()); FAIL(4); } } while (0)
 
 typedef struct {
    int rank, n_ranks, device, S, C, K, W, rc;
@@ -40,6 +45,8 @@ typedef struct {
    const int16_t *pcm;                 /* host, [n_ranks * S][K * C * CHUNK] or NULL */
    float *dump;                        /* host (rank 0), [K][n_ranks * S][C][2] or NULL */
    ncclComm_t comm;
+   int *failed;                        /* shared: some rank has failed */
+   int aborted;                        /* this rank's communicator was aborted (not to be destroyed) */
    pthread_barrier_t *bar;
    double t_begin, t_end;              /* rank 0: the timed region */
 } Worker;
@@ -63,6 +70,21 @@ static void synth_stream(int16_t *dst, size_t n, unsigned seed)
       const int tri = (int)(i % (size_t)period) * 2 - period;                    /* triangle wave */
       int v = burst ? tri * (12000 / period) + noise / 8 : noise / 64;
       dst[i] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+   }
+}
+
+/* wait for a stream without blocking in the runtime: a peer's failure must be able to end the wait.  1 = drained, 0 = given up (communicator aborted) */
+static int drain_or_abort(Worker *w, hipStream_t s)
+{
+   for (;;) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess) return 1;
+      if (q != hipErrorNotReady) return 0;
+      if (__atomic_load_n(w->failed, __ATOMIC_ACQUIRE)) {
+         if (!w->aborted) { (void)ncclCommAbort(w->comm); w->aborted = 1; }
+         return 0;
+      }
+      usleep(100);
    }
 }
 
@@ -94,7 +116,7 @@ static void *worker_main(void *arg)
       /* verification mode: every step's window of every local stream resident before the first call */
       d_in_all = (int16_t **)calloc((size_t)w->K, sizeof(int16_t *));
       h_tmp = (int16_t *)malloc(step_samples * sizeof(int16_t));
-      if (!d_in_all || !h_tmp) { w->rc = 5; goto out; }
+      if (!d_in_all || !h_tmp) FAIL(5);
       const size_t per_stream = (size_t)w->K * w->C * CHUNK;
       for (int k = 0; k < w->K; ++k) {
          HIP_OK(hipMalloc((void **)&d_in_all[k], step_samples * sizeof(int16_t)));
@@ -104,7 +126,7 @@ static void *worker_main(void *arg)
       }
    } else {
       h_tmp = (int16_t *)malloc(step_samples * sizeof(int16_t));
-      if (!h_tmp) { w->rc = 5; goto out; }
+      if (!h_tmp) FAIL(5);
       for (int b = 0; b < NBUF; ++b) {
          HIP_OK(hipMalloc((void **)&d_in[b], step_samples * sizeof(int16_t)));
          for (int s = 0; s < w->S; ++s) synth_stream(h_tmp + (size_t)s * w->C * CHUNK, (size_t)w->C * CHUNK, (unsigned)((w->rank * w->S + s) * NBUF + b));
@@ -121,6 +143,7 @@ static void *worker_main(void *arg)
          if (w->rank == 0) w->t_begin = now_s();
       }
       for (int i = 0; i < n; ++i) {
+         if (__atomic_load_n(w->failed, __ATOMIC_ACQUIRE)) { if (!w->rc) w->rc = 6; goto out; }      /* a peer has failed: issue nothing more */
          const int b = i % NBUF;
          const int16_t *in = w->pcm ? d_in_all[i] : d_in[b];
          /* this step's probability buffer was last read by the gather of step i - NBUF: the call (all its internal streams) waits for that */
@@ -130,11 +153,11 @@ static void *worker_main(void *arg)
          NCCL_OK(ncclGather(d_probs[b], d_gather[b], step_probs, ncclFloat, 0, w->comm, sg));
          HIP_OK(hipEventRecord(ev_g[b], sg));
          if (phase == 1 && w->dump && w->rank == 0) {            /* verification mode only: every step's gathered block to the host */
-            HIP_OK(hipStreamSynchronize(sg));
+            if (!drain_or_abort(w, sg)) FAIL(6);
             HIP_OK(hipMemcpy(w->dump + (size_t)i * step_probs * w->n_ranks, d_gather[b], step_probs * w->n_ranks * sizeof(float), hipMemcpyDeviceToHost));
          }
       }
-      HIP_OK(hipStreamSynchronize(sg));
+      if (!drain_or_abort(w, sg)) FAIL(6);
       ENG_OK(vadc_amd_synchronize(eng));
       if (phase == 1) {
          pthread_barrier_wait(w->bar); ++waits;                  /* the slowest rank ends the region */
@@ -143,8 +166,9 @@ static void *worker_main(void *arg)
    }
 out:
    while (waits < 2) { pthread_barrier_wait(w->bar); ++waits; }   /* a rank that failed must not leave the others in a barrier */
+   if (w->rc && !w->aborted && w->comm) { (void)ncclCommAbort(w->comm); w->aborted = 1; }      /* whatever this rank still has enqueued on the communicator ends here */
    if (st) (void)hipStreamSynchronize(st);
-   if (sg) (void)hipStreamSynchronize(sg);
+   if (sg && !w->rc) (void)hipStreamSynchronize(sg);
    for (int b = 0; b < NBUF; ++b) {
       if (d_in[b]) (void)hipFree(d_in[b]);
       if (d_probs[b]) (void)hipFree(d_probs[b]);
@@ -175,25 +199,40 @@ static void *read_file(const char *path, size_t *len)
 
 int main(int argc, char **argv)
 {
-   const char *model = NULL, *pcm_path = NULL, *dump_path = NULL;
+   const char *model = NULL, *pcm_path = NULL, *dump_path = NULL, *dev_list = NULL;
    int gpus = 0, S = 256, C = 96, K = 20, W = 5;
    for (int i = 1; i < argc; ++i) {
       const char *a = argv[i], *v = i + 1 < argc ? argv[i + 1] : NULL;
       if (!strcmp(a, "--model") && v) { model = v; ++i; }
       else if (!strcmp(a, "--gpus") && v) { gpus = atoi(v); ++i; }
+      else if (!strcmp(a, "--devices") && v) { dev_list = v; ++i; }
       else if (!strcmp(a, "--streams-per-gpu") && v) { S = atoi(v); ++i; }
       else if (!strcmp(a, "--chunks") && v) { C = atoi(v); ++i; }
       else if (!strcmp(a, "--steps") && v) { K = atoi(v); ++i; }
       else if (!strcmp(a, "--warmup") && v) { W = atoi(v); ++i; }
       else if (!strcmp(a, "--pcm") && v) { pcm_path = v; ++i; }
       else if (!strcmp(a, "--dump") && v) { dump_path = v; ++i; }
-      else { fprintf(stderr, "usage: %s --model weights.testtensor [--gpus N] [--streams-per-gpu S] [--chunks C] [--steps K] [--warmup W] [--pcm in.s16 --dump out.f32]\n", argv[0]); return 1; }
+      else { fprintf(stderr, "usage: %s --model weights.testtensor [--gpus N | --devices a,b,...] [--streams-per-gpu S] [--chunks C] [--steps K] [--warmup W] [--pcm in.s16 --dump out.f32]\n", argv[0]); return 1; }
    }
    if (!model || S <= 0 || C <= 0 || K <= 0 || W < 0) { fprintf(stderr, "vadc_hip_multi: --model is required; S, C, K > 0\n"); return 1; }
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "vadc_hip_multi: no HIP device (this host has no CPU path)\n"); return 2; }
+   int devs_arg[64], n_arg = 0;
+   if (dev_list) {                                               /* an explicit list: every entry a visible device, none twice */
+      for (const char *p = dev_list; *p && n_arg < 64;) {
+         char *end;
+         const long d = strtol(p, &end, 10);
+         if (end == p || d < 0 || d >= ndev) { fprintf(stderr, "vadc_hip_multi: --devices %s: '%s' is not one of the %d visible device(s) 0 .. %d\n", dev_list, p, ndev, ndev - 1); return 1; }
+         for (int j = 0; j < n_arg; ++j) if (devs_arg[j] == (int)d) { fprintf(stderr, "vadc_hip_multi: --devices %s names device %ld twice\n", dev_list, d); return 1; }
+         devs_arg[n_arg++] = (int)d;
+         p = *end == ',' ? end + 1 : end;
+         if (*end && *end != ',') { fprintf(stderr, "vadc_hip_multi: --devices wants a comma-separated list of device numbers\n"); return 1; }
+      }
+      if (gpus > 0 && gpus != n_arg) { fprintf(stderr, "vadc_hip_multi: --gpus %d but --devices lists %d\n", gpus, n_arg); return 1; }
+      gpus = n_arg;
+   }
    if (gpus <= 0) gpus = ndev;
-   if (gpus > ndev) { fprintf(stderr, "vadc_hip_multi: --gpus %d, but %d device(s) are visible\n", gpus, ndev); return 1; }
+   if (gpus > ndev) { fprintf(stderr, "vadc_hip_multi: %d GPUs asked for, but only %d device(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n", gpus, ndev); return 1; }
    size_t blob_len = 0, pcm_len = 0;
    void *blob = read_file(model, &blob_len);
    if (!blob) { fprintf(stderr, "vadc_hip_multi: cannot read %s\n", model); return 1; }
@@ -205,38 +244,56 @@ int main(int argc, char **argv)
    }
    float *dump = NULL;
    const size_t dump_floats = (size_t)K * gpus * S * C * 2;
-   if (dump_path) { dump = (float *)malloc(dump_floats * sizeof(float)); if (!dump) return 5; }
+   if (dump_path) { dump = (float *)malloc(dump_floats * sizeof(float)); if (!dump) { free(blob); free(pcm); return 5; } }
 
+   int rc = 0, failed = 0, comms_up = 0;
    ncclComm_t *comms = (ncclComm_t *)calloc((size_t)gpus, sizeof(ncclComm_t));
    int *devs = (int *)calloc((size_t)gpus, sizeof(int));
    Worker *ws = (Worker *)calloc((size_t)gpus, sizeof(Worker));
    pthread_t *th = (pthread_t *)calloc((size_t)gpus, sizeof(pthread_t));
-   if (!comms || !devs || !ws || !th) return 5;
-   for (int r = 0; r < gpus; ++r) devs[r] = r;
-   ncclResult_t nr = ncclCommInitAll(comms, gpus, devs);          /* one process, one communicator per device: rank r = device r */
-   if (nr != ncclSuccess) { fprintf(stderr, "vadc_hip_multi: ncclCommInitAll failed: %s\n", ncclGetErrorString(nr)); return 3; }
    pthread_barrier_t bar;
+   int bar_up = 0, started = 0;
+   if (!comms || !devs || !ws || !th) { rc = 5; goto done; }
+   for (int r = 0; r < gpus; ++r) devs[r] = dev_list ? devs_arg[r] : r;
+   {
+      ncclResult_t nr = ncclCommInitAll(comms, gpus, devs);       /* one process, one communicator per device: rank r = devs[r] */
+      if (nr != ncclSuccess) {
+         fprintf(stderr, "vadc_hip_multi: ncclCommInitAll over %d device(s) failed: %s (%d device(s) are visible)\n", gpus, ncclGetErrorString(nr), ndev);
+         rc = 3; goto done;
+      }
+      comms_up = 1;
+   }
    pthread_barrier_init(&bar, NULL, (unsigned)gpus);
+   bar_up = 1;
    for (int r = 0; r < gpus; ++r) {
       ws[r] = (Worker){.rank = r, .n_ranks = gpus, .device = devs[r], .S = S, .C = C, .K = K, .W = W, .rc = 0, .blob = blob, .blob_len = blob_len,
-                       .pcm = pcm, .dump = dump, .comm = comms[r], .bar = &bar};
-      if (pthread_create(&th[r], NULL, worker_main, &ws[r]) != 0) { fprintf(stderr, "vadc_hip_multi: pthread_create failed\n"); return 5; }
+                       .pcm = pcm, .dump = dump, .comm = comms[r], .failed = &failed, .aborted = 0, .bar = &bar};
+      if (pthread_create(&th[r], NULL, worker_main, &ws[r]) != 0) {
+         fprintf(stderr, "vadc_hip_multi: pthread_create failed\n");
+         /* the ranks already running wait in a barrier sized for all of them: nothing sane is left but to leave */
+         rc = 5; __atomic_store_n(&failed, 1, __ATOMIC_RELEASE); _exit(5);
+      }
+      ++started;
    }
-   int rc = 0;
-   for (int r = 0; r < gpus; ++r) { pthread_join(th[r], NULL); if (ws[r].rc) rc = ws[r].rc; }
-   for (int r = 0; r < gpus; ++r) (void)ncclCommDestroy(comms[r]);
-   if (rc) { fprintf(stderr, "vadc_hip_multi: failed (rc %d)\n", rc); return rc; }
+   for (int r = 0; r < started; ++r) { pthread_join(th[r], NULL); if (ws[r].rc && (!rc || ws[r].rc != 6)) rc = ws[r].rc; }
+   if (rc) { fprintf(stderr, "vadc_hip_multi: failed (rc %d)\n", rc); goto done; }
    if (dump_path) {
       FILE *f = fopen(dump_path, "wb");
-      if (!f || fwrite(dump, sizeof(float), dump_floats, f) != dump_floats) { fprintf(stderr, "vadc_hip_multi: cannot write %s\n", dump_path); return 1; }
-      fclose(f);
+      if (!f || fwrite(dump, sizeof(float), dump_floats, f) != dump_floats) { fprintf(stderr, "vadc_hip_multi: cannot write %s\n", dump_path); rc = 1; }
+      if (f) fclose(f);
+      if (rc) goto done;
    }
+   {
    const double wall = ws[0].t_end - ws[0].t_begin;
    const double audio_s = (double)gpus * S * C * K * (CHUNK / 16000.0);
    printf("{\"metric\": \"audio-seconds/sec (= real-time streams), Silero v3.1 16k\", \"value\": %.1f, \"unit\": \"audio-s/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
           "\"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"data\": \"%s\", \"host\": \"C (host/vadc_hip_multi.c), one thread per GPU, ncclGather to device 0 per step\", "
           "\"config\": {\"workload\": \"Silero v3.1 16k, %d streams/GPU x %d chunks per step, contiguous stream blocks\", \"streams_per_gpu\": %d, \"chunks_per_step\": %d}}\n",
           wall > 0 ? audio_s / wall : 0.0, gpus, K, pcm ? 0 : W, wall * 1e3 / K, pcm ? "file" : "synthetic", S, C, S, C);
+   }
+done:
+   if (comms_up) for (int r = 0; r < gpus; ++r) if (!ws || !ws[r].aborted) (void)ncclCommDestroy(comms[r]);      /* (an aborted communicator is already gone) */
+   if (bar_up) pthread_barrier_destroy(&bar);
    free(blob); free(pcm); free(dump); free(comms); free(devs); free(ws); free(th);
-   return 0;
+   return rc;
 }

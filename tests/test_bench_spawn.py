@@ -22,12 +22,16 @@ def _run(*args, env=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
 def test_bench_spawns_its_own_ranks(n):
+    """world 8 = the node the driver's scaling run uses (BASELINE config 5): spawn, rendezvous, contiguous stream blocks, the per-step gather and max-over-ranks
+    timing with EIGHT ranks, over gloo; every rank keeps to its own share of the CPUs this job may use"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     d = _run("--gpus", str(n), "--dry-run", "--steps", "4", "--warmup", "0", "--streams", "5", "--chunks-per-step", "3", env=env)
     assert d["n_gpus"] == n and d["dry_run"] is True and d["gather_verified"] is True
     assert d["total_streams"] == 5 * n and d["steps"] == 4 and d["scaling"] == "weak"
+    have = len(os.sched_getaffinity(0))
+    assert d["rank_cpus"] == (have // n if n > 1 and have >= n else have)
 
 
 def test_bench_runs_as_one_rank_under_a_launcher():
@@ -65,7 +69,7 @@ def test_multi_rank_gpu_code_path_on_one_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,total", [(1, 21), (2, 37), (3, 100)])
+@pytest.mark.parametrize("world,total", [(1, 21), (2, 37), (3, 100), (6, 83)])      # (six ranks: as many processes as a one-GPU box lets onto its card at once)
 def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
     """the N > 1 rank path PROVES its answers on one GPU: `--one-gpu-rehearsal --verify-dump` runs the rank code (per-rank engines on a RAGGED
     contiguous partition of the streams, deferred joins, side-stream gathers behind vadc_amd_join, five steps back to back from reset state) and

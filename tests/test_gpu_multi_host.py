@@ -57,3 +57,23 @@ def test_bench_line_of_the_c_host():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config"):
         assert k in line
     assert line["warmup"] == 2 and abs(line["value"] - 64 * 32 * 6 * 0.096 / (line["ms_per_step"] * 6e-3)) / line["value"] < 1e-3
+
+
+def test_devices_list_and_its_errors(tmp_path):
+    """--devices names the HIP devices in rank order; a device that is not visible, a device named twice and more GPUs than are visible are refused with a message that
+    says how many devices there are (no hang, no crash, exit code 1)"""
+    import torch
+    n = torch.cuda.device_count()
+    fout = str(tmp_path / "out.f32")
+    pcm = synth.make_streams(8, 2 * 3, seed0=2300)
+    fin = str(tmp_path / "in.s16")
+    np.ascontiguousarray(pcm).tofile(fin)
+    base = [_exe(), "--model", WEIGHTS, "--streams-per-gpu", "8", "--chunks", "3", "--steps", "2"]
+    r = subprocess.run(base + ["--devices", "0", "--pcm", fin, "--dump", fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(fout, np.float32).reshape(2, 8, 3, 2)
+    want = O.Oracle(open(WEIGHTS, "rb").read()).forward_streams(pcm)
+    assert float(np.abs(np.concatenate([got[k, :, :, 1] for k in range(2)], axis=1) - want).max()) <= PROB_TOL
+    for extra, text in ((["--devices", str(n)], "visible device"), (["--devices", "0,0"], "twice"), (["--gpus", str(n + 1)], "visible"), (["--devices", "0", "--gpus", "2"], "lists 1")):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and text in r.stderr, (extra, r.returncode, r.stderr[-500:])

@@ -1,4 +1,4 @@
-"""The N > 1 path of bench.py (stream sharding + final probability gather) on CPU: world_size 2 over gloo."""
+"""The N > 1 path of bench.py (stream sharding + final probability gather) on CPU: world_size 2 and 8 over gloo."""
 import os
 import socket
 
@@ -58,9 +58,9 @@ def _worker(rank, world, port, total_streams, chunks, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total_streams", [8, 7])
-def test_gather_over_gloo_world2(total_streams):
-    world, chunks = 2, 5
+@pytest.mark.parametrize("world,total_streams", [(2, 8), (2, 7), (8, 61), (8, 5)])      # world 8 = the node of the scaling run; 61: ragged blocks; 5: three ranks own nothing
+def test_gather_over_gloo(world, total_streams):
+    chunks = 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
