@@ -23,9 +23,9 @@ for kind in ("registered numpy", "torch pinned"):
     for parts in (1, 2, 3, 4):
         e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
         e.set_option("h2d_streams", parts); e.set_option("graph", 1)
-        for i in range(6): e.run_async(host[i % NB], outs[i % NB])
+        for i in range(18): e.run_async(host[i % NB], outs[i % NB])
         e.wait_async()
-        n = 20
+        n = 48
         t = time.perf_counter()
         for i in range(n): e.run_async(host[i % NB], outs[i % NB])
         e.wait_async()
