@@ -36,23 +36,27 @@ constexpr bool quads_of_a_half_hit_disjoint_banks()
 }
 static_assert(quads_of_a_half_hit_disjoint_banks(), "LDS banks");
 
-// the chunk image: 12,900 bytes from the 16-byte boundary below the chunk's first byte (lead <= 12) fit 808 units of 16 bytes = 13 pieces of 64 lanes,
-// the last one 40 lanes
-static_assert(kL1ChunkFloats * 4 + 12 <= kL1BufBytes && kL1BufBytes == 808 * 16 && 12 * 64 + 40 == 808, "chunk image");
+// the chunk image: 12,900 bytes from the 16-byte boundary below the chunk's first byte (lead <= 12) fit 808 units of 16 bytes
+static_assert(kL1ChunkFloats * 4 + 12 <= kL1BufBytes && kL1BufBytes == 808 * 16, "chunk image");
 static_assert(kL1YSlackBytes >= kL1BufBytes - kL1ChunkFloats * 4, "the last chunk's copy stays inside the allocation");
-// group g of the next chunk (units [192 g, 192 (g + 1))) overwrites only bytes k block g has consumed (k block g reads [lead + 3200 g, lead + 3200 (g + 1)));
-// k block g of the next chunk needs units below ceil((12 + 3200 (g + 1)) / 16) = 200 (g + 1) + 1: groups 0 .. g and the FIRST piece of group g + 1
-constexpr bool dma_groups_are_safe()
+// k_layer1_regs: group kb = 208 units (3 pieces of 64 lanes and one of 16) from unit 200 kb of that image.  It holds k block kb's bytes
+// [lead + 3200 kb, lead + 3200 (kb + 1)) -- and, kb = 3, the Nyquist channel's 100 behind them -- whatever the lead, and group 3 ends where the image ends
+constexpr bool dma_groups_hold_their_k_blocks()
 {
-   for (int g = 0; g < 3; ++g) {
-      if (192 * (g + 1) * 16 > 3200 * (g + 1)) return false;                 // overwritten <= consumed (lead = 0 is the tight case)
-      if (200 * (g + 1) + 1 > 192 * (g + 1) + 64) return false;              // needed <= groups 0..g + one piece
-   }
-   return true;
+   for (int kb = 0; kb < 4; ++kb)
+      for (int lead = 0; lead <= 12; lead += 4) {
+         const int first = lead + 3200 * kb, last = lead + 3200 * (kb + 1) + (kb == 3 ? 100 : 0);      // bytes of the image the k block reads: [first, last)
+         if (first < 200 * kb * 16 || last > 200 * kb * 16 + kL1SlabBytes) return false;
+      }
+   return 3 * 64 + 16 == kL1SlabBytes / 16 && 200 * 3 * 16 + kL1SlabBytes == kL1BufBytes;
 }
-static_assert(dma_groups_are_safe(), "DMA groups");
-// the image and eight wave buffers fit a CU's 160 KB of LDS; fragments and vectors are 16-byte aligned
-static_assert(kL1ImgBytes + 8 * kL1BufBytes + 64 <= 160 * 1024, "LDS budget");
+static_assert(dma_groups_hold_their_k_blocks(), "DMA groups");
+// the taps of a channel: the four lane quads of one ds_read_b128 read 32 bytes apart (quads 256 bytes apart met in the same banks: tools/lds_conflict_probe.hip)
+static_assert(L1Layout::v_taps % 4 == 0, "taps");
+// the image and the waves' buffers fit a CU's 160 KB of LDS (k_layer1_regs: twelve rings of three slabs; k_layer1_regs_v4: eight whole-chunk images);
+// fragments and vectors are 16-byte aligned
+static_assert(kL1ImgBytes + kL1Waves * kL1RingBytes + 64 <= 160 * 1024, "LDS budget");
+static_assert(kL1V4ImgBytes + 8 * kL1BufBytes + 64 <= 160 * 1024, "LDS budget (v4)");
 static_assert(L1Layout::f_tail % 16 == 0 && L1Layout::f_qkv % 16 == 0 && L1Layout::f_end % 16 == 0 && L1Layout::v_tail % 4 == 0 && L1Layout::v_cb_b % 4 == 0 &&
               L1Layout::v_q_b % 4 == 0 && L1Layout::v_cv_b % 4 == 0, "alignment of 16-byte LDS reads");
 // k_enc_fused's images: phase B is the larger one and fits beside nothing else

@@ -155,7 +155,7 @@ def test_counted_wait_kernels_do_not_spill(tmp_path):
     # a listing with one DMA piece missing, and one with a spill inside the layer-1 kernel, must be rejected
     txt = open(outs[0]).read()
     bad1 = str(tmp_path / "missing_piece.s")
-    i = txt.index("_ZN4vadc13k_layer1_regsILi8ELi0")
+    i = txt.index("_ZN4vadc13k_layer1_regsILi12ELi0")
     j = txt.index("global_load_lds_dwordx4", txt.index(":", i))
     open(bad1, "w").write(txt[:j] + "s_nop 0 ;" + txt[j + len("global_load_lds_dwordx4"):])
     assert ccw.check(bad1)[0]

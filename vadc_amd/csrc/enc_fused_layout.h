@@ -127,7 +127,7 @@ struct L1Layout {
    static constexpr int f_cv   = f_l2 + kFrag4Bytes;                 // LayerNorm 2's scale folded into its columns
    static constexpr int f_end  = f_cv + kFrag4Bytes;
    // vectors (floats, relative to the vector base at byte f_end)
-   static constexpr int v_taps = 0;                                  // [4 kb][4 q][8 e][8]: k0 k1 k2 k3 | k4 bias bias 0
+   static constexpr int v_taps = 0;                                  // [4 kb][8 e][4 q][8]: k0 k1 k2 k3 | k4 bias bias 0 -- the four quads of a read 32 B apart: quads 256 B apart (q outside e) met in the same banks, 2.63 against 1.84 cycles per ds_read_b128 (tools/lds_conflict_probe.hip)
    static constexpr int v_tail = v_taps + 4 * 4 * 8 * 8;             // channel 128: the same 8 floats
    static constexpr int v_cb_b = v_tail + 8;
    static constexpr int v_q_b  = v_cb_b + 16, v_k_b = v_q_b + 16;
@@ -141,7 +141,11 @@ struct L1Layout {
 constexpr int kL1ImgBytes = L1Layout::f_end + L1Layout::v_end * 4;
 static_assert(kL1ImgBytes % 16 == 0, "the image is copied in 16-byte pieces");
 constexpr int kL1ChunkFloats = 129 * 25;
-constexpr int kL1BufBytes = 808 * 16;        // a wave's chunk image: 12,900 bytes from the 16-byte boundary below the chunk (<= 12 bytes of lead)
+constexpr int kL1BufBytes = 808 * 16;        // a chunk's image: 12,900 bytes from the 16-byte boundary below the chunk (<= 12 bytes of lead) (k_layer1_regs_v4: one per wave)
+constexpr int kL1SlabBytes = 208 * 16;       // k_layer1_regs: one k block's 3,200 bytes (+ the Nyquist channel's 100 behind k block 3) from the 16-byte boundary below them
+constexpr int kL1RingBytes = 3 * kL1SlabBytes;      // a wave's ring of three slabs
+constexpr int kL1Waves = 12;                 // waves per workgroup of k_layer1_regs (three per SIMD)
+static_assert(600 * 16 + kL1SlabBytes == kL1BufBytes, "group 3 ends where the whole-chunk image ended");
 constexpr int kL1YSlackBytes = 64;           // the DMA of the last chunk reads up to 28 bytes past it
 
 struct L1RegsArgs {
@@ -163,7 +167,7 @@ struct L1V4Layout {
    static constexpr int f_tail = f_conv + 16 * kFragBytes;
    static constexpr int f_cv   = f_tail + kFrag4Bytes;               // strided 1x1 conv (BatchNorm folded by the exporter)
    static constexpr int f_end  = f_cv + kFrag4Bytes;
-   static constexpr int v_taps = 0;                                  // [8 vb][4 q][8 e][8]: k0 k1 k2 k3 | k4 bias bias 0
+   static constexpr int v_taps = 0;                                  // [8 vb][8 e][4 q][8]: k0 k1 k2 k3 | k4 bias bias 0 (as L1Layout::v_taps)
    static constexpr int v_tail = v_taps + 8 * 4 * 8 * 8;             // bin 128: magnitude's 8 floats, normalized's 8 floats
    static constexpr int v_cb_b = v_tail + 16;
    static constexpr int v_cv_b = v_cb_b + 16;

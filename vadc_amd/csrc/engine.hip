@@ -599,7 +599,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       };
       for (int kb = 0; kb < 4; ++kb)
          for (int q = 0; q < 4; ++q)
-            for (int el = 0; el < 8; ++el) put_taps(v + L1Layout::v_taps + ((kb * 4 + q) * 8 + el) * 8, l1_channel(kb, q, el));
+            for (int el = 0; el < 8; ++el) put_taps(v + L1Layout::v_taps + ((kb * 8 + el) * 4 + q) * 8, l1_channel(kb, q, el));
       put_taps(v + L1Layout::v_tail, 128);
       for (int o = 0; o < D; ++o) {
          v[L1Layout::v_cb_b + o] = r.pw_b[o] + r.pj_b[o];
@@ -760,7 +760,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       };
       for (int vb = 0; vb < 8; ++vb)
          for (int q = 0; q < 4; ++q)
-            for (int el = 0; el < 8; ++el) put_taps(v + L1V4Layout::v_taps + ((vb * 4 + q) * 8 + el) * 8, (vb & 1) * kBins + l1_channel(vb >> 1, q, el));
+            for (int el = 0; el < 8; ++el) put_taps(v + L1V4Layout::v_taps + ((vb * 8 + el) * 4 + q) * 8, (vb & 1) * kBins + l1_channel(vb >> 1, q, el));
       put_taps(v + L1V4Layout::v_tail, 128);
       put_taps(v + L1V4Layout::v_tail + 8, kBins + 128);
       for (int o = 0; o < D; ++o) { v[L1V4Layout::v_cb_b + o] = r0.cb_b[o]; v[L1V4Layout::v_cv_b + o] = r0.cv_b[o]; }

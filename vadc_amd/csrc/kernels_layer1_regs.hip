@@ -37,29 +37,26 @@ __device__ unsigned long long g_l1r_phase[8];
 #define L1R_PH(i) do { } while (0)
 #endif
 
-// four input channels of a k block (half of a B operand): x at this lane's step in both tiles, and the channels' depthwise taps
-struct L1Stage { f2 x[4]; f4 ka[4], kb[4]; };      // x[c] = (tile 0, tile 1)
-__device__ __forceinline__ L1Stage l1_load_stage(const float *xb, const float *tp, int kb, int half)
+// one input channel of a k block on its way out of LDS: x at this lane's step in both tiles, and the channel's depthwise taps.  xb = the k block's slab
+// + the chunk's lead + this lane's (quad, column) part; tp = the taps of this lane's quad
+struct L1Chan { f2 x; f4 ka, kb; };      // x = (tile 0, tile 1)
+__device__ __forceinline__ L1Chan l1_load_chan(const float *xb, const float *tp, int kb, int e)
 {
-   L1Stage s;
-#pragma unroll
-   for (int c = 0; c < 4; ++c) {
-      const int e = 4 * half + c;
-      s.x[c] = f2{xb[(32 * kb + e) * 25], xb[(32 * kb + e) * 25 + 9]};
-      s.ka[c] = lds_vec4(tp, (kb * 32 + e) * 8);
-      s.kb[c] = lds_vec4(tp, (kb * 32 + e) * 8 + 4);
-   }
+   L1Chan s;
+   s.x = f2{xb[e * 25], xb[e * 25 + 9]};
+   s.ka = lds_vec4(tp, (kb * 8 + e) * 32);
+   s.kb = lds_vec4(tp, (kb * 8 + e) * 32 + 4);
    return s;
 }
-// x - offset (misc.c:84-96), relu(dw(x) + bias) for channel c of the stage in both tiles; (x0, x1) of a channel are one register pair as they come out
-// of the LDS read: the subtraction is one packed instruction
-__device__ __forceinline__ void l1_channel_math(const L1Stage &s, int c, float off, f4 &x0, f4 &x1, f4 &d0, f4 &d1)
+// x - offset (misc.c:84-96), relu(dw(x) + bias) of the channel in both tiles; (x0, x1) are one register pair as they come out of the LDS read: the
+// subtraction is one packed instruction
+__device__ __forceinline__ void l1_channel_math(const L1Chan &s, float off, float &x0, float &x1, float &d0, float &d1)
 {
-   const f2 xp = s.x[c] - f2{off, off};
-   x0[c] = xp[0]; x1[c] = xp[1];
+   const f2 xp = s.x - f2{off, off};
+   x0 = xp[0]; x1 = xp[1];
    float a, b;
-   dw5x2(xp[0], xp[1], s.ka[c][0], s.ka[c][1], s.ka[c][2], s.ka[c][3], s.kb[c][0], s.kb[c][1], a, b);
-   d0[c] = relu(a); d1[c] = relu(b);
+   dw5x2(xp[0], xp[1], s.ka[0], s.ka[1], s.ka[2], s.ka[3], s.kb[0], s.kb[1], a, b);
+   d0 = relu(a); d1 = relu(b);
 }
 
 // step of column lc of tile t, and whether the tile owns it
@@ -185,25 +182,32 @@ template <int NW, int TAP>
 __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
 {
    constexpr bool ENTER = TAP != 0 && TAP != 4;                 // the chunk enters behind the conv block: no input pipeline
-   __shared__ __attribute__((aligned(16))) char lds[kL1ImgBytes + (ENTER ? 16 : NW * kL1BufBytes)];
+   __shared__ __attribute__((aligned(16))) char lds[kL1ImgBytes + (ENTER ? 16 : NW * kL1RingBytes)];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, lc = lane & 15;
-   const int slot = blockIdx.x * NW + wave, nslots = gridDim.x * NW;
+   // wave-major: the last, partial round of the grid's (waves x workgroups) slots is then one or two waves on EVERY CU -- a wave alone on its SIMD runs
+   // twice as fast -- instead of full workgroups on a few CUs beside idle ones (24,576 chunks on 224 CUs x 12 waves: 9.14 rounds)
+   const int slot = wave * gridDim.x + blockIdx.x, nslots = gridDim.x * NW;
    const char *img = lds;
    const float *vec = reinterpret_cast<const float *>(lds + LL::f_end);
-   char *buf = lds + kL1ImgBytes + (ENTER ? 0 : wave * kL1BufBytes);
+   char *buf = lds + kL1ImgBytes + (ENTER ? 0 : wave * kL1RingBytes);
 
    // ---- the input pipeline -----------------------------------------------------------------------------------------------------------------
-   // A chunk's bytes travel from the 16-byte boundary below its first one into this wave's buffer as 13 LDS-DMA pieces of 1 KB in four GROUPS --
-   // 16-byte units [0, 192), [192, 384), [384, 576), [576, 808) -- and group g of the NEXT chunk is issued as soon as k block g of the current one
-   // has been read: k block g reads bytes [lead + 3200 g, lead + 3200 (g + 1)), lead <= 12, so units below 192 (g + 1) hold consumed bytes only.
-   // Every piece so has most of a chunk's time to arrive (issued in one go behind the conv block, the copy had the transformer block's time only and
-   // a wave spent a quarter of its time waiting for it).  K block g of the next chunk needs units below 200 (g + 1) + 1: groups 0 .. g and the FIRST
-   // piece of group g + 1.  The four partial bin sums of the chunk's frames (lanes 0..24) are loaded ahead of group 0, by inline asm as well: hipcc
-   // does not count the DMA pieces, and its own s_waitcnt for a load it knows would wait for every piece issued before it.
-   // Vector-memory operations complete in issue order; per iteration a wave issues, in this order: 4 loads (sums), 3 + 3 + 3 + 4 pieces, 4 stores =
-   // 21.  The waits below count from that (see L1R_WAIT); the first iteration starts behind a full drain, where every counted wait passes at once.
+   // A chunk travels in four GROUPS, one per k block: k block kb reads bytes [3200 kb, 3200 (kb + 1)) of the chunk (kb = 3: and the Nyquist channel's
+   // 100 behind them), and group kb is the 208 16-byte units from the 16-byte boundary below byte 3200 kb -- four LDS-DMA instructions, the last with 16
+   // lanes -- copied as they lie into one SLAB (3,328 B) of the wave's ring of three: group j of the wave's sequence (j = 4 * iteration + kb) lives in
+   // slab j mod 3, and group j + 3 is issued as soon as k block j's last LDS read has returned.  A wave so holds 10 KB of LDS instead of a whole chunk
+   // (12.9 KB: round 4), which lets a third wave per SIMD in -- 12 x 10 KB + the 35-KB weight image = 155 of 160 KB -- and every group has two to
+   // three k blocks' time to arrive.  The four partial bin sums of the chunk's frames (lanes 0..24) are loaded by inline asm as well, ahead of the
+   // group that follows k block 0: hipcc does not count the DMA instructions, and its own s_waitcnt for a load it knows would wait for all of them.
+   //
+   // The waits count LOADS only.  Loads complete in issue order among themselves, but a store may complete before an older load: a wait that counted
+   // on the four stores of an iteration still being outstanding could pass with its load in flight.  Each wait below allows as many outstanding
+   // operations as there are loads YOUNGER than the one it needs; stores still in flight then make it wait a little longer than it must, never less.
+   // Issue order per iteration i: [W0] k block 0 (W1 inside, before its 7th channel) -> sums(i + 1), G(i, 3) -> k block 1 (W2) -> G(i + 1, 0) ->
+   // k block 2 (W3) -> G(i + 1, 1) -> k block 3 -> G(i + 1, 2) -> 4 stores.  Younger loads at W0: G(i, 1), G(i, 2) = 8; W1: G(i, 2) = 4;
+   // W2: sums(i + 1), G(i, 3) = 8 (last iteration: 4); W3: G(i + 1, 0) = 4 (last iteration: 0).
    float fmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
    const int lo16 = lane * 16;
    auto chunk_base = [&](int nn) -> const char * {
@@ -216,14 +220,16 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
 #pragma unroll
       for (int k = 0; k < 4; ++k) asm volatile("global_load_dword %0, %1, %2" : "=v"(fmv[k]) : "v"(lo4), "s"(fmp + k * a.fm_stride) : "memory");
    };
-   auto issue_group = [&](int nn, int g) {
-      const char *src = chunk_base(nn);
-      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf;
+   int ring = 0;                                              // slab of k block 0 of the current chunk (wave-uniform): (4 * iteration) mod 3
+   auto slab_of = [&](int kb) { const int r = ring + kb; return r >= 3 ? r - 3 : r; };      // kb <= 3, ring <= 2: r <= 5
+   auto issue_group = [&](int nn, int kb, int slab) {
+      const char *src = chunk_base(nn) + 3200 * kb;
+      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf + (unsigned)slab * kL1SlabBytes;
 #ifndef VADC_L1R_ABL_NODMA        // (timing-only ablations, tools/l1r_ablate.sh: results are wrong)
 #pragma unroll
-      for (int j = 3 * g; j < 3 * g + 3; ++j)
+      for (int j = 0; j < 3; ++j)
          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + j * 1024), "v"(lo16), "s"(src + j * 1024) : "memory");
-      if (g == 3 && lane < 40) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 12 * 1024), "v"(lo16), "s"(src + 12 * 1024) : "memory");
+      if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 3 * 1024), "v"(lo16), "s"(src + 3 * 1024) : "memory");
 #else
       asm volatile("" :: "s"(dst), "s"(src), "v"(lo16));
 #endif
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
       const int n0 = a.map(slot);
       issue_sums(n0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) issue_group(n0, g);
+      for (int g = 0; g < 3; ++g) issue_group(n0, g, g);
    }
    {  // image -> LDS, 8 loads in flight per thread
       const uint4 *src = reinterpret_cast<const uint4 *>(a.img);
@@ -278,8 +284,8 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
       const bool more = item + nslots < a.n_chunks;           // wave-uniform
       const int nnext = more ? a.map(item + nslots) : n;      // (the index arithmetic of the next chunk once per iteration, in scalar registers)
       L1R_PH(0);
-      // outstanding, oldest first: sums 4, groups 3 3 3 4, stores 4.  The sums have landed when 17 are left.
-      asm volatile("s_waitcnt vmcnt(17)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
+      // W0: the chunk's sums and group 0 (younger loads: groups 1 and 2)
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
       L1R_PH(1);
       // ---- adaptive normalization offset of the chunk (misc.c:65-82): frame means, 7-tap smoothing with reflect padding, mean over the frames ----
       float off;
@@ -316,15 +322,19 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
       L1R_PH(2);
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x))        conv.c:761-814 ----
       const int lead = (int)(((size_t)n * (kL1ChunkFloats * 4)) & 15);
-      const float *xb = reinterpret_cast<const float *>(buf + lead) + (16 * (q & 1) + 8 * (q >> 1)) * 25 + lc;
-      const float *tp = vec + LL::v_taps + q * 64;
+      const int lane_part = lead + ((16 * (q & 1) + 8 * (q >> 1)) * 25 + lc) * 4;      // this lane's (quad, column) inside a slab
+      auto slab_ptr = [&](int kb) { return reinterpret_cast<const float *>(buf + slab_of(kb) * kL1SlabBytes + lane_part); };
+      const float *tp = vec + LL::v_taps + q * 8;
       f4 acc[2];
       acc[0] = acc[1] = lds_vec4(vec, LL::v_cb_b + 4 * q);
-      asm volatile("s_waitcnt vmcnt(13)" ::: "memory");        // k block 0: group 0 and the first piece of group 1 (8 done)
-      L1Stage sa = l1_load_stage(xb, tp, 0, 0), sb;
-      Frag wd = lds_frag(img + LL::f_conv, 0, lane), wx = lds_frag(img + LL::f_conv, 4, lane);
-      // The 12 MFMAs of k block kb - 1 are issued ONE AT A TIME between the channel groups of k block kb (about 14 vector instructions each), not in
-      // a clump behind their operands' splits.  The scheduling barriers pin that order.
+      // The channels come out of LDS two ahead of the one being worked on (a window of three: 30 registers -- two stages of four channels each held 80,
+      // and with the weights of three k blocks the kernel stood at 208 registers, two waves per SIMD); the 12 MFMAs of k block kb - 1 are issued ONE AT
+      // A TIME between the channels of k block kb (about 14 vector instructions each), not in a clump behind their operands' splits, and their weights
+      // are fetched when the previous k block's have been used.  The scheduling barriers pin that order.
+      L1Chan ch[3];
+      const float *xb = slab_ptr(0);
+      ch[0] = l1_load_chan(xb, tp, 0, 0);
+      ch[1] = l1_load_chan(xb, tp, 0, 1);
       Frag pd0, pd1, px0, px1, pwd, pwx;                         // pending: operands and weights of the previous k block
       auto pending_mfma = [&](int i) {
          const int t = i & 1, term = i >> 1;
@@ -336,42 +346,40 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
          const bool have = kb > 0;
-         sb = l1_load_stage(xb, tp, kb, 1);
-         __builtin_amdgcn_sched_barrier(0);
          f4 xl0, xl1, dl0, dl1, xh0, xh1, dh0, dh1;
+         const float *xbn = xb;
 #pragma unroll
-         for (int c = 0; c < 4; ++c) {
-            l1_channel_math(sa, c, off, xl0, xl1, dl0, dl1);
+         for (int c = 0; c < 8; ++c) {
+            const int j = 8 * kb + c;                           // the channel's place in the chunk's sequence of 33
+            if (c == 6 && kb < 3) {                             // the next k block's first channels are read from here on: its group must have landed
+               if (kb == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W1
+               if (kb == 1) L1R_WAIT(more, 8, 4);                                 // W2
+               if (kb == 2) L1R_WAIT(more, 4, 0);                                 // W3
+               xbn = slab_ptr(kb + 1);
+            }
+            if (j + 2 < 32) ch[(j + 2) % 3] = l1_load_chan(c + 2 < 8 ? xb : xbn, tp, (j + 2) >> 3, (j + 2) & 7);
+            else if (j + 2 == 32) {
+               // the Nyquist channel (128), for every lane: k = 0 relu(dw(x)), k = 1 x; only quad 0's weights are not zero.  It lies behind k block 3's 32
+               // channels in the same slab
+               const float *xt = reinterpret_cast<const float *>(buf + slab_of(3) * kL1SlabBytes + lead) + 32 * 25 + lc;
+               ch[2].x = f2{xt[0], xt[9]};
+               ch[2].ka = lds_vec4(vec, LL::v_tail); ch[2].kb = lds_vec4(vec, LL::v_tail + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               float x0, x1, d0, d1;
+               l1_channel_math(ch[j % 3], off, x0, x1, d0, d1);
+               if (c < 4) { xl0[c] = x0; xl1[c] = x1; dl0[c] = d0; dl1[c] = d1; }
+               else       { xh0[c - 4] = x0; xh1[c - 4] = x1; dh0[c - 4] = d0; dh1[c - 4] = d1; }
+            }
             if (have) pending_mfma(c);
             __builtin_amdgcn_sched_barrier(0);
          }
-         Frag wdn = wd, wxn = wx;
-         // k block kb + 1 needs its groups 0 .. kb + 1 and the first piece of group kb + 2.  Done so far must be 11 / 14 / 17 of the 21 operations
-         // of the last iteration; this one has issued 0 / 7 / 10 more (if it issues at all)
-         if (kb == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-         if (kb == 1) L1R_WAIT(more, 14, 7);
-         if (kb == 2) L1R_WAIT(more, 14, 4);
-         if (kb < 3) {
-            sa = l1_load_stage(xb, tp, kb + 1, 0);
-            wdn = lds_frag(img + LL::f_conv, kb + 1, lane); wxn = lds_frag(img + LL::f_conv, 4 + kb + 1, lane);
-         } else {
-            // the Nyquist channel (128), for every lane: k = 0 relu(dw(x)), k = 1 x; only quad 0's weights are not zero
-            const float *xt = reinterpret_cast<const float *>(buf + lead) + 128 * 25 + lc;
-            sa.x[0] = f2{xt[0], xt[9]};
-            sa.ka[0] = lds_vec4(vec, LL::v_tail); sa.kb[0] = lds_vec4(vec, LL::v_tail + 4);
-         }
-         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-         for (int c = 0; c < 4; ++c) {
-            l1_channel_math(sb, c, off, xh0, xh1, dh0, dh1);
-            if (have) pending_mfma(4 + c);
-            __builtin_amdgcn_sched_barrier(0);
-         }
-         // k block kb has been read (every value of its two stages has been used): group kb of the next chunk may overwrite it
-         if (more && kb < 3) {
-            if (kb == 0) issue_sums(nnext);
-            issue_group(nnext, kb);
-         }
+         // k block kb has been read (every value of its channels has been used): the group three further on may overwrite its slab
+         if (kb == 0) {
+            if (more) issue_sums(nnext);
+            issue_group(n, 3, slab_of(0));
+         } else if (more && kb < 3) issue_group(nnext, kb - 1, slab_of(kb));      // (k block 3's slab also holds the Nyquist channel: behind the tail's read)
          const Frag df0 = split8(dl0, dh0);
          if (have) pending_mfma(8);
          __builtin_amdgcn_sched_barrier(0);
@@ -384,26 +392,24 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs(L1RegsArgs a)
          const Frag xf1 = split8(xl1, xh1);
          if (have) pending_mfma(11);
          __builtin_amdgcn_sched_barrier(0);
-         pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1; pwd = wd; pwx = wx;
-         wd = wdn; wx = wxn;
+         pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1;
+         pwd = lds_frag(img + LL::f_conv, kb, lane); pwx = lds_frag(img + LL::f_conv, 4 + kb, lane);
+         xb = xbn;
       }
       {
          const AOp wt = lds_aop(img + LL::f_tail, lane);
-         const float x0 = sa.x[0][0] - off, x1 = sa.x[0][1] - off;      // (uses the last LDS read of the chunk)
-         if (more) issue_group(nnext, 3);
+         float x0, x1, d0, d1;
+         l1_channel_math(ch[2], off, x0, x1, d0, d1);           // (uses the last LDS read of the chunk)
+         if (more) issue_group(nnext, 2, slab_of(3));
 #pragma unroll
-         for (int i = 0; i < 4; ++i) pending_mfma(i);
-         float d0, d1;
-         dw5x2(x0, x1, sa.ka[0][0], sa.ka[0][1], sa.ka[0][2], sa.ka[0][3], sa.kb[0][0], sa.kb[0][1], d0, d1);
-         d0 = relu(d0); d1 = relu(d1);
-#pragma unroll
-         for (int i = 4; i < 8; ++i) pending_mfma(i);
+         for (int i = 0; i < 6; ++i) pending_mfma(i);
          const h8 b0 = split4_hl(f4{d0, x0, 0.0f, 0.0f}), b1 = split4_hl(f4{d1, x1, 0.0f, 0.0f});
 #pragma unroll
-         for (int i = 8; i < 12; ++i) pending_mfma(i);
+         for (int i = 6; i < 12; ++i) pending_mfma(i);
          acc[0] = mm(wt, b0, acc[0]);
          acc[1] = mm(wt, b1, acc[1]);
       }
+      ring = slab_of(1);                                         // four groups on: (ring + 4) mod 3
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -452,14 +458,14 @@ extern "C" int vadc_amd_debug_l1r_phases(unsigned long long *out, int reset)
 }
 #endif
 
-// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain).  8 waves per workgroup: 2 per SIMD, up to 256 registers each -- the counted
-// waits of the input pipeline rely on a register allocation without spills (an in-flight load's destination must not be moved); 10 waves (168
-// registers: 45 spilled) were also slower, 0.14 against 0.12 ms.
+// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain).  12 waves per workgroup: 3 per SIMD, up to 168 registers each -- the counted
+// waits of the input pipeline rely on a register allocation without spills (a scratch access is a vector-memory operation the waits do not count:
+// tools/kernel_regs.py checks the build).
 void launch_layer1_regs(const L1RegsArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   const int g = std::min(max_wgs, (a.n_chunks + 7) / 8);
-   hipLaunchKernelGGL((k_layer1_regs<8, 0>), dim3(g), dim3(512), 0, st, a);
+   const int g = std::min(max_wgs, (a.n_chunks + kL1Waves - 1) / kL1Waves);
+   hipLaunchKernelGGL((k_layer1_regs<kL1Waves, 0>), dim3(g), dim3(64 * kL1Waves), 0, st, a);
 }
 
 // stage taps for the op-level fixtures (vadc_amd_debug_layer1_block): a.y = [n][16][25] (what = 4: [n][129][25] + a.fm), a.out = [n][16][25]
@@ -470,7 +476,7 @@ void launch_layer1_regs_tap(int what, const L1RegsArgs &a, hipStream_t st)
    if (what == 1)      hipLaunchKernelGGL((k_layer1_regs<4, 1>), dim3(g), dim3(256), 0, st, a);
    else if (what == 2) hipLaunchKernelGGL((k_layer1_regs<4, 2>), dim3(g), dim3(256), 0, st, a);
    else if (what == 3) hipLaunchKernelGGL((k_layer1_regs<4, 3>), dim3(g), dim3(256), 0, st, a);
-   else if (what == 4) hipLaunchKernelGGL((k_layer1_regs<8, 4>), dim3(std::min(256, (a.n_chunks + 7) / 8)), dim3(512), 0, st, a);      // the product's shape: 8 waves, the input pipeline
+   else if (what == 4) hipLaunchKernelGGL((k_layer1_regs<kL1Waves, 4>), dim3(std::min(256, (a.n_chunks + kL1Waves - 1) / kL1Waves)), dim3(64 * kL1Waves), 0, st, a);      // the product's shape and input pipeline
    else                hipLaunchKernelGGL((k_layer1_regs<4, 5>), dim3(g), dim3(256), 0, st, a);
 }
 

@@ -32,8 +32,8 @@ __device__ __forceinline__ L1V4Stage l1v4_load_stage(const float *xb, const floa
    for (int c = 0; c < 4; ++c) {
       const int e = 4 * half + c;
       s.x[c] = f2{xb[(32 * kb + e) * kT4], xb[(32 * kb + e) * kT4 + 8]};
-      s.ka[c] = lds_vec4(tp, (vb * 32 + e) * 8);
-      s.kb[c] = lds_vec4(tp, (vb * 32 + e) * 8 + 4);
+      s.ka[c] = lds_vec4(tp, (vb * 8 + e) * 32);
+      s.kb[c] = lds_vec4(tp, (vb * 8 + e) * 32 + 4);
    }
    return s;
 }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
       }
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x)), x = concat(magnitude, normalized) ----
       const float *xb = reinterpret_cast<const float *>(buf) + (16 * (q & 1) + 8 * (q >> 1)) * kT4 + lc;
-      const float *tp = vec + L4::v_taps + q * 64;
+      const float *tp = vec + L4::v_taps + q * 8;
       f4 acc[2];
       acc[0] = acc[1] = lds_vec4(vec, L4::v_cb_b + 4 * q);
       asm volatile("s_waitcnt vmcnt(13)" ::: "memory");        // k block 0: group 0 (and the first piece of group 1)
