@@ -53,10 +53,10 @@ constexpr bool dma_groups_hold_their_k_blocks()
 static_assert(dma_groups_hold_their_k_blocks(), "DMA groups");
 // the taps of a channel: the four lane quads of one ds_read_b128 read 32 bytes apart (quads 256 bytes apart met in the same banks: tools/lds_conflict_probe.hip)
 static_assert(L1Layout::v_taps % 4 == 0, "taps");
-// the image and the waves' buffers fit a CU's 160 KB of LDS (k_layer1_regs: twelve rings of three slabs; k_layer1_regs_v4: eight whole-chunk images);
+// the image and the waves' buffers fit a CU's 160 KB of LDS (twelve rings of three slabs);
 // fragments and vectors are 16-byte aligned
 static_assert(kL1ImgBytes + kL1Waves * kL1RingBytes + 64 <= 160 * 1024, "LDS budget");
-static_assert(kL1V4ImgBytes + 8 * kL1BufBytes + 64 <= 160 * 1024, "LDS budget (v4)");
+static_assert(kL1V4ImgBytes + kL1Waves * kL1V4RingBytes + 64 <= 160 * 1024, "LDS budget (v4)");
 static_assert(L1Layout::f_tail % 16 == 0 && L1Layout::f_qkv % 16 == 0 && L1Layout::f_end % 16 == 0 && L1Layout::v_tail % 4 == 0 && L1Layout::v_cb_b % 4 == 0 &&
               L1Layout::v_q_b % 4 == 0 && L1Layout::v_cv_b % 4 == 0, "alignment of 16-byte LDS reads");
 // k_enc_fused's images: phase B is the larger one and fits beside nothing else

@@ -12,7 +12,7 @@ import sys
 # kernel name fragment (Itanium-mangled, after _ZN4vadc<len>) -> expectations on its listing
 RULES = {
     "k_layer1_regsILi12ELi0": {"dma": 28, "load_dword": 8, "min_store_dword": 4},         # per iteration: 4 partial sums, 4 groups of 4 pieces, 4 stores; sums and three groups once more in the prologue
-    "k_layer1_regs_v4ILi8": {"dma": 26, "load_dword": 8, "min_store_dword": 4},
+    "k_layer1_regs_v4ILi12": {"dma": 22, "load_dword": 8, "min_store_dword": 4},          # per iteration 3 + 3 + 3 + 4 pieces; 9 in the prologue
     # ring prologue 4 + one per slot.  hipcc keeps the state write-back's addresses in scratch across the slot loop (two stores in the prologue, two loads in the
     # epilogue: older than every piece the loop waits for, so the counts stand); INSIDE the loop there must be none
     "k_lstm_layerILi7ELi0ELi0ELb0ELb0": {"dma": 5, "scratch_outside_loop_ok": True},

@@ -178,6 +178,9 @@ static_assert(kL1V4ImgBytes % 16 == 0, "the image is copied in 16-byte pieces");
 constexpr int kL1V4Frames = 24;
 constexpr int kL1V4ChunkFloats = 129 * kL1V4Frames;                  // 12,384 bytes = 774 units of 16: a chunk always starts on a 16-byte boundary
 constexpr int kL1V4BufBytes = 774 * 16;
+constexpr int kL1V4SlabBytes = 198 * 16;     // k_layer1_regs_v4: a k block's 192 units (+ bin 128's 6 behind k block 3)
+constexpr int kL1V4RingBytes = 3 * kL1V4SlabBytes;
+static_assert(3 * 192 * 16 + kL1V4SlabBytes == kL1V4BufBytes, "group 3 ends where the chunk ends");
 static_assert(kL1V4ChunkFloats * 4 == kL1V4BufBytes && 32 * kL1V4Frames * 4 == 192 * 16, "a k block's 32 channels are exactly one DMA group of 192 units");
 
 }  // namespace vadc

@@ -1,6 +1,7 @@
 // kernels_layer1_regs_v4.hip -- the first encoder stage of Silero v4 at its default window (258 channels x 24 frames -> 16 channels x 12 steps), every
 // activation in registers: k_layer1_regs' conv block (kernels_layer1_regs.hip: two overlapping 16-column tiles per chunk, the chunk by LDS-DMA in four
-// groups with counted waits, split-fp16 MFMAs, the MFMAs of a k block issued between the next block's channel groups) without a transformer block.
+// groups into a ring of three slabs per wave with counted waits, twelve waves per workgroup, split-fp16 MFMAs, the MFMAs of a k block issued between
+// the next block's channels) without a transformer block.
 //
 // Replaces (reference file:line): the first ConvBlock + strided conv + ReLU of silero_vad.py's v4 graph (conv_block: conv.c:761-814, dw :17-113,
 // pw / proj :532-589; conv k = 1 stride 2: conv.c:597-709), the concat(magnitude, normalized) in front of it and the last step of the adaptive
@@ -9,7 +10,7 @@
 //   the front end writes no magnitude array) and Y - offset (bins 129..257).  A k block of 32 bins is processed twice from the same LDS bytes -- 8
 //   virtual k blocks vb = 2 kb + which, K = 516 + 4.
 // * 24 frames: tile 0 carries steps 0..15 and owns 0..11, tile 1 carries steps 8..23 and owns 12..23.  A chunk is 12,384 bytes = 774 units of 16: it
-//   starts on a 16-byte boundary and a k block's 32 bins are exactly one DMA group of 192 units.
+//   starts on a 16-byte boundary and a k block's 32 bins are exactly one DMA group of 192 units (group 3: and bin 128's 6 units behind them).
 // * stride 2 keeps the even steps, which sit on even lanes in BOTH tiles: tile 1's results move one lane up (DPP) so that every lane owns at most one
 //   output and the four stores per iteration that the waits count stay four.
 #include "common.h"
@@ -23,18 +24,15 @@ namespace vadc {
 typedef L1V4Layout L4;
 constexpr int kT4 = kL1V4Frames;
 
-struct L1V4Stage { f2 x[4]; f4 ka[4], kb[4]; };      // x[c] = Y at this lane's step in (tile 0, tile 1)
-__device__ __forceinline__ L1V4Stage l1v4_load_stage(const float *xb, const float *tp, int vb, int half)
+// one bin of a virtual k block on its way out of LDS: Y at this lane's step in (tile 0, tile 1) and the channel's depthwise taps.  xb = the k block's
+// slab + this lane's (quad, column) part; tp = the taps of this lane's quad
+struct L1V4Chan { f2 x; f4 ka, kb; };
+__device__ __forceinline__ L1V4Chan l1v4_load_chan(const float *xb, const float *tp, int vb, int e)
 {
-   L1V4Stage s;
-   const int kb = vb >> 1;
-#pragma unroll
-   for (int c = 0; c < 4; ++c) {
-      const int e = 4 * half + c;
-      s.x[c] = f2{xb[(32 * kb + e) * kT4], xb[(32 * kb + e) * kT4 + 8]};
-      s.ka[c] = lds_vec4(tp, (vb * 8 + e) * 32);
-      s.kb[c] = lds_vec4(tp, (vb * 8 + e) * 32 + 4);
-   }
+   L1V4Chan s;
+   s.x = f2{xb[e * kT4], xb[e * kT4 + 8]};
+   s.ka = lds_vec4(tp, (vb * 8 + e) * 32);
+   s.kb = lds_vec4(tp, (vb * 8 + e) * 32 + 4);
    return s;
 }
 // magnitude from Y = log1p(2^20 m) (k_layer_mfma's form: one v_exp_f32 and one fma), or Y - offset (misc.c:84-96)
@@ -46,29 +44,32 @@ __device__ __forceinline__ f2 l1v4_input(const f2 &y, float off)
    return y - f2{off, off};
 }
 template <int WHICH>
-__device__ __forceinline__ void l1v4_channel_math(const L1V4Stage &s, int c, float off, f4 &x0, f4 &x1, f4 &d0, f4 &d1)
+__device__ __forceinline__ void l1v4_channel_math(const L1V4Chan &s, float off, float &x0, float &x1, float &d0, float &d1)
 {
-   const f2 xp = l1v4_input<WHICH>(s.x[c], off);
-   x0[c] = xp[0]; x1[c] = xp[1];
+   const f2 xp = l1v4_input<WHICH>(s.x, off);
+   x0 = xp[0]; x1 = xp[1];
    float a, b;
-   dw5x2(xp[0], xp[1], s.ka[c][0], s.ka[c][1], s.ka[c][2], s.ka[c][3], s.kb[c][0], s.kb[c][1], a, b);
-   d0[c] = relu(a); d1[c] = relu(b);
+   dw5x2(xp[0], xp[1], s.ka[0], s.ka[1], s.ka[2], s.ka[3], s.kb[0], s.kb[1], a, b);
+   d0 = relu(a); d1 = relu(b);
 }
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
 {
-   __shared__ __attribute__((aligned(16))) char lds[kL1V4ImgBytes + NW * kL1V4BufBytes];
+   __shared__ __attribute__((aligned(16))) char lds[kL1V4ImgBytes + NW * kL1V4RingBytes];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, lc = lane & 15;
-   const int slot = blockIdx.x * NW + wave, nslots = gridDim.x * NW;
+   const int slot = wave * gridDim.x + blockIdx.x, nslots = gridDim.x * NW;      // wave-major: see k_layer1_regs
    const char *img = lds;
    const float *vec = reinterpret_cast<const float *>(lds + L4::f_end);
-   char *buf = lds + kL1V4ImgBytes + wave * kL1V4BufBytes;
+   char *buf = lds + kL1V4ImgBytes + wave * kL1V4RingBytes;
 
-   // the input pipeline of k_layer1_regs: per iteration 4 loads (partial sums), 3 + 3 + 3 + 4 DMA pieces (groups of 192 units = the four k blocks; the
-   // last piece: bin 128, 6 units), 4 stores, in that order; counted waits below
+   // the input pipeline of k_layer1_regs (see there): group kb = the 192 units of k block kb (kb = 3: and bin 128's 6 units, a fourth instruction of 6
+   // lanes) into slab (4 * iteration + kb) mod 3 of the wave's ring, issued when the k block three groups back has been read by BOTH of its virtual k
+   // blocks.  The waits count LOADS only (a store may complete before an older load); issue order per iteration i: [W0] vb 0, 1 (W1 before vb 1's 7th
+   // channel) -> sums(i + 1) 4, G(i, 3) 4 -> vb 2, 3 (W2) -> G(i + 1, 0) 3 -> vb 4, 5 (W3) -> G(i + 1, 1) 3 -> vb 6, 7, bin 128 -> G(i + 1, 2) 3 -> 4 stores.
+   // Younger loads at W0: G(i, 1), G(i, 2) = 6; W1: G(i, 2) = 3; W2: sums(i + 1), G(i, 3) = 8 (last iteration: 4); W3: G(i + 1, 0) = 3 (last: 0).
    float fmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
    const int lo16 = lane * 16;
    auto issue_sums = [&](int nn) {
@@ -77,20 +78,22 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
 #pragma unroll
       for (int k = 0; k < 4; ++k) asm volatile("global_load_dword %0, %1, %2" : "=v"(fmv[k]) : "v"(lo4), "s"(fmp + k * a.fm_stride) : "memory");
    };
-   auto issue_group = [&](int nn, int g) {
-      const char *src = reinterpret_cast<const char *>(a.y) + (size_t)nn * kL1V4BufBytes;
-      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf;
+   int ring = 0;                                              // slab of k block 0 of the current chunk (wave-uniform)
+   auto slab_of = [&](int kb) { const int r = ring + kb; return r >= 3 ? r - 3 : r; };
+   auto issue_group = [&](int nn, int kb, int slab) {
+      const char *src = reinterpret_cast<const char *>(a.y) + (size_t)nn * kL1V4BufBytes + 3072 * kb;
+      const unsigned dst = (unsigned)(uintptr_t)(l1_lds_void_t *)buf + (unsigned)slab * kL1V4SlabBytes;
 #pragma unroll
-      for (int j = 3 * g; j < 3 * g + 3; ++j)
+      for (int j = 0; j < 3; ++j)
          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + j * 1024), "v"(lo16), "s"(src + j * 1024) : "memory");
-      if (g == 3 && lane < 6) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 12 * 1024), "v"(lo16), "s"(src + 12 * 1024) : "memory");
+      if (kb == 3 && lane < 6) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 3 * 1024), "v"(lo16), "s"(src + 3 * 1024) : "memory");
    };
 #define L1V4_WAIT(more, n_more, n_last) do { if (more) asm volatile("s_waitcnt vmcnt(" #n_more ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n_last ")" ::: "memory"); } while (0)
    if (slot < a.n_chunks) {
       const int n0 = a.map(slot);
       issue_sums(n0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) issue_group(n0, g);
+      for (int g = 0; g < 3; ++g) issue_group(n0, g, g);
    }
    {  // image -> LDS, 8 loads in flight per thread
       const uint4 *src = reinterpret_cast<const uint4 *>(a.img);
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
       const int n = a.map(item);
       const bool more = item + nslots < a.n_chunks;           // wave-uniform
       const int nnext = more ? a.map(item + nslots) : n;
-      // outstanding, oldest first: sums 4, groups 3 3 3 4, stores 4.  The sums have landed when 17 are left.
-      asm volatile("s_waitcnt vmcnt(17)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
+      // W0: the chunk's sums and group 0 (younger loads: groups 1 and 2)
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
       // ---- adaptive normalization offset of the chunk (misc.c:65-82) over its 24 frames ----
       float off;
       {
@@ -139,13 +142,17 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
          off = total / (float)kT4;
       }
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x)), x = concat(magnitude, normalized) ----
-      const float *xb = reinterpret_cast<const float *>(buf) + (16 * (q & 1) + 8 * (q >> 1)) * kT4 + lc;
+      const int lane_part = ((16 * (q & 1) + 8 * (q >> 1)) * kT4 + lc) * 4;      // this lane's (quad, column) inside a slab
+      auto slab_ptr = [&](int kb) { return reinterpret_cast<const float *>(buf + slab_of(kb) * kL1V4SlabBytes + lane_part); };
       const float *tp = vec + L4::v_taps + q * 8;
       f4 acc[2];
       acc[0] = acc[1] = lds_vec4(vec, L4::v_cb_b + 4 * q);
-      asm volatile("s_waitcnt vmcnt(13)" ::: "memory");        // k block 0: group 0 (and the first piece of group 1)
-      L1V4Stage sa = l1v4_load_stage(xb, tp, 0, 0), sb;
-      Frag wd = lds_frag(img + L4::f_conv, 0, lane), wx = lds_frag(img + L4::f_conv, 8, lane);
+      // channels two ahead of the one in work (a window of three), the 12 MFMAs of virtual k block vb - 1 one at a time between the channels of vb,
+      // their weights fetched when the previous block's have been used: k_layer1_regs
+      L1V4Chan ch[3];
+      const float *xb = slab_ptr(0);
+      ch[0] = l1v4_load_chan(xb, tp, 0, 0);
+      ch[1] = l1v4_load_chan(xb, tp, 0, 1);
       Frag pd0, pd1, px0, px1, pwd, pwx;                         // pending: operands and weights of the previous virtual k block
       auto pending_mfma = [&](int i) {
          const int t = i & 1, term = i >> 1;
@@ -154,47 +161,44 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
          const int k = term % 3;
          acc[t] = k == 0 ? MFMA16(w.lo, o.hi, acc[t]) : (k == 1 ? MFMA16(w.hi, o.lo, acc[t]) : MFMA16(w.hi, o.hi, acc[t]));
       };
-      f2 ytail = {0.0f, 0.0f};
 #pragma unroll
       for (int vb = 0; vb < 8; ++vb) {
          const bool have = vb > 0;
          const int kb = vb >> 1;
-         sb = l1v4_load_stage(xb, tp, vb, 1);
-         __builtin_amdgcn_sched_barrier(0);
          f4 xl0, xl1, dl0, dl1, xh0, xh1, dh0, dh1;
+         const float *xbn = xb;                                 // the slab the channels of the NEXT virtual k block are read from: the same one behind an even vb
 #pragma unroll
-         for (int c = 0; c < 4; ++c) {
-            if (vb & 1) l1v4_channel_math<1>(sa, c, off, xl0, xl1, dl0, dl1); else l1v4_channel_math<0>(sa, c, off, xl0, xl1, dl0, dl1);
+         for (int c = 0; c < 8; ++c) {
+            const int j = 8 * vb + c;                           // the channel's place in the chunk's sequence of 64 (+ bin 128 twice)
+            if (c == 6 && (vb & 1) && kb < 3) {                 // the next k block's first channels are read from here on: its group must have landed
+               if (kb == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // W1
+               if (kb == 1) L1V4_WAIT(more, 8, 4);                                // W2
+               if (kb == 2) L1V4_WAIT(more, 3, 0);                                // W3
+               xbn = slab_ptr(kb + 1);
+            }
+            if (j + 2 < 64) ch[(j + 2) % 3] = l1v4_load_chan(c + 2 < 8 ? xb : xbn, tp, (j + 2) >> 3, (j + 2) & 7);
+            else {
+               // bin 128, behind k block 3's 32 bins in the same slab: as magnitude (j + 2 = 64) and as normalized log-magnitude (65)
+               const float *xt = reinterpret_cast<const float *>(buf + slab_of(3) * kL1V4SlabBytes) + 32 * kT4 + lc;
+               const int w = j + 2 - 64;
+               ch[(j + 2) % 3].x = f2{xt[0], xt[8]};
+               ch[(j + 2) % 3].ka = lds_vec4(vec, L4::v_tail + 8 * w); ch[(j + 2) % 3].kb = lds_vec4(vec, L4::v_tail + 8 * w + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               float x0, x1, d0, d1;
+               if (vb & 1) l1v4_channel_math<1>(ch[j % 3], off, x0, x1, d0, d1); else l1v4_channel_math<0>(ch[j % 3], off, x0, x1, d0, d1);
+               if (c < 4) { xl0[c] = x0; xl1[c] = x1; dl0[c] = d0; dl1[c] = d1; }
+               else       { xh0[c - 4] = x0; xh1[c - 4] = x1; dh0[c - 4] = d0; dh1[c - 4] = d1; }
+            }
             if (have) pending_mfma(c);
             __builtin_amdgcn_sched_barrier(0);
          }
-         Frag wdn = wd, wxn = wx;
-         // the next virtual k block's first stage: k block kb + 1 needs its group (done so far must be 11 / 14 / 17 of the last iteration's 21
-         // operations; this one has issued 0 / 7 / 10 more if it issues at all) -- the same k block's second half is already there
-         if (vb == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-         if (vb == 3) L1V4_WAIT(more, 14, 7);
-         if (vb == 5) L1V4_WAIT(more, 14, 4);
-         if (vb < 7) {
-            sa = l1v4_load_stage(xb, tp, vb + 1, 0);
-            wdn = lds_frag(img + L4::f_conv, vb + 1, lane); wxn = lds_frag(img + L4::f_conv, 8 + vb + 1, lane);
-         } else {
-            const float *xt = reinterpret_cast<const float *>(buf) + 128 * kT4 + lc;      // bin 128
-            ytail = f2{xt[0], xt[8]};
-            sa.ka[0] = lds_vec4(vec, L4::v_tail); sa.kb[0] = lds_vec4(vec, L4::v_tail + 4);
-            sa.ka[1] = lds_vec4(vec, L4::v_tail + 8); sa.kb[1] = lds_vec4(vec, L4::v_tail + 12);
-         }
-         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-         for (int c = 0; c < 4; ++c) {
-            if (vb & 1) l1v4_channel_math<1>(sb, c, off, xh0, xh1, dh0, dh1); else l1v4_channel_math<0>(sb, c, off, xh0, xh1, dh0, dh1);
-            if (have) pending_mfma(4 + c);
-            __builtin_amdgcn_sched_barrier(0);
-         }
-         // k block kb has been read by both of its halves: group kb of the next chunk may overwrite it
-         if (more && (vb & 1) && kb < 3) {
-            if (kb == 0) issue_sums(nnext);
-            issue_group(nnext, kb);
-         }
+         // k block kb has been read by both of its halves: the group three further on may overwrite its slab
+         if (vb == 1) {
+            if (more) issue_sums(nnext);
+            issue_group(n, 3, slab_of(0));
+         } else if (more && (vb & 1) && kb < 3) issue_group(nnext, kb - 1, slab_of(kb));      // (k block 3's slab also holds bin 128: behind the tail's read)
          const Frag df0 = split8(dl0, dh0);
          if (have) pending_mfma(8);
          __builtin_amdgcn_sched_barrier(0);
@@ -207,26 +211,25 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
          const Frag xf1 = split8(xl1, xh1);
          if (have) pending_mfma(11);
          __builtin_amdgcn_sched_barrier(0);
-         pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1; pwd = wd; pwx = wx;
-         wd = wdn; wx = wxn;
+         pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1;
+         pwd = lds_frag(img + L4::f_conv, vb, lane); pwx = lds_frag(img + L4::f_conv, 8 + vb, lane);
+         xb = xbn;
       }
       {
          const AOp wt = lds_aop(img + L4::f_tail, lane);
-         const f2 m = l1v4_input<0>(ytail, off), nn2 = l1v4_input<1>(ytail, off);      // (uses the last LDS read of the chunk)
-         if (more) issue_group(nnext, 3);
+         float m0, m1, n0_, n1_, dm0, dm1, dn0, dn1;
+         l1v4_channel_math<0>(ch[64 % 3], off, m0, m1, dm0, dm1);      // (use the last LDS reads of the chunk)
+         l1v4_channel_math<1>(ch[65 % 3], off, n0_, n1_, dn0, dn1);
+         if (more) issue_group(nnext, 2, slab_of(3));
 #pragma unroll
-         for (int i = 0; i < 4; ++i) pending_mfma(i);
-         float dm0, dm1, dn0, dn1;
-         dw5x2(m[0], m[1], sa.ka[0][0], sa.ka[0][1], sa.ka[0][2], sa.ka[0][3], sa.kb[0][0], sa.kb[0][1], dm0, dm1);
-         dw5x2(nn2[0], nn2[1], sa.ka[1][0], sa.ka[1][1], sa.ka[1][2], sa.ka[1][3], sa.kb[1][0], sa.kb[1][1], dn0, dn1);
+         for (int i = 0; i < 6; ++i) pending_mfma(i);
+         const h8 b0 = split4_hl(f4{dm0, dn0, m0, n0_}), b1 = split4_hl(f4{dm1, dn1, m1, n1_});
 #pragma unroll
-         for (int i = 4; i < 8; ++i) pending_mfma(i);
-         const h8 b0 = split4_hl(f4{relu(dm0), relu(dn0), m[0], nn2[0]}), b1 = split4_hl(f4{relu(dm1), relu(dn1), m[1], nn2[1]});
-#pragma unroll
-         for (int i = 8; i < 12; ++i) pending_mfma(i);
+         for (int i = 6; i < 12; ++i) pending_mfma(i);
          acc[0] = mm(wt, b0, acc[0]);
          acc[1] = mm(wt, b1, acc[1]);
       }
+      ring = slab_of(1);                                         // four groups on: (ring + 4) mod 3
       // ---- conv k = 1 stride 2 -> ReLU on every step; the store keeps the even ones ----
       const AOp wc = lds_aop(img + L4::f_cv, lane);
       const f4 bc = lds_vec4(vec, L4::v_cv_b + 4 * q);
@@ -256,12 +259,12 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
    }
 }
 
-// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain); 8 waves per workgroup (see launch_layer1_regs)
+// max_wgs: workgroups the grid may use (CUs not held by the LSTM chain); 12 waves per workgroup (see launch_layer1_regs)
 void launch_layer1_regs_v4(const L1RegsArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   const int g = std::min(max_wgs, (a.n_chunks + 7) / 8);
-   hipLaunchKernelGGL((k_layer1_regs_v4<8>), dim3(g), dim3(512), 0, st, a);
+   const int g = std::min(max_wgs, (a.n_chunks + kL1Waves - 1) / kL1Waves);
+   hipLaunchKernelGGL((k_layer1_regs_v4<kL1Waves>), dim3(g), dim3(64 * kL1Waves), 0, st, a);
 }
 
 }  // namespace vadc
