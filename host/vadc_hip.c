@@ -205,11 +205,17 @@ int main(int argc, char **argv)
    int seq = o.sequence_count;
    if (seq < caps.input_size_min) seq = caps.input_size_min;
    if (seq > caps.input_size_max) seq = caps.input_size_max;
-   if (caps.input_size_min != caps.input_size_max) {               /* a third, two thirds or all of the maximum: 512 / 1024 / 1536 (8 kHz: 256 / 512 / 768) */
-      const int third = caps.input_size_max / 3;
-      seq = seq >= 3 * third ? 3 * third : (seq >= 2 * third ? 2 * third : third);
+   if (caps.input_size_step > 0)                                   /* a third, two thirds or all of the maximum: 512 / 1024 / 1536 (8 kHz: 256 / 512 / 768) */
+      seq = caps.input_size_min + (seq - caps.input_size_min) / caps.input_size_step * caps.input_size_step;
+   if (seq != o.sequence_count) {
+      fprintf(stderr, "--sequence_count %d: the backend runs %d-sample chunks", o.sequence_count, seq);
+      if (caps.input_size_step > 0) {
+         fprintf(stderr, " (it serves");
+         for (int w = caps.input_size_min; w <= caps.input_size_max; w += caps.input_size_step) fprintf(stderr, " %d", w);
+         fprintf(stderr, "; the reference's onnxruntime path takes any count in %d .. %d)", caps.input_size_min, caps.input_size_max);
+      }
+      fprintf(stderr, "\n");
    }
-   if (seq != o.sequence_count) fprintf(stderr, "--sequence_count %d: the backend runs %d-sample chunks\n", o.sequence_count, seq);
    if (seq != caps.window_samples && vadc_amd_set_option(eng, "window", seq) != VADC_AMD_OK) { fprintf(stderr, "cannot set the window: %s\n", vadc_amd_last_error()); return -1; }
    const int chunk = seq;
    fprintf(stderr, "Running with sequence count %d\n", chunk);     /* vadc.c:753 */

@@ -106,6 +106,8 @@ typedef struct vadc_amd_caps {
    int32_t context_size;                  /* 0; 64 for Silero v5 (vadc.c:697-701): kept per stream on the device, callers pass windows only */
    int32_t cu_partition_ok;               /* 1: the device has the CU-mask layout the LSTM partition rules were measured on (256 CUs, mask bit i -> XCD i % 8: checked at
                                              create) and the partition may be used; 0: any other layout (CPX / DPX mode, another part): no CU partition, plain streams */
+   int32_t input_size_step;               /* the windows served are input_size_min + k * input_size_step <= input_size_max; 0: one window.  Silero v4: 512 (8 kHz: 256) --
+                                             the reference's onnxruntime path admits every count in 512 .. 1536 (onnx_helpers.c:164-170), this engine the thirds only */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -28,7 +28,7 @@ class Caps(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch_size_restriction", "is_silero_v5", "input_size_min", "input_size_max", "output_dims",
         "output_stride", "silero_probability_out_index", "lstm_hidden_size", "max_streams",
-        "max_chunks_per_call", "device", "precision", "model_kind", "lstm_steps_per_chunk", "window_samples", "sample_rate", "context_size", "cu_partition_ok")]
+        "max_chunks_per_call", "device", "precision", "model_kind", "lstm_steps_per_chunk", "window_samples", "sample_rate", "context_size", "cu_partition_ok", "input_size_step")]
 
 
 _lib = None

@@ -1116,6 +1116,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    const int wmax = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);     // v5: onnx_helpers.c:158-160
    caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
    caps->input_size_max = wmax;
+   caps->input_size_step = caps->input_size_min != wmax ? wmax / 3 : 0;
    caps->context_size = e->model == VADC_AMD_MODEL_V5 ? 64 : 0;
    caps->window_samples = e->window;
    caps->sample_rate = e->sample_rate;
