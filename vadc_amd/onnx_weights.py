@@ -173,11 +173,56 @@ def silero_v4_16k_tensors(onnx_path: str, sr: int = 16000):
     return [(n, np.ascontiguousarray(a, dtype=np.float32)) for n, a in out]
 
 
+# ---- Silero v3 / v3.1 (silero_vad_v3.onnx) -> the 99-tensor container of the reference's C backend (tensor.h:114-191) -------------------------
+# The exporter folded every BatchNorm into the strided conv in front of it and stored the Linear weights transposed (MatMul operands); the C backend
+# wants them as PyTorch does (silero_v3.c:72-215 reads conv + BatchNorm separately, transformer.c:237-295).  The folded conv goes out as the conv and
+# the BatchNorm as the identity (weight 1, bias 0, mean 0, var 1 - eps: batch_norm, misc.c:98-141, then divides by sqrt(1.0)).
+V3_LAYERS = (  # conv block, transformer block, MatMul initializers (QKV, out, linear1, linear2), folded conv (weight, bias), has projection
+    ("first_layer.0", "encoder.0", ("896", "897", "898", "899"), ("879", "880"), True),
+    ("encoder.4.0", "encoder.5", ("900", "901", "902", "903"), ("882", "883"), True),
+    ("encoder.9.0", "encoder.10", ("904", "905", "906", "907"), ("885", "886"), False),
+    ("encoder.14.0", "encoder.15", ("908", "909", "910", "911"), ("888", "889"), True),
+)
+V3_LSTM = (("929", "930", "931"), ("949", "950", "951"))
+V3_BN_EPS = 1e-5
+
+
+def silero_v3_tensors(onnx_path: str):
+    """-> [(name, array)] x 99 in the positional order of tensor.h:114-191 (names as in testdata/silero_v31_16k.testtensor)"""
+    t, _ = load_onnx_tensors(onnx_path)
+    out = [("forward_basis_buffer", t["feature_extractor.forward_basis_buffer"])]
+    for i, (cb, tb, mm, fold, proj) in enumerate(V3_LAYERS):
+        L = f"transformer_l{i + 1}"
+        out += [(f"{L}.dw_conv_weights", t[f"{cb}.dw_conv.0.weight"]), (f"{L}.dw_conv_biases", t[f"{cb}.dw_conv.0.bias"]),
+                (f"{L}.pw_conv_weights", t[f"{cb}.pw_conv.0.weight"]), (f"{L}.pw_conv_biases", t[f"{cb}.pw_conv.0.bias"])]
+        if proj:
+            out += [(f"{L}.proj_weights", t[f"{cb}.proj.weight"]), (f"{L}.proj_biases", t[f"{cb}.proj.bias"])]
+        out += [(f"{L}.attention_weights", t[mm[0]].T), (f"{L}.attention_biases", t[f"{tb}.attention.QKV.bias"]),
+                (f"{L}.attention_proj_weights", t[mm[1]].T), (f"{L}.attention_proj_biases", t[f"{tb}.attention.out_proj.bias"]),
+                (f"{L}.norm1_weights", t[f"{tb}.norm1.weight"]), (f"{L}.norm1_biases", t[f"{tb}.norm1.bias"]),
+                (f"{L}.linear1_weights", t[mm[2]].T), (f"{L}.linear1_biases", t[f"{tb}.linear1.bias"]),
+                (f"{L}.linear2_weights", t[mm[3]].T), (f"{L}.linear2_biases", t[f"{tb}.linear2.bias"]),
+                (f"{L}.norm2_weights", t[f"{tb}.norm2.weight"]), (f"{L}.norm2_biases", t[f"{tb}.norm2.bias"])]
+        d = t[fold[1]].shape[0]
+        out += [(f"{L}.conv_weights", t[fold[0]]), (f"{L}.conv_biases", t[fold[1]]),
+                (f"{L}.batch_norm_weights", np.ones(d, np.float32)), (f"{L}.batch_norm_biases", np.zeros(d, np.float32)),
+                (f"{L}.batch_norm_running_mean", np.zeros(d, np.float32)), (f"{L}.batch_norm_running_var", np.full(d, 1.0 - V3_BN_EPS, np.float32))]
+    ws, bs = zip(*[_lstm_onnx_to_c(t[a], t[b], t[c]) for a, b, c in V3_LSTM])
+    out += [("weights", np.stack(ws)), ("biases", np.stack(bs))]
+    out += [("decoder_weights", t["decoder.1.weight"]), ("decoder_biases", t["decoder.1.bias"])]
+    return [(n, np.ascontiguousarray(a, dtype=np.float32)) for n, a in out]
+
+
 if __name__ == "__main__":
     import sys
     from . import testtensor
     if len(sys.argv) not in (3, 4):
-        sys.exit("usage: python -m vadc_amd.onnx_weights silero_vad_v4.onnx out.testtensor [8000]")
+        sys.exit("usage: python -m vadc_amd.onnx_weights silero_vad_v4.onnx out.testtensor [8000]   |   silero_vad_v3.onnx out.testtensor v3")
+    if len(sys.argv) == 4 and sys.argv[3] == "v3":
+        ts = silero_v3_tensors(sys.argv[1])
+        testtensor.dump(sys.argv[2], ts)
+        print(f"wrote {sys.argv[2]}: {len(ts)} tensors, {sum(a.size for _, a in ts)} floats")
+        sys.exit(0)
     ts = silero_v4_16k_tensors(sys.argv[1], int(sys.argv[3]) if len(sys.argv) == 4 else 16000)
     testtensor.dump(sys.argv[2], ts)
     print(f"wrote {sys.argv[2]}: {len(ts)} tensors, {sum(a.size for _, a in ts)} floats")
