@@ -66,6 +66,13 @@ PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole p
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)", 4: "k_frontend_ri"}
 
 
+def frontend_name(eng, fe_kernel):
+    """the front-end kernel that ran, by name: the engine reports 2 for either GEMM form, and this bench feeds s16 (option "fe_gemm" = 2: k_frontend_gemm2)"""
+    if fe_kernel == 2 and eng.get_option("fe_gemm") == 2:
+        return "k_frontend_gemm2"
+    return FRONTEND_KERNELS.get(fe_kernel)
+
+
 def dtype_label(mode, fe_kernel):
     """what the arithmetic runs in -- by the front-end kernel that ran, not by the precision mode alone (Silero v4's STFT is the GEMM form in every mode)"""
     gemms = "split-f16x3 GEMMs (f32 accumulate)"
@@ -340,7 +347,7 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
            "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
-           "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
+           "frontend_kernel": frontend_name(eng, fe_kernel),
            "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
     if opts:
         out["options"] = dict(opts)
@@ -579,7 +586,7 @@ def run_rank(args, world, rank, local_rank):
             name = "latest_pmc_traffic.json" if default_workload else f"latest_pmc_traffic_{args.model}_{args.precision}_{S}x{Cn}.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             if (prof.get("streams") == S and prof.get("chunks_per_step") == Cn and prof.get("model", "v31") == args.model
-                    and prof.get("precision", "fp32") == args.precision and prof.get("frontend_kernel") == FRONTEND_KERNELS.get(fe_kernel)
+                    and prof.get("precision", "fp32") == args.precision and prof.get("frontend_kernel") == frontend_name(eng, fe_kernel)
                     and dom in prof.get("kernels", {})):
                 traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
                 traffic_source = f"profiles/{name} (rocprofv3 --pmc pass of this workload, committed; not measured in this run)"
@@ -593,7 +600,7 @@ def run_rank(args, world, rank, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(mode, fe_kernel), "data": "synthetic",
             "config": {"workload": f"Silero {'v3.1' if args.model == 'v31' else 'v4'} 16k, batch={S} streams/GPU x {Cn} chunks/step, "
                                    f"{workload_label(args.model, mode, fe_kernel)}, s16le input resident in HBM",
-                       "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": FRONTEND_KERNELS.get(fe_kernel),
+                       "streams_per_gpu": S, "chunks_per_step": Cn, "hipgraph": bool(args.graph), "frontend_kernel": frontend_name(eng, fe_kernel),
                        "parallelism": f"streams sharded over {world} GPU(s), RCCL gather of probabilities"},
             "roofline": {"bound": "mfma" if d["pipe"] in ("fp16", "fp32") else "valu", "kernel": dom, "achieved": d["executed_tflops"], "peak": PEAKS[d["pipe"]],
                          "unit": "TFLOP/s", "frac": d["frac_of_pipe_peak"], "traffic": traffic, "traffic_source": traffic_source,

@@ -229,10 +229,12 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 produce the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
  *   "frontend"    Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins 0..32, the other 96 bins from the basis'
  *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
- *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = k_frontend_gemm (default), 1 = the tree kernel with the v4 geometry
+ *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = the GEMM front end (default), 1 = the tree kernel with the v4 geometry
+ *   "fe_gemm"     which GEMM front end (Silero v4; v3.1 in FAST_STFT precision): 2 (default) = k_frontend_gemm2 for s16 input (32x32x16 MFMAs, the basis
+ *                 resident in registers, fold operands exact in fp16), k_frontend_gemm for f32 input; 1 = k_frontend_gemm for both
  *   "encoder"     0 (default) = first layer as one launch, layers 2-4 of Silero v3.1 fused into ONE persistent launch (k_enc_fused: activations in registers,
  *                 split-fp16 MFMA; falls back to one launch per layer when a weight does not fit fp16); 2 = first stage as the LDS slab path instead of the
- *                 K = 1 MFMA form; 3 = one launch per layer with fp32 MFMA for the GEMMs of layers 2-4; 5 (Silero v3.1) = one launch per layer with split-fp16
+ *                 K = 1 MFMA form (Silero v4, default window and rate: stages 2-4 likewise in one launch, k_enc_fused_v4); 3 = one launch per layer with fp32 MFMA for the GEMMs of layers 2-4; 5 (Silero v3.1) = one launch per layer with split-fp16
  *                 MFMA (round 2's hot path); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per workgroup instead of 8 waves / 5 chunks
  *   "encoder_batch" form of the fused launch: 0 / 1 (default) = 12 waves per workgroup, two chunks per wave and batch; 2 = 8 waves, four chunks
  *   "layer1"      the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4 (Silero v4, default window): input by LDS-DMA,
@@ -243,7 +245,10 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves); 0: layer 1 starts when layer 0 has finished.  Same bits.
  *                 Used only in a process whose kernels were SEEN to overlap at create ("kernels_overlap"): a tool that lets one kernel onto the device at a
  *                 time (rocprofv3 --pmc) would start layer 0 when layer 1 has ended -- there the engine launches the two one after the other by itself
- *                 ("lstm_trail_used" says what the last call did).  "overlap_check" 2: behave as if that probe had failed (tests)
+ *                 ("lstm_trail_used" says what the last call did).  "overlap_check" 2: behave as if that probe had failed (tests).
+ *                 A hand-over that fails at run time (layer 1's bounded wait of about 2 s runs out, a ticket imbalance, an XCC mismatch) does not trap: the
+ *                 kernels set a host-mapped error word, the next vadc_amd_synchronize / vadc_amd_wait_async / synchronous vadc_amd_run_* returns
+ *                 VADC_AMD_EHIP and the engine launches the pair in turn from then on.  "trail_fault" 1 (tests): the next pair is launched without its layer 0
  *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
  *   "fe_opt"      the exact-tree front end of Silero v3.1: 3 (default) = k_frontend_sym with bin 0 without the tree of its all-zero im row, the 9-bin split rotating over
  *                 the waves; 0 = round 3's kernel; 11 = k_frontend_ri (packed pairs = (re, im) of one tree lane: the derived rows' sums, re^2 + im^2 and the logarithm
@@ -257,7 +262,7 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 sized by the engine) */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
 /* Reads a switch back, plus read-only facts: "lstm_cus" = CUs reserved for the LSTM by the last call (0 = no partition), "lstm_kernel" = the LSTM variant it ran
- * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 k_frontend_gemm, 3 k_frontend v4 tree), "layer1_kernel" = the first
+ * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 a GEMM front end -- k_frontend_gemm2 or k_frontend_gemm, see "fe_gemm" --, 3 k_frontend v4 tree), "layer1_kernel" = the first
  * layer's form that runs (0 register-resident, 1 per-layer: option "layer1" is the request), "layer1_selfcheck" (1: the register-resident first layer agreed
  * with the per-layer form on the probe chunks at create; 0: it did not and the per-layer form serves; -1: not applicable), "zero_im0" (the basis' im row of
  * bin 0 is all zeros: k_frontend_sym skips its tree), "cu_layout_ok" (the device has the CU-mask layout the partition rules assume), "pinned_ranges" (host

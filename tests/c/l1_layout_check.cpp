@@ -35,6 +35,25 @@ constexpr bool quads_of_a_half_hit_disjoint_banks()
    return true;
 }
 static_assert(quads_of_a_half_hit_disjoint_banks(), "LDS banks");
+// the same for Silero v4's [channel][24] image and its own map
+constexpr bool v4_channels_are_a_bijection_on_disjoint_banks()
+{
+   bool seen[128] = {};
+   for (int kb = 0; kb < 4; ++kb)
+      for (int q = 0; q < 4; ++q)
+         for (int e = 0; e < 8; ++e) {
+            const int c = l1v4_channel(kb, q, e);
+            if (c < 0 || c >= 128 || seen[c]) return false;
+            seen[c] = true;
+         }
+   for (int e = 0; e < 8; ++e)
+      for (int half = 0; half < 2; ++half) {
+         const int a = l1v4_channel(0, 2 * half, e) * 24, b = l1v4_channel(0, 2 * half + 1, e) * 24;
+         if (((b - a) % 32 + 32) % 32 != 16) return false;
+      }
+   return true;
+}
+static_assert(v4_channels_are_a_bijection_on_disjoint_banks(), "l1v4_channel");
 
 // the chunk image: 12,900 bytes from the 16-byte boundary below the chunk's first byte (lead <= 12) fit 808 units of 16 bytes
 static_assert(kL1ChunkFloats * 4 + 12 <= kL1BufBytes && kL1BufBytes == 808 * 16, "chunk image");

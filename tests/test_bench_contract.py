@@ -88,6 +88,25 @@ def test_round4_fields_of_the_line():
     assert len(json.dumps(d, separators=(",", ":"))) < 6000                                      # the driver reads the tail of stdout: the line stays short
 
 
+def test_round5_fields_of_the_line():
+    """round 5: BASELINE config 4 (Silero v4, 4096 streams x 16 chunks) is timed by the same run -- last, an engine created in front of the 10,240 x 1 configuration
+    cost that one 40 % -- with the front-end kernel that ran named (the engine has two GEMM forms); host_fed is a sustained rate; and every BASELINE
+    configuration has its kernel trace, PMC traffic and PMC compute summaries committed beside the line"""
+    d = _latest_default()
+    assert list(d["configs"])[-1] == "v4_4096x16"
+    c = d["configs"]["v4_4096x16"]
+    want = 4096 * 16 * 0.096 / (c["ms_per_step"] * 1e-3)
+    assert abs(c["value"] - want) / want < 1e-3 and c["hipgraph"] is True
+    assert c["frontend_kernel"] == "k_frontend_gemm2" and c["roofline_kernel"] == "k_frontend" and 0 < c["roofline_frac"] <= 1.0
+    assert d["host_fed"]["pcie_gb_per_s"] > 0 and d["host_fed"]["value"] < d["value"]
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")))[-1]
+    for tag in ("bench_256x96", "bench_split16_4096x16", "bench_v4_4096x16"):
+        for suffix in ("_kernel_stats.csv", "_pmc_traffic.json", "_pmc_compute.json"):
+            assert os.path.exists(os.path.join(os.path.dirname(latest), tag + suffix)), tag + suffix
+    v4 = json.load(open(os.path.join(os.path.dirname(latest), "bench_v4_4096x16_pmc_traffic.json")))
+    assert v4["frontend_kernel"] == "k_frontend_gemm2" and "k_frontend_gemm2" in open(os.path.join(os.path.dirname(latest), "bench_v4_4096x16_kernel_stats.csv")).read()
+
+
 def test_kernel_stats_list_every_kernel_of_the_step():
     """the tracked rocprofv3 summary carries all five kernels of the step, the two k_lstm_layer launches (whose names rocprofv3 leaves mangled) included"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_256x96_kernel_stats.csv")))

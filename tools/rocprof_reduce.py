@@ -13,7 +13,7 @@ import argparse, csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 SHORT = [("k_frontend", "k_frontend"), ("k_lstm", "k_lstm")]
-FE_NAMES = ["k_frontend_ri", "k_frontend_sym", "k_frontend_fl", "k_frontend_gemm", "k_frontend"]     # most specific first
+FE_NAMES = ["k_frontend_ri", "k_frontend_sym", "k_frontend_fl", "k_frontend_gemm2", "k_frontend_gemm", "k_frontend"]     # most specific first
 FE_SEEN = set()
 
 

@@ -116,6 +116,10 @@ struct EncV4Args {
 // K = 16 fragments of 2 KB: lane (q, m) holds W[m][4 q + e], e < 4, twice -- as 16 bytes [lo x 4 | hi x 4] (block LH, 1 KB) and as [hi x 4 | 0 x 4]
 // (block H0, 1 KB): kernels_layer1_regs.hip, mm() -- an accumulator tile's four registers are the other operand as they are.
 __host__ __device__ constexpr int l1_channel(int kb, int q, int e) { return 32 * kb + 16 * (q & 1) + 8 * (q >> 1) + e; }
+// Silero v4's first stage reads a [channel][24] image: 24 * 16 = 0 (mod 32) -- with the map above the two quads of a half would meet in the same banks (they did:
+// SQ_LDS_BANK_CONFLICT 14.9 M of 71.6 M LDS cycles per launch of 65,536 chunks).  24 * d = 16 (mod 32) needs d = 2 (mod 4): the quads of a half sit TWO channels
+// apart, the halves one, a lane's eight channels four apart.
+__host__ __device__ constexpr int l1v4_channel(int kb, int q, int e) { return 32 * kb + 4 * e + 2 * (q & 1) + (q >> 1); }
 constexpr int kFrag4Bytes = 2048;
 struct L1Layout {
    static constexpr int f_conv = 0;                                  // 8 x 2 KB

@@ -739,7 +739,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
          const int vb = f & 7, kb = vb >> 1, which = vb & 1;
          for (int l = 0; l < 64; ++l)
             for (int el = 0; el < 8; ++el)
-               put_h(&h[l * 8 + el], &h[512 + l * 8 + el], W[(size_t)(l & 15) * C + which * kBins + l1_channel(kb, l >> 4, el)]);
+               put_h(&h[l * 8 + el], &h[512 + l * 8 + el], W[(size_t)(l & 15) * C + which * kBins + l1v4_channel(kb, l >> 4, el)]);
       }
       auto put_frag4 = [&](int off, auto W) {                 // W(m, k): K = 16 fragment, lane (q, m) holds k = 4 q + e: block LH [lo x 4 | hi x 4], block H0 [hi x 4 | 0 x 4]
          _Float16 *h = reinterpret_cast<_Float16 *>(img + off);
@@ -760,7 +760,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       };
       for (int vb = 0; vb < 8; ++vb)
          for (int q = 0; q < 4; ++q)
-            for (int el = 0; el < 8; ++el) put_taps(v + L1V4Layout::v_taps + ((vb * 8 + el) * 4 + q) * 8, (vb & 1) * kBins + l1_channel(vb >> 1, q, el));
+            for (int el = 0; el < 8; ++el) put_taps(v + L1V4Layout::v_taps + ((vb * 8 + el) * 4 + q) * 8, (vb & 1) * kBins + l1v4_channel(vb >> 1, q, el));
       put_taps(v + L1V4Layout::v_tail, 128);
       put_taps(v + L1V4Layout::v_tail + 8, kBins + 128);
       for (int o = 0; o < D; ++o) { v[L1V4Layout::v_cb_b + o] = r0.cb_b[o]; v[L1V4Layout::v_cv_b + o] = r0.cv_b[o]; }

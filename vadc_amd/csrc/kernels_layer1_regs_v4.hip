@@ -30,7 +30,7 @@ struct L1V4Chan { f2 x; f4 ka, kb; };
 __device__ __forceinline__ L1V4Chan l1v4_load_chan(const float *xb, const float *tp, int vb, int e)
 {
    L1V4Chan s;
-   s.x = f2{xb[e * kT4], xb[e * kT4 + 8]};
+   s.x = f2{xb[4 * e * kT4], xb[4 * e * kT4 + 8]};                  // l1v4_channel: a lane's channels are four apart
    s.ka = lds_vec4(tp, (vb * 8 + e) * 32);
    s.kb = lds_vec4(tp, (vb * 8 + e) * 32 + 4);
    return s;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
          off = total / (float)kT4;
       }
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x)), x = concat(magnitude, normalized) ----
-      const int lane_part = ((16 * (q & 1) + 8 * (q >> 1)) * kT4 + lc) * 4;      // this lane's (quad, column) inside a slab
+      const int lane_part = ((2 * (q & 1) + (q >> 1)) * kT4 + lc) * 4;      // this lane's (quad, column) inside a slab (l1v4_channel)
       auto slab_ptr = [&](int kb) { return reinterpret_cast<const float *>(buf + slab_of(kb) * kL1V4SlabBytes + lane_part); };
       const float *tp = vec + L4::v_taps + q * 8;
       f4 acc[2];
