@@ -948,7 +948,7 @@ def test_layer1_regs_is_not_used_for_weights_outside_fp16_range(weights_blob, go
 
 @pytest.mark.parametrize("S,kernel,cus", [(256, 7, 32), (288, 7, 48), (320, 7, 32), (832, 7, 32), (2048, 7, 32), (2064, 6, 0)])
 def test_lstm_schedule_by_stream_count(weights_blob, orc, S, kernel, cus):
-    """round 3's sweep, pinned: a large call's LSTM is the layer-major pair on CUs of its own -- one CU per workgroup up to 16 stream
+    """round 3's sweep (profiles/EXPERIMENTS.md item 7), pinned: a large call's LSTM is the layer-major pair on CUs of its own -- one CU per workgroup up to 16 stream
     tiles (and for 17 .. 19), a fixed 32 CUs from 20 tiles to half a chip of tiles -- and one workgroup per tile with no partition beyond; whatever the schedule,
     the answers are the oracle's (first, a middle and the last stream)"""
     Cn = 8                                                       # S x 8 >= 2048 chunk items: the call forks onto the engine's streams

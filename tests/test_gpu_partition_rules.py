@@ -1,7 +1,6 @@
 """The engine's scheduling rules (which LSTM kernel: resolve_lstm, engine.hip; how many CUs the recurrence gets for itself: lstm_partition_cus) were fitted
 to sweeps on one box.  This test holds them against the box it runs on: at the shapes either side of each rule's thresholds, the rule's own choice is timed
-against the forced alternatives, and must be within 5 % of the best of them -- so a box with another clock or CU layout reopens a cliff of DESIGN.md
-section 7 item 7 loudly, not silently.  (The arithmetic is that of silero_v3.c:72-215 whichever way the rules fall: the kernels are bit-identical,
+against the forced alternatives, and must be within 5 % of the best of them -- so a box with another clock or CU layout reopens a cliff of profiles/EXPERIMENTS.md item 7 loudly, not silently.  (The arithmetic is that of silero_v3.c:72-215 whichever way the rules fall: the kernels are bit-identical,
 tests/test_gpu_parity.py::test_lstm_variants_agree.)"""
 import os
 import sys

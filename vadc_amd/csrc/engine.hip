@@ -1592,7 +1592,7 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
    if (e->lstm_variant >= 6) return e->lstm_variant;
    if (!forked) return 6;
    const int tiles = (n_streams + kLstmTile - 1) / kLstmTile;
-   // Tree front end (Silero v3.1), round-3 sweep: the layer-major pair on a small partition of its own is the best or within 1 % of it
+   // Tree front end (Silero v3.1), round-3 sweep (profiles/EXPERIMENTS.md item 7): the layer-major pair on a small partition of its own is the best or within 1 % of it
    // up to half a chip of tiles (2048 streams), whether or not the chain is the critical path; beyond, one workgroup per tile beside the next call's front end
    // (round 4: calls of one or two chunks per stream over more tiles than that -- the north star's serving shape, 10,240 streams x 1 chunk -- take the pair as well: a
    // workgroup of k_lstm_wavefront_h3 loads and splits both layers' weights (128 KB) for 7 slots of work and holds half a CU's registers meanwhile; 4096 x 1 2.18 -> 2.22 M,
@@ -1616,7 +1616,7 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    const int lstm_wgs = (lk == 7 ? 2 : 1) * ((n_streams + 15) / 16);
    // measured (v3.1, audio-s/s, partition vs none): 512 streams 730 K vs 589 K, 1024: 790 K vs 722 K, 2048: 786 K vs 810 K,
    // 4096: 806 K vs 895 K -- with more than n_cus/2 tiles the chain is throughput work and gets the whole chip
-   // Round 3, tree front end (v3.1), from a sweep over 64 .. 4096 streams: with more than 16 stream tiles the layer-major pair gets
+   // Round 3, tree front end (v3.1), from a sweep over 64 .. 4096 streams (profiles/EXPERIMENTS.md item 7): with more than 16 stream tiles the layer-major pair gets
    // 32 CUs of its OWN (16 per layer; the mask's 4 CUs per XCD, one per shader engine) and its workgroups share them -- two co-resident, the rest in turn: a
    // slot then costs 1.3 - 3 us instead of 0.75, which the chain can afford as soon as the encoder's time per call exceeds it (320 streams: 3.10 -> 3.21 M,
    // 832: 2.48 -> 3.33 M, 1280: 2.94 -> 3.40 M, 2048: 2.96 -> 3.43 M).  Larger or shared partitions lost everywhere: the persistent encoder kernels scale
