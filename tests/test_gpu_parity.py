@@ -930,6 +930,30 @@ def test_layer1_forms_agree(eng, orc, gold_py, n):
     assert float(np.abs(b - np.stack(want)).max()) < 1e-4
 
 
+def test_layer1_regs_over_many_rounds_of_its_input_ring(weights_blob, orc):
+    """k_layer1_regs keeps a wave's input in a ring of three k-block slabs whose phase advances by one per chunk (round 5), twelve waves per workgroup, slots
+    wave-major with a ragged last round: 10,007 distinct chunks are 3.3 rounds of the grid's 12 x CUs slots -- every phase of the ring, waves that issue for a next
+    chunk and waves that do not.  Every chunk against the K = 1 fp32-MFMA form (another kernel, no ring), 48 of them spread over the rounds against the oracle."""
+    n = 10007
+    rng = np.random.default_rng(7)
+    base = synth.make_streams(8, 16, seed0=91).astype(np.float32).reshape(-1, 1536) / np.float32(32768)        # 128 chunks of signal
+    x = base[rng.integers(0, base.shape[0], n)] * rng.uniform(0.05, 1.0, (n, 1)).astype(np.float32)          # 10,007 chunks, no two alike
+    e = Engine(weights_blob, max_streams=256, max_chunks_per_call=40, device=0)
+    try:
+        e.set_option("layer1", 1); a = e.stage_from_samples(x, "layer1")
+        e.set_option("layer1", 0); b = e.stage_from_samples(x, "layer1")
+        assert e.get_option("layer1_kernel") == 0
+    finally:
+        e.close()
+    assert not np.array_equal(bits(a), bits(b))
+    d = np.abs(a - b).reshape(n, -1).max(axis=1)
+    assert float(d.max()) < 2e-4, (float(d.max()), int(d.argmax()))               # two fp32-grade forms of one layer: a ring slip would be a gross error
+    for i in list(np.linspace(0, n - 1, 48).astype(int)) + [int(d.argmax())]:      # ... and the chunk the two disagree on most is the oracle's too
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i], h, c, taps=True)
+        assert float(np.abs(b[i] - taps["l1"]).max()) < 1e-4, int(i)
+
+
 def test_layer1_regs_is_not_used_for_weights_outside_fp16_range(weights_blob, gold_py):
     """a layer-1 weight that does not fit fp16: no LDS image is built, the engine keeps the fp32 form for the first stage (bit-identical to option layer1=1)"""
     ts = tt.loads(weights_blob)

@@ -202,6 +202,31 @@ def test_first_stage_register_kernel_agrees_with_the_k1_form(eng, orc, gold, n):
     assert float(np.abs(b - np.stack(want)).max()) < TAP_TOL * max(1.0, float(np.abs(b).max()))
 
 
+def test_first_stage_over_many_rounds_of_its_input_ring(blob, orc):
+    """k_layer1_regs_v4 with its ring of three k-block slabs per wave, twelve waves per workgroup, wave-major slots (round 5): 10,007 distinct chunks = 3.3
+    rounds of the grid, every phase of the ring.  Every chunk against the K = 1 fp32-MFMA form, 48 spread over the rounds against the oracle."""
+    from vadc_amd import synth
+    n = 10007
+    rng = np.random.default_rng(11)
+    base = synth.make_streams(8, 16, seed0=57).astype(np.float32).reshape(-1, 1536) / np.float32(32768)
+    x = base[rng.integers(0, base.shape[0], n)] * rng.uniform(0.05, 1.0, (n, 1)).astype(np.float32)
+    e = Engine(blob, max_streams=256, max_chunks_per_call=40, device=0)
+    try:
+        e.set_option("layer1", 1); a = e.stage_from_samples(x, "layer1")
+        e.set_option("layer1", 0); b = e.stage_from_samples(x, "layer1")
+        assert e.get_option("layer1_kernel") == 0
+    finally:
+        e.close()
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    scale = max(1.0, float(np.abs(a).max()))
+    d = np.abs(a - b).reshape(n, -1).max(axis=1)
+    assert float(d.max()) < 2e-4 * scale, (float(d.max()), int(d.argmax()))      # two fp32-grade forms of one stage: a ring slip would be a gross error
+    for i in list(np.linspace(0, n - 1, 48).astype(int)) + [int(d.argmax())]:      # ... and the chunk the two disagree on most is the oracle's too
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i], h, c, taps=True)
+        assert float(np.abs(b[i] - taps["l1"]).max()) < TAP_TOL * scale, int(i)
+
+
 def test_magnitude_recovered_from_log_magnitude_agrees_with_stored_magnitude(eng, gold):
     """default: the first stage takes the magnitude half of its input as (e^Y - 1) 2^-20 from the log-magnitudes; option v4_mag=1: from the magnitude
     array the front end then writes.  Same first-stage output to rounding noise, same probabilities to well inside the parity bar."""
