@@ -299,7 +299,9 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, lc = lane & 15;
-   const int slot = blockIdx.x * NW + wave, nslots = gridDim.x * NW;
+   // wave-major slots: the last, partial round of batches is then a few waves on EVERY CU (each with more of its SIMD) instead of full workgroups on some CUs beside
+   // idle ones (12,288 batches on 224 x 12 slots: 4.57 rounds) -- as in k_layer1_regs.  Both phases use the same map, so a batch meets its own scratch again
+   const int slot = wave * gridDim.x + blockIdx.x, nslots = gridDim.x * NW;
    const int nb = (a.n_chunks + 2 * NP - 1) / (2 * NP);
 
    // image -> LDS, 8 loads in flight per thread (one load per trip made 6 + 11 dependent round trips to L2 per workgroup)

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused_v4(EncV4Args a)
    const float *v2 = reinterpret_cast<const float *>(lds + kEncV4_V2), *v3 = reinterpret_cast<const float *>(lds + kEncV4_V3),
                *v4 = reinterpret_cast<const float *>(lds + kEncV4_V4);
    const int nb = (a.n_chunks + 1) / 2;
-   for (int b = blockIdx.x * NW + wave; b < nb; b += gridDim.x * NW) {
+   for (int b = wave * gridDim.x + blockIdx.x; b < nb; b += gridDim.x * NW) {      // wave-major slots: a partial last round is a few waves on every CU (k_enc_fused)
       const int item0 = 2 * b;
       // ---- stage 2 on two tiles (one 12-step chunk each): conv block with inputs from memory -- lane (q, t) takes channels 8 (q & 1) + e; quads 0, 1 feed
       //      relu(dw(x)), quads 2, 3 feed x into the stacked [pointwise | projection] GEMM (K = 32)
