@@ -198,14 +198,14 @@ int main(int argc, char **argv)
    free(blob);
    fprintf(stderr, "Running with batch size %d\n", o.batch);       /* vadc.c:716 */
    /* vadc.c:743-752: the desired sequence count is clamped to what backend_init reported.  The C backend's range is 1536..1536 (silero.h:41-42); a
-    * Silero v4 container reports 512..1536 like the reference's onnxruntime path (onnx_helpers.c:164-170), of which this backend runs 512 / 1024 /
-    * 1536: other requests are rounded DOWN to the next of those. */
+    * Silero v4 container reports 512..1536 like the reference's onnxruntime path (onnx_helpers.c:164-170), of which this backend runs 512 / 768 /
+    * 1024 / 1280 / 1536: other requests are rounded DOWN to the next of those. */
    vadc_amd_caps caps;
    if (vadc_amd_get_caps(eng, &caps) != VADC_AMD_OK) { fprintf(stderr, "get_caps failed: %s\n", vadc_amd_last_error()); return -1; }
    int seq = o.sequence_count;
    if (seq < caps.input_size_min) seq = caps.input_size_min;
    if (seq > caps.input_size_max) seq = caps.input_size_max;
-   if (caps.input_size_step > 0)                                   /* a third, two thirds or all of the maximum: 512 / 1024 / 1536 (8 kHz: 256 / 512 / 768) */
+   if (caps.input_size_step > 0)                                   /* the served windows are input_size_step apart: 512 / 768 / 1024 / 1280 / 1536 (8 kHz: 256 / 512 / 768) */
       seq = caps.input_size_min + (seq - caps.input_size_min) / caps.input_size_step * caps.input_size_step;
    if (seq != o.sequence_count) {
       fprintf(stderr, "--sequence_count %d: the backend runs %d-sample chunks", o.sequence_count, seq);

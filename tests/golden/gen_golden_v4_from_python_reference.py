@@ -136,6 +136,17 @@ def main():
     pathw = os.path.join(HERE, "python_reference_v4_windows.npz")
     np.savez_compressed(pathw, **outw)
     print("wrote", pathw, os.path.getsize(pathw), "bytes  (pcm: the streams of python_reference_v4.npz)")
+    # windows between the thirds (round 5): 768 and 1280 samples = 12 and 20 STFT frames, whose strided stages meet ODD lengths (12 -> 6 -> 3 -> 2, 20 -> 10 -> 5 -> 3)
+    outm = {}
+    for window in (768, 1280):
+        for name in ("speech0", "speech1", "noise", "square"):
+            x = pcm[name][: (pcm[name].size // window) * window]
+            p64, h64, c64 = run_stream(m64, x, torch.float64, window)
+            outm[f"probs64_w{window}_{name}"] = p64; outm[f"h64_w{window}_{name}"] = h64; outm[f"c64_w{window}_{name}"] = c64
+            print(f"window {window} {name}: {p64.size} chunks, p[min,max]=({p64.min():.4f},{p64.max():.4f})")
+    pathm = os.path.join(HERE, "python_reference_v4_windows_768_1280.npz")
+    np.savez_compressed(pathm, **outm)
+    print("wrote", pathm, os.path.getsize(pathm), "bytes  (pcm: the streams of python_reference_v4.npz)")
     # the 8 kHz branch of the v4 graph (silero_vad.py::Silero_V4(8000): third strided conv with stride 1; weights `model_8k.*` of the reference's
     # silero_vad_v4.onnx -> tests/golden/silero_v4_8k.testtensor): windows of 768 / 512 / 256 samples = 12 / 8 / 4 STFT frames.  The streams
     # are the same sample sequences, now read as 8 kHz audio.

@@ -308,18 +308,20 @@ def test_cli_with_v4_weights(gold):
 
 
 # ---------------------------------------------------------------------------------------------- window sizes (vadc --sequence_count)
-@pytest.mark.parametrize("window", [512, 1024])
+@pytest.mark.parametrize("window", [512, 768, 1024, 1280])
 def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
-    """Silero v4 with 512- and 1024-sample windows (option "window": the v4 graph takes 512 ... 1536 samples, onnx_helpers.c:164-170): caps report the
-    range, probabilities against the float64 PyTorch goldens and the oracle, many ragged streams, state carried over calls, forked calls"""
-    gw = np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz"))
+    """Silero v4 with 512- ... 1280-sample windows (option "window": the v4 graph takes 512 ... 1536 samples, onnx_helpers.c:164-170; 768 and 1280 -- 12 and 20
+    frames, odd lengths in the strided stages: 12 -> 6 -> 3 -> 2, 20 -> 10 -> 5 -> 3 -- since round 5): caps report the range, probabilities against the float64
+    PyTorch goldens and the oracle, many ragged streams, state carried over calls, forked calls"""
+    gw = np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz" if window in (512, 1024) else "python_reference_v4_windows_768_1280.npz"))
     e = Engine(blob, max_streams=40, max_chunks_per_call=150, device=0)
     try:
         c = e.caps()
         assert (c["input_size_min"], c["input_size_max"], c["window_samples"]) == (512, 1536, 1536)
         e.set_window(window)
         c = e.caps()
-        assert c["window_samples"] == window and c["lstm_steps_per_chunk"] == window // 512 and e.get_option("window") == window
+        assert c["input_size_step"] == 256
+        assert c["window_samples"] == window and c["lstm_steps_per_chunk"] == {512: 1, 768: 2, 1024: 2, 1280: 3}[window] and e.get_option("window") == window
         for name in ("speech0", "speech1", "noise", "square"):
             pcm = gold[f"pcm_{name}"]
             pcm = pcm[: (pcm.size // window) * window]
@@ -337,9 +339,11 @@ def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
         # stage taps have the window's shapes
         x = f32(gold["pcm_speech0"])[: 5 * window]
         assert e.stage_from_samples(x, "magnitude").shape == (5, 129, window // 64)
-        assert e.stage_from_samples(x, "layer4").shape == (5, 64, window // 512)
+        assert e.stage_from_samples(x, "layer4").shape == (5, 64, {512: 1, 768: 2, 1024: 2, 1280: 3}[window])
         with pytest.raises(VadcAmdError):
-            e.set_option("window", 768)
+            e.set_option("window", 800)                               # not a multiple of 256
+        with pytest.raises(VadcAmdError):
+            e.set_option("window", 1792)
         e.set_window(1536)
         e.reset_streams()
         p = e.run(gold["pcm_speech0"].reshape(1, -1))[0]
@@ -362,14 +366,15 @@ def test_window_option_is_v4_only():
 
 
 def test_cli_sequence_count_selects_the_v4_window(gold):
-    """`--sequence_count` (vadc.c:743-752, 1117): clamped to the backend's range; with a Silero v4 container 512 / 1024 / 1536 are run (other
-    values rounded down), one %f line per FULL chunk of that size"""
+    """`--sequence_count` (vadc.c:743-752, 1117): clamped to the backend's range; with a Silero v4 container 512 / 768 / 1024 / 1280 / 1536 are run (other
+    values rounded down to one of them), one %f line per FULL chunk of that size"""
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "host", "vadc_hip")
-    gw = np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz"))
+    gw = dict(np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz")))
+    gw.update(np.load(os.path.join(GOLDEN, "python_reference_v4_windows_768_1280.npz")))
     pcm = gold["pcm_speech0"]
-    for arg, window in (("512", 512), ("1024", 1024), ("1100", 1024), ("100", 512), ("9999", 1536)):
+    for arg, window in (("512", 512), ("1024", 1024), ("1100", 1024), ("100", 512), ("9999", 1536), ("768", 768), ("1000", 768), ("1280", 1280), ("1500", 1280)):
         r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities", "--sequence_count", arg], input=pcm.tobytes(), capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr.decode()
         assert f"Running with sequence count {window}" in r.stderr.decode()

@@ -118,8 +118,8 @@ static const LayerShape kLayersV4[4] = {{258, 16, 24, 2, 1}, {16, 32, 12, 2, 1},
 // (frames 24 / 16 / 8), T -> T/2 -> T/4 -> T/4 -> T/4 in the 8 kHz branch (third strided conv with stride 1; frames 12 / 8 / 4)
 static void stage_elems_v4(int frames, int stride3, int (&out)[VADC_AMD_STAGE_COUNT])
 {
-   const int t3 = stride3 == 2 ? frames / 8 : frames / 4;
-   out[0] = out[1] = 129 * frames; out[2] = 16 * (frames / 2); out[3] = 32 * (frames / 4); out[4] = 32 * t3; out[5] = 64 * t3;
+   const int t1 = (frames + 1) / 2, t2 = (t1 + 1) / 2, t3 = stride3 == 2 ? (t2 + 1) / 2 : t2;      // 1 + (T - 1) / stride per strided conv
+   out[0] = out[1] = 129 * frames; out[2] = 16 * t1; out[3] = 32 * t2; out[4] = 32 * t3; out[5] = 64 * t3;
 }
 
 struct Packer {
@@ -147,7 +147,7 @@ struct vadc_amd_engine {
    int v4_geo() const                           // k_frontend_gemm geometry of the window in effect
    {
       if (sample_rate == 8000) return window == 768 ? 4 : (window == 512 ? 3 : 5);
-      return window == 1024 ? 2 : (window == 512 ? 3 : 1);
+      return window == 1024 ? 2 : (window == 512 ? 3 : (window == 768 ? 4 : (window == 1280 ? 6 : 1)));
    }
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
@@ -1116,7 +1116,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    const int wmax = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);     // v5: onnx_helpers.c:158-160
    caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
    caps->input_size_max = wmax;
-   caps->input_size_step = caps->input_size_min != wmax ? wmax / 3 : 0;
+   caps->input_size_step = caps->input_size_min != wmax ? 256 : 0;      // 16 kHz: 512, 768, 1024, 1280, 1536; 8 kHz: 256, 512, 768
    caps->context_size = e->model == VADC_AMD_MODEL_V5 ? 64 : 0;
    caps->window_samples = e->window;
    caps->sample_rate = e->sample_rate;
@@ -1255,11 +1255,13 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
       // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which 512 / 1024 / 1536 (8 / 16 / 24 STFT frames) are built here
       if (value == e->window) return VADC_AMD_OK;
       const int wmax = e->sample_rate == 8000 ? 768 : kChunk;     // 8 kHz branch: 256 / 512 / 768 samples = the same 32 / 64 / 96 ms
-      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || (value != wmax / 3 && value != 2 * wmax / 3 && value != wmax))
-         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 1024 or 1536 "
+      const int wstep = 256;                                       // 16 kHz: 512, 768, 1024, 1280, 1536 (round 5: the two between the thirds)
+      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || value < wmax / 3 || value > wmax || value % wstep != 0)
+         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 768, 1024, 1280 or 1536 "
                                       "(its 8 kHz branch 256, 512 or 768)", value);
       { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
-      e->window = value; e->frames = value / 64; e->lstm_steps = e->stride3() == 2 ? e->frames / 8 : e->frames / 4;
+      e->window = value; e->frames = value / 64;
+      { const int t1 = (e->frames + 1) / 2, t2 = (t1 + 1) / 2; e->lstm_steps = e->stride3() == 2 ? (t2 + 1) / 2 : t2; }
       stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
       return VADC_AMD_OK;
    }

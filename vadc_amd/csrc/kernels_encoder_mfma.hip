@@ -1146,7 +1146,8 @@ void launch_layer1_tap(int what, const float *y, const LayerWeightsM &w, float *
 }
 
 // Silero v4 encoder stages (silero_vad.py:157-189, is_v4, strides 2, 2, 2, 1).  T0 = frames of the window = samples / 64 (onnx_helpers.c:164-170
-// lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 16 -> 8 -> 4 -> 2 -> 2 (1024), 8 -> 4 -> 2 -> 1 -> 1 (512).
+// lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 20 -> 10 -> 5 -> 3 -> 3 (1280), 16 -> 8 -> 4 -> 2 -> 2 (1024), 12 -> 6 -> 3 -> 2 -> 2 (768),
+// 8 -> 4 -> 2 -> 1 -> 1 (512).
 // chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.  S3 = stride of the third strided conv.
 template <int T0, int NCH, bool SLAB, int FIRSTK>
 static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st, bool narrow)
@@ -1163,7 +1164,7 @@ template <int T0, int S3>
 static void launch_v4_t(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
                         int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, bool narrow)
 {
-   constexpr int T1 = T0 / 2, T2 = T0 / 4, T3 = S3 == 2 ? T0 / 8 : T2;
+   constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = S3 == 2 ? (T2 + 1) / 2 : T2;      // a k = 1 conv of stride 2 keeps 1 + (T - 1) / 2 steps (12 -> 6 -> 3 -> 2, 20 -> 10 -> 5 -> 3)
    constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
    switch (layer) {
    case 0:
@@ -1193,6 +1194,8 @@ void launch_layer_v4(int layer, const float *in, const float *in2, const float *
       return;
    }
    if (frames == 16)     launch_v4_t<16, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+   else if (frames == 12) launch_v4_t<12, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);      // 768-sample window (round 5)
+   else if (frames == 20) launch_v4_t<20, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);      // 1280-sample window
    else if (frames == 8) launch_v4_t<8, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
    else                  launch_v4_t<24, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
 }

@@ -76,6 +76,8 @@ template <> struct GemmGeo<3> { static constexpr int samples = 512, pad = 96, fr
 // the 8 kHz branch of the v4 graph (same basis, same hop): 768- and 256-sample windows (512 is GEO 3)
 template <> struct GemmGeo<4> { static constexpr int samples = 768, pad = 96, frames = 12, blocks = 15, chunks = 8; static constexpr bool mag = true; };
 template <> struct GemmGeo<5> { static constexpr int samples = 256, pad = 96, frames = 4, blocks = 7, chunks = 16; static constexpr bool mag = true; };
+// Silero v4, 16 kHz, the 1280-sample window (round 5; its 768-sample window is GEO 4): 4 x 20 = 80 positions = 5 column tiles of 16
+template <> struct GemmGeo<6> { static constexpr int samples = 1280, pad = 96, frames = 20, blocks = 23, chunks = 4; static constexpr bool mag = true; };
 
 __device__ __forceinline__ void g_stage8(const float *src, float (&v)[8])
 {
@@ -329,6 +331,7 @@ static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, floa
    case 3:  launch_gemm_geo<T, 3>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    case 4:  launch_gemm_geo<T, 4>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    case 5:  launch_gemm_geo<T, 5>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 6:  launch_gemm_geo<T, 6>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    default: launch_gemm_geo<T, 0>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
    }
 }

@@ -49,6 +49,7 @@ template <> struct G2Geo<2> { static constexpr int samples = 1024, pad = 96, fra
 template <> struct G2Geo<3> { static constexpr int samples = 512, pad = 96, frames = 8, chunks = 12; };
 template <> struct G2Geo<4> { static constexpr int samples = 768, pad = 96, frames = 12, chunks = 8; };
 template <> struct G2Geo<5> { static constexpr int samples = 256, pad = 96, frames = 4, chunks = 24; };
+template <> struct G2Geo<6> { static constexpr int samples = 1280, pad = 96, frames = 20, chunks = 8; };      // Silero v4 16 kHz, 1280-sample window: 160 positions = 5 tiles
 
 constexpr int kG2BlockPitch = 72;                 // halves per 64-sample block of the padded chunk
 constexpr unsigned kG2Oob = 0x80000000u;          // OR-ed into the buffer-store offset of a masked lane (>= num_records: the store is dropped)
@@ -403,7 +404,7 @@ void launch_frontend_gemm2_s16(const int16_t *pcm, const float *afrag2, const fl
       else     hipLaunchKernelGGL((k_frontend_gemm2<GEO, false>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, MAG, FM, n, map, fm_stride); \
    } break;
    switch (geo) {
-   VADC_G2_CASE(1) VADC_G2_CASE(2) VADC_G2_CASE(3) VADC_G2_CASE(4) VADC_G2_CASE(5)
+   VADC_G2_CASE(1) VADC_G2_CASE(2) VADC_G2_CASE(3) VADC_G2_CASE(4) VADC_G2_CASE(5) VADC_G2_CASE(6)
    default: VADC_G2_CASE(0)
    }
 #undef VADC_G2_CASE

@@ -58,7 +58,7 @@ class Engine:
         self.window = self.caps()["window_samples"]     # 512 for the v5 shapes (plus 64 samples of context the engine keeps per stream)
 
     def set_window(self, samples: int):
-        """samples per chunk: 1536 (default); Silero v4 also 1024 / 512 (option "window": --sequence_count of the reference's onnxruntime path)"""
+        """samples per chunk: 1536 (default); Silero v4 also 1280 / 1024 / 768 / 512 (option "window": --sequence_count of the reference's onnxruntime path)"""
         self.set_option("window", samples)
         self._set_v4_shapes(samples)
 
@@ -66,8 +66,9 @@ class Engine:
         self.window = samples
         if self.model == MODEL_V4:
             t = samples // 64
-            t3 = t // 4 if self.sample_rate == 8000 else t // 8
-            self.stage_shapes = {0: (129, t), 1: (129, t), 2: (16, t // 2), 3: (32, t // 4), 4: (32, t3), 5: (64, t3)}
+            t1 = (t + 1) // 2; t2 = (t1 + 1) // 2                 # a k = 1 conv of stride 2 keeps 1 + (T - 1) // 2 steps
+            t3 = t2 if self.sample_rate == 8000 else (t2 + 1) // 2
+            self.stage_shapes = {0: (129, t), 1: (129, t), 2: (16, t1), 3: (32, t2), 4: (32, t3), 5: (64, t3)}
 
     @classmethod
     def from_file(cls, path: str, **kw) -> "Engine":
