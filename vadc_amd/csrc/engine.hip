@@ -138,8 +138,8 @@ struct vadc_amd_engine {
    int device = 0;
    int model = VADC_AMD_MODEL_V31;              // decided by the weights container: 99 tensors = v3.1, 36 = v4
    int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
-   int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 2, 1 (v4 with 1536-, 1024-, 512-sample windows)
-   int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1024 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
+   int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 3, 2, 2, 1 (v4 with 1536-, 1280-, 1024-, 768-, 512-sample windows)
+   int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1280 / 1024 / 768 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
    V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
    float *d_gx5[2] = {nullptr, nullptr}, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512] (one per hand-off parity); per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
@@ -1112,7 +1112,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    if (!e || !caps) return fail(VADC_AMD_EINVAL, "get_caps: NULL argument");
    caps->batch_size_restriction = -1;          // silero.h:39
    caps->is_silero_v5 = e->model == VADC_AMD_MODEL_V5;   // silero.h:40 / onnx_helpers.c:154-156
-   // silero.h:41-42 (the C backend: 1536 only); onnx_helpers.c:164-170 for the v4 graph: 512 ... 1536, of which this engine runs 512 / 1024 / 1536
+   // silero.h:41-42 (the C backend: 1536 only); onnx_helpers.c:164-170 for the v4 graph: 512 ... 1536, of which this engine runs the multiples of 256
    const int wmax = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);     // v5: onnx_helpers.c:158-160
    caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
    caps->input_size_max = wmax;
@@ -1252,7 +1252,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
       // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
-      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which 512 / 1024 / 1536 (8 / 16 / 24 STFT frames) are built here
+      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which the multiples of 256 (8 / 12 / 16 / 20 / 24 STFT frames) are built here
       if (value == e->window) return VADC_AMD_OK;
       const int wmax = e->sample_rate == 8000 ? 768 : kChunk;     // 8 kHz branch: 256 / 512 / 768 samples = the same 32 / 64 / 96 ms
       const int wstep = 256;                                       // 16 kHz: 512, 768, 1024, 1280, 1536 (round 5: the two between the thirds)
