@@ -38,6 +38,8 @@ typedef struct {
    int batch, raw_probabilities, centiseconds, stats;
    const char *model;
    int sequence_count;          /* --sequence_count (vadc.c:1117, default 1536) */
+   const char *probabilities_in; /* --probabilities_in FILE (this program only): float32 speech probabilities, one per chunk, in place of the forward pass -- the
+                                    segmenter alone, on any machine (tests/test_segmenter_vs_reference.py feeds it what the reference's own segmenter code was fed) */
 } Options;
 
 static double g_total_speech = 0.0;
@@ -130,6 +132,7 @@ static int parse_options(int argc, char **argv, Options *o)
       if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a); return -1; }
       const char *v = argv[++i];
       if (!strcmp(a, "--model")) { o->model = v; continue; }
+      if (!strcmp(a, "--probabilities_in")) { o->probabilities_in = v; continue; }
       float f = (float)atof(v);
       if (f <= 0.0f) continue;                                   /* vadc.c:1215-1218 */
       if (!strcmp(a, "--min_silence")) o->min_silence_ms = f;
@@ -160,6 +163,41 @@ __asm__(".section .rodata\n"
 extern const unsigned char vadc_embedded_weights_begin[], vadc_embedded_weights_end[];
 #endif
 
+/* --probabilities_in: the segmenter over given probabilities (no engine, no GPU): the same rounding, feeding, merging, flush and printing as main() below */
+static int segment_probabilities_file(const Options *o)
+{
+   FILE *f = fopen(o->probabilities_in, "rb");
+   if (!f) { fprintf(stderr, "cannot open %s\n", o->probabilities_in); return -1; }
+   const int chunk = o->sequence_count, sample_rate = 16000;
+   if (chunk < 1) { fclose(f); return 2; }
+   const float chunk_ms = chunk / (float)sample_rate * 1000.0f;    /* vadc.c:756 */
+   int min_speech = (int)(o->min_speech_ms / chunk_ms + 0.5f);   if (min_speech < 1) min_speech = 1;
+   int min_silence = (int)(o->min_silence_ms / chunk_ms + 0.5f); if (min_silence < 1) min_silence = 1;
+   const float spc = (float)chunk / sample_rate;                   /* vadc.c:846 */
+   const float neg_thr = o->threshold - o->neg_threshold_relative; /* vadc.c:1243 */
+   FeedState st = {0, 0, 0};
+   Segment buffered = {0, 0, 0};
+   int global_idx = 0;
+   float p;
+   g_sample_rate = sample_rate;
+   while (fread(&p, sizeof p, 1, f) == 1) {
+      Segment r = feed_probability(&st, min_silence, min_speech, p, o->threshold, neg_thr, global_idx);
+      if (r.valid) buffered = combine_or_emit(buffered, r, o, spc);
+      ++global_idx;
+   }
+   fclose(f);
+   if (st.triggered) {                                             /* vadc.c:1005-1027 */
+      int audio_len = (global_idx - 1) * chunk;
+      if (audio_len - (st.current_start * chunk) > (min_speech * chunk)) {
+         Segment fin = {st.current_start, audio_len / chunk, 1};
+         buffered = combine_or_emit(buffered, fin, o, spc);
+      }
+   }
+   if (buffered.valid) emit_segment(buffered, o, spc);
+   fflush(stdout);
+   return 0;
+}
+
 int main(int argc, char **argv)
 {
 #ifdef VADC_EMBED_WEIGHTS
@@ -167,9 +205,10 @@ int main(int argc, char **argv)
 #else
    const char *default_model = "silero_v31_16k.testtensor";
 #endif
-   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model, CHUNK};  /* vadc.c:1110-1124 */
+   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model, CHUNK, NULL};  /* vadc.c:1110-1124 */
    if (parse_options(argc, argv, &o)) return 2;
    if (o.batch > WINDOW_CHUNKS) o.batch = WINDOW_CHUNKS;
+   if (o.probabilities_in) return segment_probabilities_file(&o);
 
    void *blob = NULL;
    long wlen = 0;
