@@ -17,15 +17,17 @@ ALTERNATIVES = [{"lstm": 6}, {"lstm": 7}, {"lstm": 6, "lstm_cus": 32}, {"lstm": 
                 {"cu_partition": 0}, {"lstm": 7, "cu_partition": 0}]
 
 
-@pytest.mark.parametrize("S,Cn", [(256, 96), (320, 96), (832, 32), (2048, 32)])
-def test_the_rules_choice_is_within_5_percent_of_the_best_forced_alternative(S, Cn):
+@pytest.mark.parametrize("model,S,Cn", [("v31", 256, 96), ("v31", 320, 96), ("v31", 832, 32), ("v31", 2048, 32),
+                                        ("v4", 256, 96), ("v4", 320, 96), ("v4", 640, 32), ("v4", 2048, 32)])      # (Silero v4: the rule of round 5, tools/v4_partition_sweep.py)
+def test_the_rules_choice_is_within_5_percent_of_the_best_forced_alternative(model, S, Cn):
     import torch
     import bench
-    blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
+    blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor") if model == "v31" else
+                os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor"), "rb").read()
     dev = torch.device("cuda", 0)
 
     def rate(opts):
-        return bench.side_config(torch, blob, dev, 0, "v31", S, Cn, 0, steps=STEPS, warmup=10, opts=opts or None)["value"]
+        return bench.side_config(torch, blob, dev, 0, model, S, Cn, 0, steps=STEPS, warmup=10, opts=opts or None)["value"]
     rule = rate({})
     alts = {tuple(sorted(o.items())): rate(o) for o in ALTERNATIVES}
     best_key = max(alts, key=alts.get)
@@ -35,5 +37,5 @@ def test_the_rules_choice_is_within_5_percent_of_the_best_forced_alternative(S, 
         rule = max(rule, rate({}))
         alts[best_key] = min(alts[best_key], again_alt)
     report = ", ".join(f"{dict(k)}: {v / 1e6:.3f} M" for k, v in sorted(alts.items(), key=lambda kv: -kv[1]))
-    print(f"\n{S} x {Cn}: rule {rule / 1e6:.3f} M; {report}")
-    assert rule >= 0.95 * max(alts.values()), f"{S} x {Cn}: the rule's choice runs at {rule / 1e6:.3f} M audio-s/s; forced alternatives: {report}"
+    print(f"\n{model} {S} x {Cn}: rule {rule / 1e6:.3f} M; {report}")
+    assert rule >= 0.95 * max(alts.values()), f"{model} {S} x {Cn}: the rule's choice runs at {rule / 1e6:.3f} M audio-s/s; forced alternatives: {report}"

@@ -1600,7 +1600,11 @@ static int resolve_lstm(const vadc_amd_engine *e, int n_streams, bool forked = t
    // workgroup of k_lstm_wavefront_h3 loads and splits both layers' weights (128 KB) for 7 slots of work and holds half a CU's registers meanwhile; 4096 x 1 2.18 -> 2.22 M,
    // 10,240 x 1 2.82 -> 2.92 M, 16,384 x 1 2.90 -> 3.15 M audio-s/s, tools/lstm_variant_sweep.py; at 4096 x 16 the single kernel stays ahead, 3.55 against 3.52 M)
    if (!e->use_gemm_frontend()) return (tiles <= e->n_cus / 2 || n_chunks <= 2) ? 7 : 6;
-   if (tiles >= 20 && tiles <= e->n_cus / 2) return 6;      // GEMM front end (Silero v4), same sweep: one workgroup per tile on the small partition is 1 % ahead of the pair
+   // GEMM front end.  Silero v4, round 5 (tools/v4_partition_sweep.py): with k_frontend_gemm2, the ring in the first stage and stages 2 - 4 in one launch the front end + encoder
+   // stream is 25 % faster than when round 3 found one workgroup per tile (6) 1 % ahead here, and the recurrence became the step between 256 and 2048 streams: the layer-major
+   // pair on CUs of its own is ahead from 16 tiles up -- 256 x 96 5.86 -> 6.57 M, 320 x 96 5.71 -> 6.46, 640 x 32 5.36 -> 6.54, 1664 x 32 6.78 -> 7.12; within 1 % at 512, 896, 1024, 2048
+   if (e->model == VADC_AMD_MODEL_V4 && tiles >= 16 && tiles <= e->n_cus / 2) return 7;
+   if (tiles >= 20 && tiles <= e->n_cus / 2) return 6;      // (Silero v3.1 in FAST_STFT precision: round 3's rule)
    const bool chain_critical = e->lstm_steps * lstm_slot_us(e, 6) > 0.5 * n_streams * enc_us_per_chunk(e);
    return (chain_critical && 2 * tiles <= e->n_cus / 2) ? 7 : 6;
 }
@@ -1628,6 +1632,9 @@ static int lstm_partition_cus(const vadc_amd_engine *e, int n_streams, bool *sha
    if (e->cu_partition == 1) {
       const int tiles = (n_streams + 15) / 16;
       if (!e->use_gemm_frontend() && tiles > e->n_cus / 2) return 0;
+      // Silero v4 (round 5, the same sweep): the pair on 32 CUs of its own from 16 tiles up; 17 .. 20 tiles (272 .. 320 streams) on 64, a CU per tile and layer -- on 2 x 16
+      // CUs the second workgroup of a CU waits for the first (288 x 96: 5.79 M against 6.39 M, 320 x 96: 6.17 against 6.46)
+      if (e->model == VADC_AMD_MODEL_V4 && e->use_gemm_frontend() && lk == 7 && tiles >= 16 && tiles <= e->n_cus / 2) { *shared = false; return (tiles >= 17 && tiles <= 20) ? 64 : 32; }
       if (tiles >= 20 && tiles <= e->n_cus / 2) { *shared = false; return 32; }      // (17 .. 19 tiles: two co-resident chains would be the step -- 288 streams 2.96 M against 3.08 M with 2 x 24 CUs)
    }
    if (lstm_wgs > e->n_cus / 2) return 0;
