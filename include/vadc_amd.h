@@ -258,6 +258,9 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 0: trust the rules anyway; 2: behave as if the check had failed (tests)
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
  *                 1: magnitudes are written by the front end and read by the first stage
+ *   "full_mask_streams" without a CU partition (many stream tiles): 2 (default) = the internal front end + encoder stream is created with a CU mask of EVERY CU, which
+ *                 gives it a hardware queue of its own -- as a plain stream it could share one with the recurrence's stream in a process that had created other
+ *                 engines before (10,240 x 1: 2.95 -> 1.77 M); 1 = all three internal streams so (the recurrence's lose their priority: -3 % at 4096 x 16); 0 = plain
  *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream
  *                 when the chain has slack, disjoint otherwise; 2: always shared; 0: never mask.  "lstm_cus": size of that partition (multiple of 8; 0 =
  *                 sized by the engine) */

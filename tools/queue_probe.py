@@ -11,7 +11,10 @@ dev=torch.device("cuda",0)
 def r(S,Cn,opts=None):
     x=bench.side_config(torch, b31, dev, 0, "v31", S, Cn, 0, steps=100, warmup=10, opts=opts)
     print(S,Cn,opts, round(x["value"]/1e6,3), x["ms_per_step"], x["kernels_ms"], flush=True)
-r(10240,1)
+FM = {"full_mask_streams": int(os.environ.get("FM", "0"))}      # the other form: 0 = plain streams (round 4), 1 = all three masked
+r(10240,1); r(10240,1, FM)
 for i in range(4):
     r(256,96, {"lstm":6} if i%2 else None)
-    r(10240,1)
+    r(10240,1); r(10240,1, FM)
+for S, Cn in ((4096, 16), (16384, 1), (3072, 32), (4096, 4)):
+    r(S, Cn); r(S, Cn, FM); r(S, Cn); r(S, Cn, FM)

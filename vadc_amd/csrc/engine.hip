@@ -152,6 +152,8 @@ struct vadc_amd_engine {
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
    const float *d_afrag2 = nullptr, *d_nyq2 = nullptr; // ... the same for its second form (k_frontend_gemm2: 32x32x16 MFMAs, s16 input)
+   int full_mask_streams = 2;                   // option "full_mask_streams": without a partition, 2 (default) = the front end + encoder stream is a CU-masked stream with EVERY CU
+                                                // (a hardware queue of its own), 1 = all three internal streams are, 0 = plain streams (round 4)
    int fe_gemm = 2;                             // option "fe_gemm": 2 = k_frontend_gemm2 for s16 input (default), 1 = the first form for everything
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
    bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_FAST_STFT)); }
@@ -1217,7 +1219,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail", "full_mask_streams"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1242,6 +1244,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3 || value == 11)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
+   if (strcmp(key, "full_mask_streams") == 0 && value >= 0 && value <= 2) { e->full_mask_streams = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "trail_fault") == 0 && (value == 0 || value == 1)) { e->trail_fault = value; return VADC_AMD_OK; }
@@ -1283,6 +1286,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
    else if (strcmp(key, "fe_gemm") == 0) *value = e->fe_gemm;
+   else if (strcmp(key, "full_mask_streams") == 0) *value = e->full_mask_streams;
    else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
@@ -1686,6 +1690,32 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, ma.data());
       hipError_t eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, mb.data()) : ea;
       hipError_t ec = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sC, (uint32_t)words, mc.data()) : eb;
+      masked = (ea == hipSuccess && eb == hipSuccess && ec == hipSuccess);
+      if (!masked) {
+         (void)hipGetLastError();
+         for (hipStream_t *ps : {&e->sA, &e->sB, &e->sC}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
+      }
+   }
+   if (!masked && e->full_mask_streams && e->cu_partition_usable()) {
+      // no partition: the front end + encoder stream still gets a CU mask -- a full one.  A masked stream has a hardware queue of its own; plain streams are dealt onto a
+      // few shared ones, and behind some predecessors in the same process stream A and the recurrence's stream ended up on one: the recurrence of call k then started when
+      // call k + 1's front end had ENDED and ran beside its persistent kernels (10,240 x 1: 2.95 -> 1.77 M, 16,384 x 1: 3.25 -> 2.6 M, every time; tools/queue_probe.py).
+      // The recurrence's streams stay plain streams of the highest priority: masked as well they lose it (4096 x 16: 3.62 -> 3.51 M)
+      want = 0;
+      const int words = (e->n_cus + 31) / 32;
+      std::vector<uint32_t> all(words, 0u);
+      for (int cu = 0; cu < e->n_cus; ++cu) all[cu / 32] |= 1u << (cu % 32);
+      hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, all.data());
+      hipError_t eb = ea, ec = ea;
+      if (e->full_mask_streams == 2) {                         // only stream A: the recurrence's streams keep their priority
+         int lo = 0, hi = 0;
+         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+         eb = (ea == hipSuccess) ? hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi) : ea;
+         ec = (eb == hipSuccess) ? hipStreamCreateWithPriority(&e->sC, hipStreamNonBlocking, hi) : eb;
+      } else {
+         eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, all.data()) : ea;
+         ec = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sC, (uint32_t)words, all.data()) : eb;
+      }
       masked = (ea == hipSuccess && eb == hipSuccess && ec == hipSuccess);
       if (!masked) {
          (void)hipGetLastError();
