@@ -2,7 +2,8 @@
  * vadc_hip.c -- POSIX command-line host for the MI355X backend: the `vadc < audio.s16le` contract of the
  * reference (README.md:52-60, vadc.c:670-1035) on Linux, in C, on top of the C-ABI of include/vadc_amd.h.
  *
- *   stdin : 16 kHz mono s16le PCM        stdout: one "start,end" line per speech segment (seconds, %.2f),
+ *   stdin : 16 kHz mono s16le PCM (or a file named on the command line, decoded by an ffmpeg child: vadc.c:531-608)
+ *                                        stdout: one "start,end" line per speech segment (seconds, %.2f),
  *                                                 or centiseconds (--output_centi_seconds), or one "%f" line per
  *                                                 1536-sample chunk (--raw_probabilities)
  *   stderr: diagnostics and --stats
@@ -16,11 +17,15 @@
  *                                        :223-260 (emit, float32 time arithmetic), :1005-1027 (final flush)
  * The forward pass itself is vadc_amd_run_s16 (GPU); there is no CPU path in this program.
  */
+#include <errno.h>
+#include <fcntl.h>
 #include <inttypes.h>
+#include <spawn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -38,6 +43,9 @@ typedef struct {
    int batch, raw_probabilities, centiseconds, stats;
    const char *model;
    int sequence_count;          /* --sequence_count (vadc.c:1117, default 1536) */
+   const char *input_file;      /* a bare argument: the file ffmpeg decodes in place of stdin (vadc.c:1225-1229, :810-815) */
+   int audio_source;            /* --audio_source N: ffmpeg's -map 0:a:N (vadc.c:537) */
+   float start_seconds;         /* --start_seconds F: ffmpeg's -ss (vadc.c:537) */
    const char *probabilities_in; /* --probabilities_in FILE (this program only): float32 speech probabilities, one per chunk, in place of the forward pass -- the
                                     segmenter alone, on any machine (tests/test_segmenter_vs_reference.py feeds it what the reference's own segmenter code was fed) */
 } Options;
@@ -125,10 +133,7 @@ static int parse_options(int argc, char **argv, Options *o)
       if (!strcmp(a, "--raw_probabilities")) { o->raw_probabilities = 1; continue; }
       if (!strcmp(a, "--output_centi_seconds")) { o->centiseconds = 1; continue; }
       if (!strcmp(a, "--stats")) { o->stats = 1; continue; }
-      if (strncmp(a, "--", 2) != 0) {                               /* vadc.c:1228-1232: a bare argument is an input file for ffmpeg (vadc.c:537) */
-         fprintf(stderr, "input file '%s': this build does not spawn ffmpeg; pipe 16 kHz mono s16le on stdin (ffmpeg -i FILE -f s16le -ac 1 -ar 16000 - | vadc_hip)\n", a);
-         return -1;
-      }
+      if (strncmp(a, "--", 2) != 0) { o->input_file = a; continue; }  /* vadc.c:1225-1229: a bare argument is the input file ffmpeg decodes (the last one named) */
       if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a); return -1; }
       const char *v = argv[++i];
       if (!strcmp(a, "--model")) { o->model = v; continue; }
@@ -142,10 +147,47 @@ static int parse_options(int argc, char **argv, Options *o)
       else if (!strcmp(a, "--speech_pad")) o->speech_pad_ms = f;
       else if (!strcmp(a, "--batch")) o->batch = (int)f;
       else if (!strcmp(a, "--sequence_count")) o->sequence_count = (int)f;     /* clamped to the backend's range after backend_init (vadc.c:743-752) */
-      else if (!strcmp(a, "--audio_source") || !strcmp(a, "--start_seconds")) { /* ffmpeg stream selection / seek (vadc.c:532-538): no effect on stdin input */ }
+      else if (!strcmp(a, "--audio_source")) o->audio_source = (int)f;          /* ffmpeg's stream selection and seek (vadc.c:532-538): no effect on stdin input */
+      else if (!strcmp(a, "--start_seconds")) o->start_seconds = f;
       else { fprintf(stderr, "unknown option %s\n", a); return -1; }
    }
    return 0;
+}
+
+/* The reference's init_buffered_stream_ffmpeg (vadc.c:531-608) on POSIX: ffmpeg decodes the named file to mono s16le at the model's rate on a pipe this program
+ * reads in place of stdin; ffmpeg gets no stdin of ours and keeps our stderr.  The same arguments as vadc.c:537, handed over as an argument vector (no shell, no
+ * quoting of the file name).  Called BEFORE the engine exists: the child is started by a process that has not touched the GPU yet.
+ * Returns the read end of the pipe, or -1. */
+static pid_t g_ffmpeg_pid = 0;
+static int spawn_ffmpeg(const Options *o, int sample_rate)
+{
+   int fds[2];
+   if (pipe(fds) != 0) { fprintf(stderr, "Error creating ffmpeg pipe\n"); return -1; }      /* vadc.c:550 */
+   char ss[32], map[32];
+   snprintf(ss, sizeof ss, "%f", o->start_seconds);
+   snprintf(map, sizeof map, "0:a:%d", o->audio_source);
+   char *const argv[] = {"ffmpeg", "-hide_banner", "-loglevel", "error", "-nostats", "-ss", ss, "-i", (char *)o->input_file, "-map", map, "-vn", "-sn", "-dn",
+                         "-ac", "1", "-ar", sample_rate == 8000 ? "8k" : "16k", "-f", "s16le", "-", NULL};
+   posix_spawn_file_actions_t fa;
+   posix_spawn_file_actions_init(&fa);
+   posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+   posix_spawn_file_actions_adddup2(&fa, fds[1], 1);
+   posix_spawn_file_actions_addclose(&fa, fds[0]);
+   posix_spawn_file_actions_addclose(&fa, fds[1]);
+   extern char **environ;
+   const int rc = posix_spawnp(&g_ffmpeg_pid, "ffmpeg", &fa, NULL, argv, environ);
+   posix_spawn_file_actions_destroy(&fa);
+   close(fds[1]);
+   if (rc != 0) { fprintf(stderr, "Error launching ffmpeg: %s\n", strerror(rc)); close(fds[0]); g_ffmpeg_pid = 0; return -1; }      /* vadc.c:570 */
+   return fds[0];
+}
+
+/* the rate the weights container runs at, from its header alone (int32 version, int32 tensor count: 37 = the v4 graph's 8 kHz branch), before any engine exists */
+static int container_sample_rate(const void *blob, long len)
+{
+   int32_t count = 0;
+   if (len >= 8) memcpy(&count, (const char *)blob + 4, 4);
+   return count == 37 ? 8000 : 16000;
 }
 
 /* Build-time weights embedding: the counterpart of the reference's cembed.c, which turns the weights file into a C array
@@ -205,7 +247,7 @@ int main(int argc, char **argv)
 #else
    const char *default_model = "silero_v31_16k.testtensor";
 #endif
-   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model, CHUNK, NULL};  /* vadc.c:1110-1124 */
+   Options o = {200.0f, 250.0f, 0.5f, 0.15f, 30.0f, WINDOW_CHUNKS, 0, 0, 0, default_model, CHUNK, NULL, 0, 0.0f, NULL};  /* vadc.c:1110-1124 */
    if (parse_options(argc, argv, &o)) return 2;
    if (o.batch > WINDOW_CHUNKS) o.batch = WINDOW_CHUNKS;
    if (o.probabilities_in) return segment_probabilities_file(&o);
@@ -228,6 +270,12 @@ int main(int argc, char **argv)
       memcpy(blob, vadc_embedded_weights_begin, (size_t)wlen);
    }
 #endif
+
+   int in_fd = 0;                                                  /* vadc.c:810-819: the named file through ffmpeg, else stdin */
+   if (o.input_file) {
+      in_fd = spawn_ffmpeg(&o, container_sample_rate(blob, wlen));
+      if (in_fd < 0) return -1;
+   }
 
    vadc_amd_engine *eng = 0;
    if (vadc_amd_create(blob, (size_t)wlen, -1, 1, WINDOW_CHUNKS, VADC_AMD_PRECISION_FP32, &eng) != VADC_AMD_OK) {
@@ -278,7 +326,7 @@ int main(int argc, char **argv)
 
    const size_t window_bytes = (size_t)WINDOW_CHUNKS * chunk * sizeof(int16_t);      /* vadc.c:799-805: chunks_count = 96 chunks of input_count samples */
    for (;;) {
-      size_t bytes = read_full(0, pcm, window_bytes);
+      size_t bytes = read_full(in_fd, pcm, window_bytes);
       size_t values = bytes / sizeof(int16_t);
       if (values == 0) break;
       total_samples += (int64_t)values;
@@ -314,6 +362,12 @@ int main(int argc, char **argv)
       if (buffered.valid) emit_segment(buffered, &o, spc);
    }
    fflush(stdout);
+   if (g_ffmpeg_pid > 0) {                                          /* the reference drops ffmpeg's handles at once (vadc.c:581-582); here its exit is collected, and a failure that left no audio is said */
+      int status = 0;
+      close(in_fd);
+      if (waitpid(g_ffmpeg_pid, &status, 0) == g_ffmpeg_pid && total_samples == 0 && !(WIFEXITED(status) && WEXITSTATUS(status) == 0))
+         fprintf(stderr, "ffmpeg gave no audio for '%s' (exit status %d)\n", o.input_file, WIFEXITED(status) ? WEXITSTATUS(status) : -1);
+   }
    if (o.stats) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       double wall = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);

@@ -1264,14 +1264,15 @@ def test_cli_with_embedded_weights(gold_c, gold_py):
 
 def test_cli_accepts_the_whole_option_table(gold_py):
     """every option of vadc.c:1110-1124 is accepted: --sequence_count is clamped to the backend's 1536 (vadc.c:743-752), the two ffmpeg
-    options have no effect on stdin input, a bare file argument (ffmpeg source, vadc.c:537) is refused with a message"""
+    options have no effect on stdin input; a bare file argument starts ffmpeg (vadc.c:537; tests/test_cli_ffmpeg_spawn.py) and without one on PATH the CLI says so"""
     import subprocess
     from conftest import ROOT, WEIGHTS
     pcm = gold_py["pcm_speech0"]
     base, _ = _run_cli(pcm, "--raw_probabilities")
     lines, err = _run_cli(pcm, "--raw_probabilities", "--sequence_count", "512", "--audio_source", "1", "--start_seconds", "2.5", "--stats")
     assert lines == base and "1536" in err
-    r = subprocess.run([os.path.join(ROOT, "host", "vadc_hip"), "--model", WEIGHTS, "clip.wav"], input=b"", capture_output=True, timeout=60)
+    r = subprocess.run([os.path.join(ROOT, "host", "vadc_hip"), "--model", WEIGHTS, "clip.wav"], input=b"", capture_output=True, timeout=60,
+                       env=dict(os.environ, PATH="/nonexistent"))
     assert r.returncode != 0 and b"ffmpeg" in r.stderr
 
 
