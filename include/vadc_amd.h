@@ -254,6 +254,8 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "fe_opt"      the exact-tree front end of Silero v3.1: 3 (default) = k_frontend_sym with bin 0 without the tree of its all-zero im row, the 9-bin split rotating over
  *                 the waves; 0 = round 3's kernel; 11 = k_frontend_ri (packed pairs = (re, im) of one tree lane: the derived rows' sums, re^2 + im^2 and the logarithm
  *                 run two values per instruction -- 8 % fewer vector instructions, the same time, the same bits)
+ *   "fe_xcd"      1 (default): the exact-tree front end's workgroups take their blocks of positions in XCD-major order -- the two workgroups that share a chunk write
+ *                 its 128-byte lines of Y behind the same L2 (same bits, 2.7 % less time); 0: in launch order
  *   "cu_mask_check" 1 (default): the LSTM's CU partition is used only on a device whose CU-mask layout passed the check at create (caps.cu_partition_ok);
  *                 0: trust the rules anyway; 2: behave as if the check had failed (tests)
  *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;

@@ -245,6 +245,9 @@ int main(int argc, char **argv)
       time_it("sym nb2 OPT3, magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
       check("sym nb2 OPT3", Y1);
       CK(hipMemset(Y1, 0, ref.size() * 4));
+      time_it("sym nb2 OPT11 (XCD-major blocks), magnitude", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 1, 2, 4, 11>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); });
+      check("sym nb2 OPT11", Y1);
+      CK(hipMemset(Y1, 0, ref.size() * 4));
       time_it("ri (re, im pairs), magnitude", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 1, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1); });
       check("ri", Y1);
       if (getenv("FE_RI_DEBUG")) {                        // mismatching words by bin
@@ -319,6 +322,10 @@ int main(int argc, char **argv)
             {"OPT3", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
             {"RI", [&] { hipLaunchKernelGGL((k_frontend_ri<int16_t, 0, 4>), grid, dim3(256), 0, g_st, pcm, basis, basis_ri, Y1, FM1, n, map, fm_stride, 1); }},
             // rows of Y on 128-byte boundaries (pitch 32 floats instead of 25: + 28 % bytes, no row straddles a 128-byte line)
+            // no Y stores at all (OPT bit 4; the partial bin sums keep every value alive): the ceiling of what a front end fused into the first stage could gain HERE
+            {"NOY", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 7>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
+            // XCD-major block order (OPT bit 8): the two workgroups that share a chunk write its lines behind the same L2
+            {"XCD", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 11>), grid, dim3(256), 0, g_st, pcm, basis, Y1, FM1, n, map, fm_stride, 1); }},
             {"YP32", [&] { hipLaunchKernelGGL((k_frontend_sym<int16_t, 0, 2, 4, 3, 32>), grid, dim3(256), 0, g_st, pcm, basis, Y32, FM1, n, map, fm_stride, 1); }},
          };
          if (getenv("FE_ONLY")) {                      // one variant, 200 launches: for a rocprofv3 --pmc pass (WRITE_SIZE per launch)

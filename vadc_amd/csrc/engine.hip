@@ -173,6 +173,7 @@ struct vadc_amd_engine {
    bool trail_possible() const { return overlap_check == 1 && kernels_overlap; }
    bool cu_partition_usable() const { return cu_mask_check == 0 || (cu_mask_check == 1 && cu_layout_ok); }
    bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
+   int fe_xcd = 1;                              // option "fe_xcd": the exact-tree front end's workgroups take their blocks of positions in XCD-major order (kernels_frontend.hip, xcd_major_block): the two workgroups that share a chunk write its lines of Y behind one L2
    int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree), or 11 = k_frontend_ri ((re, im)-packed trees and epilogue: 8 % fewer instructions, the same time -- kernels_frontend.hip)
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
@@ -1219,7 +1220,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail", "full_mask_streams"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail", "full_mask_streams", "fe_xcd"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1243,6 +1244,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3 || value == 11)) { e->fe_opt = value; return VADC_AMD_OK; }
+   if (strcmp(key, "fe_xcd") == 0 && (value == 0 || value == 1)) { e->fe_xcd = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
    if (strcmp(key, "full_mask_streams") == 0 && value >= 0 && value <= 2) { e->full_mask_streams = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
@@ -1285,6 +1287,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
    else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
+   else if (strcmp(key, "fe_xcd") == 0) *value = e->fe_xcd;
    else if (strcmp(key, "fe_gemm") == 0) *value = e->fe_gemm;
    else if (strcmp(key, "full_mask_streams") == 0) *value = e->full_mask_streams;
    else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
@@ -1560,8 +1563,8 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
       } else if (fk == 0) {
          // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
-         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
-         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
+         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
+         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
       } else {
          // any basis, any alignment: the full tree for all 129 bins
          if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
@@ -2371,7 +2374,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
                                e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt, e->zero_im0, e->d_basis_ri);
+   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);

@@ -729,6 +729,16 @@ __device__ __forceinline__ void sym_stage_chunks(float *xs, const T *__restrict_
    }
 }
 
+// Workgroups of a launch are dealt to the 8 XCDs in turn ((start + blockIdx) % 8, start unknown: tools/xcd_map_probe.hip), so neighbours in blockIdx sit behind two different
+// L2s.  The exact-tree front ends give neighbouring workgroups neighbouring blocks of 64 positions, and two such blocks share a chunk: they write the two parts of the same
+// 128-byte lines of Y.  XCD-major order hands the workgroups of one residue (= one XCD) CONSECUTIVE blocks, so a line's parts meet in one L2 before it is written back:
+// tools/fe_bench FE_POWER, 24,576 chunks on 224 CUs: 0.4312 -> 0.4197 ms (without any Y store: 0.4055).  A permutation of which workgroup computes which block: no bit changes.
+__device__ __forceinline__ unsigned xcd_major_block(unsigned bid, unsigned n_blocks)
+{
+   const unsigned q = n_blocks >> 3, r = n_blocks & 7, x = bid & 7, i = bid >> 3;
+   return x * q + (x < r ? x : r) + i;
+}
+
 // OPT (bit mask; NB = 2 only): 1 = the base-bin split a wave serves rotates with the workgroup -- the 9-bin split (17 - 18 trees against 16) then loads every
 // SIMD in turn instead of always the one wave 0 lands on; 2 = split 0 runs bin 0 as its batch of one and, when `zero_im0` (the loaded basis' im row of bin 0 is
 // all +-0, checked by the engine at create), without that row's tree and without the emit of the row pair that bin 0 does not have.  Both keep every bit
@@ -747,9 +757,10 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
    constexpr int kFlChunks = fl_chunks(1);
    __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
    const int tid = threadIdx.x, lane = tid & 63;
-   const int wave = (OPT & 1) ? ((__builtin_amdgcn_readfirstlane(tid >> 6) + (int)blockIdx.x) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);   // base-bin split
+   const unsigned bid = (OPT & 8) ? xcd_major_block(blockIdx.x, gridDim.x) : blockIdx.x;      // OPT 8: XCD-major block order (above)
+   const int wave = (OPT & 1) ? ((__builtin_amdgcn_readfirstlane(tid >> 6) + (int)bid) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);   // base-bin split
    const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * 64;
+   const long p0 = (long)bid * 64;
    const int item0 = (int)(p0 / kFrames);
 
    sym_stage_chunks<T>(xs, pcm, map, item0, n_chunks, tid);
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
       } else {
          val = sqrtf(p2);                                                      // stft.c:209
       }
-      if (writer && counted) yout[bin * YP] = val;
+      if (writer && counted && !(OPT & 4)) yout[bin * YP] = val;          // OPT 4 (tools/fe_bench only): no Y at all -- what the stores cost, the bin sums keep every value alive
    };
    auto emit = [&](int b, const float *y8) {
       const int bins[4] = {b, 128 - b, 64 - b, 64 + b};
@@ -967,7 +978,7 @@ __device__ __forceinline__ f2v log1p_hw2(f2v x)
    return __builtin_elementwise_fma(c, E, y);
 }
 
-template <typename T, int MODE, int MINW = 4, bool SRC1 = false>
+template <typename T, int MODE, int MINW = 4, bool SRC1 = false, bool XCD = false>
 __global__ __launch_bounds__(256, MINW) void k_frontend_ri(const T *__restrict__ pcm,          // [n_chunks][1536], 16-byte aligned
                                                           const float *__restrict__ basis,    // [258][256] permuted (k_frontend's): bin 0
                                                           const float *__restrict__ basis_ri, // [33][4][4][2][8][2]: base bins, (re, im) interleaved
@@ -978,9 +989,10 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_ri(const T *__restrict__
    constexpr int kFlChunks = fl_chunks(1);
    __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
    const int tid = threadIdx.x, lane = tid & 63;
-   const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)blockIdx.x) & 3;       // base-bin split, rotating with the workgroup (k_frontend_sym's OPT 1)
+   const unsigned bid = XCD ? xcd_major_block(blockIdx.x, gridDim.x) : blockIdx.x;
+   const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)bid) & 3;              // base-bin split, rotating with the workgroup (k_frontend_sym's OPT 1)
    const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)blockIdx.x * 64;
+   const long p0 = (long)bid * 64;
    const int item0 = (int)(p0 / kFrames);
    sym_stage_chunks<T>(xs, pcm, map, item0, n_chunks, tid);
    __syncthreads();
@@ -1136,19 +1148,23 @@ void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, fl
 // k_frontend_sym: the default v3.1 front end (basis symmetries verified by the engine, pcm 16-byte aligned)
 // opt: the kernel's OPT mask (0 = round 3's kernel; 3 = rotating splits + bin 0 as a batch of one, its im tree skipped when zero_im0)
 constexpr int kSymNB = 2;   // tools/fe_bench sym, 16,384 chunks: NB = 2 0.300 ms, NB = 3 0.329 ms (k_frontend_fl: 1.07 ms)
-// opt & 8 (and a basis_ri): k_frontend_ri, the (re, im)-packed form
+// opt & 8 (and a basis_ri): k_frontend_ri, the (re, im)-packed form;  opt & 16: XCD-major block order (xcd_major_block), the engine's option "fe_xcd"
 template <typename T>
 static void launch_frontend_sym(const T *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0, const float *basis_ri)
 {
    const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
+   const bool xcd = (opt & 16) != 0;                    // option "fe_xcd" (default on): XCD-major block order
+   opt &= 15;
    if ((opt & 8) && basis_ri) {
-      if (mode != 0) hipLaunchKernelGGL((k_frontend_ri<T, 1, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
-      else           hipLaunchKernelGGL((k_frontend_ri<T, 0, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
+      if (mode != 0)  hipLaunchKernelGGL((k_frontend_ri<T, 1, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
+      else if (xcd)   hipLaunchKernelGGL((k_frontend_ri<T, 0, 4, false, true>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
+      else            hipLaunchKernelGGL((k_frontend_ri<T, 0, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
       return;
    }
-   if (mode != 0)     hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else if (opt == 3) hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else               hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   if (mode != 0)            hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else if (opt == 3 && xcd) hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 11>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else if (opt == 3)        hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else                      hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
 }
 void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0, const float *basis_ri)
 {
