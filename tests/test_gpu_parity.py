@@ -148,6 +148,30 @@ def test_zero_im_row_of_bin0_is_skipped_bit_exactly(weights_blob):
         assert np.array_equal(bits(out[3][0][i]), bits(taps["magnitude"])), i
 
 
+@pytest.mark.parametrize("S,C", [(1, 1), (3, 5), (37, 5), (300, 3), (256, 96)])
+def test_frontend_blocks_in_xcd_major_order_change_no_bit(weights_blob, orc, S, C):
+    """option "fe_xcd" (default 1): the exact-tree front end's workgroups take their blocks of 64 positions in XCD-major order (kernels_frontend.hip xcd_major_block:
+    workgroup b computes block (b % 8) * ceil(n / 8) + b / 8, so that the two workgroups sharing a chunk sit behind one L2) -- a permutation of who computes what:
+    log-magnitudes and probabilities are the bits of launch order, for both forms of the kernel, at block counts that are and are not multiples of 8; and the oracle's"""
+    pcm = np.ascontiguousarray(np.tile(synth.make_streams(min(S, 6), C, seed0=900 + S), ((S + 5) // 6, 1))[:S])
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=C, device=0)
+    try:
+        assert e.get_option("fe_xcd") == 1
+        out = {}
+        for fe_opt in (3, 11):
+            for xcd in (1, 0):
+                e.set_option("fe_opt", fe_opt); e.set_option("fe_xcd", xcd); e.reset_streams()
+                y = e.stage_from_samples(f32(pcm[:2, : min(C, 3) * 1536]).reshape(-1), "normalized")
+                out[fe_opt, xcd] = (y, e.run(pcm))
+                assert e.get_option("frontend_kernel") == 0
+        for k in out:
+            assert np.array_equal(bits(out[k][0]), bits(out[3, 0][0])) and np.array_equal(bits(out[k][1]), bits(out[3, 0][1])), k
+    finally:
+        e.close()
+    want = orc.forward_stream(pcm[S - 1])[:, 1]
+    assert float(np.abs(out[3, 1][1][S - 1, :, 1] - want).max()) <= PROB_TOL
+
+
 def test_nonzero_im_row_of_bin0_reenables_its_tree(weights_blob):
     """a basis whose im row of bin 0 is NOT zero: one tap of row 129 set to 0.25.  (The DFT symmetries force that row to zero, so such a basis has none of
     them: the engine reports zero_im0 = 0 and runs the full tree, whose magnitudes are the bits of the oracle built from the same weights -- bin 0 included.)"""
