@@ -477,6 +477,16 @@ struct FlStages<NB, 16 * NB, ABL> {
    static __device__ __forceinline__ void run(FlState<NB> &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
 };
 
+// Workgroups of a launch are dealt to the 8 XCDs in turn ((start + blockIdx) % 8, start unknown: tools/xcd_map_probe.hip), so neighbours in blockIdx sit behind two different
+// L2s.  The exact-tree front ends give neighbouring workgroups neighbouring blocks of 64 positions, and two such blocks share a chunk: they write the two parts of the same
+// 128-byte lines of Y.  XCD-major order hands the workgroups of one residue (= one XCD) CONSECUTIVE blocks, so a line's parts meet in one L2 before it is written back:
+// tools/fe_bench FE_POWER, 24,576 chunks on 224 CUs: 0.4312 -> 0.4197 ms (without any Y store: 0.4055).  A permutation of which workgroup computes which block: no bit changes.
+__device__ __forceinline__ unsigned xcd_major_block(unsigned bid, unsigned n_blocks)
+{
+   const unsigned q = n_blocks >> 3, r = n_blocks & 7, x = bid & 7, i = bid >> 3;
+   return x * q + (x < r ? x : r) + i;
+}
+
 // MODE as k_frontend (0: Y = log1p(2^20 m) + FM partial bin sums; 1: Y = magnitude).  NB = bins per batch; kBinsPerSplit = 33 and
 // the last split's 30 bins are both multiples of 3.
 // NPS = position sets (of 64) per workgroup: the NPS waves that work on the same bin split start together and read the same
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__rest
    const int n_units = (int)((total_pos + 64 * NPS - 1) / (64 * NPS));
 #pragma unroll 1
    for (int round = 0;; ++round) {
-   int unit = blockIdx.x;
+   int unit = PERSIST ? 0 : (int)xcd_major_block(blockIdx.x, gridDim.x);      // neighbouring units share a chunk's lines of Y: one XCD's workgroups take consecutive units
    if (PERSIST) {
       if (round) __syncthreads();                          // the previous unit's readers of xs / unit_s are done
       if (tid == 0) unit_s = atomicAdd(work_counter, 1);
@@ -729,16 +739,6 @@ __device__ __forceinline__ void sym_stage_chunks(float *xs, const T *__restrict_
    }
 }
 
-// Workgroups of a launch are dealt to the 8 XCDs in turn ((start + blockIdx) % 8, start unknown: tools/xcd_map_probe.hip), so neighbours in blockIdx sit behind two different
-// L2s.  The exact-tree front ends give neighbouring workgroups neighbouring blocks of 64 positions, and two such blocks share a chunk: they write the two parts of the same
-// 128-byte lines of Y.  XCD-major order hands the workgroups of one residue (= one XCD) CONSECUTIVE blocks, so a line's parts meet in one L2 before it is written back:
-// tools/fe_bench FE_POWER, 24,576 chunks on 224 CUs: 0.4312 -> 0.4197 ms (without any Y store: 0.4055).  A permutation of which workgroup computes which block: no bit changes.
-__device__ __forceinline__ unsigned xcd_major_block(unsigned bid, unsigned n_blocks)
-{
-   const unsigned q = n_blocks >> 3, r = n_blocks & 7, x = bid & 7, i = bid >> 3;
-   return x * q + (x < r ? x : r) + i;
-}
-
 // OPT (bit mask; NB = 2 only): 1 = the base-bin split a wave serves rotates with the workgroup -- the 9-bin split (17 - 18 trees against 16) then loads every
 // SIMD in turn instead of always the one wave 0 lands on; 2 = split 0 runs bin 0 as its batch of one and, when `zero_im0` (the loaded basis' im row of bin 0 is
 // all +-0, checked by the engine at create), without that row's tree and without the emit of the row pair that bin 0 does not have.  Both keep every bit
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
    constexpr int kFlChunks = fl_chunks(1);
    __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
    const int tid = threadIdx.x, lane = tid & 63;
-   const unsigned bid = (OPT & 8) ? xcd_major_block(blockIdx.x, gridDim.x) : blockIdx.x;      // OPT 8: XCD-major block order (above)
+   const unsigned bid = (OPT & 8) ? xcd_major_block(blockIdx.x, gridDim.x) : blockIdx.x;      // OPT 8: XCD-major block order (xcd_major_block)
    const int wave = (OPT & 1) ? ((__builtin_amdgcn_readfirstlane(tid >> 6) + (int)bid) & 3) : __builtin_amdgcn_readfirstlane(tid >> 6);   // base-bin split
    const long total_pos = (long)n_chunks * kFrames;
    const long p0 = (long)bid * 64;
