@@ -66,6 +66,14 @@ PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole p
 FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)", 4: "k_frontend_ri"}
 
 
+def metric_label(model, world):
+    """N = 1: BASELINE.json's metric.  N > 1: `value` is the whole job (the driver's contract) -- the label says so, and value_per_gpu carries the metric's per-GPU figure"""
+    m = "Silero v3.1 16k" if model == "v31" else "Silero v4 16k (BASELINE config 4; not the headline metric)"
+    if world == 1:
+        return f"audio-seconds/sec (= real-time streams) per GPU, {m}"
+    return f"audio-seconds/sec (= real-time streams), WHOLE JOB over {world} GPUs (value_per_gpu = value / {world}), {m}"
+
+
 def frontend_name(eng, fe_kernel):
     """the front-end kernel that ran, by name: the engine reports 2 for either GEMM form, and this bench feeds s16 (option "fe_gemm" = 2: k_frontend_gemm2)"""
     if fe_kernel == 2 and eng.get_option("fe_gemm") == 2:
@@ -265,65 +273,145 @@ def spawn_ranks(n):
 # ------------------------------------------------------------------------------------------------- dry run (CPU, gloo)
 def dry_run(args, world, rank):
     """The rank skeleton without a GPU: gloo rendezvous, stream sharding, the per-step gather through the SAME helper the GPU path uses,
-    barrier + max-over-ranks timing, rank 0 prints the line.  The engine is replaced by values that encode (global stream, chunk, column, step)."""
+    barrier + max-over-ranks timing, rank 0 prints the line with the N-rank schema of the real run (job total under a truthful metric label, value_per_gpu,
+    total_streams, what the process group reports, and the BASELINE config 5 entry configs["<N>xSxC"] timed under the same ranks).  The engine is replaced
+    by values that encode (global stream, chunk, column, step)."""
     import torch
     import torch.distributed as dist
     from vadc_amd import shard
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def region(S, Cn, steps):
+        total = S * world
+        lo, hi = shard.stream_block(rank, world, total)
+        g = shard.ProbabilityGather(total, Cn, "cpu")
+        s = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
+        c = torch.arange(Cn, dtype=torch.float32).view(1, -1, 1)
+        k = torch.arange(2, dtype=torch.float32).view(1, 1, 2)
+        ok = True
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            g.gather(s * 1000 + c * 2 + k + i * 0.25)              # the stand-in's [S, Cn, 2] "probabilities": the gather ships element 1 alone
+            if rank == 0 and i == steps - 1:
+                sa = torch.arange(total, dtype=torch.float32).view(-1, 1)
+                ok = bool(torch.equal(g.result(), sa * 1000 + c[:, :, 0] * 2 + 1 + i * 0.25))
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        return ok, total, dt, round(total * Cn * steps * CHUNK_SECONDS / dt, 1), collective_facts(torch, dist, world, False, g)
+
     S, Cn = args.streams, args.chunks_per_step
-    total = S * world
-    lo, hi = shard.stream_block(rank, world, total)
-    g = shard.ProbabilityGather(total, Cn, "cpu")
-    s = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
-    c = torch.arange(Cn, dtype=torch.float32).view(1, -1, 1)
-    k = torch.arange(2, dtype=torch.float32).view(1, 1, 2)
-    ok = True
+    ok, total, dt, value, facts = region(S, Cn, args.steps)
+    out = {"metric": "dry run (no GPU, stand-in engine): " + metric_label(args.model, world), "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "dry_run": True, "gather_verified": ok, "total_streams": total, "value_per_gpu": round(value / world, 1), "rccl": facts, "rank_cpus": args.rank_cpus_n,
+           "config": {"workload": f"stand-in engine, {S} streams/rank x {Cn} chunks/step", "streams_per_gpu": S, "chunks_per_step": Cn,
+                      "parallelism": f"streams sharded over {world} rank(s), gloo gather"}}
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        g.gather(s * 1000 + c * 2 + k + i * 0.25)
-        if rank == 0 and i == args.steps - 1:
-            sa = torch.arange(total, dtype=torch.float32).view(-1, 1, 1)
-            ok = bool(torch.equal(g.result(), sa * 1000 + c * 2 + k + i * 0.25))
-    if world > 1:
-        dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one = one_gpu_figures(args.one_gpu_json)
+        out["efficiency_vs_1gpu"] = vs_one_gpu(value, world, one, f"{S}x{Cn}")
+        c5_S, c5_C = (int(v) for v in args.config5_shape.lower().split("x"))
+        ok5, total5, dt5, value5, facts5 = region(c5_S, c5_C, args.config5_steps)
+        ok = ok and ok5
+        out["gather_verified"] = ok
+        out["configs"] = {f"{world}x{c5_S}x{c5_C}": {"value": value5, "per_gpu": round(value5 / world, 1), "ms_per_step": round(dt5 / args.config5_steps * 1e3, 4),
+                                                     "steps": args.config5_steps, "n_gpus": world, "total_streams": total5, "streams_per_gpu": c5_S, "chunks_per_step": c5_C,
+                                                     "rccl": facts5, "efficiency_vs_1gpu": vs_one_gpu(value5, world, one, f"{c5_S}x{c5_C}"),
+                                                     "one_gpu_figure": one.get(f"{c5_S}x{c5_C}")}}
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU): rank skeleton over gloo", "value": None, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "dry_run": True, "gather_verified": ok, "total_streams": total, "rank_cpus": args.rank_cpus_n,
-                          "config": {"workload": f"stand-in engine, {S} streams/rank x {Cn} chunks/step", "parallelism": f"streams sharded over {world} rank(s), gloo gather"}}), flush=True)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
 
 
-# ------------------------------------------------------------------------------------------------- the largest single-GPU configuration, beside the headline
-def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20, warmup=5, opts=None, latency=False, host_fed=False):
-    """Another configuration timed in the same run, after the headline's timed region: same step discipline (deferred joins, one issuing stream, three
-    input buffers, graph replay), device time from torch's synchronize on both sides.  Reported beside `value`, never instead of it.
+# ------------------------------------------------------------------------------------------------- one rank's step discipline
+class StepLoop:
+    """How one rank issues its steps -- shared by the headline's timed region and by every configuration timed beside it, at any number of ranks.
+    NB input / output buffers used in turn.  Deferred joins (default): every step is issued from streams[0], which a call does not block (engine option
+    defer_join); with several ranks a side stream joins the call (vadc_amd_join: a device-side wait) and carries the ONE collective, the gather of the
+    step's speech probabilities (4 B per chunk) to rank 0, so that step k's gather runs beside step k + 1's kernels.  strict: NB caller streams in turn,
+    each strictly ordered."""
+
+    def __init__(self, torch, eng, S, Cn, d_in, d_probs, gather, world=1, rehearsal=False, defer_join=True):
+        self.torch, self.eng, self.S, self.Cn, self.d_in, self.d_probs = torch, eng, S, Cn, d_in, d_probs
+        self.NB = len(d_in)
+        self.gather, self.world, self.rehearsal, self.defer_join = gather, world, rehearsal, defer_join
+        self.streams = [torch.cuda.Stream() for _ in range(max(self.NB, 2 if world > 1 else 1))]
+        self.gathered = [None] * self.NB          # per step buffer: the event behind the gather that last read it (several ranks only)
+        if defer_join:
+            eng.set_option("defer_join", 1)
+
+    def step(self, i, gather=None):
+        torch, eng, S, Cn = self.torch, self.eng, self.S, self.Cn
+        gather = gather if gather is not None else self.gather
+        b = i % self.NB
+        if self.defer_join:
+            if self.world > 1 and self.gathered[b] is not None:
+                self.streams[0].wait_event(self.gathered[b])          # the gather that read d_probs[b] NB steps ago comes before this call rewrites it
+            eng.run_device(self.d_in[b].data_ptr(), np.int16, S, Cn, self.d_probs[b].data_ptr(), self.streams[0].cuda_stream)
+            if self.world > 1:
+                side = self.streams[1 + b % (len(self.streams) - 1)]
+                eng.join(side.cuda_stream)
+                with torch.cuda.stream(side):
+                    gather.gather(self.d_probs[b].cpu() if self.rehearsal else self.d_probs[b])
+                    self.gathered[b] = torch.cuda.Event()
+                    self.gathered[b].record(side)
+            return
+        st = self.streams[b]
+        with torch.cuda.stream(st):
+            eng.run_device(self.d_in[b].data_ptr(), np.int16, S, Cn, self.d_probs[b].data_ptr(), st.cuda_stream)
+            if self.world > 1:
+                gather.gather(self.d_probs[b].cpu() if self.rehearsal else self.d_probs[b])       # the only collective: final probability gather (RCCL)
+
+
+def collective_facts(torch, dist, world, rehearsal, gather):
+    """what the process group itself reports about the job's one collective (not what the command line asked for)"""
+    if world == 1 or not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "collective": None}
+    out = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "gather -> rank 0, one per step, on a side stream behind vadc_amd_join",
+           "bytes_per_chunk": gather.bytes_per_chunk, "bytes_per_rank_and_step": gather.bytes_per_chunk * gather.mx * gather.send.shape[1]}
+    if out["backend"] == "nccl":
+        try:
+            out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())      # ncclGetVersion of the RCCL this process loaded
+        except Exception as ex:                                                               # noqa: BLE001 -- a fact we report, never a reason to fail the run
+            out["nccl_version"] = f"unavailable ({type(ex).__name__})"
+    if rehearsal:
+        out["note"] = "one-GPU rehearsal: gloo through the host, all ranks on GPU 0 -- exercises the rank code, not RCCL / xGMI"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- configurations timed beside the headline
+def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20, warmup=5, opts=None, latency=False, host_fed=False,
+                world=1, rank=0, rehearsal=False):
+    """Another configuration timed in the same run, after the headline's timed region: same step discipline (StepLoop: deferred joins, one issuing stream,
+    three input buffers, graph replay), device time from torch's synchronize on both sides.  Reported beside `value`, never instead of it.
+    world > 1: EVERY rank runs the configuration on its own S streams under the same process group -- the gather inside the timed region, barriers on both
+    sides, max over ranks -- and the entry carries the job's total, the per-GPU figure and what the process group reports.
     latency: also the time of ONE isolated call from its issue to its probabilities being complete (median of 20); host_fed: also the rate through
     vadc_amd_run_s16_async (page-locked host buffers in and out)."""
-    from vadc_amd import synth
+    import torch.distributed as dist
+    from vadc_amd import shard, synth
     from vadc_amd.engine import Engine
     eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank, precision=precision)
     for k_, v_ in (opts or {}).items():
         eng.set_option(k_, v_)
     NB = 3
-    base = synth.make_streams(16, NB * Cn, seed0=777)
+    base = synth.make_streams(16, NB * Cn, seed0=777 + 100 * rank)
     pcm = np.ascontiguousarray(np.tile(base, (S // 16 + 1, 1))[:S])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
     d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
-    st = torch.cuda.Stream()
-    eng.set_option("defer_join", 1)
+    gather = shard.ProbabilityGather(S * world, Cn, "cpu" if rehearsal else dev)
+    loop = StepLoop(torch, eng, S, Cn, d_in, d_out, gather, world, rehearsal, True)
     eng.set_option("groups", 1)
-
-    def step(i):
-        eng.run_device(d_in[i % NB].data_ptr(), np.int16, S, Cn, d_out[i % NB].data_ptr(), st.cuda_stream)
+    step = loop.step
+    st = loop.streams[0]
     for i in range(2 * NB):
         step(i)
     torch.cuda.synchronize()
@@ -331,24 +419,37 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     for i in range(2 * NB + warmup):
         step(i)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     eng.reset_kernel_times()
     t0 = time.perf_counter()
     for i in range(steps):
         eng.set_profiling(i % 8 == min(3, steps - 1))
         step(i)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     eng.set_profiling(False)
     kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
     fe_kernel = eng.get_option("frontend_kernel")
     dom = max(kt, key=kt.get)
     _, exe = kernel_cost(model, dom, fe_kernel, "k_lstm_l1" in kt, eng.get_option("layer1_kernel") == 0)
     pipe = max(exe, key=lambda p_: exe[p_] / PEAKS[p_])
-    out = {"value": round(S * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+    out = {"value": round(S * world * Cn * steps * CHUNK_SECONDS / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
            "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
            "frontend_kernel": frontend_name(eng, fe_kernel),
            "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
+    if world > 1:
+        out.update({"n_gpus": world, "total_streams": S * world, "streams_per_gpu": S, "chunks_per_step": Cn, "per_gpu": round(out["value"] / world, 1),
+                    "rccl": collective_facts(torch, dist, world, rehearsal, gather)})
     if opts:
         out["options"] = dict(opts)
     if latency:
@@ -375,8 +476,24 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
         eng.wait_async()
         dta = time.perf_counter() - t1
         out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dta, 1), "ms_per_step": round(dta / n_host * 1e3, 3), "pcie_gb_per_s": round(S * Cn * 3072 * n_host / dta / 1e9, 1)}
+    torch.cuda.synchronize()
     eng.close()
     return out
+
+
+def one_gpu_figures(path):
+    """the 1-GPU figures an N-rank run compares itself with: written by the N = 1 run of this bench (same box, same tree), or handed over with --one-gpu-json"""
+    try:
+        d = json.load(open(path))
+        return d if isinstance(d, dict) else {}
+    except (OSError, ValueError):
+        return {}
+
+
+def vs_one_gpu(entry_value, world, one, key):
+    """efficiency = (job total / N) / the 1-GPU figure of the same shape -- informative only; the driver computes its own from the per-N lines"""
+    ref = one.get(key)
+    return round(entry_value / world / ref, 4) if ref else None
 
 
 # ------------------------------------------------------------------------------------------------- one rank
@@ -436,37 +553,13 @@ def run_rank(args, world, rank, local_rank):
         pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
     d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
-    gather = shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev)      # weak scaling: S streams per GPU, contiguous blocks
+    gather = shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev)      # weak scaling: S streams per GPU, contiguous blocks; 4 B per chunk
     assert gather.hi - gather.lo == S
     # The engine's internal in-order streams overlap the stages of consecutive steps: front end + encoder of step k+2 beside LSTM layer 0 of step
     # k+1 beside layer 1 of step k (layer-major LSTM, <= 512 streams), or front end + encoder beside the whole LSTM.  Default: all steps issued
-    # from streams[0], which a call does not block (defer_join); --strict-join: NB caller streams in turn, each strictly ordered.
-    streams = [torch.cuda.Stream() for _ in range(NB)]
-    gathered = [None] * NB                    # per step buffer: the event behind the gather that last read it (multi-GPU only)
-
-    if args.defer_join:
-        eng.set_option("defer_join", 1)
-
-    def step(i, gather=gather):
-        b = i % NB
-        if args.defer_join:
-            # ONE issuing stream: the call does not block it; a side stream joins the call (device-side wait) and carries the gather
-            if world > 1 and gathered[b] is not None:
-                streams[0].wait_event(gathered[b])                    # the gather that read d_probs[b] NB steps ago comes before this call rewrites it
-            eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), streams[0].cuda_stream)
-            if world > 1:
-                side = streams[1 + b % (NB - 1)]
-                eng.join(side.cuda_stream)
-                with torch.cuda.stream(side):
-                    gather.gather(d_probs[b].cpu() if rehearsal else d_probs[b])
-                    gathered[b] = torch.cuda.Event()
-                    gathered[b].record(side)
-            return
-        st = streams[b]
-        with torch.cuda.stream(st):
-            eng.run_device(d_in[b].data_ptr(), np.int16, S, Cn, d_probs[b].data_ptr(), st.cuda_stream)
-            if world > 1:
-                gather.gather(d_probs[b].cpu() if rehearsal else d_probs[b])               # the only collective: final probability gather (RCCL)
+    # from ONE stream, which a call does not block (defer_join); --strict-join: NB caller streams in turn, each strictly ordered.
+    loop = StepLoop(torch, eng, S, Cn, d_in, d_probs, gather, world, rehearsal, args.defer_join)
+    step, streams, gathered = loop.step, loop.streams, loop.gathered
 
     for i in range(2 * NB):                # setup, not warm-up: the first calls create the engine's internal streams / CU masks and touch every buffer once
         step(i)
@@ -521,7 +614,7 @@ def run_rank(args, world, rank, local_rank):
     if args.verify_dump:
         # The N-rank path proves its answers: from reset state, K steps issued back to back exactly as in the timed region (deferred joins, side-stream
         # gathers behind vadc_amd_join, no host synchronisation in between), each step gathered into a buffer set of its own; rank 0 writes the K gathered
-        # [total_streams, chunks, 2] tensors.  tests/test_bench_spawn.py recomputes sampled streams of EVERY rank with the CPU oracle.
+        # [total_streams, chunks] speech probabilities.  tests/test_bench_spawn.py recomputes sampled streams of EVERY rank with the CPU oracle.
         K = 2 * NB - 1
         eng.synchronize(); torch.cuda.synchronize()
         eng.set_option("graph", 1 if args.graph else 0)
@@ -538,7 +631,7 @@ def run_rank(args, world, rank, local_rank):
                 if args.defer_join:
                     eng.join(streams[0].cuda_stream)
                 with torch.cuda.stream(streams[0] if args.defer_join else streams[i % NB]):
-                    single.append(d_probs[i % NB].clone())
+                    single.append(d_probs[i % NB][:, :, 1].clone())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -546,6 +639,7 @@ def run_rank(args, world, rank, local_rank):
             res = np.stack([(g.result() if world > 1 else single[i]).detach().cpu().numpy().copy() for i, g in enumerate(gv)])
             np.savez(args.verify_dump, probs=res, total_streams=total_streams, world=world, chunks=Cn, buffers=NB, steps=K)
 
+    out = None
     if rank == 0:
         chunks_per_step = total_streams * Cn
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
@@ -593,8 +687,7 @@ def run_rank(args, world, rank, local_rank):
         except (OSError, ValueError):
             pass
         out = {
-            "metric": "audio-seconds/sec (= real-time streams) per GPU, Silero v3.1 16k" if args.model == "v31" else
-                      "audio-seconds/sec (= real-time streams) per GPU, Silero v4 16k (BASELINE config 4; not the headline metric)",
+            "metric": metric_label(args.model, world),
             "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(mode, fe_kernel), "data": "synthetic",
@@ -626,7 +719,13 @@ def run_rank(args, world, rank, local_rank):
             "stage_fracs": {k: [v["frac_of_pipe_peak"], v["pipe"]] for k, v in per_kernel.items()},
             "chunks_per_sec": round(chunks_per_step * args.steps / elapsed, 1),
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 4),   # what graph replay saves is host time: compare with --no-graph
+            # `value` is the WHOLE JOB over all ranks (the driver's contract); the metric's "per GPU" figure is this one
+            "value_per_gpu": round(value / world, 1), "total_streams": total_streams,
+            "rccl": collective_facts(torch, dist, world, rehearsal, gather),
         }
+        one = one_gpu_figures(args.one_gpu_json) if world > 1 else {}
+        if world > 1:
+            out["efficiency_vs_1gpu"] = vs_one_gpu(value, world, one, f"{S}x{Cn}")      # null without a 1-GPU figure of this shape (--one-gpu-json / the N = 1 run's cache)
         if world == 1 and not args.no_host_fed:
             # PCIe-inclusive rates of the host-buffer entry points (what a drop-in backend_run caller pays); reported, never `value`.
             #   value       -- vadc_amd_run_s16_async: page-locked host buffers, H2D of call k+1 beside the kernels of call k beside the D2H of call k-1
@@ -663,7 +762,7 @@ def run_rank(args, world, rank, local_rank):
             eng.close()
             eng = None
             blob_v4 = open(os.path.join(ROOT, "tests", "golden", "silero_v4_16k.testtensor"), "rb").read()
-            out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1),
+            out["configs"] = {"4096x16": side_config(torch, blob, dev, local_rank, args.model, 4096, 16, 1, steps=60, warmup=10),      # (60 steps: what the N-rank entry configs["<N>x4096x16"] runs)
                               "10240x1": side_config(torch, blob, dev, local_rank, args.model, 10240, 1, 0, steps=200, warmup=20, latency=True, host_fed=True),
                               "256x96_fp32_mfma": side_config(torch, blob, dev, local_rank, args.model, 256, 96, 0, opts={"encoder": 3, "lstm": 3, "layer1": 1}),
                               # BASELINE config 4: Silero v4 at 4096 streams.  Last: an engine created in front of the 10,240 x 1 configuration moved that one's internal
@@ -671,6 +770,32 @@ def run_rank(args, world, rank, local_rank):
                               "v4_4096x16": side_config(torch, blob_v4, dev, local_rank, "v4", 4096, 16, 0, steps=100, warmup=10)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
+
+    # BASELINE config 5's shape under the SAME N ranks and the same collective: 4096 streams per GPU x 16 chunks per step, SPLIT16 (config 3's arithmetic),
+    # graph replay, the gather inside the timed region, barriers on both sides, max over ranks.  Every rank takes part; rank 0 reports it as
+    # configs["<N>x4096x16"].  `value` stays on the default shape so that the N = 1 line agrees with the single-GPU bench.
+    c5_S, c5_C = (int(v) for v in args.config5_shape.lower().split("x"))
+    if world > 1 and not args.no_side_config and not args.verify_dump and args.model == "v31":
+        if eng is not None:
+            eng.close()
+            eng = None
+        c5 = side_config(torch, blob, dev, local_rank, args.model, c5_S, c5_C, 1, steps=args.config5_steps, warmup=10, world=world, rank=rank, rehearsal=rehearsal)
+        if rank == 0:
+            c5["efficiency_vs_1gpu"] = vs_one_gpu(c5["value"], world, one, f"{c5_S}x{c5_C}")
+            c5["one_gpu_figure"] = one.get(f"{c5_S}x{c5_C}")
+            out.setdefault("configs", {})[f"{world}x{c5_S}x{c5_C}"] = c5
+
+    if rank == 0:
+        if world == 1 and args.model == "v31" and not args.verify_dump:
+            # what an N-rank run of this bench on the same box compares itself with (efficiency_vs_1gpu): this run's figures by shape
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.one_gpu_json)), exist_ok=True)
+                figs = {f"{S}x{Cn}": out["value"]}
+                figs.update({k: v["value"] for k, v in out.get("configs", {}).items() if k in ("4096x16",)})
+                with open(args.one_gpu_json, "w") as f:
+                    json.dump(figs, f)
+            except OSError:
+                pass
         # The line the driver parses stays SHORT (it reads the tail of stdout): the per-kernel accounting and the long notes go to a details file
         # (the same object, verbose), the line keeps every contract field plus the per-kernel launch times.
         try:
@@ -740,6 +865,12 @@ def main():
     ap.add_argument("--caller-streams", type=int, default=3, help="step buffers used in turn (= caller streams with --strict-join)")
     ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
                     help="where the verbose form of the line goes (per-kernel executed / algorithmic FLOP, pipes, notes)")
+    ap.add_argument("--config5-shape", default="4096x16", metavar="SxC",
+                    help="with --gpus N > 1: streams per GPU x chunks per step of the BASELINE config 5 measurement that rides along as configs[\"<N>xSxC\"] (default 4096x16; "
+                         "tests use small blocks)")
+    ap.add_argument("--config5-steps", type=int, default=60)
+    ap.add_argument("--one-gpu-json", default=os.path.join(ROOT, "gpurun_out", "bench_one_gpu.json"),
+                    help="the 1-GPU figures by shape ({\"256x96\": v, \"4096x16\": v}): written by an N = 1 run, read by an N > 1 run for efficiency_vs_1gpu")
     ap.add_argument("--one-gpu-rehearsal", action="store_true",
                     help="N ranks share GPU 0 and gather over gloo through the host: rehearses the multi-rank code path on a one-GPU box (its numbers mean nothing)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse spawn / rendezvous / sharding / gather / timing over gloo on the CPU")

@@ -3,17 +3,19 @@
  *
  * The north star's partitioning (BASELINE.json): streams are independent, so the batch is cut into contiguous blocks --
  * global stream s lives on GPU s / streams_per_gpu -- weights are replicated, no data-path collective exists, and the one exchange is the gather of
- * the per-chunk speech probabilities on device 0: ncclGather of [streams_per_gpu x chunks x 2] fp32 per step, issued on a side stream behind
- * vadc_amd_join (a device-side wait), so that step k's gather runs beside step k + 1's kernels.  Counterpart of the reference's single-engine
+ * the per-chunk speech probabilities on device 0: ncclGather of [streams_per_gpu x chunks] fp32 per step (4 B per chunk: element 1 of the engine's
+ * pair, packed by vadc_amd_speech_probabilities), issued on a side stream behind vadc_amd_join (a device-side wait), so that step k's gather runs
+ * beside step k + 1's kernels.  Counterpart of the reference's single-engine
  * main (vadc.c:1127-1276) for N engines; the per-engine calls are the ones vadc.c:56-103 makes (backend_run on a window of chunks).
  *
  *   vadc_hip_multi --model weights.testtensor [--gpus N | --devices a,b,...] [--streams-per-gpu S] [--chunks C] [--steps K] [--warmup W]
  *                  [--pcm in.s16 --dump out.f32]
  *   --devices  the HIP devices to use, in rank order (rank r = the r-th entry; the gather lands on the first); default: devices 0 .. N - 1
  *   --pcm   s16le [N * S][K * C * 1536]: step k feeds every stream its k-th window of C chunks, from reset state (warm-up steps are not run)
- *   --dump  the gathered probabilities of every step as float32 [K][N * S][C][2]  (what the tests compare with the CPU oracle)
+ *   --dump  the gathered speech probabilities of every step as float32 [K][N * S][C]  (what the tests compare with the CPU oracle)
  *   without --pcm: synthetic tones + noise, resident in HBM before the timed region
- *   stdout: ONE JSON line with the fields of bench.py's line (value = audio-seconds per second over all GPUs).
+ *   stdout: ONE JSON line with the fields of bench.py's line (value = audio-seconds per second over ALL GPUs under a label that says so, value_per_gpu,
+ *           total_streams, and "rccl": what the communicator itself reports -- ncclCommCount, ncclGetVersion -- and the bytes the gather ships).
  * Host code is C; the only GPU code is inside libvadc_amd.so (HIP runtime and RCCL are called through their C APIs).
  */
 #include <pthread.h>
@@ -43,7 +45,7 @@ typedef struct {
    int rank, n_ranks, device, S, C, K, W, rc;
    const void *blob; size_t blob_len;
    const int16_t *pcm;                 /* host, [n_ranks * S][K * C * CHUNK] or NULL */
-   float *dump;                        /* host (rank 0), [K][n_ranks * S][C][2] or NULL */
+   float *dump;                        /* host (rank 0), [K][n_ranks * S][C] or NULL */
    ncclComm_t comm;
    int *failed;                        /* shared: some rank has failed */
    int aborted;                        /* this rank's communicator was aborted (not to be destroyed) */
@@ -96,8 +98,8 @@ static void *worker_main(void *arg)
    hipEvent_t ev_g[NBUF] = {0};
    int16_t *d_in[NBUF] = {0};
    int16_t **d_in_all = NULL;          /* --pcm: one resident buffer per step */
-   float *d_probs[NBUF] = {0}, *d_gather[NBUF] = {0};
-   const size_t step_samples = (size_t)w->S * w->C * CHUNK, step_probs = (size_t)w->S * w->C * 2;
+   float *d_probs[NBUF] = {0}, *d_speech[NBUF] = {0}, *d_gather[NBUF] = {0};
+   const size_t step_samples = (size_t)w->S * w->C * CHUNK, step_probs = (size_t)w->S * w->C;      /* gathered: the speech probability alone, 4 B per chunk */
    int16_t *h_tmp = NULL;
    int waits = 0;                      /* barrier waits done: every rank makes exactly two, whatever happens to it */
 
@@ -109,7 +111,8 @@ static void *worker_main(void *arg)
    HIP_OK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking));
    for (int b = 0; b < NBUF; ++b) {
       HIP_OK(hipEventCreateWithFlags(&ev_g[b], hipEventDisableTiming));
-      HIP_OK(hipMalloc((void **)&d_probs[b], step_probs * sizeof(float)));
+      HIP_OK(hipMalloc((void **)&d_probs[b], step_probs * 2 * sizeof(float)));      /* the engine's output: [S][C][2] */
+      HIP_OK(hipMalloc((void **)&d_speech[b], step_probs * sizeof(float)));
       if (w->rank == 0) HIP_OK(hipMalloc((void **)&d_gather[b], step_probs * w->n_ranks * sizeof(float)));
    }
    if (w->pcm) {
@@ -150,7 +153,8 @@ static void *worker_main(void *arg)
          if (i >= NBUF) HIP_OK(hipStreamWaitEvent(st, ev_g[b], 0));
          ENG_OK(vadc_amd_run_device_s16(eng, in, w->S, w->C, d_probs[b], st));
          ENG_OK(vadc_amd_join(eng, sg));                         /* device-side: the side stream continues when this call's probabilities are complete */
-         NCCL_OK(ncclGather(d_probs[b], d_gather[b], step_probs, ncclFloat, 0, w->comm, sg));
+         ENG_OK(vadc_amd_speech_probabilities(eng, d_probs[b], w->S, w->C, d_speech[b], sg));
+         NCCL_OK(ncclGather(d_speech[b], d_gather[b], step_probs, ncclFloat, 0, w->comm, sg));
          HIP_OK(hipEventRecord(ev_g[b], sg));
          if (phase == 1 && w->dump && w->rank == 0) {            /* verification mode only: every step's gathered block to the host */
             if (!drain_or_abort(w, sg)) FAIL(6);
@@ -172,6 +176,7 @@ out:
    for (int b = 0; b < NBUF; ++b) {
       if (d_in[b]) (void)hipFree(d_in[b]);
       if (d_probs[b]) (void)hipFree(d_probs[b]);
+      if (d_speech[b]) (void)hipFree(d_speech[b]);
       if (d_gather[b]) (void)hipFree(d_gather[b]);
       if (ev_g[b]) (void)hipEventDestroy(ev_g[b]);
    }
@@ -243,7 +248,7 @@ int main(int argc, char **argv)
       if (!pcm || pcm_len != want) { fprintf(stderr, "vadc_hip_multi: %s must hold [%d][%d] s16 samples (%zu bytes)\n", pcm_path, gpus * S, K * C * CHUNK, want); return 1; }
    }
    float *dump = NULL;
-   const size_t dump_floats = (size_t)K * gpus * S * C * 2;
+   const size_t dump_floats = (size_t)K * gpus * S * C;
    if (dump_path) { dump = (float *)malloc(dump_floats * sizeof(float)); if (!dump) { free(blob); free(pcm); return 5; } }
 
    int rc = 0, failed = 0, comms_up = 0;
@@ -286,10 +291,17 @@ int main(int argc, char **argv)
    {
    const double wall = ws[0].t_end - ws[0].t_begin;
    const double audio_s = (double)gpus * S * C * K * (CHUNK / 16000.0);
-   printf("{\"metric\": \"audio-seconds/sec (= real-time streams), Silero v3.1 16k\", \"value\": %.1f, \"unit\": \"audio-s/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
+   const double value = wall > 0 ? audio_s / wall : 0.0;
+   int comm_count = 0, nccl_ver = 0;
+   (void)ncclCommCount(comms[0], &comm_count);                   /* what the communicator reports, not what the command line asked for */
+   (void)ncclGetVersion(&nccl_ver);
+   printf("{\"metric\": \"audio-seconds/sec (= real-time streams), WHOLE JOB over %d GPU(s) (value_per_gpu = value / %d), Silero v3.1 16k\", \"value\": %.1f, \"value_per_gpu\": %.1f, "
+          "\"total_streams\": %d, \"unit\": \"audio-seconds/sec\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
           "\"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"data\": \"%s\", \"host\": \"C (host/vadc_hip_multi.c), one thread per GPU, ncclGather to device 0 per step\", "
+          "\"rccl\": {\"backend\": \"rccl (ncclCommInitAll, one process)\", \"world_size\": %d, \"nccl_version\": %d, \"collective\": \"ncclGather -> device 0, one per step, on a side stream behind vadc_amd_join\", "
+          "\"bytes_per_chunk\": 4, \"bytes_per_rank_and_step\": %zu}, "
           "\"config\": {\"workload\": \"Silero v3.1 16k, %d streams/GPU x %d chunks per step, contiguous stream blocks\", \"streams_per_gpu\": %d, \"chunks_per_step\": %d}}\n",
-          wall > 0 ? audio_s / wall : 0.0, gpus, K, pcm ? 0 : W, wall * 1e3 / K, pcm ? "file" : "synthetic", S, C, S, C);
+          gpus, gpus, value, value / gpus, gpus * S, gpus, K, pcm ? 0 : W, wall * 1e3 / K, pcm ? "file" : "synthetic", comm_count, nccl_ver, (size_t)S * C * 4, S, C, S, C);
    }
 done:
    if (comms_up) for (int r = 0; r < gpus; ++r) if (!ws || !ws[r].aborted) (void)ncclCommDestroy(comms[r]);      /* (an aborted communicator is already gone) */

@@ -156,6 +156,10 @@ int  vadc_amd_synchronize(vadc_amd_engine *e);
  * beside LSTM layer 0 of call k+1 beside layer 1 of call k) -- and this is how a consumer of the probabilities orders itself behind them. */
 int  vadc_amd_join(vadc_amd_engine *e, void *hip_stream);
 
+/* The speech probability alone: d_speech[stream][chunk] = d_probs[stream][chunk][1] (the element vadc reads, vadc.c:704-713), enqueued on `hip_stream`
+ * (typically the stream that joined the call).  What the multi-GPU hosts gather: 4 B per chunk instead of the pair's 8. */
+int  vadc_amd_speech_probabilities(vadc_amd_engine *e, const float *d_probs, int n_streams, int n_chunks, float *d_speech, void *hip_stream);
+
 /* Host buffers, ASYNCHRONOUS: what a real backend_run caller holds -- host samples in, host probabilities out (vadc.c:873-909: the stream reader fills
  * host memory; silero.h:53-74 hands it to the backend) -- without the copy -> run -> copy serialisation of vadc_amd_run_*.  A call returns as soon as its
  * work is enqueued: the H2D copy on a copy stream of its own, the kernels behind it, the 8 bytes per chunk of probabilities back on a third stream

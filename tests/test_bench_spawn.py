@@ -22,16 +22,55 @@ def _run(*args, env=None):
     return json.loads(lines[0])
 
 
+def _assert_n_rank_schema(d, n, S, Cn, c5_S, c5_C, backend):
+    """what the first 8-GPU run must carry to be decisive (BASELINE config 5): `value` = the whole job under a label that says so, the per-GPU figure
+    beside it, the totals, what the PROCESS GROUP reports about the one collective (4 B per chunk), and config 5's shape timed under the same ranks"""
+    assert d["n_gpus"] == n and d["total_streams"] == S * n and d["scaling"] == "weak"
+    assert abs(d["value_per_gpu"] - d["value"] / n) <= 0.06
+    assert d["config"]["streams_per_gpu"] == S and d["config"]["chunks_per_step"] == Cn
+    if n == 1:
+        assert "per GPU" in d["metric"] and "WHOLE JOB" not in d["metric"] and d["rccl"]["world_size"] == 1 and "configs" not in d or not any(k.startswith("1x") for k in d.get("configs", {}))
+        return
+    assert f"WHOLE JOB over {n} GPUs" in d["metric"] and "value_per_gpu" in d["metric"]
+    r = d["rccl"]
+    assert r["backend"] == backend and r["world_size"] == n and r["bytes_per_chunk"] == 4 and r["bytes_per_rank_and_step"] == 4 * S * Cn
+    assert "efficiency_vs_1gpu" in d
+    c = d["configs"][f"{n}x{c5_S}x{c5_C}"]
+    for k in ("value", "per_gpu", "ms_per_step", "steps", "n_gpus", "total_streams", "streams_per_gpu", "chunks_per_step", "rccl", "efficiency_vs_1gpu", "one_gpu_figure"):
+        assert k in c, k
+    assert c["n_gpus"] == n and c["total_streams"] == n * c5_S and c["streams_per_gpu"] == c5_S and c["chunks_per_step"] == c5_C
+    assert abs(c["per_gpu"] - c["value"] / n) <= 0.06 and c["rccl"]["world_size"] == n and c["rccl"]["bytes_per_rank_and_step"] == 4 * c5_S * c5_C
+    want = n * c5_S * c5_C * 0.096 / (c["ms_per_step"] * 1e-3)
+    assert abs(c["value"] - want) / want < 1e-2
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 8])
-def test_bench_spawns_its_own_ranks(n):
+def test_bench_spawns_its_own_ranks(n, tmp_path):
     """world 8 = the node the driver's scaling run uses (BASELINE config 5): spawn, rendezvous, contiguous stream blocks, the per-step gather and max-over-ranks
-    timing with EIGHT ranks, over gloo; every rank keeps to its own share of the CPUs this job may use"""
+    timing with EIGHT ranks, over gloo; every rank keeps to its own share of the CPUs this job may use; the line has the N-rank schema, and with a 1-GPU
+    figure at hand (the cache an N = 1 run leaves, or --one-gpu-json) the efficiencies are filled in"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    d = _run("--gpus", str(n), "--dry-run", "--steps", "4", "--warmup", "0", "--streams", "5", "--chunks-per-step", "3", env=env)
+    one = tmp_path / "one.json"
+    one.write_text(json.dumps({"5x3": 1000.0, "7x2": 500.0}))
+    d = _run("--gpus", str(n), "--dry-run", "--steps", "4", "--warmup", "0", "--streams", "5", "--chunks-per-step", "3", "--config5-shape", "7x2", "--config5-steps", "3",
+             "--one-gpu-json", str(one), env=env)
     assert d["n_gpus"] == n and d["dry_run"] is True and d["gather_verified"] is True
     assert d["total_streams"] == 5 * n and d["steps"] == 4 and d["scaling"] == "weak"
     have = len(os.sched_getaffinity(0))
     assert d["rank_cpus"] == (have // n if n > 1 and have >= n else have)
+    _assert_n_rank_schema(d, n, 5, 3, 7, 2, "gloo")
+    if n > 1:
+        assert abs(d["efficiency_vs_1gpu"] - d["value"] / n / 1000.0) < 1e-3
+        c = d["configs"][f"{n}x7x2"]
+        assert c["one_gpu_figure"] == 500.0 and abs(c["efficiency_vs_1gpu"] - c["value"] / n / 500.0) < 1e-3
+
+
+def test_default_config5_shape_is_baselines():
+    """BASELINE config 5 = 32,768 streams sharded 4096 per GPU: what `--gpus 8` times beside the headline unless told otherwise"""
+    src = open(BENCH).read()
+    assert '"--config5-shape", default="4096x16"' in src
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "32768 total streams sharded 4096/GPU" in base["configs"][4]
 
 
 def test_bench_runs_as_one_rank_under_a_launcher():
@@ -58,14 +97,18 @@ def test_cpu_baseline_worker_reports_a_rate():
 
 
 @pytest.mark.gpu
-def test_multi_rank_gpu_code_path_on_one_gpu():
-    """`--one-gpu-rehearsal`: two ranks share GPU 0 and gather over gloo through the host -- a one-GPU box cannot form an RCCL group, but everything
+@pytest.mark.parametrize("n", [2, 6])       # (six ranks: as many processes as a one-GPU box lets onto its card at once)
+def test_multi_rank_gpu_code_path_on_one_gpu(n):
+    """`--one-gpu-rehearsal`: N ranks share GPU 0 and gather over gloo through the host -- a one-GPU box cannot form an RCCL group, but everything
     else of the multi-rank GPU path runs: per-rank engines, deferred joins, the side-stream gather behind vadc_amd_join, per-buffer gather events,
-    barrier and max-over-ranks timing"""
+    barrier and max-over-ranks timing -- for the headline shape AND for the config 5 entry (small blocks here), with the N-rank schema of the line"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    d = _run("--gpus", "2", "--one-gpu-rehearsal", "--steps", "7", "--warmup", "2", "--streams", "32", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed", env=env)
-    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["config"]["streams_per_gpu"] == 32
+    d = _run("--gpus", str(n), "--one-gpu-rehearsal", "--steps", "7", "--warmup", "2", "--streams", "32", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed",
+             "--config5-shape", "48x4", "--config5-steps", "6", env=env)
+    assert d["steps"] == 7 and d["value"] > 0
+    _assert_n_rank_schema(d, n, 32, 8, 48, 4, "gloo")
+    c = d["configs"][f"{n}x48x4"]
+    assert c["precision"] == "split16" and c["hipgraph"] is True and c["value"] > 0 and "rehearsal" in c["rccl"]["note"]
 
 
 @pytest.mark.gpu
@@ -73,7 +116,7 @@ def test_multi_rank_gpu_code_path_on_one_gpu():
 def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
     """the N > 1 rank path PROVES its answers on one GPU: `--one-gpu-rehearsal --verify-dump` runs the rank code (per-rank engines on a RAGGED
     contiguous partition of the streams, deferred joins, side-stream gathers behind vadc_amd_join, five steps back to back from reset state) and
-    writes rank 0's gathered [total_streams, chunks, 2] of every step; streams of EVERY rank -- first, middle and last of its block -- are recomputed
+    writes rank 0's gathered [total_streams, chunks] of every step; streams of EVERY rank -- first, middle and last of its block -- are recomputed
     with the CPU oracle.  A wrong stream -> rank mapping, a gather that reads a buffer before its call has finished, or state that does not carry
     from step to step fails here."""
     import numpy as np
@@ -88,7 +131,7 @@ def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
     assert d["n_gpus"] == world
     g = np.load(dump)
     probs, NB, K = g["probs"], int(g["buffers"]), int(g["steps"])
-    assert probs.shape == (K, total, Cn, 2) and int(g["world"]) == world
+    assert probs.shape == (K, total, Cn) and int(g["world"]) == world             # the gather ships the speech probability alone (4 B per chunk)
     blob = open(os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), "rb").read()
     orc = O.Oracle(blob)
     for r in range(world):
@@ -96,7 +139,7 @@ def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
         for s in sorted({lo, (lo + hi) // 2, hi - 1}):
             pcm = synth.make_streams(1, NB * Cn, seed0=5000 + s)[0]                     # bench.py --verify-dump: seed = 5000 + global stream id
             seq = np.concatenate([pcm[(k % NB) * Cn * 1536:((k % NB) + 1) * Cn * 1536] for k in range(K)])
-            want = orc.forward_stream(seq).reshape(K, Cn, 2)
+            want = orc.forward_stream(seq).reshape(K, Cn, 2)[:, :, 1]
             assert float(np.abs(probs[:, s] - want).max()) <= 1e-4, (r, s)
 
 
@@ -107,5 +150,8 @@ def test_rccl_gather_between_two_gpus():
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU visible: RCCL needs two")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    d = _run("--gpus", "2", "--steps", "5", "--warmup", "2", "--streams", "64", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed", env=env)
+    d = _run("--gpus", "2", "--steps", "5", "--warmup", "2", "--streams", "64", "--chunks-per-step", "8", "--no-cpu-baseline", "--no-host-fed",
+             "--config5-shape", "128x4", "--config5-steps", "6", env=env)
     assert d["n_gpus"] == 2 and d["value"] > 0
+    _assert_n_rank_schema(d, 2, 64, 8, 128, 4, "nccl")
+    assert "nccl_version" in d["rccl"]

@@ -246,6 +246,94 @@ def test_stage_vs_oracle(eng, orc, gold_py, stage, tol):
     assert worst < tol, worst
 
 
+# ---------------------------------------------------------------------------------------------- the front end AS IT SHIPS (template MODE 0)
+def _normalized_from_magnitude(mag):
+    """misc.c:1-124 in float64 on bit-exact magnitudes [n, 129, 25]: log1p(2^20 m), frame means, reflect pad 3, the 7-tap filter (misc.c:5-13), mean over
+    the frames, one scalar per chunk subtracted"""
+    fir = np.array([0.03663284704089164733887, 0.11128076165914535522461, 0.21674531698226928710938, 0.27068215608596801757812,
+                    0.21674531698226928710938, 0.11128076165914535522461, 0.03663284704089164733887], np.float64)
+    y = np.log1p(mag.astype(np.float64) * 1048576.0)
+    m = y.mean(axis=1)                                                   # [n, 25]
+    mp = np.concatenate([m[:, 3:0:-1], m, m[:, -2:-5:-1]], axis=1)      # reflect pad 3 (no edge repeat)
+    sm = sum(fir[k] * mp[:, k:k + 25] for k in range(7))
+    return y - sm.mean(axis=1)[:, None, None]
+
+
+def test_fir_constants_of_the_host_restatement_are_the_oracles(orc):
+    """(the float64 restatement above is only a checker of a checker: pin it on the oracle's own normalized tap first)"""
+    x = f32(synth.speech_like(3 * 1536, seed=77))
+    for i in range(3):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        assert float(np.abs(_normalized_from_magnitude(taps["magnitude"][None])[0] - taps["normalized"]).max()) < 2e-5
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_product_mode_frontend_vs_oracle_all_golden_streams(eng, orc, gold_py, name):
+    """The bit-exact STFT tests read the MAGNITUDE tap = the front end's template MODE 1 (sqrtf, magnitudes out).  What ships is MODE 0: v_sqrt_f32 + the hardware
+    log1p, log-magnitudes and frame means out (kernels_frontend.hip) -- the `normalized` tap runs exactly that instantiation plus the offset subtraction.  Here it is
+    held against the oracle over every chunk of all six golden streams (speech x 3, zeros, noise, square), not ten chunks of one stream (stft.c:194-213, misc.c:40-63)."""
+    pcm = gold_py["pcm_" + name]
+    n = min(len(pcm) // 1536, 64)
+    x = f32(pcm)[: n * 1536]
+    got = eng.stage_from_samples(x, "normalized")
+    worst = 0.0
+    for i in range(n):
+        h, c = orc.new_state()
+        _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+        worst = max(worst, float(np.abs(got[i] - taps["normalized"]).max()))
+    assert worst < 2e-5, (name, worst)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 61, 64, 123])
+def test_product_mode_frontend_ragged_counts(weights_blob, orc, n):
+    """the same for chunk counts that leave the wave tiling ragged: first, middle and last chunk against the oracle; EVERY chunk against the float64 normalization of
+    the bit-exact MODE 1 magnitudes of the same launch shape"""
+    e = Engine(weights_blob, max_streams=8, max_chunks_per_call=16, device=0)
+    try:
+        x = f32(synth.speech_like(n * 1536, seed=1900 + n))
+        got = e.stage_from_samples(x, "normalized")
+        mag = e.stage_from_samples(x, "magnitude")
+        for i in sorted({0, n // 2, n - 1}):
+            h, c = orc.new_state()
+            _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+            assert np.array_equal(bits(mag[i]), bits(taps["magnitude"])), (n, i)
+            assert float(np.abs(got[i] - taps["normalized"]).max()) < 2e-5, (n, i)
+        assert float(np.abs(got - _normalized_from_magnitude(mag)).max()) < 1e-5, n
+    finally:
+        e.close()
+
+
+def test_product_mode_frontend_at_the_bench_shape(weights_blob, orc):
+    """256 streams x 96 chunks = 24,576 chunks through ONE launch of the shipped instantiation (the headline's grid: XCD-major blocks, every wave slot in use):
+    every value against log1p(2^20 sqrt(re^2 + im^2)) - offset evaluated in float64 from the MODE 1 tap's bit-exact magnitudes of the same 24,576 chunks (v_sqrt_f32 is
+    within 1 ulp of sqrtf, the hardware log1p within 2e-6 here: the bound is 1e-5, a wrong tree lane moves a near-silent bin by 1e-2), the control streams among them,
+    and 96 sampled chunks against the oracle itself at 2e-5 with their magnitudes bit for bit."""
+    S, Cn = 256, 96
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        pcm = np.ascontiguousarray(np.tile(synth.make_streams(16, Cn, seed0=4242), (S // 16, 1)))
+        for k, kind in enumerate(("zeros", "noise", "square")):
+            pcm[17 + 40 * k] = synth.control_stream(kind, Cn * 1536, seed=5 + k)
+        x = f32(pcm).reshape(-1)
+        got = e.stage_from_samples(x, "normalized")
+        mag = e.stage_from_samples(x, "magnitude")
+        assert got.shape == (S * Cn, 129, 25)
+        worst = 0.0
+        for lo in range(0, S * Cn, 2048):
+            worst = max(worst, float(np.abs(got[lo:lo + 2048] - _normalized_from_magnitude(mag[lo:lo + 2048])).max()))
+        assert worst < 1e-5, worst
+        rng = np.random.default_rng(3)
+        picks = sorted(set(rng.integers(0, S * Cn, 90).tolist()) | {0, S * Cn - 1, 17 * Cn + 3, 57 * Cn + 50, 97 * Cn + 95})
+        for i in picks:
+            h, c = orc.new_state()
+            _, taps = orc.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
+            assert np.array_equal(bits(mag[i]), bits(taps["magnitude"])), i
+            assert float(np.abs(got[i] - taps["normalized"]).max()) < 2e-5, i
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------------------------------------- reference fixtures on the GPU
 def _blob_with(weights_blob, replace):
     ts = tt.loads(weights_blob)

@@ -43,17 +43,22 @@ def _worker(rank, world, port, total_streams, chunks, q):
     c = torch.arange(chunks, dtype=torch.float32).view(1, -1, 1)
     k = torch.arange(2, dtype=torch.float32).view(1, 1, 2)
     local = s * 1000 + c * 2 + k
-    out = shard.gather_probabilities(local, total_streams, dst=0)
-    # the persistent form bench.py uses: preallocated buffers, one dist.gather per step, several steps
+    out = shard.gather_probabilities(local, total_streams, dst=0, slot=None)       # both elements, as the engine wrote them: 8 B per chunk
+    # the persistent form bench.py uses: preallocated buffers, one dist.gather per step, several steps -- and the speech probability alone (element 1:
+    # vadc.c:704-713), 4 B per chunk on the wire
     g = shard.ProbabilityGather(total_streams, chunks, "cpu")
+    assert g.bytes_per_chunk == 4 and g.slot == 1
     for i in range(3):
         g.gather(local + i)
         if rank == 0:
-            assert torch.equal(g.result(), out + i)
+            assert g.result().shape == (total_streams, chunks) and torch.equal(g.result(), out[:, :, 1] + i)
+    both = shard.ProbabilityGather(total_streams, chunks, "cpu", slot=None)
+    both.gather(local + 7)
     if rank == 0:
+        assert torch.equal(both.result(), out + 7)
         q.put(out.numpy())
     else:
-        assert out is None
+        assert out is None and both.result() is None and g.result() is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -16,7 +16,7 @@ SYMBOLS = [
     "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps", "vadc_amd_get_caps_sized",
     "vadc_amd_run_f32", "vadc_amd_run_s16", "vadc_amd_run_device_f32", "vadc_amd_run_device_s16",
     "vadc_amd_run_s16_async", "vadc_amd_run_f32_async", "vadc_amd_wait_async",
-    "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
+    "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_speech_probabilities", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
     "vadc_amd_get_context", "vadc_amd_set_context",
     "vadc_amd_debug_stage_from_samples", "vadc_amd_debug_stage_from_stage", "vadc_amd_debug_lstm_decoder", "vadc_amd_debug_layer1_block", "vadc_amd_debug_decoder", "vadc_amd_unpin",
     "vadc_amd_set_option", "vadc_amd_get_option", "vadc_amd_set_profiling", "vadc_amd_get_kernel_time", "vadc_amd_reset_kernel_times",
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     L.vadc_amd_set_context.argtypes = [vp, i32, vp]
     L.vadc_amd_synchronize.argtypes = [vp]
     L.vadc_amd_join.argtypes = [vp, vp]
+    L.vadc_amd_speech_probabilities.argtypes = [vp, vp, i32, i32, vp, vp]
     L.vadc_amd_reset_streams.argtypes = [vp, vp, i32]
     L.vadc_amd_get_state.argtypes = [vp, i32, vp, vp]
     L.vadc_amd_set_state.argtypes = [vp, i32, vp, vp]

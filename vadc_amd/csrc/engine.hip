@@ -2073,6 +2073,27 @@ extern "C" int vadc_amd_join(vadc_amd_engine *e, void *hip_stream)
    return VADC_AMD_OK;
 }
 
+// element 1 of every [2] pair (the speech probability, vadc.c:704-713) made contiguous: 4 B per chunk for the multi-GPU gather
+__global__ __launch_bounds__(256) void k_pack_speech(const float2 *__restrict__ probs, float *__restrict__ speech, size_t n)
+{
+   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) speech[i] = probs[i].y;
+}
+
+extern "C" int vadc_amd_speech_probabilities(vadc_amd_engine *e, const float *d_probs, int n_streams, int n_chunks, float *d_speech, void *hip_stream)
+{
+   if (!e) return fail(VADC_AMD_EINVAL, "speech_probabilities: NULL engine");
+   if (!d_probs || !d_speech || n_streams < 0 || n_chunks < 0) return fail(VADC_AMD_EINVAL, "speech_probabilities: bad argument");
+   if (((uintptr_t)d_probs & 7) != 0) return fail(VADC_AMD_EINVAL, "speech_probabilities: d_probs must be 8-byte aligned");
+   HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+   const size_t n = (size_t)n_streams * n_chunks;
+   if (!n) return VADC_AMD_OK;
+   const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+   hipLaunchKernelGGL(k_pack_speech, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, (const float2 *)d_probs, d_speech, n);
+   hipError_t he = hipGetLastError();
+   if (he != hipSuccess) return fail(VADC_AMD_EHIP, "speech_probabilities: %s", hipGetErrorString(he));
+   return VADC_AMD_OK;
+}
+
 extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, int n_chunks, float *probs)
 {
    int rc = check_shape(e, n_streams, n_chunks, "run_f32");

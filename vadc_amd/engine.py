@@ -150,6 +150,11 @@ class Engine:
         """make `hip_stream` wait for every call issued so far (see option "defer_join")"""
         self._check(self._L.vadc_amd_join(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
+    def speech_probabilities(self, d_probs: int, n_streams: int, n_chunks: int, d_speech: int, hip_stream: int = 0):
+        """d_speech[stream][chunk] = d_probs[stream][chunk][1] on the device, enqueued on `hip_stream` (what a multi-GPU host gathers: 4 B per chunk)"""
+        self._check(self._L.vadc_amd_speech_probabilities(self._h, C.c_void_p(d_probs), n_streams, n_chunks, C.c_void_p(d_speech),
+                                                         C.c_void_p(hip_stream) if hip_stream else None))
+
     # ---- state ----
     def reset_streams(self, ids: Optional[np.ndarray] = None):
         if ids is None:
