@@ -251,9 +251,14 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 Used only in a process whose kernels were SEEN to overlap at create ("kernels_overlap"): a tool that lets one kernel onto the device at a
  *                 time (rocprofv3 --pmc) would start layer 0 when layer 1 has ended -- there the engine launches the two one after the other by itself
  *                 ("lstm_trail_used" says what the last call did).  "overlap_check" 2: behave as if that probe had failed (tests).
- *                 A hand-over that fails at run time (layer 1's bounded wait of about 2 s runs out, a ticket imbalance, an XCC mismatch) does not trap: the
- *                 kernels set a host-mapped error word, the next vadc_amd_synchronize / vadc_amd_wait_async / synchronous vadc_amd_run_* returns
- *                 VADC_AMD_EHIP and the engine launches the pair in turn from then on.  "trail_fault" 1 (tests): the next pair is launched without its layer 0
+ *                 FAIL-SAFE: a hand-over that fails at run time (layer 1's bounded wait of about 2 s runs out -- a time-sliced GPU, a tool that started serialising
+ *                 kernels --, or a tile's pair sits on two XCDs) neither traps nor loses state: that layer-1 workgroup writes no state, and a REDO launch behind
+ *                 the pair (always there, a no-op otherwise) does its tiles again from the pre-call state, in stream order -- the call's probabilities and state are
+ *                 what the pair in turn produces, bit for bit, later calls consume only repaired state, and NO error is returned.  get_option "trail_recoveries"
+ *                 counts the tiles done again; from the next host synchronisation on the engine launches the two layers in turn ("lstm_trail" reads 0).
+ *                 Not repairable: a tile whose LAYER 0 never ran.  Then every later call -- a deferred vadc_amd_run_device_* and vadc_amd_join included, without
+ *                 any synchronisation: the word is host memory -- fails with VADC_AMD_EHIP until vadc_amd_reset_streams(e, NULL, 0).
+ *                 Tests: "trail_fault" 1 = the next pair's layer 0 comes late (behind its layer 1), 2 = never; "trail_wait" = polls before layer 1 gives up
  *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
  *   "fe_opt"      the exact-tree front end of Silero v3.1: 3 (default) = k_frontend_sym with bin 0 without the tree of its all-zero im row, the 9-bin split rotating over
  *                 the waves; 0 = round 3's kernel; 11 = k_frontend_ri (packed pairs = (re, im) of one tree lane: the derived rows' sums, re^2 + im^2 and the logarithm

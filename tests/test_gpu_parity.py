@@ -582,24 +582,106 @@ def test_lstm_layer1_beside_layer0_of_the_same_call(weights_blob, orc, S, Cn, ca
     assert float(np.abs(out[1][0][:3, :, 1] - want).max()) <= PROB_TOL
 
 
-def test_lstm_trail_failure_is_reported_not_trapped(weights_blob, orc):
-    """A layer 1 whose layer 0 never comes (test hook "trail_fault": the pair launched without its layer 0) runs out its bounded wait (~2 s), REPORTS it through the
-    engine's error word and ends -- no trap (which would take the HIP context, every engine and stream of the process, with it): the call fails with VADC_AMD_EHIP,
-    "lstm_trail" turns itself off, and the same engine and a fresh one in the same process go on to give the oracle's answers"""
-    S, Cn = 256, 8
-    base = synth.make_streams(16, Cn, seed0=4242)
+def test_lstm_trail_failure_is_recovered(weights_blob, orc):
+    """FAIL-SAFE of the layer-major pair.  A layer 1 whose layer 0 comes LATE (test hook "trail_fault" = 1: layer 0 of the next pair is held back until its layer 1
+    has run out its bounded wait -- a time-sliced GPU, a tool that serialises kernels) gives up WITHOUT writing state or marking its tiles done; the REDO launch behind the
+    pair does the tiles again from the untouched pre-call state over the complete h0 sequence.  With the fault in the MIDDLE of five back-to-back deferred calls --
+    nothing between them but the device-side ordering of the engine's streams -- all five calls' probabilities are the oracle's and the caller sees no error; the
+    engine counts the redone tiles ("trail_recoveries") and launches pairs in turn from the next synchronisation on."""
+    import torch
+    S, Cn, K = 256, 8, 5
+    base = synth.make_streams(16, K * Cn, seed0=4242)
     pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
     e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
     try:
         e.set_option("lstm", 7)
+        e.set_option("trail_wait", 400000)                     # ~0.2 s instead of ~2 s: the test need not wait longer
+        e.run(pcm[:, : Cn * 1536])
+        if not e.get_option("lstm_trail_used"):
+            pytest.skip("the TRAIL pair is not in use here (kernels do not overlap in this process, or no CU partition)")
+        e.reset_streams()
+        assert e.get_option("trail_recoveries") == 0
+        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536])).cuda() for k in range(K)]
+        d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda") for _ in range(K)]
+        st = torch.cuda.Stream()
+        e.set_option("defer_join", 1)
+        for k in range(K):
+            if k == 2:
+                e.set_option("trail_fault", 1)
+            e.run_device(d_in[k].data_ptr(), np.int16, S, Cn, d_out[k].data_ptr(), st.cuda_stream)      # no host synchronisation between the calls
+            assert e.get_option("lstm_trail_used") == 1
+        e.join(st.cuda_stream)
+        st.synchronize()
+        e.synchronize()                                        # no error: the fault was repaired on the device
+        got = np.concatenate([o.cpu().numpy() for o in d_out], axis=1)
+        assert e.get_option("trail_recoveries") == S // 16     # every tile of the faulted call was done again, once
+        assert e.get_option("lstm_trail") == 0                 # ... and the engine has stopped launching pairs side by side
+        hs = [e.get_state(s_) for s_ in (0, 100, 255)]
+        e.set_option("defer_join", 0)
+        again = e.run(pcm[:, : Cn * 1536])                      # the engine goes on
+        assert e.get_option("lstm_trail_used") == 0
+    finally:
+        e.close()
+    want = orc.forward_streams(base)
+    assert float(np.abs(got[:16, :, 1] - want).max()) <= PROB_TOL
+    assert np.array_equal(got[:16], got[16:32]) and np.array_equal(got[:16], got[-16:])       # (the 16 signals repeat over the tiles: every tile the same bits)
+    # the same five calls with no fault, pairs in turn: the recovered run produced THE SAME BITS (state included) -- the REDO form is layer 1's arithmetic
+    e2 = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)      # the context survived
+    try:
+        e2.set_option("lstm", 7)
+        e2.set_option("lstm_trail", 0)
+        ref = np.concatenate([e2.run(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536]) for k in range(K)], axis=1)
+        assert np.array_equal(bits(ref), bits(got))
+        for (h, c), s_ in zip(hs, (0, 100, 255)):
+            h2, c2 = e2.get_state(s_)
+            assert np.array_equal(bits(h), bits(h2)) and np.array_equal(bits(c), bits(c2))
+    finally:
+        e2.close()
+    assert again.shape == (S, Cn, 2)
+
+
+def test_lstm_trail_unrecoverable_failure_is_sticky_until_reset(weights_blob, orc):
+    """The one failure the REDO launch cannot repair: a tile whose LAYER 0 never ran (test hook "trail_fault" = 2: the pair launched without its layer 0; in the field: a
+    workgroup that never drew its tile).  No trap (which would take the HIP context, every engine and stream of the process, with it), no state written by layer 1:
+    the fatal word is set, the NEXT call of any kind -- a deferred run_device included, without any synchronisation -- fails with VADC_AMD_EHIP, and so does every call
+    until vadc_amd_reset_streams(all); then the same engine and a fresh one in the same process give the oracle's answers."""
+    import torch
+    S, Cn = 256, 8
+    base = synth.make_streams(16, Cn, seed0=4243)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
+    e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    try:
+        e.set_option("lstm", 7)
+        e.set_option("trail_wait", 400000)
         e.run(pcm)
         if not e.get_option("lstm_trail_used"):
             pytest.skip("the TRAIL pair is not in use here (kernels do not overlap in this process, or no CU partition)")
-        e.set_option("trail_fault", 1)
+        e.reset_streams()
+        before = [e.get_state(s_) for s_ in (0, 255)]
+        d_in = torch.from_numpy(pcm).cuda()
+        d_out = torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda")
+        st = torch.cuda.Stream()
+        e.set_option("defer_join", 1)
+        e.set_option("trail_fault", 2)
+        e.run_device(d_in.data_ptr(), np.int16, S, Cn, d_out.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()                               # (the caller's own synchronisation: the engine has not been asked anything yet)
+        with pytest.raises(VadcAmdError, match="reset_streams"):
+            e.run_device(d_in.data_ptr(), np.int16, S, Cn, d_out.data_ptr(), st.cuda_stream)
+        with pytest.raises(VadcAmdError):
+            e.join(st.cuda_stream)
+        with pytest.raises(VadcAmdError):
+            e.synchronize()
         with pytest.raises(VadcAmdError):
             e.run(pcm)
         assert e.get_option("lstm_trail") == 0
+        e.reset_streams(np.array([3], np.int32))                # a partial reset does not make the other streams' state defined
+        with pytest.raises(VadcAmdError):
+            e.run(pcm)
         e.reset_streams()
+        for (h, c), s_ in zip(before, (0, 255)):                # (zero state again)
+            h2, c2 = e.get_state(s_)
+            assert np.array_equal(h, h2) and np.array_equal(c, c2)
+        e.set_option("defer_join", 0)
         got = e.run(pcm)
         assert e.get_option("lstm_trail_used") == 0
     finally:

@@ -31,7 +31,7 @@ void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, fl
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
-void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int, int *, int, int *, int, int *);
+void launch_lstm_layer(int, const float *, float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int, int *, int, int *, int, int *, int *, int);
 void launch_lstm_decoder_tap(const float *, const LstmWeights &, float *, int, hipStream_t, int, int);
 struct LayerWeightsM {
    const float *dw_w, *dw_b, *pw_f, *pj_f, *cb_b, *qkv_f, *qkv_b, *out_f, *out_b, *n1_w, *n1_b, *l1_f, *l1_b, *l2_f, *l2_b,
@@ -233,9 +233,16 @@ struct vadc_amd_engine {
    int lstm_epoch = 0;
    int lstm_trail = 1;
    int lstm_trail_used = 0;                     // whether the last call's layer-major launches were a TRAIL pair (option "lstm_trail_used", read only)
-   int trail_fault = 0;                         // option "trail_fault" (tests): the next TRAIL pair is launched WITHOUT its layer 0, so that layer 1's bounded wait runs out
-   volatile int *h_trail_err = nullptr;         // the TRAIL kernels OR error bits in here instead of trapping (1 ticket imbalance, 2 layer 0 did not come, 4 a tile's pair on two XCDs)
+   int trail_fault = 0;                         // option "trail_fault" (tests): 1 = the next TRAIL pair's layer 0 is held back until its layer 1 has given up (a LATE layer 0: recovered by
+                                                // the REDO launch); 2 = the next pair is launched WITHOUT its layer 0 (a layer 0 that NEVER ran: not recoverable, the fatal word)
+   int trail_wait_limit = 4000000;              // option "trail_wait": polls (of ~0.5 us) after which a layer-1 workgroup gives up on its layer 0: ~2 s
+   volatile int *h_trail_err = nullptr;         // FATAL word (host memory mapped into the device; one plain store of 1 by the REDO launch): a tile's layer 0 never finished, so
+                                                // the call could not be recovered -- stream state is inconsistent; every later call fails until vadc_amd_reset_streams(all)
    int *d_trail_err = nullptr;                  // ... its device address
+   int *d_trail_recov = nullptr;                // device counter: tiles the REDO launches have done again (read at host synchronisation points and by "trail_recoveries")
+   int trail_recoveries = 0;                    // ... as of the last look
+   bool trail_lost = false;                     // the fatal word was seen: calls are refused until every stream has been reset
+   hipEvent_t ev_redo = nullptr;                // trail_fault 1: layer 0 of the faulted pair waits for its layer 1 to have given up
    int *d_lstm_tickets = nullptr;               // [2 layers][8 XCDs]: the counters a TRAIL workgroup draws its tile from (L2-local atomics); ticket_base = what earlier launches drew per XCD
    unsigned ticket_base = 0;
    // (round 1 also double buffered Y / FM for a front end on a third stream, option "fe_overlap"; measured slower and removed)
@@ -938,6 +945,8 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->h_trail_err) (void)hipHostFree(const_cast<int *>(e->h_trail_err));
+   if (e->d_trail_recov) (void)hipFree(e->d_trail_recov);
+   if (e->ev_redo) (void)hipEventDestroy(e->ev_redo);
    for (auto &sl : e->aslot) {
       if (sl.d_in) (void)hipFree(sl.d_in);
       if (sl.d_probs) (void)hipFree(sl.d_probs);
@@ -1063,14 +1072,17 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->progress_tiles = (padded_streams / kLstmTile + 7) / 8 * 8;
    if (he == hipSuccess) he = hipMalloc(&e->d_lstm_tickets, 16 * sizeof(int));
    if (he == hipSuccess) he = hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));
-   // the TRAIL kernels' error word: host memory mapped into the device, so that the host reads it at its synchronisation points without a copy
+   if (he == hipSuccess) he = hipMalloc(&e->d_trail_recov, sizeof(int));
+   if (he == hipSuccess) he = hipMemset(e->d_trail_recov, 0, sizeof(int));
+   if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_redo, hipEventDisableTiming);
+   // the TRAIL pair's FATAL word: host memory mapped into the device, so that the host reads it at the head of every call without a copy or a synchronisation
    { void *hp = nullptr, *dp = nullptr;
-     if (he == hipSuccess) he = hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped);
-     if (he == hipSuccess) { *static_cast<int *>(hp) = 0; he = hipHostGetDevicePointer(&dp, hp, 0); }
+     if (he == hipSuccess) he = hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped);      // [0] fatal, [1] "a tile was done again" (then the device counter is worth a copy)
+     if (he == hipSuccess) { static_cast<int *>(hp)[0] = static_cast<int *>(hp)[1] = 0; he = hipHostGetDevicePointer(&dp, hp, 0); }
      e->h_trail_err = static_cast<volatile int *>(hp); e->d_trail_err = static_cast<int *>(dp); }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) {
-      he = hipMalloc(&e->d_lstm_progress[p], vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));      // per group: [tiles] counts, [tiles] XCC ids
-      if (he == hipSuccess) he = hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int));
+      he = hipMalloc(&e->d_lstm_progress[p], vadc_amd_engine::kMaxGroups * 3 * e->progress_tiles * sizeof(int));      // per group: [tiles] counts, [tiles] XCC ids, [tiles] layer 1 done
+      if (he == hipSuccess) he = hipMemset(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 3 * e->progress_tiles * sizeof(int));
    }
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
@@ -1208,6 +1220,7 @@ extern "C" const char *vadc_amd_kernel_name(int kernel)
 }
 
 static int wait_all_prior_fwd(vadc_amd_engine *e);
+static void look_at_trail_recoveries(vadc_amd_engine *e);
 extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value)
 {
    if (!e || !key) return fail(VADC_AMD_EINVAL, "set_option: NULL argument");
@@ -1248,8 +1261,9 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
    if (strcmp(key, "full_mask_streams") == 0 && value >= 0 && value <= 2) { e->full_mask_streams = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
-   if (strcmp(key, "lstm_trail") == 0 && value >= 0 && value <= 2) { e->lstm_trail = value; return VADC_AMD_OK; }
-   if (strcmp(key, "trail_fault") == 0 && (value == 0 || value == 1)) { e->trail_fault = value; return VADC_AMD_OK; }
+   if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
+   if (strcmp(key, "trail_fault") == 0 && value >= 0 && value <= 2) { e->trail_fault = value; return VADC_AMD_OK; }
+   if (strcmp(key, "trail_wait") == 0 && value >= 1000) { e->trail_wait_limit = value; return VADC_AMD_OK; }
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -1296,6 +1310,12 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "lstm_trail") == 0) *value = e->lstm_trail;
    else if (strcmp(key, "kernels_overlap") == 0) *value = e->kernels_overlap ? 1 : 0;
    else if (strcmp(key, "lstm_trail_used") == 0) *value = e->lstm_trail_used;
+   else if (strcmp(key, "trail_recoveries") == 0) {           // tiles done again by the REDO launches so far (waits for the calls issued before)
+      HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
+      { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
+      look_at_trail_recoveries(e);
+      *value = e->trail_recoveries;
+   }
    else if (strcmp(key, "lstm_epoch") == 0) *value = e->lstm_epoch;
    else if (strcmp(key, "cu_mask_check") == 0) *value = e->cu_mask_check;
    else if (strcmp(key, "cu_layout_ok") == 0) *value = e->cu_layout_ok ? 1 : 0;
@@ -1455,9 +1475,11 @@ static int cu_mask_layout_flags(int device, int n_cus)
    return flags;
 }
 
+static int check_trail_error(vadc_amd_engine *e, const char *where);
 static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const char *who)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "%s: NULL engine", who);
+   { int rc_ = check_trail_error(e, who); if (rc_) return rc_; }      // (a memory read: a call whose streams are in an undefined state is refused at its head)
    if (n_streams <= 0 || n_chunks <= 0) return fail(VADC_AMD_EINVAL, "%s: n_streams=%d n_chunks=%d must be positive", who, n_streams, n_chunks);
    if (n_streams > e->max_streams) return fail(VADC_AMD_EINVAL, "%s: n_streams=%d exceeds max_streams=%d", who, n_streams, e->max_streams);
    if ((size_t)n_streams * n_chunks > e->max_items)
@@ -1761,15 +1783,11 @@ static int pick_groups(const vadc_amd_engine *e, int n_chunks)
 static void launch_lstm_on(vadc_amd_engine *e, int lk, float *d_probs, int n_streams, int n_chunks, int c0, int cg, hipStream_t st)
 {
    if (lk == 7) {
-      // ("lstm_trail" = 2, measurements only: the TRAIL kernels one after the other on this stream -- what their bookkeeping costs with nothing to wait for)
-      int *progress = nullptr;
-      if (e->lstm_trail == 2) { if (++e->lstm_epoch > 2047) e->lstm_epoch = 1; progress = e->d_lstm_progress[e->xpar]; }
-      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err); }
+      { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_lstm_layer(0, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0, nullptr, nullptr, 0); }
       {
          KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, st);
-         launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
+         launch_lstm_layer(1, e->d_act[3], e->d_h0pair[e->xpar], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, st, e->model, e->lstm_steps, nullptr, 0, nullptr, 0, nullptr, nullptr, 0);
       }
-      if (progress) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);
       return;
    }
    KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st);
@@ -1974,24 +1992,43 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
                   // the layer-1 stream goes on behind the clear
                   (void)hipEventRecord(e->ev_wrap[0], e->sC);
                   (void)hipStreamWaitEvent(e->sB, e->ev_wrap[0], 0);
-                  for (int p = 0; p < 2; ++p) (void)hipMemsetAsync(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 2 * e->progress_tiles * sizeof(int), e->sB);
+                  for (int p = 0; p < 2; ++p) (void)hipMemsetAsync(e->d_lstm_progress[p], 0, vadc_amd_engine::kMaxGroups * 3 * e->progress_tiles * sizeof(int), e->sB);
                   (void)hipEventRecord(e->ev_wrap[1], e->sB);
                   (void)hipStreamWaitEvent(e->sC, e->ev_wrap[1], 0);
                   e->lstm_epoch = 1;
                }
-               progress = e->d_lstm_progress[xp] + (size_t)gi * 2 * e->progress_tiles;
+               progress = e->d_lstm_progress[xp] + (size_t)gi * 3 * e->progress_tiles;
             }
-            if (trail && e->trail_fault) e->trail_fault = 0;      // (tests: layer 1 alone -- its tickets still advance, as they would beside a layer 0 that never started)
-            else {
+            // (tests) trail_fault 1: this pair's layer 0 comes LATE -- it is held back until its layer 1 has given up; 2: it never comes (its tickets still advance,
+            // as they would beside a layer 0 that never started)
+            const int fault = trail ? e->trail_fault : 0;
+            if (trail) e->trail_fault = 0;
+            bool l0_failed = false;
+            if (fault == 0) {
                KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB);
-               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err, e->d_trail_recov, e->trail_wait_limit);
+               l0_failed = trail && hipGetLastError() != hipSuccess;      // a layer 0 that was never launched must not be polled for: the pair in turn then
             }
-            const bool l0_failed = trail && hipGetLastError() != hipSuccess;      // a layer 0 that was never launched must not be polled for: the pair in turn then
             hipEvent_t l0_done = last_group ? e->ev_b[xp] : e->ev_l0[gi];   // the call's last record on this stream is also this hand-off pair's "layer 0 done"
-            (void)hipEventRecord(l0_done, e->sB);
+            if (fault != 1) (void)hipEventRecord(l0_done, e->sB);
             if (!trail || l0_failed) (void)hipStreamWaitEvent(e->sC, l0_done, 0);
-            KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
-            launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err);
+            {
+               KernelTimer t(e, VADC_AMD_KERNEL_LSTM_L1, e->sC);
+               launch_lstm_layer(1, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err, e->d_trail_recov, e->trail_wait_limit);
+            }
+            if (fault == 1) {                                   // the late layer 0: behind its layer 1 (which therefore gives up), then "layer 0 done" as always
+               (void)hipEventRecord(e->ev_redo, e->sC);
+               (void)hipStreamWaitEvent(e->sB, e->ev_redo, 0);
+               launch_lstm_layer(0, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sB, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err, e->d_trail_recov, e->trail_wait_limit);
+               (void)hipEventRecord(l0_done, e->sB);
+            }
+            if (trail && !l0_failed) {
+               // FAIL-SAFE: behind the pair -- and behind layer 0's END (a kernel boundary) -- the REDO form of layer 1: every workgroup leaves at once unless its tile's
+               // layer 1 gave up (its wait ran out; its pair on another XCD; its workgroup never ran), in which case the tile is done again from the untouched
+               // pre-call state over the complete h0 sequence.  Later calls are ordered behind it like behind any layer-1 launch, so none consumes a faulted state.
+               (void)hipStreamWaitEvent(e->sC, l0_done, 0);
+               launch_lstm_layer(2, e->d_act[3], e->d_h0pair[xp], e->lstm, e->d_h, e->d_c, d_probs, n_streams, n_chunks, c0, cg, e->sC, e->model, e->lstm_steps, progress, e->lstm_epoch, e->d_lstm_tickets, (int)e->ticket_base, e->d_trail_err, e->d_trail_recov, e->trail_wait_limit);
+            }
             if (trail) e->ticket_base += (unsigned)(((n_streams + kLstmTile - 1) / kLstmTile + 7) / 8);      // every XCD's counter of either layer has advanced by grid / 8
          }
          c0 += cg;
@@ -2034,18 +2071,38 @@ extern "C" int vadc_amd_run_device_s16(vadc_amd_engine *e, const int16_t *d_pcm,
    return run_device<int16_t>(e, d_pcm, n_streams, n_chunks, d_probs, (hipStream_t)hip_stream);
 }
 
-// The TRAIL kernels report instead of trapping (kernels_lstm.hip): read their error word behind a synchronisation point.  A set word = layer 1 left without its
-// probabilities: the call's results are invalid -> VADC_AMD_EHIP, and the engine launches the pair in turn from now on.
+// The TRAIL pair is fail-safe (kernels_lstm.hip, FAIL-SAFE): a layer 1 that gave up on its layer 0 is done again on the device by the REDO launch, in stream order, and
+// the caller sees correct probabilities and no error.  What the host does about it, at its synchronisation points: it looks at the counter of redone tiles and, when it
+// has moved, stops launching pairs side by side (an environment in which layer 0 comes seconds late -- a time-sliced GPU, a tool that serialises kernels -- would cost
+// every call its bounded wait) and puts the ticket counters back in step.
+static void look_at_trail_recoveries(vadc_amd_engine *e)
+{
+   if (!e->d_trail_recov || !e->h_trail_err || !e->h_trail_err[1]) return;      // (the flag is host memory: no copy unless a REDO workgroup has worked)
+   e->h_trail_err[1] = 0;
+   int n = 0;
+   if (hipMemcpy(&n, e->d_trail_recov, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+   if (n != e->trail_recoveries) {
+      e->trail_recoveries = n;
+      e->lstm_trail = 0;
+      if (e->d_lstm_tickets) (void)hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));      // (every launch that drew tickets has finished: this runs behind a synchronisation)
+      e->ticket_base = 0;
+   }
+}
+// The one failure the REDO launch cannot repair -- a tile whose LAYER 0 never ran (a workgroup that never got its tile: ticket imbalance) -- sets the fatal word: the
+// layer-0 state of the streams has or has not advanced tile by tile, layer 1's has not.  The word is host memory: it is looked at WITHOUT any synchronisation at the head
+// of every call (run_device, join, synchronize, the host-buffer entry points), so a caller that only ever issues deferred calls gets the error on its next call, and
+// it stays set -- every call fails -- until vadc_amd_reset_streams(all) has put the streams into a defined state again.
 static int check_trail_error(vadc_amd_engine *e, const char *where)
 {
-   if (!e->h_trail_err || !*e->h_trail_err) return VADC_AMD_OK;
-   const int word = *e->h_trail_err;
-   *e->h_trail_err = 0;
-   e->lstm_trail = 0;
-   if (e->d_lstm_tickets) (void)hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int));      // the pair's ticket counters may be out of step: start over
-   e->ticket_base = 0;
-   return fail(VADC_AMD_EHIP, "%s: the recurrence's second layer gave up on its first (bits %d: 1 ticket imbalance, 2 layer 0 did not come within 2 s, 4 XCD mismatch); "
-                              "this call's probabilities are invalid, lstm_trail is now off", where, word);
+   if (e->h_trail_err && *e->h_trail_err) {
+      if (!e->trail_lost) {
+         e->trail_lost = true;
+         e->lstm_trail = 0;
+      }
+   }
+   if (!e->trail_lost) return VADC_AMD_OK;
+   return fail(VADC_AMD_EHIP, "%s: a stream tile's first recurrence layer never ran beside its second (layer-major LSTM pair) and the call could not be recovered: the "
+                              "state of the streams is inconsistent and the probabilities since then are invalid -- vadc_amd_reset_streams(e, NULL, 0) clears this (lstm_trail is now off)", where);
 }
 
 extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
@@ -2058,12 +2115,14 @@ extern "C" int vadc_amd_synchronize(vadc_amd_engine *e)
       HIP_TRY(hipEventSynchronize(e->last_c), VADC_AMD_EHIP);
    }
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   look_at_trail_recoveries(e);
    return check_trail_error(e, "synchronize");
 }
 
 extern "C" int vadc_amd_join(vadc_amd_engine *e, void *hip_stream)
 {
    if (!e) return fail(VADC_AMD_EINVAL, "join: NULL engine");
+   { int rc_ = check_trail_error(e, "join"); if (rc_) return rc_; }
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    if (e->ev_last_valid) {
       wait_last_all(e, (hipStream_t)hip_stream);
@@ -2107,6 +2166,7 @@ extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   look_at_trail_recoveries(e);
    return check_trail_error(e, "run_f32");
 }
 
@@ -2123,6 +2183,7 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
    HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
+   look_at_trail_recoveries(e);
    return check_trail_error(e, "run_s16");
 }
 
@@ -2284,6 +2345,7 @@ extern "C" int vadc_amd_wait_async(vadc_amd_engine *e)
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    for (auto &sl : e->aslot)
       if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.out_done), VADC_AMD_EHIP); sl.busy = false; }
+   look_at_trail_recoveries(e);
    return check_trail_error(e, "wait_async");
 }
 
@@ -2312,6 +2374,12 @@ extern "C" int vadc_amd_reset_streams(vadc_amd_engine *e, const int32_t *ids, in
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_last_lstm(e); if (rc_) return rc_; }
    if (!ids) {
+      if (e->trail_lost || (e->h_trail_err && e->h_trail_err[0])) {      // every stream gets a defined state again: the fatal condition of a TRAIL pair ends here
+         if (e->h_trail_err) e->h_trail_err[0] = 0;
+         e->trail_lost = false;
+         if (e->d_lstm_tickets) HIP_TRY(hipMemset(e->d_lstm_tickets, 0, 16 * sizeof(int)), VADC_AMD_EHIP);
+         e->ticket_base = 0;
+      }
       if (e->d_ctx5) HIP_TRY(hipMemsetAsync(e->d_ctx5, 0, (size_t)e->max_streams * 64 * sizeof(float), e->stream), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_h, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_c, 0, (size_t)e->max_streams * 128 * sizeof(float), e->stream), VADC_AMD_EHIP);

@@ -446,14 +446,23 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wavefront_fused(const float *__
 // (Measured on the way: the same hand-over with device-scope accesses -- sc0 sc1 on the tile stores, the tile loads and the count -- is correct on any XCD
 // placement but takes every access to the fabric: both chains 0.5 -> 1.0 ms.  An earlier attempt with agent-scope FENCES wrote back and invalidated the whole
 // L2 at every hand-over and cost the front end 2 %: DESIGN.md 4.4.)
-template <int TS, int DEC, int L, bool TAPDEC = false, bool TRAIL = false>
+// FAIL-SAFE (round 6): a layer-1 workgroup whose hand-over failed -- its bounded wait ran out, or its pair sits on another XCD -- no longer leaves wrong state behind:
+// it still runs on over whatever the hand-off buffer holds (no second exit from the slot loop, see wait_for), but it writes NEITHER the streams' state NOR its
+// "done" word (progress[2 grid + tile] = epoch).  The engine launches the REDO form of layer 1 behind the pair, ordered behind layer 0's end by an event (a kernel
+// boundary: plain loads see everything): a workgroup whose tile is marked done leaves at once (one load); one whose tile is not done AND whose layer 0 is complete
+// (progress[tile] = the call's total) runs layer 1 for the tile from the untouched pre-call state over the complete h0 sequence -- the call's probabilities and
+// state are then what the pair in turn would have produced, bit for bit -- and counts itself in `recov`; a tile whose layer 0 is NOT complete (a workgroup that
+// never ran: ticket imbalance) cannot be recovered here: the fatal word (host-mapped, one plain store) is set, the layer-1 state stays as it was before the call,
+// and the engine refuses further calls until the streams are reset.
+template <int TS, int DEC, int L, bool TAPDEC = false, bool TRAIL = false, bool REDO = false>
 __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restrict__ in_tiles,   // split-fp16 tiles [tile][n_chunks][TS][hi|lo][16][64]: encoder output (L = 0) / h0 sequence (L = 1)
                                                        _Float16 *__restrict__ h0seq,            // L = 0: the h0 sequence, same layout
                                                        LstmWeights w,
                                                        float *__restrict__ hs, float *__restrict__ cs,
                                                        float *__restrict__ probs,               // L = 1
                                                        int n_streams, int n_chunks, int c0, int cg, const float *__restrict__ tap_h = nullptr,
-                                                       int *__restrict__ progress = nullptr, int epoch = 0, int *__restrict__ tickets = nullptr, int ticket_base = 0, int *__restrict__ err = nullptr)
+                                                       int *__restrict__ progress = nullptr, int epoch = 0, int *__restrict__ tickets = nullptr, int ticket_base = 0, int *__restrict__ err = nullptr,
+                                                       int pgrid = 0, int *__restrict__ recov = nullptr, int wait_limit = 4000000)
 {
    // [parity][hi / lo][stream][unit]: the CURRENT h of this layer as split fp16
    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][kTileS * kHPitch];
@@ -478,13 +487,22 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          xcc &= 7u;
          const unsigned j = (unsigned)atomicAdd(tickets + L * 8 + (int)xcc, 1) - (unsigned)ticket_base;      // (both counts wrap together)
          tile_s = (int)xcc + 8 * (int)j;
-         // an XCD that got more than its share of the grid (another would leave tiles undone): reported, not trapped -- a trap takes the whole HIP context, every engine
-         // and stream of the process, with it.  The error word (`err`: host memory mapped into the device) is read by the host at its next synchronisation point: VADC_AMD_EHIP, TRAIL off.
-         if (j >= gridDim.x / 8) { atomicOr(err, 1); tile_s = -1; }
+         // an XCD that got more than its share of the grid (another then leaves tiles undone): this workgroup leaves -- no trap (a trap takes the whole HIP context,
+         // every engine and stream of the process, with it) and no error word of its own: an undone tile has no "done" word (layer 1) or no final count (layer 0),
+         // and the REDO launch behind the pair recovers the former and reports the latter
+         if (j >= gridDim.x / 8) tile_s = -1;
       }
       __syncthreads();
       tile = tile_s;
       if (tile < 0 || tile >= (n_streams + kTileS - 1) / kTileS) return;
+   }
+   if (REDO) {                                             // (workgroup-uniform: every lane loads the same two words)
+      if (progress[2 * pgrid + tile] == epoch) return;      // the pair's layer 1 finished this tile: nothing to do (the common case)
+      const int raw0 = progress[tile];
+      if ((raw0 >> 20) != epoch || (raw0 & 0xFFFFF) != TS * cg) {      // layer 0 never finished this tile: not recoverable from here
+         if (tid == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(err), "v"(1) : "memory");
+         return;
+      }
    }
    const int col = lane & 15;
    const int quad = lane >> 4;
@@ -571,9 +589,9 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       return v;
    };
    // Layer 0 did not come within ~2 s (a time-sliced GPU, a tool that started serialising kernels after the create-time probe, a failed layer-0 launch): the
-   // workgroup REPORTS it (error word) and stops waiting -- it runs on over whatever the hand-off buffer holds (memory-safe: the engine's own allocation) and ends;
-   // the host sees the word at its next synchronisation point and fails the call.  Never a hang, and no trap (see the ticket above).  No early return either: a
-   // second exit from the block loop made hipcc put an s_waitcnt vmcnt(0) at the head of the slot loop.
+   // workgroup GIVES UP (avail = 2^30) and stops waiting -- it runs on over whatever the hand-off buffer holds (memory-safe: the engine's own allocation), writes
+   // no state and no "done" word, and ends; the REDO launch behind the pair does the tile again.  Never a hang, and no trap (see the ticket above).  No early
+   // return either: a second exit from the block loop made hipcc put an s_waitcnt vmcnt(0) at the head of the slot loop.
    auto wait_for = [&](int need) {                             // workgroup-uniform: every wave calls it with the same `need` and the same `avail`
       unsigned spins = 0;
       while (avail < need) {
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
          __syncthreads();
          if (avail < need) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > 4000000u) { if (tid == 0) publish(err, 2); avail = 1 << 30; }
+            if (++spins > (unsigned)wait_limit) avail = 1 << 30;
          }
       }
    };
@@ -595,7 +613,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       int other = 0;
       for (int tries = 0; tries < 1000 && (other >> 20) != epoch; ++tries)       // (stored before the first count by the same lane; a few more looks cost nothing)
          asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(other) : "s"(progress + gridDim.x + tile) : "memory");
-      if (((other >> 20) != epoch || (unsigned)(other & 0xf) != (xcc & 0xf)) && avail < (1 << 30) && tid == 0) publish(err, 4);      // reported; the tiles may then be stale
+      if ((other >> 20) != epoch || (unsigned)(other & 0xf) != (xcc & 0xf)) avail = 1 << 30;      // the tiles may then be stale (another L2): give up, the REDO launch does the tile
    }
    if (TRAIL && L == 0) {
       unsigned xcc;
@@ -797,12 +815,18 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
       __syncthreads();
       if (tid == 448) publish(progress + tile, (epoch << 20) | total);
    }
-   if (!TAPDEC && col_ok) {
+   const bool gave_up = TRAIL && L == 1 && avail >= (1 << 30);      // workgroup-uniform
+   if (!TAPDEC && col_ok && !gave_up) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
          cs[(size_t)s_col * 128 + L * 64 + u0 + m] = c[m];
          hs[(size_t)s_col * 128 + L * 64 + u0 + m] = hlast[m];
       }
+   }
+   if (TRAIL && L == 1 && !gave_up && tid == 0) progress[2 * pgrid + tile] = epoch;      // this tile of layer 1 is done (read by the REDO launch, behind a kernel boundary)
+   if (REDO && tid == 0) {                                    // counted (device memory), and flagged where the host sees it without a copy (err[1]: host-mapped, a plain store)
+      atomicAdd(recov, 1);
+      asm volatile("global_store_dword %0, %1, off" :: "v"(err + 1), "v"(1) : "memory");
    }
 }
 
@@ -811,29 +835,32 @@ __global__ __launch_bounds__(512, 4) void k_lstm_layer(const _Float16 *__restric
 // progress != nullptr: the TRAIL form (layer 1 may run beside layer 0 of the same call); epoch in [1, 2048); tickets / ticket_base: see the kernel
 template <int TS, int DEC>
 static void launch_layer_ts(int layer, const _Float16 *x, _Float16 *h, const LstmWeights &w, float *hs, float *cs, float *probs,
-                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int *progress, int epoch, int *tickets, int ticket_base, int *err)
+                            int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int *progress, int epoch, int *tickets, int ticket_base, int *err, int *recov, int wait_limit)
 {
    const int tiles = (n_streams + kTileS - 1) / kTileS;
    const float *no_tap = nullptr;
    if (progress) {
       const dim3 grid((tiles + 7) / 8 * 8), block(512);          // a multiple of 8: every XCD gets the same number of workgroups
-      if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0, false, true>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
-      else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, true>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
+      const int pgrid = (int)grid.x;
+      if (layer == 0)      hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0, false, true>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err, pgrid, recov, wait_limit);
+      else if (layer == 1) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, true>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err, pgrid, recov, wait_limit);
+      else                 hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1, false, false, true>), dim3(tiles), block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err, pgrid, recov, wait_limit);      // layer 2 = the REDO form of layer 1, behind the pair
       return;
    }
    const dim3 grid(tiles), block(512);
-   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
-   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err);
+   if (layer == 0) hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 0>), grid, block, 0, st, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err, 0, recov, wait_limit);
+   else            hipLaunchKernelGGL((k_lstm_layer<TS, DEC, 1>), grid, block, 0, st, h, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, no_tap, progress, epoch, tickets, ticket_base, err, 0, recov, wait_limit);
 }
+// layer: 0 / 1 = the two layers; 2 (TRAIL pairs only: progress != nullptr) = the REDO form of layer 1 behind the pair (see the kernel)
 void launch_lstm_layer(int layer, const float *enc, float *h0seq, const LstmWeights &w, float *hs, float *cs, float *probs,
-                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps, int *progress, int epoch, int *tickets, int ticket_base, int *err)
+                       int n_streams, int n_chunks, int c0, int cg, hipStream_t st, int model, int steps, int *progress, int epoch, int *tickets, int ticket_base, int *err, int *recov, int wait_limit)
 {
    const _Float16 *x = reinterpret_cast<const _Float16 *>(enc);
    _Float16 *h = reinterpret_cast<_Float16 *>(h0seq);
-   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
-   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
-   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
-   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err);
+   if (model == 0)      launch_layer_ts<7, 0>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err, recov, wait_limit);
+   else if (steps == 3) launch_layer_ts<3, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err, recov, wait_limit);
+   else if (steps == 2) launch_layer_ts<2, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err, recov, wait_limit);
+   else                 launch_layer_ts<1, 1>(layer, x, h, w, hs, cs, probs, n_streams, n_chunks, c0, cg, st, progress, epoch, tickets, ticket_base, err, recov, wait_limit);
 }
 
 // stage tap: the decoder of k_lstm_layer<.., 1> on n items of [64][steps] (one chunk each), probs [n][2]
