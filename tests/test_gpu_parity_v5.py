@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import oracle as O
-from vadc_amd import synth
+from vadc_amd import synth, testtensor as tt
 from vadc_amd.engine import Engine, VadcAmdError, MODEL_V5
 
 pytestmark = pytest.mark.gpu
@@ -128,6 +128,58 @@ def test_forked_calls_and_fp32_recurrence(blob, orc):
         finally:
             e.close()
     assert float(np.abs(out[0] - out[3]).max()) < PROB_TOL
+
+
+def test_encoder_forms_agree_and_fall_back(blob, orc):
+    """round 6: the encoder's GEMMs (folded STFT, four k = 3 convs, the LSTM's input projection) run as split-fp16 MFMAs at fp32 accuracy (k_v5_encoder_h3:
+    "frontend_kernel" 2) when every weight x 256 fits fp16's range and the basis has the real-DFT fold symmetries; option "encoder" = 3, a weight outside that
+    range or a basis without the symmetries select the fp32-MFMA form (k_v5_encoder: 1).  Every form holds the 1e-4 bar against the oracle on ragged tiles of 16."""
+    S, n = 21, 37                                               # 777 windows: 48 whole tiles of 16 and a ragged one, tiles across stream boundaries
+    pcm = streams512(S, n, seed0=4711)
+    ref = orc.forward_streams(pcm)
+    out = {}
+    for enc in (0, 3):
+        e = Engine(blob, max_streams=S, max_chunks_per_call=n, device=0)
+        try:
+            e.set_option("encoder", enc)
+            out[enc] = e.run(pcm)
+            assert e.get_option("frontend_kernel") == (1 if enc == 3 else 2)
+            assert float(np.abs(out[enc][:, :, 1] - ref).max()) < PROB_TOL
+            e.reset_streams()
+            assert np.array_equal(e.run(pcm.astype(np.float32) / np.float32(32768)), out[enc])       # f32 samples of 16-bit audio: the same integers
+        finally:
+            e.close()
+    assert float(np.abs(out[0] - out[3]).max()) < PROB_TOL
+    ts = tt.loads(blob)
+    big = [(k, v.copy()) for k, v in ts]
+    big[3][1][5, 7, 1] = 300.0                                  # x 256 leaves fp16's range
+    odd = [(k, v.copy()) for k, v in ts]
+    odd[0][1][40, 0, 100] *= 1.0000001                          # re row of bin 40 no longer even about tap 128
+    for other in (big, odd):
+        b2 = tt.dumps(other)
+        e = Engine(b2, max_streams=S, max_chunks_per_call=n, device=0)
+        try:
+            got = e.run(pcm)
+            assert e.get_option("frontend_kernel") == 1
+            assert float(np.abs(got[:, :, 1] - O.OracleV5(b2).forward_streams(pcm)).max()) < PROB_TOL
+        finally:
+            e.close()
+
+
+def test_encoder_h3_at_the_bench_shape(blob, orc):
+    """256 streams x 288 windows (what tools/v5_rate.py and bench.py's configs["v5_256x288"] time) through the split-fp16 encoder, forked: sampled streams against the oracle"""
+    S, n = 256, 288
+    base = streams512(16, n, seed0=11)
+    pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
+    e = Engine(blob, max_streams=S, max_chunks_per_call=n, device=0)
+    try:
+        got = e.run(pcm)
+        assert e.get_option("frontend_kernel") == 2
+    finally:
+        e.close()
+    ref = orc.forward_streams(base[:6])
+    assert float(np.abs(got[:6, :, 1] - ref).max()) < PROB_TOL
+    assert np.array_equal(got[:16], got[16:32]) and np.array_equal(got[:16], got[-16:])
 
 
 def test_reset_of_selected_streams_clears_context_and_state(eng):

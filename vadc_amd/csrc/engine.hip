@@ -49,9 +49,10 @@ void launch_layer1_regs_v4(const L1RegsArgs &, int, hipStream_t);
 struct V5Weights {
    const float *stft_f; const float *conv_f[4]; const float *conv_b[4]; const float *wih_f; const float *lstm_b; const float *whh; const _Float16 *whh_h;
    const float *dec_w; const float *dec_b;
+   const _Float16 *h_stft; const _Float16 *h_conv[4]; const _Float16 *h_wih; const float *wny;      // k_v5_encoder_h3's split-fp16 operands (kernels_v5.hip); null: k_v5_encoder serves
 };
-void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, int, int, hipStream_t);
-void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, int, int, hipStream_t);
+void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, int, int, bool, hipStream_t);
+void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, int, int, bool, hipStream_t);
 void launch_v5_lstm(const V5Weights &, const float *, float *, float *, float *, int, int, bool, hipStream_t);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int, bool);
 }  // namespace vadc
@@ -141,6 +142,7 @@ struct vadc_amd_engine {
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 3, 2, 2, 1 (v4 with 1536-, 1280-, 1024-, 768-, 512-sample windows)
    int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1280 / 1024 / 768 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
    V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
+   bool v5_enc_h3_ok = false;                   // ... its encoder's split-fp16 operands exist (weights x 256 inside fp16's range, basis with the fold symmetries): k_v5_encoder_h3 runs
    float *d_gx5[2] = {nullptr, nullptr}, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512] (one per hand-off parity); per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
    int stride3() const { return sample_rate == 8000 ? 1 : 2; }
@@ -913,6 +915,71 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
    memcpy(whf.data(), wh.data(), wh.size() * sizeof(_Float16));
    const size_t o_whh_h = pk.add(whf.data(), whf.size());
    e->lstm_h3_ok = h3_ok;
+   // k_v5_encoder_h3: every A operand of the encoder as split-fp16 fragments x 256, [m-tile][k-block][hi | lo][lane][8]; lane l holds row 16 mt + (l & 15),
+   // k = 32 kb + 8 (l >> 4) + e.  The STFT rows are FOLDED (kernels_v5.hip): that needs re rows even and im rows odd about tap 128, tap 0 zero, the im row of bin 128
+   // zero -- checked bit for bit on the loaded basis; a basis without them, or a weight x 256 outside fp16's range, leaves the fp32-MFMA encoder in charge.
+   bool enc_ok = true;
+   std::vector<_Float16> eh;
+   size_t oh_stft = 0, oh_conv[4] = {0, 0, 0, 0}, oh_wih = 0;
+   std::vector<float> wny(128, 0.0f);
+   {
+      std::vector<float> basis;
+      copy_unaligned(basis, ts[0]);
+      auto B = [&](int row, int n) { return basis[(size_t)row * 256 + n]; };
+      for (int k = 0; k < kBins && enc_ok; ++k) {
+         if (B(k, 0) != 0.0f || B(kBins + k, 0) != 0.0f || B(kBins + k, 128) != 0.0f) enc_ok = false;
+         for (int n = 1; n < 128 && enc_ok; ++n)
+            if (B(k, n) != B(k, 256 - n) || B(kBins + k, n) != -B(kBins + k, 256 - n)) enc_ok = false;
+      }
+      for (int n = 0; n < 256 && enc_ok; ++n) if (B(kBins + 128, n) != 0.0f) enc_ok = false;
+      auto push = [&](float x) {                                     // one weight -> (hi, lo) appended 8 halves apart by the caller's loop structure
+         const float sx = 256.0f * x;
+         if (!(fabsf(sx) < 60000.0f)) enc_ok = false;
+         const _Float16 hi = (_Float16)sx;
+         return std::pair<_Float16, _Float16>(hi, (_Float16)(sx - (float)hi));
+      };
+      // value(mt, kb, lane, e) by stage
+      auto pack = [&](int MT, int KB, auto &&value) {
+         const size_t off = eh.size();
+         eh.resize(off + (size_t)MT * KB * 2 * 512);
+         for (int mt = 0; mt < MT; ++mt)
+            for (int kb = 0; kb < KB; ++kb)
+               for (int l = 0; l < 64; ++l)
+                  for (int el = 0; el < 8; ++el) {
+                     const auto hl = push(value(16 * mt + (l & 15), kb, l >> 4, el));
+                     eh[off + ((size_t)(mt * KB + kb) * 2 + 0) * 512 + l * 8 + el] = hl.first;
+                     eh[off + ((size_t)(mt * KB + kb) * 2 + 1) * 512 + l * 8 + el] = hl.second;
+                  }
+         return off;
+      };
+      if (enc_ok) {
+         oh_stft = pack(16, 4, [&](int row, int kb, int kq, int el) {
+            const int slot = 32 * kb + 8 * kq + el, n = slot + 1;
+            if (row < 128) return slot == 127 ? 0.5f * B(row, 128) : B(row, n);
+            return slot == 127 ? 0.0f : B(kBins + (row - 128), n);
+         });
+         for (int slot = 0; slot < 128; ++slot) wny[slot] = slot == 127 ? 0.5f * B(128, 128) : B(128, slot + 1);
+         std::vector<float> cw[4];
+         for (int c = 0; c < 4; ++c) copy_unaligned(cw[c], ts[1 + 2 * c]);
+         auto CW = [&](int c, int o, int i, int tap) { return cw[c][((size_t)o * ci[c] + i) * 3 + tap]; };
+         oh_conv[0] = pack(8, 13, [&](int o, int kb, int kq, int el) {
+            if (kb < 12) return CW(0, o, 32 * (kb & 3) + 8 * kq + el, kb >> 2);
+            return (kq < 3 && el == 0) ? CW(0, o, 128, kq) : 0.0f;           // channel 128 of tap kq
+         });
+         oh_conv[1] = pack(4, 12, [&](int o, int kb, int kq, int el) { return CW(1, o, 32 * (kb & 3) + 8 * kq + el, kb >> 2); });
+         oh_conv[2] = pack(4, 4, [&](int o, int kb, int kq, int el) { return CW(2, o, 32 * (kb & 1) + 8 * kq + el, 1 + (kb >> 1)); });      // taps 1, 2 (tap 0 only ever meets padding)
+         oh_conv[3] = pack(8, 2, [&](int o, int kb, int kq, int el) { return CW(3, o, 32 * kb + 8 * kq + el, 1); });                        // tap 1 (one input step)
+         oh_wih = pack(32, 4, [&](int r, int kb, int kq, int el) { return W[(size_t)r * 256 + 32 * kb + 8 * kq + el]; });
+      }
+   }
+   size_t o_eh = 0, o_wny = 0;
+   if (enc_ok) {
+      std::vector<float> ehf((eh.size() + 1) / 2);
+      memcpy(ehf.data(), eh.data(), eh.size() * sizeof(_Float16));
+      o_eh = pk.add(ehf.data(), ehf.size());
+      o_wny = pk.add(wny.data(), wny.size());
+   }
+   e->v5_enc_h3_ok = enc_ok;
    copy_unaligned(v, ts[10]); const size_t o_lb = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[11]); const size_t o_dw = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[12]); const size_t o_db = pk.add(v.data(), v.size());
@@ -923,6 +990,13 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
    for (int c = 0; c < 4; ++c) { e->v5.conv_f[c] = base + o_cf[c]; e->v5.conv_b[c] = base + o_cb[c]; }
    e->v5.whh_h = h3_ok ? reinterpret_cast<const _Float16 *>(base + o_whh_h) : nullptr;
    e->v5.wih_f = base + o_wih; e->v5.whh = base + o_whh; e->v5.lstm_b = base + o_lb; e->v5.dec_w = base + o_dw; e->v5.dec_b = base + o_db;
+   {
+      const _Float16 *hb = enc_ok ? reinterpret_cast<const _Float16 *>(base + o_eh) : nullptr;
+      e->v5.h_stft = enc_ok ? hb + oh_stft : nullptr;
+      for (int c = 0; c < 4; ++c) e->v5.h_conv[c] = enc_ok ? hb + oh_conv[c] : nullptr;
+      e->v5.h_wih = enc_ok ? hb + oh_wih : nullptr;
+      e->v5.wny = enc_ok ? base + o_wny : nullptr;
+   }
    return VADC_AMD_OK;
 }
 
@@ -1853,15 +1927,18 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       // Silero v5 shapes: encoder + LSTM input projection (+ the streams' new context), then LSTM(128) + decoder.  Small calls run on the caller's
       // stream; larger ones fork like the other models: stream A = encoder, stream B = the recurrence, so that the next call's encoder runs beside it
       const bool fp32 = e->lstm_variant == 3;
+      const bool enc_fp32 = e->encoder_variant == 3 || !e->v5_enc_h3_ok;      // option "encoder" = 3, or no split-fp16 operands: k_v5_encoder (fp32 MFMA)
+      e->last_frontend_kernel = enc_fp32 ? 1 : 2;
       auto enc = [&](float *gx, hipStream_t s_) {
-         if (sizeof(T) == 2) launch_v5_encoder_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, s_);
-         else                launch_v5_encoder_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, s_);
+         KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, s_);
+         if (sizeof(T) == 2) launch_v5_encoder_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, enc_fp32, s_);
+         else                launch_v5_encoder_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, enc_fp32, s_);
       };
       e->last_lstm_kernel = (fp32 || !e->v5.whh_h) ? 3 : 6;
       if ((long)n_streams * n_chunks < 2048) {
          wait_last_all(e, st);
          enc(e->d_gx5[0], st);
-         launch_v5_lstm(e->v5, e->d_gx5[0], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, st);
+         { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, st); launch_v5_lstm(e->v5, e->d_gx5[0], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, st); }
          record_last_on(e, st);
       } else {
          int rc5 = ensure_pipeline_streams(e, n_streams, 6);
@@ -1882,7 +1959,7 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
          (void)hipEventRecord(e->ev_fe[0], e->sA);
          e->last_a = e->ev_fe[0]; e->last_a_on = e->sA; e->ev_last_valid = true; e->last_on_valid = true;
          (void)hipStreamWaitEvent(e->sB, e->ev_fe[0], 0);
-         launch_v5_lstm(e->v5, e->d_gx5[xp], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, e->sB);
+         { KernelTimer t(e, VADC_AMD_KERNEL_LSTM, e->sB); launch_v5_lstm(e->v5, e->d_gx5[xp], e->d_h, e->d_c, d_probs, n_streams, n_chunks, fp32, e->sB); }
          (void)hipEventRecord(e->ev_b[xp], e->sB);
          e->ev_b_valid[xp] = true;
          e->last_b = e->last_c = e->ev_b[xp]; e->last_b_on = e->last_c_on = e->sB;

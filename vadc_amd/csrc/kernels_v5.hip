@@ -32,6 +32,14 @@ struct V5Weights {
                                // does not fit fp16's range; k_v5_lstm runs)
    const float *dec_w;         // [128]
    const float *dec_b;         // [1]
+   // k_v5_encoder_h3 (round 6): every A operand as split-fp16 fragments for v_mfma_f32_16x16x32_f16, x 256 (a power of two: exact), [m-tile][k-block][hi | lo][lane][8]:
+   // lane l holds row 16 mt + (l & 15), k = 32 kb + 8 (l >> 4) + e.  All null when a weight x 256 leaves fp16's range or the basis lacks the real-DFT fold symmetries
+   // (then k_v5_encoder, fp32 MFMA, serves).
+   const _Float16 *h_stft;     // [16][4]: m-tile t < 8 = re of bins 16 t + r, t >= 8 = im of bins 16 (t - 8) + r; k = fold slot (slot j pairs taps j + 1 and 255 - j)
+   const _Float16 *h_conv[4];  // conv 0: [8][13]  k-blocks 0..11 = (tap, channel block of 32 of channels 0..127), 12 = channel 128 of tap (l >> 4) in element 0
+                               // conv 1: [4][12]  (tap, 128 channels); conv 2: [4][4] taps 1, 2 x 64 channels (tap 0 only ever meets padding); conv 3: [8][2] tap 1
+   const _Float16 *h_wih;      // [32][4]
+   const float *wny;           // [128] bin 128's re weights by fold slot (unscaled fp32: that bin is a vector dot product in the fold)
 };
 
 constexpr int kV5Window = 512, kV5Context = 64, kV5Hidden = 128, kV5Gates = 512;
@@ -404,6 +412,252 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__
    }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// k_v5_encoder_h3 (round 6): the same stages on the fp16 matrix pipe at fp32 accuracy -- every contraction as three v_mfma_f32_16x16x32_f16 on split operands
+// (a = hi + lo: Al.Bh + Ah.Bl + Ah.Bh, fp32 accumulation; the form the v3.1 / v4 kernels use), 16 chunks per 512-thread workgroup.
+//  * STFT: REAL-INPUT FOLD as in the v4 front end (kernels_frontend_gemm2.hip): slot j = 0 .. 127 pairs taps j + 1 and 255 - j, s_j = x[j + 1] + x[255 - j] feeds the
+//    re rows, d_j = x[j + 1] - x[255 - j] the im rows (slot 127 pairs the centre tap with itself: re weight halved, im weight zero; tap 0's weight is zero) -- K = 128
+//    instead of 256.  Samples are kept as INTEGERS (s16 as they come; f32 x 32768), so a fold value of s16 input is a 17-bit integer: hi = round toward zero, lo = the
+//    exact rest.  Wave w owns the re AND the im rows of bins 16 w .. 16 w + 15 (its A fragments stay in 64 registers over both column passes): the magnitude
+//    is formed in registers.  Bin 128 (im row identically zero) is a 128-term dot product per column, done by the fold's threads in fp32.
+//  * Activations live in LDS as [hi | lo][column][channel] halves (pitch channels + 8: a lane's B fragment of a k-block is one 16-byte read per plane, its four output
+//    channels one 8-byte write per plane); magnitudes x 256 (bounded by 2^15: |x| <= 1 and the window sums to 128), conv outputs unscaled.
+//  * A k = 3 conv is a GEMM with K = (tap, channel) whose B fragment is read with the tap's column shift (zero outside the chunk); the weights' fragments stream from
+//    L2 once per workgroup (16 chunks: 39 KB per chunk) into registers ahead of their MFMAs.
+// Scales are powers of two: A x 256 everywhere, magnitudes x 256 => one fma(acc, 2^-8 or 2^-16, bias) in each epilogue.
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 v5h2 __attribute__((ext_vector_type(2)));
+typedef float v5f2 __attribute__((ext_vector_type(2)));
+constexpr int kH3Chunks = 16;                        // chunks per workgroup
+constexpr int kH3XP = 648;                           // floats per chunk row of the staged samples (640 + 8)
+constexpr int kH3P128 = 136, kH3P64 = 72;            // halves per column of a 128- / 64-channel activation plane
+
+struct V5Frag { v5h8 hi, lo; };
+__device__ __forceinline__ V5Frag v5_afrag(const _Float16 *base, int mt, int kbs, int kb, int lane)
+{
+   const v5h8 *p = reinterpret_cast<const v5h8 *>(base + ((size_t)(mt * kbs + kb) * 2) * 512 + lane * 8);
+   return V5Frag{p[0], p[64]};
+}
+__device__ __forceinline__ f4v5 v5_mfma3(const V5Frag &a, const v5h8 &bh, const v5h8 &bl, f4v5 acc)
+{
+   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, bh, acc, 0, 0, 0);
+   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, bl, acc, 0, 0, 0);
+   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, bh, acc, 0, 0, 0);
+}
+// two values -> packed (hi, lo) halves: hi = round toward zero (never overflows), lo = v - hi
+__device__ __forceinline__ void v5_split2(float a, float b, v5h2 &hi, v5h2 &lo)
+{
+   hi = __builtin_bit_cast(v5h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+   const v5f2 r = {a - (float)hi[0], b - (float)hi[1]};
+   lo = __builtin_convertvector(r, v5h2);
+}
+__device__ __forceinline__ void v5_split4_store(const float (&v)[4], _Float16 *hi_p, _Float16 *lo_p)
+{
+   v5h2 h0, l0, h1, l1;
+   v5_split2(v[0], v[1], h0, l0);
+   v5_split2(v[2], v[3], h1, l1);
+   *reinterpret_cast<v5h4 *>(hi_p) = (v5h4){h0[0], h0[1], h1[0], h1[1]};
+   *reinterpret_cast<v5h4 *>(lo_p) = (v5h4){l0[0], l0[1], l1[0], l1[1]};
+}
+
+// One conv stage (or the LSTM input projection) for ONE m-tile of 16 output channels and NN n-tiles of 16 columns starting at n-tile nt0.
+//   in: planes [hi | lo][columns][PIN]; K = NT taps (the first is tap TAP0) x CB channel blocks of 32, + (EXTRA) one block carrying channel 128 of tap (lane >> 4)
+//   OUTF = false: bias, ReLU, split, planes [hi | lo][columns][POUT];  OUTF = true: bias, fp32 rows of gx (the LSTM input projection)
+template <int CB, int NT, int TAP0, int TIN, int TOUT, int STRIDE, int NN, int PIN, int POUT, bool EXTRA, bool OUTF>
+__device__ __forceinline__ void v5_conv_h3(const _Float16 *__restrict__ in, int in_plane, _Float16 *__restrict__ out, int out_plane,
+                                           const _Float16 *__restrict__ wfrag, const float *__restrict__ bias, float scale, int mt, int nt0, int lane,
+                                           float *__restrict__ gx, int item0, int n_items)
+{
+   constexpr int KB = NT * CB + (EXTRA ? 1 : 0);
+   constexpr int NCOL = kH3Chunks * TOUT;
+   const int lc = lane & 15, kq = lane >> 4;
+   V5Frag a[KB];
+#pragma unroll
+   for (int kb = 0; kb < KB; ++kb) a[kb] = v5_afrag(wfrag, mt, KB, kb, lane);
+   const float4 b4 = *reinterpret_cast<const float4 *>(bias + 16 * mt + 4 * kq);
+   f4v5 acc[NN];
+#pragma unroll
+   for (int ni = 0; ni < NN; ++ni) acc[ni] = (f4v5){0.0f, 0.0f, 0.0f, 0.0f};
+   const v5h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+   for (int ti = 0; ti < NT; ++ti) {
+      const int tap = TAP0 + ti;
+#pragma unroll
+      for (int ni = 0; ni < NN; ++ni) {
+         const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT, q = t * STRIDE + tap - 1;
+         const bool ok = col < NCOL && q >= 0 && q < TIN;
+         const _Float16 *src = in + (size_t)(ok ? j * TIN + q : 0) * PIN + 8 * kq;
+#pragma unroll
+         for (int cb = 0; cb < CB; ++cb) {
+            v5h8 bh = *reinterpret_cast<const v5h8 *>(src + 32 * cb), bl = *reinterpret_cast<const v5h8 *>(src + in_plane + 32 * cb);
+            if (!ok) { bh = zero; bl = zero; }
+            acc[ni] = v5_mfma3(a[ti * CB + cb], bh, bl, acc[ni]);
+         }
+      }
+   }
+   if (EXTRA) {                                         // channel 128 (bin 128): k slot 8 tap + 0 = this lane's tap kq (kq = 3: nothing)
+#pragma unroll
+      for (int ni = 0; ni < NN; ++ni) {
+         const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT, q = t * STRIDE + kq - 1;
+         const bool ok = col < NCOL && kq < 3 && q >= 0 && q < TIN;
+         const _Float16 *src = in + (size_t)(ok ? j * TIN + q : 0) * PIN + 128;
+         v5h8 bh = *reinterpret_cast<const v5h8 *>(src), bl = *reinterpret_cast<const v5h8 *>(src + in_plane);
+         if (!ok) { bh = zero; bl = zero; }
+         acc[ni] = v5_mfma3(a[KB - 1], bh, bl, acc[ni]);
+      }
+   }
+#pragma unroll
+   for (int ni = 0; ni < NN; ++ni) {
+      const int col = 16 * (nt0 + ni) + lc;
+      float v[4] = {fmaf(acc[ni][0], scale, b4.x), fmaf(acc[ni][1], scale, b4.y), fmaf(acc[ni][2], scale, b4.z), fmaf(acc[ni][3], scale, b4.w)};
+      if (OUTF) {
+         if (col < NCOL && item0 + col < n_items) *reinterpret_cast<float4 *>(gx + (size_t)(item0 + col) * kV5Gates + 16 * mt + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (col < NCOL) {
+#pragma unroll
+         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+         _Float16 *o = out + (size_t)col * POUT + 16 * mt + 4 * kq;
+         v5_split4_store(v, o, o + out_plane);
+      }
+   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void k_v5_encoder_h3(const T *__restrict__ pcm,       // [S][C][512]
+                                                          const float *__restrict__ ctx,   // [S][64]
+                                                          V5Weights w,
+                                                          float *__restrict__ gx,          // [S * C][512]
+                                                          int n_items, int n_chunks)
+{
+   // region A: staged samples (integers as fp32) + the fold planes of one column pass; later conv 0's output.  region B: magnitudes; later conv 1 / 2 / 3's outputs
+   constexpr int kXBytes = kH3Chunks * kH3XP * 4;                       // 41,472
+   constexpr int kBFPlane = 32 * kH3P128;                               // halves per fold plane (32 columns x 128 slots)
+   constexpr int kABytes = kXBytes + 4 * kBFPlane * 2;                  // 76,288
+   constexpr int kMGPlane = 64 * kH3P128;                               // halves per magnitude / conv 0 plane (64 columns)
+   constexpr int kBBytes = 2 * kMGPlane * 2;                            // 34,816
+   constexpr int kC1Plane = 32 * kH3P64, kC2Plane = 16 * kH3P64, kC3Plane = 16 * kH3P128;
+   static_assert(2 * (kC1Plane + kC2Plane + kC3Plane) * 2 <= kBBytes, "conv 1-3 outputs fit the magnitude region");
+   __shared__ __attribute__((aligned(16))) unsigned char RA[kABytes];
+   __shared__ __attribute__((aligned(16))) unsigned char RB[kBBytes];
+   __shared__ float NYs[32];
+   float *X = reinterpret_cast<float *>(RA);
+   _Float16 *BF = reinterpret_cast<_Float16 *>(RA + kXBytes);           // [s hi, s lo, d hi, d lo][32 columns][136]
+   _Float16 *C0 = reinterpret_cast<_Float16 *>(RA);                     // [hi | lo][64][136]
+   _Float16 *MG = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo][64][136]: channels 0..127 = bins, 128 = bin 128, 129..135 = 0
+   _Float16 *C1 = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo][32][72]
+   _Float16 *C2 = C1 + 2 * kC1Plane;                                    // [hi | lo][16][72]
+   _Float16 *C3 = C2 + 2 * kC2Plane;                                    // [hi | lo][16][136]
+   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int lc = lane & 15, kq = lane >> 4;
+   const int item0 = blockIdx.x * kH3Chunks;
+
+   // this wave's STFT A fragments: re tile `wave`, im tile 8 + `wave`, 4 k-blocks each: 64 registers, used by both column passes
+   V5Frag are[4], aim[4];
+#pragma unroll
+   for (int kb = 0; kb < 4; ++kb) { are[kb] = v5_afrag(w.h_stft, wave, 4, kb, lane); aim[kb] = v5_afrag(w.h_stft, 8 + wave, 4, kb, lane); }
+
+   // ---- stage: [context 64 | window 512 | reflect 64] per chunk as integers (s16 as they are, f32 x 32768) ----
+   for (int i = tid; i < kH3Chunks * 640; i += 512) {
+      const int j = i / 640, p = i - j * 640;
+      const int item = min(item0 + j, n_items - 1);
+      const int s = item / n_chunks, c = item - s * n_chunks;
+      const int q = p < 576 ? p : 2 * 575 - p;                           // F.pad(input, (0, 64), "reflect"): padded[576 + k] = input[574 - k]
+      constexpr float kToInt = sizeof(T) == 2 ? 1.0f : 32768.0f;          // s16 samples are integers already; f32 samples are in [-1, 1)
+      float v;
+      if (q >= kV5Context) v = (float)pcm[(size_t)item * kV5Window + (q - kV5Context)] * kToInt;
+      else if (c > 0)      v = (float)pcm[(size_t)(item - 1) * kV5Window + (kV5Window - kV5Context + q)] * kToInt;     // the previous window's tail (vadc.c:132-135)
+      else                 v = ctx[(size_t)s * kV5Context + q] * 32768.0f;                                           // carried from the previous call (vadc.c:124): kept / 32768 for either type
+      X[j * kH3XP + p] = v;
+   }
+   __syncthreads();
+
+   const int fq = tid & 15, fcol = tid >> 4;                              // the fold: thread = (column of the pass, slots 8 fq .. 8 fq + 7)
+   float wny[8];
+#pragma unroll
+   for (int e = 0; e < 8; ++e) wny[e] = w.wny[8 * fq + e];
+#pragma unroll 1
+   for (int pass = 0; pass < 2; ++pass) {
+      {
+         const int gcol = 32 * pass + fcol, j = gcol >> 2, fr = gcol & 3;
+         const float *x = X + j * kH3XP + 128 * fr;
+         const float4 d0 = *reinterpret_cast<const float4 *>(x + 8 * fq), d1 = *reinterpret_cast<const float4 *>(x + 8 * fq + 4);
+         const float d8 = x[8 * fq + 8];
+         const float4 m0 = *reinterpret_cast<const float4 *>(x + 248 - 8 * fq), m1 = *reinterpret_cast<const float4 *>(x + 252 - 8 * fq);
+         const float dv[8] = {d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d8};                // x[8 fq + 1 + e]
+         const float mv[8] = {m1.w, m1.z, m1.y, m1.x, m0.w, m0.z, m0.y, m0.x};              // x[255 - 8 fq - e]
+         float sv[8], dd[8];
+#pragma unroll
+         for (int e = 0; e < 8; ++e) { sv[e] = dv[e] + mv[e]; dd[e] = dv[e] - mv[e]; }
+         v5h8 sh, sl, dh, dl;
+#pragma unroll
+         for (int e = 0; e < 8; e += 2) {
+            v5h2 hi, lo;
+            v5_split2(sv[e], sv[e + 1], hi, lo); sh[e] = hi[0]; sh[e + 1] = hi[1]; sl[e] = lo[0]; sl[e + 1] = lo[1];
+            v5_split2(dd[e], dd[e + 1], hi, lo); dh[e] = hi[0]; dh[e + 1] = hi[1]; dl[e] = lo[0]; dl[e + 1] = lo[1];
+         }
+         _Float16 *bp = BF + (size_t)fcol * kH3P128 + 8 * fq;
+         *reinterpret_cast<v5h8 *>(bp) = sh;
+         *reinterpret_cast<v5h8 *>(bp + kBFPlane) = sl;
+         *reinterpret_cast<v5h8 *>(bp + 2 * kBFPlane) = dh;
+         *reinterpret_cast<v5h8 *>(bp + 3 * kBFPlane) = dl;
+         float ny = wny[0] * sv[0];
+#pragma unroll
+         for (int e = 1; e < 8; ++e) ny = fmaf(wny[e], sv[e], ny);
+         ny += __shfl_xor(ny, 1); ny += __shfl_xor(ny, 2); ny += __shfl_xor(ny, 4); ny += __shfl_xor(ny, 8);      // the 16 threads of a column are 16 consecutive lanes
+         if (fq == 0) NYs[fcol] = ny;                                       // 2^15 x re of bin 128
+      }
+      __syncthreads();
+      {
+         f4v5 ar[2], ai[2];
+#pragma unroll
+         for (int ni = 0; ni < 2; ++ni) { ar[ni] = (f4v5){0.0f, 0.0f, 0.0f, 0.0f}; ai[ni] = ar[ni]; }
+#pragma unroll
+         for (int ni = 0; ni < 2; ++ni) {
+            const _Float16 *bp = BF + (size_t)(16 * ni + lc) * kH3P128 + 8 * kq;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+               const v5h8 s_h = *reinterpret_cast<const v5h8 *>(bp + 32 * kb), s_l = *reinterpret_cast<const v5h8 *>(bp + kBFPlane + 32 * kb);
+               const v5h8 d_h = *reinterpret_cast<const v5h8 *>(bp + 2 * kBFPlane + 32 * kb), d_l = *reinterpret_cast<const v5h8 *>(bp + 3 * kBFPlane + 32 * kb);
+               ar[ni] = v5_mfma3(are[kb], s_h, s_l, ar[ni]);
+               ai[ni] = v5_mfma3(aim[kb], d_h, d_l, ai[ni]);
+            }
+         }
+         // accumulators = 2^23 x (re, im); magnitudes are kept x 2^8: sqrt(.) x 2^-15
+#pragma unroll
+         for (int ni = 0; ni < 2; ++ni) {
+            float m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = __builtin_amdgcn_sqrtf(fmaf(ar[ni][r], ar[ni][r], ai[ni][r] * ai[ni][r])) * 3.0517578125e-05f;
+            _Float16 *o = MG + (size_t)(32 * pass + 16 * ni + lc) * kH3P128 + 16 * wave + 4 * kq;
+            v5_split4_store(m, o, o + kMGPlane);
+         }
+         if (tid < 32) {                                                   // bin 128 and the zero channels behind it: 2^8 x |re| = |NYs| x 2^-7
+            v5h2 hi, lo;
+            v5_split2(fabsf(NYs[tid]) * 0.0078125f, 0.0f, hi, lo);
+            _Float16 *o = MG + (size_t)(32 * pass + tid) * kH3P128 + 128;
+            *reinterpret_cast<v5h8 *>(o) = (v5h8){hi[0], 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<v5h8 *>(o + kMGPlane) = (v5h8){lo[0], 0, 0, 0, 0, 0, 0, 0};
+         }
+      }
+      __syncthreads();
+   }
+   // conv 0: [129, 4] -> [128, 4]: wave = m-tile, four n-tiles (64 columns); A x 256, magnitudes x 256 => 2^-16
+   v5_conv_h3<4, 3, 0, 4, 4, 1, 4, kH3P128, kH3P128, true, false>(MG, kMGPlane, C0, kMGPlane, w.h_conv[0], w.conv_b[0], 1.52587890625e-05f, wave, 0, lane, nullptr, 0, 0);
+   __syncthreads();
+   // conv 1: [128, 4] -> [64, 2], stride 2: wave = (m-tile wave & 3, n-tile wave >> 2)
+   v5_conv_h3<4, 3, 0, 4, 2, 2, 1, kH3P128, kH3P64, false, false>(C0, kMGPlane, C1, kC1Plane, w.h_conv[1], w.conv_b[1], 0.00390625f, wave & 3, wave >> 2, lane, nullptr, 0, 0);
+   __syncthreads();
+   // conv 2: [64, 2] -> [64, 1], stride 2: taps 1 and 2 (tap 0 reads step -1: padding); waves 0-3
+   if (wave < 4) v5_conv_h3<2, 2, 1, 2, 1, 2, 1, kH3P64, kH3P64, false, false>(C1, kC1Plane, C2, kC2Plane, w.h_conv[2], w.conv_b[2], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
+   __syncthreads();
+   // conv 3: [64, 1] -> [128, 1]: tap 1 only
+   v5_conv_h3<2, 1, 1, 1, 1, 1, 1, kH3P64, kH3P128, false, false>(C2, kC2Plane, C3, kC3Plane, w.h_conv[3], w.conv_b[3], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
+   __syncthreads();
+   // LSTM input projection: GX[item][512] = W_ih [512 x 128] . c3 [128 x 16 chunks] + (b_ih + b_hh): wave owns m-tiles 4 w .. 4 w + 3
+#pragma unroll 1
+   for (int mi = 0; mi < 4; ++mi)
+      v5_conv_h3<4, 1, 1, 1, 1, 1, 1, kH3P128, 0, false, true>(C3, kC3Plane, nullptr, 0, w.h_wih, w.lstm_b, 0.00390625f, 4 * wave + mi, 0, lane, gx, item0, n_items);
+}
+
 template <typename T>
 __global__ void k_v5_context(const T *__restrict__ pcm, float *__restrict__ ctx, int n_streams, int n_chunks)
 {
@@ -415,19 +669,21 @@ __global__ void k_v5_context(const T *__restrict__ pcm, float *__restrict__ ctx,
 
 // front half of a call: encoder + LSTM input projection -> gx, then the streams' new context (read by the next call's encoder on the same stream)
 template <typename T>
-static void launch_v5_enc_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
+static void launch_v5_enc_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
 {
    const int n_items = n_streams * n_chunks;
-   hipLaunchKernelGGL((k_v5_encoder<T>), dim3((n_items + kV5Chunks - 1) / kV5Chunks), dim3(256), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
+   if (!fp32 && w.h_stft) hipLaunchKernelGGL((k_v5_encoder_h3<T>), dim3((n_items + kH3Chunks - 1) / kH3Chunks), dim3(512), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
+   else                   hipLaunchKernelGGL((k_v5_encoder<T>), dim3((n_items + kV5Chunks - 1) / kV5Chunks), dim3(256), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
    hipLaunchKernelGGL((k_v5_context<T>), dim3((n_streams * kV5Context + 255) / 256), dim3(256), 0, st, pcm, ctx, n_streams, n_chunks);
 }
-void launch_v5_encoder_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
+// fp32 = true (or no split-fp16 operands: a weight outside fp16's range, a basis without the fold symmetries): k_v5_encoder, fp32 MFMA
+void launch_v5_encoder_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
 {
-   launch_v5_enc_t<float>(pcm, ctx, w, gx, n_streams, n_chunks, st);
+   launch_v5_enc_t<float>(pcm, ctx, w, gx, n_streams, n_chunks, fp32, st);
 }
-void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, hipStream_t st)
+void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
 {
-   launch_v5_enc_t<int16_t>(pcm, ctx, w, gx, n_streams, n_chunks, st);
+   launch_v5_enc_t<int16_t>(pcm, ctx, w, gx, n_streams, n_chunks, fp32, st);
 }
 // back half: the recurrence + decoder over the call's chunks.  fp32 = true (or no split-fp16 weights): W_hh h as fp32 MFMAs
 void launch_v5_lstm(const V5Weights &w, const float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, bool fp32, hipStream_t st)
