@@ -481,6 +481,50 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
     return out
 
 
+def side_config_v5(torch, blob, dev, local_rank, S, Cn, steps=60, warmup=10):
+    """Silero v5 SHAPES (process_chunks_v5 vadc.c:105-162, silero_vad.py:290-434) on seeded weights -- the reference ships none, so this is no
+    BASELINE config: S streams x Cn 512-sample windows (32 ms each) per call, s16 resident in HBM, deferred joins (the encoder of call k + 1 beside the recurrence
+    of call k).  value = audio-seconds per second; the encoder's executed split-fp16 MFMA FLOP against the fp16 matrix peak."""
+    from vadc_amd import synth
+    from vadc_amd.engine import Engine
+    W = 512
+    eng = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=local_rank)
+    NB = 3
+    base = synth.make_streams(16, -(-NB * Cn * W // 1536), seed0=11)[:, :NB * Cn * W]
+    pcm = np.ascontiguousarray(np.tile(base, (-(-S // 16), 1))[:S])
+    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * W:(i + 1) * Cn * W])).to(dev) for i in range(NB)]
+    d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
+    st = torch.cuda.Stream()
+    eng.set_option("defer_join", 1)
+
+    def step(i):
+        eng.run_device(d_in[i % NB].data_ptr(), np.int16, S, Cn, d_out[i % NB].data_ptr(), st.cuda_stream)
+    for i in range(2 * NB + warmup):
+        step(i)
+    torch.cuda.synchronize()
+    eng.reset_kernel_times()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.set_profiling(i % 8 == min(3, steps - 1))
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    kt = {k: ms / n for k, (n, ms) in eng.kernel_times().items() if n}
+    # k_v5_encoder_h3 per tile of 16 windows, v_mfma_f32_16x16x32_f16 (16,384 FLOP each, three per fp32 product): folded STFT 768, conv 0 1,248, conv 1 288,
+    # conv 2 48, conv 3 48, W_ih 384 = 2,784 -> 174 per window
+    exe = 174 * 16384
+    out = {"value": round(S * Cn * steps * (W / 16000.0) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "window": W,
+           "encoder_kernel": {1: "k_v5_encoder (fp32 MFMA)", 2: "k_v5_encoder_h3 (split-fp16 MFMA)"}.get(eng.get_option("frontend_kernel")),
+           "kernels_ms": {k: round(v, 4) for k, v in kt.items()},
+           "note": "Silero v5 shapes on SEEDED weights (the reference ships none): not a BASELINE config"}
+    if "k_frontend" in kt and eng.get_option("frontend_kernel") == 2:
+        out["roofline_kernel"] = "k_frontend"
+        out["roofline_frac"] = round(exe * S * Cn / (kt["k_frontend"] * 1e-3) / 1e12 / PEAKS["fp16"], 4)
+    eng.close()
+    return out
+
+
 def one_gpu_figures(path):
     """the 1-GPU figures an N-rank run compares itself with: written by the N = 1 run of this bench (same box, same tree), or handed over with --one-gpu-json"""
     try:
@@ -768,6 +812,10 @@ def run_rank(args, world, rank, local_rank):
                               # BASELINE config 4: Silero v4 at 4096 streams.  Last: an engine created in front of the 10,240 x 1 configuration moved that one's internal
                               # streams onto other hardware queues and cost it 40 % (1.80 against 2.94 M alone and in this order: DESIGN.md section 6)
                               "v4_4096x16": side_config(torch, blob_v4, dev, local_rank, "v4", 4096, 16, 0, steps=100, warmup=10)}
+            # Silero v5 shapes, after every BASELINE configuration: 256 streams x 288 windows (= 96 v3.1 chunks of audio per stream and call) and 4096 x 48
+            blob_v5 = open(os.path.join(ROOT, "tests", "golden", "silero_v5_seeded.testtensor"), "rb").read()
+            out["configs"]["v5_256x288"] = side_config_v5(torch, blob_v5, dev, local_rank, 256, 288)
+            out["configs"]["v5_4096x48"] = side_config_v5(torch, blob_v5, dev, local_rank, 4096, 48)
         if cpu is not None:
             out["cpu_baseline"] = cpu
 
@@ -816,7 +864,7 @@ def run_rank(args, world, rank, local_rank):
             line["cpu_baseline"] = c
         line["details"] = os.path.relpath(os.path.abspath(args.details), ROOT)
         if "configs" in line:
-            line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk != "kernels_ms"} for k, v in out["configs"].items()}
+            line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("kernels_ms", "note")} for k, v in out["configs"].items()}
         print(json.dumps(line, separators=(",", ":")), flush=True)
     if eng is not None:
         eng.close()

@@ -414,23 +414,26 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 // k_v5_encoder_h3 (round 6): the same stages on the fp16 matrix pipe at fp32 accuracy -- every contraction as three v_mfma_f32_16x16x32_f16 on split operands
-// (a = hi + lo: Al.Bh + Ah.Bl + Ah.Bh, fp32 accumulation; the form the v3.1 / v4 kernels use), 16 chunks per 512-thread workgroup.
+// (a = hi + lo: Al.Bh + Ah.Bl + Ah.Bh, fp32 accumulation; the form the v3.1 / v4 kernels use), 16 chunks per 512-thread workgroup, TWO workgroups per CU (<= 80 KB
+// of LDS and <= 128 registers for s16 input), so that one workgroup's vector / LDS phases run under the other's matrix phases.
 //  * STFT: REAL-INPUT FOLD as in the v4 front end (kernels_frontend_gemm2.hip): slot j = 0 .. 127 pairs taps j + 1 and 255 - j, s_j = x[j + 1] + x[255 - j] feeds the
 //    re rows, d_j = x[j + 1] - x[255 - j] the im rows (slot 127 pairs the centre tap with itself: re weight halved, im weight zero; tap 0's weight is zero) -- K = 128
-//    instead of 256.  Samples are kept as INTEGERS (s16 as they come; f32 x 32768), so a fold value of s16 input is a 17-bit integer: hi = round toward zero, lo = the
-//    exact rest.  Wave w owns the re AND the im rows of bins 16 w .. 16 w + 15 (its A fragments stay in 64 registers over both column passes): the magnitude
-//    is formed in registers.  Bin 128 (im row identically zero) is a 128-term dot product per column, done by the fold's threads in fp32.
-//  * Activations live in LDS as [hi | lo][column][channel] halves (pitch channels + 8: a lane's B fragment of a k-block is one 16-byte read per plane, its four output
-//    channels one 8-byte write per plane); magnitudes x 256 (bounded by 2^15: |x| <= 1 and the window sums to 128), conv outputs unscaled.
+//    instead of 256.  Samples stay INTEGERS (s16 as they come, in LDS as s16; f32 x 32768 as fp32), so a fold value of s16 input is a 17-bit integer: hi = round
+//    toward zero, lo = the exact rest.  Wave w owns the re AND the im rows of bins 16 w .. 16 w + 15 (its A fragments stay in 64 registers over the four column
+//    passes of 16 columns): the magnitude is formed in registers.  Bin 128 (im row identically zero) is a 128-term fp32 dot product per column, done by the fold.
+//  * Activations live in LDS PIECE-MAJOR: plane [hi | lo][k quarter kq][channel block kb][column][8 halves], channel = 32 kb + 8 kq + e -- the 16-byte B fragment of
+//    lane (column lc, quarter kq) of a k-block; the 16 lanes of a ds_read_b128 group (two quarters x 8 columns each, MI355X_MICROARCH.md LDS table) then read 16
+//    consecutive 16-byte pieces of one or two piece planes whose distance is a multiple of 256 B: conflict-free.  ([column][channel] with pitch 136 -- the LSTM
+//    kernels' h tile -- is 2-way conflicted in every group: 48 % of this kernel's LDS cycles in its first form.)  Magnitudes are kept x 256 (bounded by 2^15:
+//    |x| <= 1 and the window sums to 128), conv outputs unscaled.
 //  * A k = 3 conv is a GEMM with K = (tap, channel) whose B fragment is read with the tap's column shift (zero outside the chunk); the weights' fragments stream from
-//    L2 once per workgroup (16 chunks: 39 KB per chunk) into registers ahead of their MFMAs.
+//    L2 once per workgroup (39 KB per chunk) through a rolling window of four k-blocks of registers.
 // Scales are powers of two: A x 256 everywhere, magnitudes x 256 => one fma(acc, 2^-8 or 2^-16, bias) in each epilogue.
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 typedef _Float16 v5h2 __attribute__((ext_vector_type(2)));
 typedef float v5f2 __attribute__((ext_vector_type(2)));
 constexpr int kH3Chunks = 16;                        // chunks per workgroup
-constexpr int kH3XP = 648;                           // floats per chunk row of the staged samples (640 + 8)
-constexpr int kH3P128 = 136, kH3P64 = 72;            // halves per column of a 128- / 64-channel activation plane
+constexpr int kH3Pre = 4;                            // k-blocks of A fragments in flight ahead of their MFMAs
 
 struct V5Frag { v5h8 hi, lo; };
 __device__ __forceinline__ V5Frag v5_afrag(const _Float16 *base, int mt, int kbs, int kb, int lane)
@@ -459,203 +462,227 @@ __device__ __forceinline__ void v5_split4_store(const float (&v)[4], _Float16 *h
    *reinterpret_cast<v5h4 *>(hi_p) = (v5h4){h0[0], h0[1], h1[0], h1[1]};
    *reinterpret_cast<v5h4 *>(lo_p) = (v5h4){l0[0], l0[1], l1[0], l1[1]};
 }
+// piece-major activation plane of CBS channel blocks x COLS columns: halves offset of the 8-half piece (quarter kq, block kb, column col)
+template <int CBS, int COLS> __device__ __forceinline__ int v5_piece(int kq, int kb, int col) { return ((kq * CBS + kb) * COLS + col) * 8; }
+// The fold planes are WRITTEN by lanes that differ in (kq, kb) at one column -- 8 pieces a multiple of 256 B apart: 8-way conflicted as they stand (43 % of the
+// kernel's LDS cycles) -- so their column index is XOR-swizzled by a value from {0..3, 12..15} chosen by (kq, kb & 1): distinct mod 8 (the 8 pieces of a
+// ds_write_b64 group land on 8 different bank quads), and bits 3 and 2 equal, which keeps a column inside its half of a ds_read_b128 lane group
+// ({0-3, 12-15} / {4-11}) -- the MFMA's fragment reads stay conflict-free.
+__device__ __forceinline__ int v5_bf_piece(int kq, int kb, int col)
+{
+   const int i = kq + 4 * (kb & 1);
+   return ((kq * 4 + kb) * 16 + (col ^ (i < 4 ? i : i + 8))) * 8;
+}
+// ... and of the four output channels 16 mt + 4 q4 .. + 3 of an accumulator (m-tile mt, accumulator quad q4) at column col
+template <int CBS, int COLS> __device__ __forceinline__ int v5_out4(int mt, int q4, int col) { return v5_piece<CBS, COLS>((2 * mt + (q4 >> 1)) & 3, mt >> 1, col) + 4 * (q4 & 1); }
 
 // One conv stage (or the LSTM input projection) for ONE m-tile of 16 output channels and NN n-tiles of 16 columns starting at n-tile nt0.
-//   in: planes [hi | lo][columns][PIN]; K = NT taps (the first is tap TAP0) x CB channel blocks of 32, + (EXTRA) one block carrying channel 128 of tap (lane >> 4)
-//   OUTF = false: bias, ReLU, split, planes [hi | lo][columns][POUT];  OUTF = true: bias, fp32 rows of gx (the LSTM input projection)
-template <int CB, int NT, int TAP0, int TIN, int TOUT, int STRIDE, int NN, int PIN, int POUT, bool EXTRA, bool OUTF>
-__device__ __forceinline__ void v5_conv_h3(const _Float16 *__restrict__ in, int in_plane, _Float16 *__restrict__ out, int out_plane,
+//   in: planes [hi | lo] piece-major, CB channel blocks x ICOLS columns; K = NT taps (the first is tap TAP0) x CB blocks of 32 channels, + (EXTRA) one block carrying
+//       channel 128 (x128: [hi | lo][ICOLS] halves) of tap (lane >> 4)
+//   OUTF = false: bias, ReLU, split, planes [hi | lo] piece-major OCB x OCOLS;  OUTF = true: bias, fp32 rows of gx (the LSTM input projection)
+template <int CB, int NT, int TAP0, int TIN, int TOUT, int STRIDE, int NN, int OCB, bool EXTRA, bool OUTF>
+__device__ __forceinline__ void v5_conv_h3(const _Float16 *__restrict__ in, const _Float16 *__restrict__ x128, _Float16 *__restrict__ out,
                                            const _Float16 *__restrict__ wfrag, const float *__restrict__ bias, float scale, int mt, int nt0, int lane,
                                            float *__restrict__ gx, int item0, int n_items)
 {
    constexpr int KB = NT * CB + (EXTRA ? 1 : 0);
-   constexpr int NCOL = kH3Chunks * TOUT;
+   constexpr int ICOLS = kH3Chunks * TIN, OCOLS = kH3Chunks * TOUT;
+   constexpr int in_plane = 4 * CB * ICOLS * 8, out_plane = 4 * OCB * OCOLS * 8;
+   constexpr int PRE = KB < kH3Pre ? KB : kH3Pre;
    const int lc = lane & 15, kq = lane >> 4;
-   V5Frag a[KB];
+   V5Frag a[KB];                                        // (fully unrolled below: at most PRE of them are live at a time)
 #pragma unroll
-   for (int kb = 0; kb < KB; ++kb) a[kb] = v5_afrag(wfrag, mt, KB, kb, lane);
+   for (int kb = 0; kb < PRE; ++kb) a[kb] = v5_afrag(wfrag, mt, KB, kb, lane);
    const float4 b4 = *reinterpret_cast<const float4 *>(bias + 16 * mt + 4 * kq);
    f4v5 acc[NN];
+   int icol[NN][NT];                                    // input column of this lane's output column per tap, -1 = padding
 #pragma unroll
-   for (int ni = 0; ni < NN; ++ni) acc[ni] = (f4v5){0.0f, 0.0f, 0.0f, 0.0f};
+   for (int ni = 0; ni < NN; ++ni) {
+      acc[ni] = (f4v5){0.0f, 0.0f, 0.0f, 0.0f};
+      const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) { const int q = t * STRIDE + TAP0 + ti - 1; icol[ni][ti] = (q >= 0 && q < TIN) ? j * TIN + q : -1; }
+   }
    const v5h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-   for (int ti = 0; ti < NT; ++ti) {
-      const int tap = TAP0 + ti;
+   for (int kb = 0; kb < KB; ++kb) {
+      if (kb < NT * CB) {
+         const int ti = kb / CB, cb = kb - ti * CB;
 #pragma unroll
-      for (int ni = 0; ni < NN; ++ni) {
-         const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT, q = t * STRIDE + tap - 1;
-         const bool ok = col < NCOL && q >= 0 && q < TIN;
-         const _Float16 *src = in + (size_t)(ok ? j * TIN + q : 0) * PIN + 8 * kq;
+         for (int ni = 0; ni < NN; ++ni) {
+            const int ic = icol[ni][ti];
+            const _Float16 *src = in + v5_piece<CB, ICOLS>(kq, cb, ic < 0 ? 0 : ic);
+            v5h8 bh = *reinterpret_cast<const v5h8 *>(src), bl = *reinterpret_cast<const v5h8 *>(src + in_plane);
+            if (ic < 0) { bh = zero; bl = zero; }
+            acc[ni] = v5_mfma3(a[kb], bh, bl, acc[ni]);
+         }
+      } else {                                          // channel 128 (bin 128): k slot 8 tap + 0 = this lane's tap kq (kq = 3: nothing)
 #pragma unroll
-         for (int cb = 0; cb < CB; ++cb) {
-            v5h8 bh = *reinterpret_cast<const v5h8 *>(src + 32 * cb), bl = *reinterpret_cast<const v5h8 *>(src + in_plane + 32 * cb);
-            if (!ok) { bh = zero; bl = zero; }
-            acc[ni] = v5_mfma3(a[ti * CB + cb], bh, bl, acc[ni]);
+         for (int ni = 0; ni < NN; ++ni) {
+            const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT, q = t * STRIDE + kq - 1;
+            const bool ok = kq < 3 && q >= 0 && q < TIN;
+            const int ic = ok ? j * TIN + q : 0;
+            v5h8 bh = zero, bl = zero;
+            bh[0] = ok ? x128[ic] : (_Float16)0; bl[0] = ok ? x128[ICOLS + ic] : (_Float16)0;
+            acc[ni] = v5_mfma3(a[kb], bh, bl, acc[ni]);
          }
       }
-   }
-   if (EXTRA) {                                         // channel 128 (bin 128): k slot 8 tap + 0 = this lane's tap kq (kq = 3: nothing)
-#pragma unroll
-      for (int ni = 0; ni < NN; ++ni) {
-         const int col = 16 * (nt0 + ni) + lc, j = col / TOUT, t = col - j * TOUT, q = t * STRIDE + kq - 1;
-         const bool ok = col < NCOL && kq < 3 && q >= 0 && q < TIN;
-         const _Float16 *src = in + (size_t)(ok ? j * TIN + q : 0) * PIN + 128;
-         v5h8 bh = *reinterpret_cast<const v5h8 *>(src), bl = *reinterpret_cast<const v5h8 *>(src + in_plane);
-         if (!ok) { bh = zero; bl = zero; }
-         acc[ni] = v5_mfma3(a[KB - 1], bh, bl, acc[ni]);
-      }
+      if (kb + PRE < KB) a[kb + PRE] = v5_afrag(wfrag, mt, KB, kb + PRE, lane);
    }
 #pragma unroll
    for (int ni = 0; ni < NN; ++ni) {
       const int col = 16 * (nt0 + ni) + lc;
       float v[4] = {fmaf(acc[ni][0], scale, b4.x), fmaf(acc[ni][1], scale, b4.y), fmaf(acc[ni][2], scale, b4.z), fmaf(acc[ni][3], scale, b4.w)};
       if (OUTF) {
-         if (col < NCOL && item0 + col < n_items) *reinterpret_cast<float4 *>(gx + (size_t)(item0 + col) * kV5Gates + 16 * mt + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
-      } else if (col < NCOL) {
+         if (item0 + col < n_items) *reinterpret_cast<float4 *>(gx + (size_t)(item0 + col) * kV5Gates + 16 * mt + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
 #pragma unroll
          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-         _Float16 *o = out + (size_t)col * POUT + 16 * mt + 4 * kq;
+         _Float16 *o = out + v5_out4<OCB, OCOLS>(mt, kq, col);
          v5_split4_store(v, o, o + out_plane);
       }
    }
 }
 
+template <typename T> struct V5X;                       // how the staged samples are kept in LDS
+template <> struct V5X<int16_t> { typedef int16_t type; };
+template <> struct V5X<float> { typedef float type; };
+
 template <typename T>
-__global__ __launch_bounds__(512, 1) void k_v5_encoder_h3(const T *__restrict__ pcm,       // [S][C][512]
+__global__ __launch_bounds__(512, 2) void k_v5_encoder_h3(const T *__restrict__ pcm,       // [S][C][512]
                                                           const float *__restrict__ ctx,   // [S][64]
                                                           V5Weights w,
                                                           float *__restrict__ gx,          // [S * C][512]
                                                           int n_items, int n_chunks)
 {
-   // region A: staged samples (integers as fp32) + the fold planes of one column pass; later conv 0's output.  region B: magnitudes; later conv 1 / 2 / 3's outputs
-   constexpr int kXBytes = kH3Chunks * kH3XP * 4;                       // 41,472
-   constexpr int kBFPlane = 32 * kH3P128;                               // halves per fold plane (32 columns x 128 slots)
-   constexpr int kABytes = kXBytes + 4 * kBFPlane * 2;                  // 76,288
-   constexpr int kMGPlane = 64 * kH3P128;                               // halves per magnitude / conv 0 plane (64 columns)
-   constexpr int kBBytes = 2 * kMGPlane * 2;                            // 34,816
-   constexpr int kC1Plane = 32 * kH3P64, kC2Plane = 16 * kH3P64, kC3Plane = 16 * kH3P128;
+   typedef typename V5X<T>::type XT;
+   // region A: staged samples (integers) + the fold planes of one column pass; later conv 0's output.  region B: magnitudes; later conv 1 / 2 / 3's outputs
+   constexpr int kXBytes = kH3Chunks * 640 * (int)sizeof(XT);            // 20,480 (s16) / 40,960 (f32)
+   constexpr int kBFPlane = 4 * 4 * 16 * 8;                              // halves per fold plane: piece-major, 4 k-blocks x 16 columns
+   constexpr int kMGPlane = 4 * 4 * 64 * 8;                              // halves per magnitude / conv 0 plane: 4 channel blocks x 64 columns
+   constexpr int kABytes = (kXBytes + 4 * kBFPlane * 2) > 2 * kMGPlane * 2 ? (kXBytes + 4 * kBFPlane * 2) : 2 * kMGPlane * 2;      // 36,864 (s16) / 57,344 (f32)
+   constexpr int kBBytes = 2 * kMGPlane * 2;                             // 32,768
+   constexpr int kC1Plane = 4 * 2 * 32 * 8, kC2Plane = 4 * 2 * 16 * 8, kC3Plane = 4 * 4 * 16 * 8;
    static_assert(2 * (kC1Plane + kC2Plane + kC3Plane) * 2 <= kBBytes, "conv 1-3 outputs fit the magnitude region");
    __shared__ __attribute__((aligned(16))) unsigned char RA[kABytes];
    __shared__ __attribute__((aligned(16))) unsigned char RB[kBBytes];
-   __shared__ float NYs[32];
-   float *X = reinterpret_cast<float *>(RA);
-   _Float16 *BF = reinterpret_cast<_Float16 *>(RA + kXBytes);           // [s hi, s lo, d hi, d lo][32 columns][136]
-   _Float16 *C0 = reinterpret_cast<_Float16 *>(RA);                     // [hi | lo][64][136]
-   _Float16 *MG = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo][64][136]: channels 0..127 = bins, 128 = bin 128, 129..135 = 0
-   _Float16 *C1 = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo][32][72]
-   _Float16 *C2 = C1 + 2 * kC1Plane;                                    // [hi | lo][16][72]
-   _Float16 *C3 = C2 + 2 * kC2Plane;                                    // [hi | lo][16][136]
+   __shared__ __attribute__((aligned(16))) _Float16 M128[2][64];        // bin 128's magnitude x 256 by column: [hi | lo]
+   __shared__ float NYs[16];
+   XT *X = reinterpret_cast<XT *>(RA);                                  // [16 chunks][640]
+   _Float16 *BF = reinterpret_cast<_Float16 *>(RA + kXBytes);           // [s hi, s lo, d hi, d lo] piece-major 4 x 16
+   _Float16 *C0 = reinterpret_cast<_Float16 *>(RA);                     // [hi | lo] piece-major 4 x 64
+   _Float16 *MG = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo] piece-major 4 x 64 (bins 0..127)
+   _Float16 *C1 = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo] piece-major 2 x 32
+   _Float16 *C2 = C1 + 2 * kC1Plane;                                    // [hi | lo] piece-major 2 x 16
+   _Float16 *C3 = C2 + 2 * kC2Plane;                                    // [hi | lo] piece-major 4 x 16
    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int lc = lane & 15, kq = lane >> 4;
    const int item0 = blockIdx.x * kH3Chunks;
 
-   // this wave's STFT A fragments: re tile `wave`, im tile 8 + `wave`, 4 k-blocks each: 64 registers, used by both column passes
+   // this wave's STFT A fragments: re tile `wave`, im tile 8 + `wave`, 4 k-blocks each: 64 registers, used by all four column passes
    V5Frag are[4], aim[4];
 #pragma unroll
    for (int kb = 0; kb < 4; ++kb) { are[kb] = v5_afrag(w.h_stft, wave, 4, kb, lane); aim[kb] = v5_afrag(w.h_stft, 8 + wave, 4, kb, lane); }
 
    // ---- stage: [context 64 | window 512 | reflect 64] per chunk as integers (s16 as they are, f32 x 32768) ----
-   for (int i = tid; i < kH3Chunks * 640; i += 512) {
-      const int j = i / 640, p = i - j * 640;
+   constexpr float kToInt = sizeof(T) == 2 ? 1.0f : 32768.0f;
+   for (int i = tid; i < kH3Chunks * 80; i += 512) {                     // 8-sample pieces: 8 of context, 64 of window, 8 of the reflected tail
+      const int j = i / 80, pc = i - j * 80;
       const int item = min(item0 + j, n_items - 1);
       const int s = item / n_chunks, c = item - s * n_chunks;
-      const int q = p < 576 ? p : 2 * 575 - p;                           // F.pad(input, (0, 64), "reflect"): padded[576 + k] = input[574 - k]
-      constexpr float kToInt = sizeof(T) == 2 ? 1.0f : 32768.0f;          // s16 samples are integers already; f32 samples are in [-1, 1)
-      float v;
-      if (q >= kV5Context) v = (float)pcm[(size_t)item * kV5Window + (q - kV5Context)] * kToInt;
-      else if (c > 0)      v = (float)pcm[(size_t)(item - 1) * kV5Window + (kV5Window - kV5Context + q)] * kToInt;     // the previous window's tail (vadc.c:132-135)
-      else                 v = ctx[(size_t)s * kV5Context + q] * 32768.0f;                                           // carried from the previous call (vadc.c:124): kept / 32768 for either type
-      X[j * kH3XP + p] = v;
+      float v[8];
+      if (pc >= 8 && pc < 72) {
+         const T *src = pcm + (size_t)item * kV5Window + 8 * (pc - 8);
+#pragma unroll
+         for (int e = 0; e < 8; ++e) v[e] = (float)src[e] * kToInt;
+      } else if (pc < 8) {
+         if (c > 0) {                                                    // the previous window's tail (vadc.c:132-135)
+            const T *src = pcm + (size_t)(item - 1) * kV5Window + (kV5Window - kV5Context) + 8 * pc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)src[e] * kToInt;
+         } else {                                                        // carried from the previous call (vadc.c:124): kept / 32768 for either type
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ctx[(size_t)s * kV5Context + 8 * pc + e] * 32768.0f;
+         }
+      } else {                                                           // F.pad(input, (0, 64), "reflect"): padded[576 + k] = input[574 - k] = window[510 - k]
+         const T *src = pcm + (size_t)item * kV5Window + 510 - 8 * (pc - 72);
+#pragma unroll
+         for (int e = 0; e < 8; ++e) v[e] = (float)src[-e] * kToInt;
+      }
+      XT *dst = X + j * 640 + 8 * pc;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = (XT)v[e];
    }
    __syncthreads();
 
-   const int fq = tid & 15, fcol = tid >> 4;                              // the fold: thread = (column of the pass, slots 8 fq .. 8 fq + 7)
-   float wny[8];
+   // the fold: thread = (column of the pass fcol, slot group fq: slots 8 fq .. 8 fq + 7, half fh: its slots 4 fh .. 4 fh + 3); a column's 32 threads are half a wave
+   const int fcol = tid >> 5, fq = (tid >> 1) & 15, fh = tid & 1;
+   float wny[4];
 #pragma unroll
-   for (int e = 0; e < 8; ++e) wny[e] = w.wny[8 * fq + e];
+   for (int e = 0; e < 4; ++e) wny[e] = w.wny[8 * fq + 4 * fh + e];
 #pragma unroll 1
-   for (int pass = 0; pass < 2; ++pass) {
+   for (int pass = 0; pass < 4; ++pass) {
       {
-         const int gcol = 32 * pass + fcol, j = gcol >> 2, fr = gcol & 3;
-         const float *x = X + j * kH3XP + 128 * fr;
-         const float4 d0 = *reinterpret_cast<const float4 *>(x + 8 * fq), d1 = *reinterpret_cast<const float4 *>(x + 8 * fq + 4);
-         const float d8 = x[8 * fq + 8];
-         const float4 m0 = *reinterpret_cast<const float4 *>(x + 248 - 8 * fq), m1 = *reinterpret_cast<const float4 *>(x + 252 - 8 * fq);
-         const float dv[8] = {d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d8};                // x[8 fq + 1 + e]
-         const float mv[8] = {m1.w, m1.z, m1.y, m1.x, m0.w, m0.z, m0.y, m0.x};              // x[255 - 8 fq - e]
-         float sv[8], dd[8];
+         const int gcol = 16 * pass + fcol, j = gcol >> 2, fr = gcol & 3;
+         const XT *x = X + j * 640 + 128 * fr;
+         const int d0 = 8 * fq + 4 * fh;                                  // direct taps x[d0 + 1 + e], mirrored taps x[255 - d0 - e]
+         typedef XT xt4 __attribute__((ext_vector_type(4)));
+         const xt4 dq = *reinterpret_cast<const xt4 *>(x + d0), mq = *reinterpret_cast<const xt4 *>(x + 252 - d0);      // x[d0 .. d0 + 3], x[252 - d0 .. 255 - d0]: aligned
+         const XT d4 = x[d0 + 4];
+         const float dv[4] = {(float)dq[1], (float)dq[2], (float)dq[3], (float)d4}, mv[4] = {(float)mq[3], (float)mq[2], (float)mq[1], (float)mq[0]};
+         float sv[4], dd[4];
 #pragma unroll
-         for (int e = 0; e < 8; ++e) { sv[e] = dv[e] + mv[e]; dd[e] = dv[e] - mv[e]; }
-         v5h8 sh, sl, dh, dl;
-#pragma unroll
-         for (int e = 0; e < 8; e += 2) {
-            v5h2 hi, lo;
-            v5_split2(sv[e], sv[e + 1], hi, lo); sh[e] = hi[0]; sh[e + 1] = hi[1]; sl[e] = lo[0]; sl[e + 1] = lo[1];
-            v5_split2(dd[e], dd[e + 1], hi, lo); dh[e] = hi[0]; dh[e + 1] = hi[1]; dl[e] = lo[0]; dl[e + 1] = lo[1];
-         }
-         _Float16 *bp = BF + (size_t)fcol * kH3P128 + 8 * fq;
-         *reinterpret_cast<v5h8 *>(bp) = sh;
-         *reinterpret_cast<v5h8 *>(bp + kBFPlane) = sl;
-         *reinterpret_cast<v5h8 *>(bp + 2 * kBFPlane) = dh;
-         *reinterpret_cast<v5h8 *>(bp + 3 * kBFPlane) = dl;
+         for (int e = 0; e < 4; ++e) { sv[e] = dv[e] + mv[e]; dd[e] = dv[e] - mv[e]; }
+         _Float16 *bp = BF + v5_bf_piece(fq & 3, fq >> 2, fcol) + 4 * fh;
+         v5_split4_store(sv, bp, bp + kBFPlane);
+         v5_split4_store(dd, bp + 2 * kBFPlane, bp + 3 * kBFPlane);
          float ny = wny[0] * sv[0];
 #pragma unroll
-         for (int e = 1; e < 8; ++e) ny = fmaf(wny[e], sv[e], ny);
-         ny += __shfl_xor(ny, 1); ny += __shfl_xor(ny, 2); ny += __shfl_xor(ny, 4); ny += __shfl_xor(ny, 8);      // the 16 threads of a column are 16 consecutive lanes
-         if (fq == 0) NYs[fcol] = ny;                                       // 2^15 x re of bin 128
+         for (int e = 1; e < 4; ++e) ny = fmaf(wny[e], sv[e], ny);
+         ny += __shfl_xor(ny, 1); ny += __shfl_xor(ny, 2); ny += __shfl_xor(ny, 4); ny += __shfl_xor(ny, 8); ny += __shfl_xor(ny, 16);
+         if ((tid & 31) == 0) NYs[fcol] = ny;                            // 2^15 x re of bin 128
       }
       __syncthreads();
       {
-         f4v5 ar[2], ai[2];
+         f4v5 ar = (f4v5){0.0f, 0.0f, 0.0f, 0.0f}, ai = ar;
 #pragma unroll
-         for (int ni = 0; ni < 2; ++ni) { ar[ni] = (f4v5){0.0f, 0.0f, 0.0f, 0.0f}; ai[ni] = ar[ni]; }
-#pragma unroll
-         for (int ni = 0; ni < 2; ++ni) {
-            const _Float16 *bp = BF + (size_t)(16 * ni + lc) * kH3P128 + 8 * kq;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-               const v5h8 s_h = *reinterpret_cast<const v5h8 *>(bp + 32 * kb), s_l = *reinterpret_cast<const v5h8 *>(bp + kBFPlane + 32 * kb);
-               const v5h8 d_h = *reinterpret_cast<const v5h8 *>(bp + 2 * kBFPlane + 32 * kb), d_l = *reinterpret_cast<const v5h8 *>(bp + 3 * kBFPlane + 32 * kb);
-               ar[ni] = v5_mfma3(are[kb], s_h, s_l, ar[ni]);
-               ai[ni] = v5_mfma3(aim[kb], d_h, d_l, ai[ni]);
-            }
+         for (int kb = 0; kb < 4; ++kb) {
+            const _Float16 *bp = BF + v5_bf_piece(kq, kb, lc);
+            const v5h8 s_h = *reinterpret_cast<const v5h8 *>(bp), s_l = *reinterpret_cast<const v5h8 *>(bp + kBFPlane);
+            const v5h8 d_h = *reinterpret_cast<const v5h8 *>(bp + 2 * kBFPlane), d_l = *reinterpret_cast<const v5h8 *>(bp + 3 * kBFPlane);
+            ar = v5_mfma3(are[kb], s_h, s_l, ar);
+            ai = v5_mfma3(aim[kb], d_h, d_l, ai);
          }
          // accumulators = 2^23 x (re, im); magnitudes are kept x 2^8: sqrt(.) x 2^-15
+         float m[4];
 #pragma unroll
-         for (int ni = 0; ni < 2; ++ni) {
-            float m[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = __builtin_amdgcn_sqrtf(fmaf(ar[ni][r], ar[ni][r], ai[ni][r] * ai[ni][r])) * 3.0517578125e-05f;
-            _Float16 *o = MG + (size_t)(32 * pass + 16 * ni + lc) * kH3P128 + 16 * wave + 4 * kq;
-            v5_split4_store(m, o, o + kMGPlane);
-         }
-         if (tid < 32) {                                                   // bin 128 and the zero channels behind it: 2^8 x |re| = |NYs| x 2^-7
+         for (int r = 0; r < 4; ++r) m[r] = __builtin_amdgcn_sqrtf(fmaf(ar[r], ar[r], ai[r] * ai[r])) * 3.0517578125e-05f;
+         _Float16 *o = MG + v5_out4<4, 64>(wave, kq, 16 * pass + lc);
+         v5_split4_store(m, o, o + kMGPlane);
+         if (tid < 16) {                                                  // bin 128: 2^8 x |re| = |NYs| x 2^-7
             v5h2 hi, lo;
             v5_split2(fabsf(NYs[tid]) * 0.0078125f, 0.0f, hi, lo);
-            _Float16 *o = MG + (size_t)(32 * pass + tid) * kH3P128 + 128;
-            *reinterpret_cast<v5h8 *>(o) = (v5h8){hi[0], 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<v5h8 *>(o + kMGPlane) = (v5h8){lo[0], 0, 0, 0, 0, 0, 0, 0};
+            M128[0][16 * pass + tid] = hi[0]; M128[1][16 * pass + tid] = lo[0];
          }
       }
       __syncthreads();
    }
    // conv 0: [129, 4] -> [128, 4]: wave = m-tile, four n-tiles (64 columns); A x 256, magnitudes x 256 => 2^-16
-   v5_conv_h3<4, 3, 0, 4, 4, 1, 4, kH3P128, kH3P128, true, false>(MG, kMGPlane, C0, kMGPlane, w.h_conv[0], w.conv_b[0], 1.52587890625e-05f, wave, 0, lane, nullptr, 0, 0);
+   v5_conv_h3<4, 3, 0, 4, 4, 1, 4, 4, true, false>(MG, &M128[0][0], C0, w.h_conv[0], w.conv_b[0], 1.52587890625e-05f, wave, 0, lane, nullptr, 0, 0);
    __syncthreads();
    // conv 1: [128, 4] -> [64, 2], stride 2: wave = (m-tile wave & 3, n-tile wave >> 2)
-   v5_conv_h3<4, 3, 0, 4, 2, 2, 1, kH3P128, kH3P64, false, false>(C0, kMGPlane, C1, kC1Plane, w.h_conv[1], w.conv_b[1], 0.00390625f, wave & 3, wave >> 2, lane, nullptr, 0, 0);
+   v5_conv_h3<4, 3, 0, 4, 2, 2, 1, 2, false, false>(C0, nullptr, C1, w.h_conv[1], w.conv_b[1], 0.00390625f, wave & 3, wave >> 2, lane, nullptr, 0, 0);
    __syncthreads();
    // conv 2: [64, 2] -> [64, 1], stride 2: taps 1 and 2 (tap 0 reads step -1: padding); waves 0-3
-   if (wave < 4) v5_conv_h3<2, 2, 1, 2, 1, 2, 1, kH3P64, kH3P64, false, false>(C1, kC1Plane, C2, kC2Plane, w.h_conv[2], w.conv_b[2], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
+   if (wave < 4) v5_conv_h3<2, 2, 1, 2, 1, 2, 1, 2, false, false>(C1, nullptr, C2, w.h_conv[2], w.conv_b[2], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
    __syncthreads();
    // conv 3: [64, 1] -> [128, 1]: tap 1 only
-   v5_conv_h3<2, 1, 1, 1, 1, 1, 1, kH3P64, kH3P128, false, false>(C2, kC2Plane, C3, kC3Plane, w.h_conv[3], w.conv_b[3], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
+   v5_conv_h3<2, 1, 1, 1, 1, 1, 1, 4, false, false>(C2, nullptr, C3, w.h_conv[3], w.conv_b[3], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
    __syncthreads();
    // LSTM input projection: GX[item][512] = W_ih [512 x 128] . c3 [128 x 16 chunks] + (b_ih + b_hh): wave owns m-tiles 4 w .. 4 w + 3
-#pragma unroll 1
+#pragma unroll
    for (int mi = 0; mi < 4; ++mi)
-      v5_conv_h3<4, 1, 1, 1, 1, 1, 1, kH3P128, 0, false, true>(C3, kC3Plane, nullptr, 0, w.h_wih, w.lstm_b, 0.00390625f, 4 * wave + mi, 0, lane, gx, item0, n_items);
+      v5_conv_h3<4, 1, 1, 1, 1, 1, 1, 4, false, true>(C3, nullptr, nullptr, w.h_wih, w.lstm_b, 0.00390625f, 4 * wave + mi, 0, lane, gx, item0, n_items);
 }
 
 template <typename T>
