@@ -51,8 +51,8 @@ struct V5Weights {
    const float *dec_w; const float *dec_b;
    const _Float16 *h_stft; const _Float16 *h_conv[4]; const _Float16 *h_wih; const float *wny;      // k_v5_encoder_h3's split-fp16 operands (kernels_v5.hip); null: k_v5_encoder serves
 };
-void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, int, int, bool, hipStream_t);
-void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, int, int, bool, hipStream_t);
+void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
+void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
 void launch_v5_lstm(const V5Weights &, const float *, float *, float *, float *, int, int, bool, hipStream_t);
 void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int, bool);
 }  // namespace vadc
@@ -143,6 +143,7 @@ struct vadc_amd_engine {
    int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1280 / 1024 / 768 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
    V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
    bool v5_enc_h3_ok = false;                   // ... its encoder's split-fp16 operands exist (weights x 256 inside fp16's range, basis with the fold symmetries): k_v5_encoder_h3 runs
+   float *d_x35 = nullptr;                      // v5: conv 3's output as split-fp16 fragment pieces, 8 KB per 16 chunks (k_v5_encoder_h3 -> k_v5_wih, same stream)
    float *d_gx5[2] = {nullptr, nullptr}, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512] (one per hand-off parity); per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
    int stride3() const { return sample_rate == 8000 ? 1 : 2; }
@@ -1016,7 +1017,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
-                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
+                   e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_x35, e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
    for (void *p : ptrs) if (p) (void)hipFree(p);
    if (e->h_trail_err) (void)hipHostFree(const_cast<int *>(e->h_trail_err));
    if (e->d_trail_recov) (void)hipFree(e->d_trail_recov);
@@ -1160,6 +1161,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    }
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[0], N * 512 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_gx5[1], N * 512 * sizeof(float));
+   if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_x35, ((N + 15) / 16) * 8192);      // conv 3 -> k_v5_wih hand-off: 8 KB per 16 chunks
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMalloc(&e->d_ctx5, (size_t)max_streams * 64 * sizeof(float));
    if (he == hipSuccess && e->model == VADC_AMD_MODEL_V5) he = hipMemset(e->d_ctx5, 0, (size_t)max_streams * 64 * sizeof(float));
    if (he == hipSuccess) he = hipMalloc(&e->d_probs, N * 2 * sizeof(float));
@@ -1931,8 +1933,8 @@ static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_ch
       e->last_frontend_kernel = enc_fp32 ? 1 : 2;
       auto enc = [&](float *gx, hipStream_t s_) {
          KernelTimer t(e, VADC_AMD_KERNEL_FRONTEND, s_);
-         if (sizeof(T) == 2) launch_v5_encoder_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, enc_fp32, s_);
-         else                launch_v5_encoder_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, gx, n_streams, n_chunks, enc_fp32, s_);
+         if (sizeof(T) == 2) launch_v5_encoder_s16(reinterpret_cast<const int16_t *>(d_in), e->d_ctx5, e->v5, gx, e->d_x35, n_streams, n_chunks, enc_fp32, encoder_cus(e, s_), s_);
+         else                launch_v5_encoder_f32(reinterpret_cast<const float *>(d_in), e->d_ctx5, e->v5, gx, e->d_x35, n_streams, n_chunks, enc_fp32, encoder_cus(e, s_), s_);
       };
       e->last_lstm_kernel = (fp32 || !e->v5.whh_h) ? 3 : 6;
       if ((long)n_streams * n_chunks < 2048) {

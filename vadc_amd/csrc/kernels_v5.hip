@@ -434,6 +434,7 @@ typedef _Float16 v5h2 __attribute__((ext_vector_type(2)));
 typedef float v5f2 __attribute__((ext_vector_type(2)));
 constexpr int kH3Chunks = 16;                        // chunks per workgroup
 constexpr int kH3Pre = 4;                            // k-blocks of A fragments in flight ahead of their MFMAs
+constexpr int kV5X3Plane = 4 * 4 * 16 * 8;           // halves per plane of a tile of conv 3's output (piece-major, 4 channel blocks x 16 columns)
 
 struct V5Frag { v5h8 hi, lo; };
 __device__ __forceinline__ V5Frag v5_afrag(const _Float16 *base, int mt, int kbs, int kb, int lane)
@@ -552,7 +553,7 @@ template <typename T>
 __global__ __launch_bounds__(512, 2) void k_v5_encoder_h3(const T *__restrict__ pcm,       // [S][C][512]
                                                           const float *__restrict__ ctx,   // [S][64]
                                                           V5Weights w,
-                                                          float *__restrict__ gx,          // [S * C][512]
+                                                          _Float16 *__restrict__ x3,       // [tiles of 16 chunks][hi | lo] piece-major 4 x 16: conv 3's output, k_v5_wih's B operand
                                                           int n_items, int n_chunks)
 {
    typedef typename V5X<T>::type XT;
@@ -562,8 +563,8 @@ __global__ __launch_bounds__(512, 2) void k_v5_encoder_h3(const T *__restrict__ 
    constexpr int kMGPlane = 4 * 4 * 64 * 8;                              // halves per magnitude / conv 0 plane: 4 channel blocks x 64 columns
    constexpr int kABytes = (kXBytes + 4 * kBFPlane * 2) > 2 * kMGPlane * 2 ? (kXBytes + 4 * kBFPlane * 2) : 2 * kMGPlane * 2;      // 36,864 (s16) / 57,344 (f32)
    constexpr int kBBytes = 2 * kMGPlane * 2;                             // 32,768
-   constexpr int kC1Plane = 4 * 2 * 32 * 8, kC2Plane = 4 * 2 * 16 * 8, kC3Plane = 4 * 4 * 16 * 8;
-   static_assert(2 * (kC1Plane + kC2Plane + kC3Plane) * 2 <= kBBytes, "conv 1-3 outputs fit the magnitude region");
+   constexpr int kC1Plane = 4 * 2 * 32 * 8, kC2Plane = 4 * 2 * 16 * 8;
+   static_assert(2 * (kC1Plane + kC2Plane) * 2 <= kBBytes, "conv 1-2 outputs fit the magnitude region");
    __shared__ __attribute__((aligned(16))) unsigned char RA[kABytes];
    __shared__ __attribute__((aligned(16))) unsigned char RB[kBBytes];
    __shared__ __attribute__((aligned(16))) _Float16 M128[2][64];        // bin 128's magnitude x 256 by column: [hi | lo]
@@ -574,7 +575,6 @@ __global__ __launch_bounds__(512, 2) void k_v5_encoder_h3(const T *__restrict__ 
    _Float16 *MG = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo] piece-major 4 x 64 (bins 0..127)
    _Float16 *C1 = reinterpret_cast<_Float16 *>(RB);                     // [hi | lo] piece-major 2 x 32
    _Float16 *C2 = C1 + 2 * kC1Plane;                                    // [hi | lo] piece-major 2 x 16
-   _Float16 *C3 = C2 + 2 * kC2Plane;                                    // [hi | lo] piece-major 4 x 16
    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int lc = lane & 15, kq = lane >> 4;
    const int item0 = blockIdx.x * kH3Chunks;
@@ -676,13 +676,56 @@ __global__ __launch_bounds__(512, 2) void k_v5_encoder_h3(const T *__restrict__ 
    // conv 2: [64, 2] -> [64, 1], stride 2: taps 1 and 2 (tap 0 reads step -1: padding); waves 0-3
    if (wave < 4) v5_conv_h3<2, 2, 1, 2, 1, 2, 1, 2, false, false>(C1, nullptr, C2, w.h_conv[2], w.conv_b[2], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
    __syncthreads();
-   // conv 3: [64, 1] -> [128, 1]: tap 1 only
-   v5_conv_h3<2, 1, 1, 1, 1, 1, 1, 4, false, false>(C2, nullptr, C3, w.h_conv[3], w.conv_b[3], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
-   __syncthreads();
-   // LSTM input projection: GX[item][512] = W_ih [512 x 128] . c3 [128 x 16 chunks] + (b_ih + b_hh): wave owns m-tiles 4 w .. 4 w + 3
+   // conv 3: [64, 1] -> [128, 1]: tap 1 only.  Its output leaves the kernel (8 KB per workgroup, in the fragment order of the next GEMM): the LSTM's input projection
+   // W_ih [512 x 128] has 16 columns per workgroup here -- every one of its 262 KB of fragments would be fetched from L2 for ONE MFMA triple, 42 % of this kernel's
+   // weight stream, and the kernel is bound by that stream (55 of the ~70 GB/s a CU gets from L2) -- so it runs as k_v5_wih, with W_ih resident in registers.
+   v5_conv_h3<2, 1, 1, 1, 1, 1, 1, 4, false, false>(C2, nullptr, x3 + (size_t)blockIdx.x * (2 * kV5X3Plane), w.h_conv[3], w.conv_b[3], 0.00390625f, wave, 0, lane, nullptr, 0, 0);
+}
+
+// LSTM input projection: GX[item][512] = W_ih [512 x 128] . c3 [128 x items] + (b_ih + b_hh), persistent: a workgroup keeps ALL of W_ih as split-fp16 A fragments in
+// registers (wave w: m-tiles 4 w .. 4 w + 3, 128 registers) and walks over tiles of 16 chunks; the B fragments are 16-byte pieces of k_v5_encoder_h3's output, one
+// coalesced load per lane and plane, fetched one tile ahead.
+__global__ __launch_bounds__(512, 1) void k_v5_wih(const _Float16 *__restrict__ x3, V5Weights w, float *__restrict__ gx, int n_items)
+{
+   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+   const int lc = lane & 15, kq = lane >> 4;
+   const int n_tiles = (n_items + kH3Chunks - 1) / kH3Chunks;
+   V5Frag a[4][4];
 #pragma unroll
    for (int mi = 0; mi < 4; ++mi)
-      v5_conv_h3<4, 1, 1, 1, 1, 1, 1, 4, false, true>(C3, nullptr, nullptr, w.h_wih, w.lstm_b, 0.00390625f, 4 * wave + mi, 0, lane, gx, item0, n_items);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) a[mi][kb] = v5_afrag(w.h_wih, 4 * wave + mi, 4, kb, lane);
+   float4 b4[4];
+#pragma unroll
+   for (int mi = 0; mi < 4; ++mi) b4[mi] = *reinterpret_cast<const float4 *>(w.lstm_b + 16 * (4 * wave + mi) + 4 * kq);
+   auto load = [&](int t, v5h8 (&bh)[4], v5h8 (&bl)[4]) {
+      const _Float16 *p = x3 + (size_t)min(t, n_tiles - 1) * (2 * kV5X3Plane);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+         bh[kb] = *reinterpret_cast<const v5h8 *>(p + v5_piece<4, 16>(kq, kb, lc));
+         bl[kb] = *reinterpret_cast<const v5h8 *>(p + kV5X3Plane + v5_piece<4, 16>(kq, kb, lc));
+      }
+   };
+   v5h8 bh[4], bl[4], nh[4], nl[4];
+   int t = blockIdx.x;
+   if (t >= n_tiles) return;
+   load(t, bh, bl);
+#pragma unroll 1
+   for (; t < n_tiles; t += gridDim.x) {
+      load(t + (int)gridDim.x, nh, nl);
+      const int item = t * kH3Chunks + lc;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+         f4v5 acc = (f4v5){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+         for (int kb = 0; kb < 4; ++kb) acc = v5_mfma3(a[mi][kb], bh[kb], bl[kb], acc);
+         if (item < n_items)
+            *reinterpret_cast<float4 *>(gx + (size_t)item * kV5Gates + 16 * (4 * wave + mi) + 4 * kq) =
+               make_float4(fmaf(acc[0], 0.00390625f, b4[mi].x), fmaf(acc[1], 0.00390625f, b4[mi].y), fmaf(acc[2], 0.00390625f, b4[mi].z), fmaf(acc[3], 0.00390625f, b4[mi].w));
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) { bh[kb] = nh[kb]; bl[kb] = nl[kb]; }
+   }
 }
 
 template <typename T>
@@ -696,21 +739,25 @@ __global__ void k_v5_context(const T *__restrict__ pcm, float *__restrict__ ctx,
 
 // front half of a call: encoder + LSTM input projection -> gx, then the streams' new context (read by the next call's encoder on the same stream)
 template <typename T>
-static void launch_v5_enc_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
+static void launch_v5_enc_t(const T *pcm, float *ctx, const V5Weights &w, float *gx, float *x3, int n_streams, int n_chunks, bool fp32, int n_cus, hipStream_t st)
 {
    const int n_items = n_streams * n_chunks;
-   if (!fp32 && w.h_stft) hipLaunchKernelGGL((k_v5_encoder_h3<T>), dim3((n_items + kH3Chunks - 1) / kH3Chunks), dim3(512), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
-   else                   hipLaunchKernelGGL((k_v5_encoder<T>), dim3((n_items + kV5Chunks - 1) / kV5Chunks), dim3(256), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
+   if (!fp32 && w.h_stft) {
+      const int tiles = (n_items + kH3Chunks - 1) / kH3Chunks;
+      hipLaunchKernelGGL((k_v5_encoder_h3<T>), dim3(tiles), dim3(512), 0, st, pcm, ctx, w, reinterpret_cast<_Float16 *>(x3), n_items, n_chunks);
+      hipLaunchKernelGGL(k_v5_wih, dim3(tiles < n_cus ? tiles : n_cus), dim3(512), 0, st, reinterpret_cast<const _Float16 *>(x3), w, gx, n_items);
+   } else                   hipLaunchKernelGGL((k_v5_encoder<T>), dim3((n_items + kV5Chunks - 1) / kV5Chunks), dim3(256), 0, st, pcm, ctx, w, gx, n_items, n_chunks);
    hipLaunchKernelGGL((k_v5_context<T>), dim3((n_streams * kV5Context + 255) / 256), dim3(256), 0, st, pcm, ctx, n_streams, n_chunks);
 }
 // fp32 = true (or no split-fp16 operands: a weight outside fp16's range, a basis without the fold symmetries): k_v5_encoder, fp32 MFMA
-void launch_v5_encoder_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
+// x3: the hand-off between k_v5_encoder_h3 and k_v5_wih, 8 KB per 16 chunks (the engine's d_x35)
+void launch_v5_encoder_f32(const float *pcm, float *ctx, const V5Weights &w, float *gx, float *x3, int n_streams, int n_chunks, bool fp32, int n_cus, hipStream_t st)
 {
-   launch_v5_enc_t<float>(pcm, ctx, w, gx, n_streams, n_chunks, fp32, st);
+   launch_v5_enc_t<float>(pcm, ctx, w, gx, x3, n_streams, n_chunks, fp32, n_cus, st);
 }
-void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, int n_streams, int n_chunks, bool fp32, hipStream_t st)
+void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, float *gx, float *x3, int n_streams, int n_chunks, bool fp32, int n_cus, hipStream_t st)
 {
-   launch_v5_enc_t<int16_t>(pcm, ctx, w, gx, n_streams, n_chunks, fp32, st);
+   launch_v5_enc_t<int16_t>(pcm, ctx, w, gx, x3, n_streams, n_chunks, fp32, n_cus, st);
 }
 // back half: the recurrence + decoder over the call's chunks.  fp32 = true (or no split-fp16 weights): W_hh h as fp32 MFMAs
 void launch_v5_lstm(const V5Weights &w, const float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, bool fp32, hipStream_t st)
