@@ -50,6 +50,8 @@ int main()
       {"read b128  [column][channel] pitch 136 halves: col*272 + kq*16  (k_lstm_* h tile, k_v5_lstm_h3)", 0, [](int l) { return (l & 15) * 272 + (l >> 4) * 16; }},
       {"read b128  [column][channel] pitch 144 halves: col*288 + kq*16", 0, [](int l) { return (l & 15) * 288 + (l >> 4) * 16; }},
       {"read b128  [column][channel] pitch 160 halves: col*320 + kq*16", 0, [](int l) { return (l & 15) * 320 + (l >> 4) * 16; }},
+      {"read b128  [column][channel] pitch 72 halves: col*144 + kq*16  (k_lstm_* h tile, rounds 2-5)", 0, [](int l) { return (l & 15) * 144 + (l >> 4) * 16; }},
+      {"read b128  [column][channel] pitch 80 halves: col*160 + kq*16  (k_lstm_* h tile, round 6)", 0, [](int l) { return (l & 15) * 160 + (l >> 4) * 16; }},
       {"read b128  piece-major: kq*4096 + col*16  (k_v5_encoder_h3 activations)", 0, [](int l) { return (l >> 4) * 4096 + (l & 15) * 16; }},
       {"read b128  piece-major, stride-2 columns: kq*4096 + col*32  (conv 1 / 2)", 0, [](int l) { return (l >> 4) * 4096 + (l & 15) * 32; }},
       {"read b128  piece-major swizzled (fold planes, kb = 1): (kq*4+1)*256 + (col ^ f)*16", 0, [](int l) { return ((l >> 4) * 4 + 1) * 256 + ((l & 15) ^ swz(l >> 4, 1)) * 16; }},

@@ -11,7 +11,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 e = Engine(blob, max_streams=S, max_chunks_per_call=C, device=0)
 rng = np.random.default_rng(1)
 x = np.abs(rng.standard_normal((S, C, 64, 7)).astype(np.float32))
-for lk, trail in ((7, 2), (7, 0), (6, 0)):      # (7, 2): the TRAIL kernels of the layer-major form, one after the other: what their bookkeeping costs
+for lk, trail in ((7, 0), (6, 0)):
     e.set_option("lstm", lk); e.set_option("lstm_trail", trail)
     e.lstm_decoder(x)
     e.reset_kernel_times(); e.set_profiling(True)

@@ -61,11 +61,13 @@ constexpr int kTileS = kLstmTile;    // streams per workgroup (= MFMA N)
 // eight v_mfma_f32_16x16x4_f32 (K = 4 x 8, 32 cycles each): 5.3x fewer matrix cycles.  Measured error of a K = 128 dot product
 // against float64: 6.0e-7 for this form, 1.07e-6 for the plain fp32 FMA chain (tools/mfma_f16_probe.hip) -- it is not a
 // reduced-precision mode.  Weights are split once per call into registers (same 128 VGPRs as the fp32 fragments); h is
-// split by the wave that produces it and lives in LDS as two fp16 tiles [stream][unit] (pitch 72: conflict-free 16-byte
-// B-fragment reads).  Operand layout (verified on the device): lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15].
+// split by the wave that produces it and lives in LDS as two fp16 tiles [stream][unit] (pitch 80 halves = 10 slots of 16 bytes: a
+// B-fragment read -- lane (stream s, quarter q) at slot 10 s + q -- is conflict-free in every lane group of ds_read_b128: the group's eight streams of quarter q
+// take the even slots mod 16, its eight of quarter q + 1 the odd ones.  Pitch 72 (rounds 2-5) was 2-way conflicted in every group: 37-39 % of the kernels' LDS
+// cycles, tools/lds_frag_probe.hip).  Operand layout (verified on the device): lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15].
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-constexpr int kHPitch = 72;                     // fp16 elements per stream row of an h tile (64 units + 8 pad)
+constexpr int kHPitch = 80;                     // fp16 elements per stream row of an h tile (64 units + 16 pad: see above)
 
 // `xh` is the encoder output in split-fp16 LSTM-native tiles (common.h lstm_xh_index, written by the last encoder stage): layer 0 runs
 // the full K = 128 = [x_t ; h0] like layer 1, its x fragments are fetched from global one slot ahead (four 16-byte loads per lane),

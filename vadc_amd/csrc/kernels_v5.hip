@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx
 // 8-byte write per tile.
 typedef _Float16 v5h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 v5h4 __attribute__((ext_vector_type(4)));
-constexpr int kV5HP = kV5Hidden + 8;                 // halves per stream row
+constexpr int kV5HP = kV5Hidden + 16;                // halves per stream row: 18 slots of 16 bytes -- conflict-free B-fragment reads (136 was 2-way conflicted: tools/lds_frag_probe.hip)
 
 __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__ gx,       // [S * C][512]
                                                        V5Weights w,
