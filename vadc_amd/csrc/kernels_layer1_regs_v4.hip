@@ -36,9 +36,19 @@ __device__ __forceinline__ L1V4Chan l1v4_load_chan(const float *xb, const float 
    return s;
 }
 // magnitude from Y = log1p(2^20 m) (k_layer_mfma's form: one v_exp_f32 and one fma), or Y - offset (misc.c:84-96)
+// Timing-only ablations (tools/l1v4_ablate.sh; results are WRONG) -- what VERDICT r5 item 4's first option could buy at most, measured before building it:
+//   VADC_L1V4_ABL_XPRESPLIT  the projection path's operands arrive as (hi, lo) halves: no split8 of x (a bit cast stands in for the load)
+//   VADC_L1V4_ABL_NOOFF      the normalization offset is folded into the biases (W (x - m 1) = W x - m rowsum(W)): no subtraction per value
+//   VADC_L1V4_ABL_NOEXP      the magnitude half arrives from the front end: no exp2 + fma per value (costs a second input array in the product: "v4_mag" = 1)
 template <int WHICH>
 __device__ __forceinline__ f2 l1v4_input(const f2 &y, float off)
 {
+#ifdef VADC_L1V4_ABL_NOEXP
+   if (WHICH == 0) return y;
+#endif
+#ifdef VADC_L1V4_ABL_NOOFF
+   if (WHICH == 1) return y;
+#endif
    if (WHICH == 0)
       return f2{fmaf(__builtin_amdgcn_exp2f(y[0] * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f), fmaf(__builtin_amdgcn_exp2f(y[1] * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f)};
    return y - f2{off, off};
@@ -205,10 +215,18 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
          const Frag df1 = split8(dl1, dh1);
          if (have) pending_mfma(9);
          __builtin_amdgcn_sched_barrier(0);
+#ifdef VADC_L1V4_ABL_XPRESPLIT
+         const Frag xf0 = Frag{__builtin_bit_cast(h8, xl0), __builtin_bit_cast(h8, xh0)};
+#else
          const Frag xf0 = split8(xl0, xh0);
+#endif
          if (have) pending_mfma(10);
          __builtin_amdgcn_sched_barrier(0);
+#ifdef VADC_L1V4_ABL_XPRESPLIT
+         const Frag xf1 = Frag{__builtin_bit_cast(h8, xl1), __builtin_bit_cast(h8, xh1)};
+#else
          const Frag xf1 = split8(xl1, xh1);
+#endif
          if (have) pending_mfma(11);
          __builtin_amdgcn_sched_barrier(0);
          pd0 = df0; pd1 = df1; px0 = xf0; px1 = xf1;
