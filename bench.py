@@ -63,7 +63,7 @@ MAC_V4 = {"k_frontend": (1_585_152, 0), "k_layer1": (232_176, 0), "k_layer2": (1
           "k_lstm": (196_608 + 192, 196_608),
           "k_enc234": (19_392 + 10_176 + 25_056, 0)}       # stages 2-4 in one launch (k_enc_fused_v4): executed work counted in kernel_cost
 PATH_FLOP_PER_CHUNK = {"v31": 2 * 2_702_477, "v4": 2 * 2_068_752}      # whole path
-FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm", 3: "k_frontend (v4 tree)", 4: "k_frontend_ri"}
+FRONTEND_KERNELS = {0: "k_frontend_sym", 1: "k_frontend_fl", 2: "k_frontend_gemm2", 3: "k_frontend (v4 tree)"}
 
 
 def metric_label(model, world):
@@ -75,9 +75,7 @@ def metric_label(model, world):
 
 
 def frontend_name(eng, fe_kernel):
-    """the front-end kernel that ran, by name: the engine reports 2 for either GEMM form, and this bench feeds s16 (option "fe_gemm" = 2: k_frontend_gemm2)"""
-    if fe_kernel == 2 and eng.get_option("fe_gemm") == 2:
-        return "k_frontend_gemm2"
+    """the front-end kernel that ran, by name: the engine reports 2 for either GEMM form; this bench feeds s16, which is k_frontend_gemm2's (f32 input: k_frontend_gemm)"""
     return FRONTEND_KERNELS.get(fe_kernel)
 
 
@@ -109,7 +107,7 @@ def kernel_cost(model, name, fe_kernel, layer_major=False, layer1_regs=False):
     alg = 2 * mac
     if name == "k_frontend":
         frames = 24 if model == "v4" else 25
-        if fe_kernel in (0, 4): # per position: 33 base bins x (2 x (256 mul + 248 add) + 56 lane-tree adds) + 129 x (re^2, im^2, +)   (k_frontend_sym and k_frontend_ri: the same FLOP)
+        if fe_kernel == 0:      # per position: 33 base bins x (2 x (256 mul + 248 add) + 56 lane-tree adds) + 129 x (re^2, im^2, +)
             return alg, {"valu_nofma": frames * (33 * (2 * 504 + 56) + 129 * 3)}
         if fe_kernel == 2:      # folded real-input DFT: 256 rows x K = 128, three split-fp16 MFMAs per k-block
             return alg, {"fp16": 3 * 2 * 256 * 128 * frames}
@@ -689,8 +687,6 @@ def run_rank(args, world, rank, local_rank):
         value = chunks_per_step * args.steps * CHUNK_SECONDS / elapsed
         kt = eng.kernel_times()
         fe_kernel = eng.get_option("frontend_kernel")
-        if fe_kernel == 0 and (eng.get_option("fe_opt") & 8):
-            fe_kernel = 4                                         # the exact-tree front end's (re, im)-packed form (option "fe_opt" = 11)
         # The LSTM chain runs concurrently on its own small CU partition; weigh every kernel's
         # time by the share of the chip it occupies so that "dominant" means dominant in CU-time, not in wall time
         # of a kernel that leaves 240 CUs to the others.

@@ -35,6 +35,12 @@
 extern "C" {
 #endif
 
+/* Revision of this interface: bumped whenever a struct below grows or an entry point changes meaning.  A binding checks vadc_amd_abi_version() against the value
+ * it was compiled with BEFORE it hands the library a struct (vadc_amd_get_caps writes sizeof(vadc_amd_caps) of ITS revision): include/vadc_backend_hip.h and
+ * vadc_amd/_lib.py do; a caller that must work across revisions uses vadc_amd_get_caps_sized. */
+#define VADC_AMD_ABI_VERSION 6
+int  vadc_amd_abi_version(void);
+
 #define VADC_AMD_CHUNK_SAMPLES 1536    /* the reference's chunk; every buffer below is [stream][chunk][window], window = 1536 unless option "window" says otherwise */
 #define VADC_AMD_HIDDEN        64
 #define VADC_AMD_LSTM_LAYERS   2
@@ -216,38 +222,53 @@ int  vadc_amd_debug_decoder(vadc_amd_engine *e, const float *x, int n, float *pr
  * pipeline and conv block (depthwise k = 5 + ReLU, pointwise + projection, ReLU: conv.c:17-113, 532-589, 761-814; test.c:545, 581, 820) with a zero
  * normalization offset and leaves behind the block's ReLU.  out [n][16][25].  Silero v3.1 only; 4 and 5 need the register-resident layer-1 kernel. */
 int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, int n, float *out);
-/* Switches (all int-valued; an unknown key or value is VADC_AMD_EINVAL):
- *   "graph"       1: kernel sequences (a whole small call; the front end + encoder of one chunk group of a forked call) are captured into hipGraphs on
- *                 first use and replayed afterwards -- the fork / join and the call-to-call ordering stay outside the graphs, so replays of consecutive
- *                 steps overlap like eager steps; 0 (default): eager launches
- *   "defer_join"  1: a forked vadc_amd_run_device_* call does not make its own stream wait for its completion (see vadc_amd_join); 0 (default): strict
- *                 stream semantics
- *   "window"      samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4 also 1280, 1024, 768 and 512 -- the
- *                 v4 graph takes 512 ... 1536 samples (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): samples / 64 STFT frames, 3 / 3 / 2 / 2 / 1
- *                 LSTM steps (every strided stage keeps 1 + (T - 1) / 2 steps).  Changes the stride of every samples / probability buffer; waits for the
- *                 calls issued before
- *   "groups"      number of chunk groups a call is pipelined in: the LSTM of group g overlaps the front end + encoder of group g+1.  0 = auto (default): up
- *                 to 4 for calls the caller waits for, 1 with "defer_join" (consecutive calls overlap instead)
- *   "lstm"        0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy -- 7 = layer-major (k_lstm_layer: layer 0 and
- *                 layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls up to half a chip of stream tiles and
- *                 for calls of one or two chunks per stream, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both layers); 6 and 7
- *                 produce the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
- *   "frontend"    Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins 0..32, the other 96 bins from the basis'
- *                 DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte aligned, else k_frontend_fl; 1 =
- *                 k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = the GEMM front end (default), 1 = the tree kernel with the v4 geometry
- *   "fe_gemm"     which GEMM front end (Silero v4; v3.1 in FAST_STFT precision): 2 (default) = k_frontend_gemm2 for s16 input (32x32x16 MFMAs, the basis
- *                 resident in registers, fold operands exact in fp16), k_frontend_gemm for f32 input; 1 = k_frontend_gemm for both
- *   "encoder"     0 (default) = first layer as one launch, layers 2-4 of Silero v3.1 fused into ONE persistent launch (k_enc_fused: activations in registers,
- *                 split-fp16 MFMA; falls back to one launch per layer when a weight does not fit fp16); 2 = first stage as the LDS slab path instead of the
- *                 K = 1 MFMA form (Silero v4, default window and rate: stages 2-4 likewise in one launch, k_enc_fused_v4); 3 = one launch per layer with fp32 MFMA for the GEMMs of layers 2-4; 5 (Silero v3.1) = one launch per layer with split-fp16
- *                 MFMA (round 2's hot path); 4 (Silero v4 only) = first stage with 4 waves / 2 chunks per workgroup instead of 8 waves / 5 chunks
- *   "encoder_batch" form of the fused launch: 0 / 1 (default) = 12 waves per workgroup, two chunks per wave and batch; 2 = 8 waves, four chunks
- *   "layer1"      the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4 (Silero v4, default window): input by LDS-DMA,
- *                 split-fp16 MFMAs, activations in registers -- when its weights fit fp16's range; 1 = the K = 1 fp32-MFMA form of k_layer_mfma (rounds 1 - 2)
- *   "h2d_streams" 1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call (vadc_amd_run_*_async)
- *   "lstm_trail"  1 (default): with the layer-major LSTM on its CU partition, layer 1 of a call is launched BESIDE layer 0 of the same call and follows its published
- *                 progress a few steps behind (same XCD, same L2: no cache maintenance) -- a call's recurrence takes one chain instead of two (the last call
- *                 of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves); 0: layer 1 starts when layer 0 has finished.  Same bits.
+/* Switches (all int-valued; an unknown key or value is VADC_AMD_EINVAL).  Each key exists for a FUNCTIONAL reason, named first -- the experiment toggles of rounds 2-5
+ * ("fe_opt", "fe_gemm", "encoder" = 2 / 4 / 5, "encoder_batch", "v4_mag", "full_mask_streams", "lstm_trail" = 2) are gone with their kernels.
+ *  How calls are issued (the caller's contract):
+ *   "graph"       [steady-state replay]  1: kernel sequences (a whole small call; the front end + encoder of one chunk group of a forked call) are captured into hipGraphs
+ *                 on first use and replayed afterwards -- the fork / join and the call-to-call ordering stay outside the graphs, so replays of consecutive steps
+ *                 overlap like eager steps; 0 (default): eager launches
+ *   "defer_join"  [a caller that pipelines calls]  1: a forked vadc_amd_run_device_* call does not make its own stream wait for its completion (see vadc_amd_join);
+ *                 0 (default): strict stream semantics
+ *   "groups"      [a single synchronous caller]  number of chunk groups a call is pipelined in: the LSTM of group g overlaps the front end + encoder of group g+1.
+ *                 0 = auto (default): up to 4 for calls the caller waits for, 1 with "defer_join" (consecutive calls overlap instead)
+ *   "window"      [Silero v4's other input sizes]  samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4 also 1280,
+ *                 1024, 768 and 512 -- the v4 graph takes 512 ... 1536 samples (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): samples / 64 STFT frames,
+ *                 3 / 3 / 2 / 2 / 1 LSTM steps (every strided stage keeps 1 + (T - 1) / 2 steps).  Changes the stride of every samples / probability buffer; waits
+ *                 for the calls issued before
+ *   "h2d_streams" [host-buffer callers on a slow link]  1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call
+ *   "pin_host"    [callers whose buffers must not be page-locked]  1 (default): the asynchronous entry points page-lock the caller's buffers and remember them
+ *                 (see vadc_amd_run_s16_async); 0: they do not
+ *  Which kernel form serves (every value other than the default is a FALLBACK the engine also takes by itself, or the literal-fp32 arithmetic):
+ *   "lstm"        [weights outside fp16's range; the recurrence's two schedules]  0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy --
+ *                 7 = layer-major (k_lstm_layer: layer 0 and layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls up to half
+ *                 a chip of stream tiles and for calls of one or two chunks per stream, else 6 = k_lstm_wavefront_h3 (one workgroup per 16-stream tile, both
+ *                 layers); 6 and 7 produce the same bits; 3 = k_lstm_wavefront_fused (fp32 MFMA), also what runs when an LSTM weight does not fit fp16's range
+ *   "frontend"    [a basis without the DFT symmetries; unaligned input]  Silero v3.1: 0 = auto (default): k_frontend_sym (the reference's exact reduction tree for bins
+ *                 0..32, the other 96 bins from the basis' DFT symmetries, bit for bit) when the loaded basis has those symmetries and the input is 16-byte
+ *                 aligned, else k_frontend_fl; 1 = k_frontend_fl (the exact tree for all 129 bins).  Silero v4: 0 = the GEMM front end (default: k_frontend_gemm2
+ *                 for s16 input, k_frontend_gemm for f32 input), 1 = the tree kernel with the v4 geometry (also what serves a basis the GEMM cannot fold)
+ *   "encoder"     [weights outside fp16's range; literal fp32]  0 (default) = first layer as one launch, layers 2-4 of Silero v3.1 fused into ONE persistent launch
+ *                 (k_enc_fused: activations in registers, split-fp16 MFMA; Silero v4, default window and rate: stages 2-4 likewise, k_enc_fused_v4; Silero v5:
+ *                 k_v5_encoder_h3 + k_v5_wih); 3 (Silero v3.1, v5) = one launch per layer with fp32 MFMA -- what the engine falls back to by itself when a weight
+ *                 does not fit fp16 (v5: or the basis lacks the fold symmetries)
+ *   "layer1"      [weights outside fp16's range; a failed self-check]  the first encoder layer / stage: 0 (default) = k_layer1_regs (Silero v3.1) / k_layer1_regs_v4
+ *                 (Silero v4, default window): input by LDS-DMA, split-fp16 MFMAs, activations in registers; 1 = the K = 1 fp32-MFMA form of k_layer_mfma, which also
+ *                 serves by itself when a weight does not fit fp16 or the register-resident kernel failed its create-time self-check ("layer1_selfcheck")
+ *  The device's partitioning (each has a condition under which the engine turns it off by itself):
+ *   "cu_partition" [another CU layout: CPX / DPX mode, another part]  1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the
+ *                 front end + encoder stream when the chain has slack, disjoint otherwise -- and without a partition the front end + encoder stream is still a
+ *                 CU-masked stream (every CU: a hardware queue of its own, as a plain stream it could share one with the recurrence's: 10,240 x 1 2.95 -> 1.77 M);
+ *                 2: always shared; 0: never mask -- plain non-blocking streams everywhere.  A CU-masked stream has hipStreamDefault flags: it synchronises with
+ *                 HIP's legacy NULL stream, so issue calls from a stream of your own.  "lstm_cus": size of that partition (multiple of 8; 0 = sized by the engine)
+ *   "cu_mask_check" 1 (default): the LSTM's CU partition is used only on a device whose CU-mask layout passed the check at create (caps.cu_partition_ok);
+ *                 0: trust the rules anyway; 2: behave as if the check had failed (tests)
+ *   "fe_xcd"      [bisecting a placement problem]  1 (default): the exact-tree front end's workgroups take their blocks of positions in XCD-major order -- the two
+ *                 workgroups that share a chunk write its 128-byte lines of Y behind the same L2 (same bits, 2.7 % less time); 0: in launch order
+ *   "lstm_trail"  [a process whose kernels do not overlap: a profiler, a time-sliced GPU]  1 (default): with the layer-major LSTM on its CU partition, layer 1 of a call
+ *                 is launched BESIDE layer 0 of the same call and follows its published progress a few steps behind (same XCD, same L2: no cache maintenance) -- a
+ *                 call's recurrence takes one chain instead of two (the last call of a run ends 0.45 ms earlier at 256 x 96, a single call's latency halves);
+ *                 0: layer 1 starts when layer 0 has finished.  Same bits.
  *                 Used only in a process whose kernels were SEEN to overlap at create ("kernels_overlap"): a tool that lets one kernel onto the device at a
  *                 time (rocprofv3 --pmc) would start layer 0 when layer 1 has ended -- there the engine launches the two one after the other by itself
  *                 ("lstm_trail_used" says what the last call did).  "overlap_check" 2: behave as if that probe had failed (tests).
@@ -258,26 +279,10 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 counts the tiles done again; from the next host synchronisation on the engine launches the two layers in turn ("lstm_trail" reads 0).
  *                 Not repairable: a tile whose LAYER 0 never ran.  Then every later call -- a deferred vadc_amd_run_device_* and vadc_amd_join included, without
  *                 any synchronisation: the word is host memory -- fails with VADC_AMD_EHIP until vadc_amd_reset_streams(e, NULL, 0).
- *                 Tests: "trail_fault" 1 = the next pair's layer 0 comes late (behind its layer 1), 2 = never; "trail_wait" = polls before layer 1 gives up
- *   "pin_host"    1 (default): the asynchronous entry points page-lock the caller's buffers and remember them (see vadc_amd_run_s16_async); 0: they do not
- *   "fe_opt"      the exact-tree front end of Silero v3.1: 3 (default) = k_frontend_sym with bin 0 without the tree of its all-zero im row, the 9-bin split rotating over
- *                 the waves; 0 = round 3's kernel; 11 = k_frontend_ri (packed pairs = (re, im) of one tree lane: the derived rows' sums, re^2 + im^2 and the logarithm
- *                 run two values per instruction -- 8 % fewer vector instructions, the same time, the same bits)
- *   "fe_xcd"      1 (default): the exact-tree front end's workgroups take their blocks of positions in XCD-major order -- the two workgroups that share a chunk write
- *                 its 128-byte lines of Y behind the same L2 (same bits, 2.7 % less time); 0: in launch order
- *   "cu_mask_check" 1 (default): the LSTM's CU partition is used only on a device whose CU-mask layout passed the check at create (caps.cu_partition_ok);
- *                 0: trust the rules anyway; 2: behave as if the check had failed (tests)
- *   "v4_mag"      0 (default): the Silero v4 first stage recovers the magnitude half of its input from the log-magnitudes, m = (e^Y - 1) 2^-20;
- *                 1: magnitudes are written by the front end and read by the first stage
- *   "full_mask_streams" without a CU partition (many stream tiles): 2 (default) = the internal front end + encoder stream is created with a CU mask of EVERY CU, which
- *                 gives it a hardware queue of its own -- as a plain stream it could share one with the recurrence's stream in a process that had created other
- *                 engines before (10,240 x 1: 2.95 -> 1.77 M); 1 = all three internal streams so (the recurrence's lose their priority: -3 % at 4096 x 16); 0 = plain
- *   "cu_partition" 1 (default): while the LSTM needs few CUs it gets CUs of its own (CU-masked streams), shared with the front end + encoder stream
- *                 when the chain has slack, disjoint otherwise; 2: always shared; 0: never mask.  "lstm_cus": size of that partition (multiple of 8; 0 =
- *                 sized by the engine) */
+ *                 Tests: "trail_fault" 1 = the next pair's layer 0 comes late (behind its layer 1), 2 = never; "trail_wait" = polls before layer 1 gives up */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
 /* Reads a switch back, plus read-only facts: "lstm_cus" = CUs reserved for the LSTM by the last call (0 = no partition), "lstm_kernel" = the LSTM variant it ran
- * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 a GEMM front end -- k_frontend_gemm2 or k_frontend_gemm, see "fe_gemm" --, 3 k_frontend v4 tree), "layer1_kernel" = the first
+ * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 a GEMM front end -- k_frontend_gemm2 for s16, k_frontend_gemm for f32 input --, 3 k_frontend v4 tree; Silero v5: 2 = k_v5_encoder_h3, 1 = k_v5_encoder), "layer1_kernel" = the first
  * layer's form that runs (0 register-resident, 1 per-layer: option "layer1" is the request), "layer1_selfcheck" (1: the register-resident first layer agreed
  * with the per-layer form on the probe chunks at create; 0: it did not and the per-layer form serves; -1: not applicable), "zero_im0" (the basis' im row of
  * bin 0 is all zeros: k_frontend_sym skips its tree), "cu_layout_ok" (the device has the CU-mask layout the partition rules assume), "pinned_ranges" (host

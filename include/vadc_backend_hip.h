@@ -58,6 +58,10 @@ static inline void *backend_init(MemoryArena *arena, String8 model_path_arg, Sil
    (void)arena;
    vadc_amd_engine *engine = 0;
    int rc;
+   if (vadc_amd_abi_version() != VADC_AMD_ABI_VERSION) {         /* this header and the library it is linked with are two revisions of the interface */
+      fprintf(stderr, "vadc_backend_hip: libvadc_amd.so speaks revision %d of vadc_amd.h, this host was compiled with revision %d\n", vadc_amd_abi_version(), VADC_AMD_ABI_VERSION);
+      return 0;
+   }
 #ifdef VADC_HIP_EMBEDDED_WEIGHTS
    (void)model_path_arg;
    rc = vadc_amd_create(silero_v31_16k_weights, sizeof(silero_v31_16k_weights), -1, 1, VADC_HIP_MAX_BATCH,
@@ -82,7 +86,8 @@ static inline void *backend_init(MemoryArena *arena, String8 model_path_arg, Sil
       return 0;                                   /* => run_inference returns -1, vadc.c:692-695 */
    }
    vadc_amd_caps caps;
-   vadc_amd_get_caps(engine, &caps);
+   memset(&caps, 0, sizeof caps);
+   vadc_amd_get_caps_sized(engine, &caps, sizeof caps);           /* never more than THIS revision's struct, whatever the library's */
    config->batch_size_restriction = caps.batch_size_restriction;     /* silero.h:39 */
    config->is_silero_v5 = caps.is_silero_v5;                         /* silero.h:40 */
    config->input_size_min = caps.input_size_min;                     /* silero.h:41 */

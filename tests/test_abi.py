@@ -28,6 +28,21 @@ def test_header_symbols_all_exported():
     assert sorted(_lib.SYMBOLS) == syms
 
 
+def test_abi_revision_is_checked_before_a_struct_crosses_the_boundary():
+    """vadc_amd_get_caps writes sizeof(vadc_amd_caps) of the LIBRARY's revision: a binding compiled against another revision must find out first.  The header's
+    VADC_AMD_ABI_VERSION, the library's vadc_amd_abi_version() and the ctypes mirror's ABI_VERSION agree; the mirror's Caps has the header's fields in its order;
+    the adapter header checks the revision in backend_init and asks for its own sizeof only"""
+    text = open(os.path.join(ROOT, "include", "vadc_amd.h")).read()
+    rev = int(re.search(r"#define\s+VADC_AMD_ABI_VERSION\s+(\d+)", text).group(1))
+    L = _lib.load()
+    assert L.vadc_amd_abi_version() == rev == _lib.ABI_VERSION
+    body = re.search(r"typedef struct vadc_amd_caps \{(.*?)\} vadc_amd_caps;", text, re.S).group(1)
+    fields = re.findall(r"int32_t\s+([a-z0-9_]+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == [n for n, _ in _lib.Caps._fields_]
+    adapter = open(os.path.join(ROOT, "include", "vadc_backend_hip.h")).read()
+    assert "vadc_amd_abi_version() != VADC_AMD_ABI_VERSION" in adapter and "vadc_amd_get_caps_sized(engine, &caps, sizeof caps)" in adapter
+
+
 def test_exports_are_plain_c_and_only_ours():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
@@ -190,5 +205,5 @@ def test_no_packed_add_takes_its_low_result_from_a_later_sources_high_dword(tmp_
                         "-o", out, os.path.join(ROOT, "vadc_amd", "csrc", "kernels_frontend.hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert cpo.check(out) == []
-    assert "k_frontend_ri" in open(out).read()                      # the shipped form is in the listing that was checked
+    assert "k_frontend_sym" in open(out).read()                     # the shipped form is in the listing that was checked
 

@@ -124,52 +124,49 @@ def test_basis_without_dft_symmetries_runs_the_full_tree(weights_blob):
 
 
 def test_zero_im_row_of_bin0_is_skipped_bit_exactly(weights_blob):
-    """the three forms of the exact-tree front end: k_frontend_sym with fe_opt = 3 (the default) and k_frontend_ri (fe_opt = 11: packed pairs = (re, im) of one tree lane, the
-    derived rows' sums and the logarithm two values per instruction) run bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis
-    (-w[n] sin 0): magnitudes, log-magnitudes and probabilities keep every bit of round 3's kernel (fe_opt = 0), which evaluated that tree, and of the oracle"""
+    """k_frontend_sym runs bin 0 without the tree of its im row, which is 256 exact zeros in the shipped basis (-w[n] sin 0): magnitudes, log-magnitudes and
+    probabilities keep every bit of the full tree for all 129 bins (k_frontend_fl, option frontend = 1, which evaluates that tree) and of the oracle"""
     pcm = synth.make_streams(5, 7, seed0=411)
     x = f32(pcm[:3]).reshape(-1)
     e = Engine(weights_blob, max_streams=8, max_chunks_per_call=8, device=0)
     try:
-        assert e.get_option("zero_im0") == 1 and e.get_option("fe_opt") == 3
+        assert e.get_option("zero_im0") == 1
         out = {}
-        for opt in (11, 3, 0):
-            e.set_option("fe_opt", opt); e.reset_streams()
-            out[opt] = (e.stage_from_samples(x, "magnitude"), e.stage_from_samples(x, "normalized"), e.run(pcm))
-            assert e.get_option("frontend_kernel") == 0
-        for a, b, c in zip(out[0], out[3], out[11]):
-            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
+        for fe in (0, 1):
+            e.set_option("frontend", fe); e.reset_streams()
+            out[fe] = (e.stage_from_samples(x, "magnitude"), e.run(pcm))
+            assert e.get_option("frontend_kernel") == fe
+        assert np.array_equal(bits(out[0][0]), bits(out[1][0]))
+        assert float(np.abs(out[0][1] - out[1][1]).max()) < 1e-5          # (the bin means are summed in another fixed order: test_frontend_sym_and_full_tree_bit_identical)
     finally:
         e.close()
     o = O.Oracle(weights_blob)
     for i in range(4):
         h, c = o.new_state()
         _, taps = o.forward_chunk(x[i * 1536:(i + 1) * 1536], h, c, taps=True)
-        assert np.array_equal(bits(out[3][0][i]), bits(taps["magnitude"])), i
+        assert np.array_equal(bits(out[0][0][i]), bits(taps["magnitude"])), i
 
 
 @pytest.mark.parametrize("S,C", [(1, 1), (3, 5), (37, 5), (300, 3), (256, 96)])
 def test_frontend_blocks_in_xcd_major_order_change_no_bit(weights_blob, orc, S, C):
     """option "fe_xcd" (default 1): the exact-tree front end's workgroups take their blocks of 64 positions in XCD-major order (kernels_frontend.hip xcd_major_block:
     workgroup b computes block (b % 8) * ceil(n / 8) + b / 8, so that the two workgroups sharing a chunk sit behind one L2) -- a permutation of who computes what:
-    log-magnitudes and probabilities are the bits of launch order, for both forms of the kernel, at block counts that are and are not multiples of 8; and the oracle's"""
+    log-magnitudes and probabilities are the bits of launch order, at block counts that are and are not multiples of 8; and the oracle's"""
     pcm = np.ascontiguousarray(np.tile(synth.make_streams(min(S, 6), C, seed0=900 + S), ((S + 5) // 6, 1))[:S])
     e = Engine(weights_blob, max_streams=S, max_chunks_per_call=C, device=0)
     try:
         assert e.get_option("fe_xcd") == 1
         out = {}
-        for fe_opt in (3, 11):
-            for xcd in (1, 0):
-                e.set_option("fe_opt", fe_opt); e.set_option("fe_xcd", xcd); e.reset_streams()
-                y = e.stage_from_samples(f32(pcm[:2, : min(C, 3) * 1536]).reshape(-1), "normalized")
-                out[fe_opt, xcd] = (y, e.run(pcm))
-                assert e.get_option("frontend_kernel") == 0
-        for k in out:
-            assert np.array_equal(bits(out[k][0]), bits(out[3, 0][0])) and np.array_equal(bits(out[k][1]), bits(out[3, 0][1])), k
+        for xcd in (1, 0):
+            e.set_option("fe_xcd", xcd); e.reset_streams()
+            y = e.stage_from_samples(f32(pcm[:2, : min(C, 3) * 1536]).reshape(-1), "normalized")
+            out[xcd] = (y, e.run(pcm))
+            assert e.get_option("frontend_kernel") == 0
+        assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(bits(out[1][1]), bits(out[0][1]))
     finally:
         e.close()
     want = orc.forward_stream(pcm[S - 1])[:, 1]
-    assert float(np.abs(out[3, 1][1][S - 1, :, 1] - want).max()) <= PROB_TOL
+    assert float(np.abs(out[1][1][S - 1, :, 1] - want).max()) <= PROB_TOL
 
 
 def test_nonzero_im_row_of_bin0_reenables_its_tree(weights_blob):
@@ -837,15 +834,6 @@ def test_reset_and_state_roundtrip(eng):
     assert np.array_equal(bits(first), bits(again))
 
 
-def test_first_stage_forms_agree(eng, gold_py):
-    """first encoder stage: K = 1 MFMA form (default) vs the LDS slab path (option encoder=2): same fp32 math, other summation order"""
-    x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
-    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
-    eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")
-    eng.set_option("encoder", 0)
-    assert float(np.abs(a - b).max()) < 5e-5, float(np.abs(a - b).max())
-
-
 def test_lstm_variants_agree(eng):
     pcm = synth.make_streams(19, 6, seed0=5)
     out, state, kern = {}, {}, {}
@@ -1089,20 +1077,16 @@ def test_encoder_gemm_forms_agree(eng, gold_py, stage):
 
 
 @pytest.mark.parametrize("stage", ["layer2", "layer3", "layer4"])
-def test_fused_encoder_forms_agree_with_the_per_layer_kernels(eng, gold_py, stage):
-    """layers 2-4 in one launch (k_enc_fused, the default; both of its batch forms) against one launch per layer (option encoder=5, round 2's hot path):
-    different kernels -- activations in registers and attention on the matrix cores vs LDS tiles and vector attention -- the same math to fp32 rounding;
-    23 chunks = ragged last batches in both forms"""
+def test_fused_encoder_agrees_with_the_per_layer_kernels(eng, gold_py, stage):
+    """layers 2-4 in one launch (k_enc_fused, the default: activations in registers, attention on the matrix cores, split-fp16 MFMA) against one launch per layer
+    (option encoder = 3: LDS tiles, vector attention, fp32 MFMA -- the fallback for weights outside fp16's range): different kernels, the same math to fp32
+    rounding; 23 chunks = a ragged last batch; the stage tap runs the fused kernel's general instantiation, the hot path its HOT one -- both against the oracle in
+    test_stage_vs_oracle / the probability tests"""
     x = f32(gold_py["pcm_speech2"])[: 23 * 1536]
-    eng.set_option("encoder", 5); ref = eng.stage_from_samples(x, stage)
-    eng.set_option("encoder", 0)
-    outs = []
-    for form in (1, 2):
-        eng.set_option("encoder_batch", form); outs.append(eng.stage_from_samples(x, stage))
-    eng.set_option("encoder_batch", 0)
-    assert not np.array_equal(bits(outs[0]), bits(ref))
-    assert np.array_equal(bits(outs[0]), bits(outs[1]))               # the two batch forms run the same arithmetic per chunk
-    assert float(np.abs(outs[0] - ref).max()) < 5e-5, float(np.abs(outs[0] - ref).max())
+    eng.set_option("encoder", 3); ref = eng.stage_from_samples(x, stage)
+    eng.set_option("encoder", 0); got = eng.stage_from_samples(x, stage)
+    assert not np.array_equal(bits(got), bits(ref))
+    assert float(np.abs(got - ref).max()) < 5e-5, float(np.abs(got - ref).max())
 
 
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 23, 100])
@@ -1859,7 +1843,7 @@ def test_runs_repeat_bit_for_bit_beside_their_own_neighbours():
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
     soak.scale = 1.0
-    for shape in ((10240, 1, 8, 40), (256, 96, 3, 8), (100, 24, 4, 20), (640, 8, 6, 16), (10240, 1, 8, 60, {"fe_opt": 11})):      # (the last: k_frontend_ri beside k_lstm_layer on shared CUs)
+    for shape in ((10240, 1, 8, 40), (256, 96, 3, 8), (100, 24, 4, 20), (640, 8, 6, 16), ):      # (_layer on shared CUs)
         rec = soak.soak(*shape)
         assert rec["runs_differing_from_the_first"] == 0, rec
 

@@ -172,15 +172,6 @@ def test_frontend_variants(eng, orc, gold):
     assert float(np.abs(gemm_n - tree_n).max()) < 5e-3     # log1p(2^20 m) amplifies rounding noise in near-silent bins
 
 
-def test_first_stage_forms_agree(eng, gold):
-    """first encoder stage (258 channels): k_layer1_regs_v4 (default) vs the LDS slab path of k_layer_mfma (option encoder=2)"""
-    x = f32(gold["pcm_speech1"])[:11 * 1536]
-    eng.set_option("encoder", 0); a = eng.stage_from_samples(x, "layer1")
-    eng.set_option("encoder", 2); b = eng.stage_from_samples(x, "layer1")
-    eng.set_option("encoder", 0)
-    assert float(np.abs(a - b).max()) < 5e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
-
-
 @pytest.mark.parametrize("n", [1, 7, 9, 23, 100])
 def test_first_stage_register_kernel_agrees_with_the_k1_form(eng, orc, gold, n):
     """k_layer1_regs_v4 (the default at the 1536-sample window: the chunk by LDS-DMA into the wave's own buffer, two overlapping 16-column tiles,
@@ -225,19 +216,6 @@ def test_first_stage_over_many_rounds_of_its_input_ring(blob, orc):
         h, c = orc.new_state()
         _, taps = orc.forward_chunk(x[i], h, c, taps=True)
         assert float(np.abs(b[i] - taps["l1"]).max()) < TAP_TOL * scale, int(i)
-
-
-def test_magnitude_recovered_from_log_magnitude_agrees_with_stored_magnitude(eng, gold):
-    """default: the first stage takes the magnitude half of its input as (e^Y - 1) 2^-20 from the log-magnitudes; option v4_mag=1: from the magnitude
-    array the front end then writes.  Same first-stage output to rounding noise, same probabilities to well inside the parity bar."""
-    x = f32(gold["pcm_speech1"])[:11 * 1536]
-    try:
-        eng.set_option("v4_mag", 0); a = eng.stage_from_samples(x, "layer1"); eng.reset_streams(); pa = eng.run(gold["pcm_speech0"][None, :])
-        eng.set_option("v4_mag", 1); b = eng.stage_from_samples(x, "layer1"); eng.reset_streams(); pb = eng.run(gold["pcm_speech0"][None, :])
-    finally:
-        eng.set_option("v4_mag", 0); eng.reset_streams()
-    assert float(np.abs(a - b).max()) < 2e-5 * max(1.0, float(np.abs(a).max())), float(np.abs(a - b).max())
-    assert float(np.abs(pa - pb).max()) < 2e-5, float(np.abs(pa - pb).max())
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -433,24 +411,20 @@ def test_cli_with_the_8khz_container(gold):
     assert float(np.abs(got - g8["probs64_w768_speech0"]).max()) < PROB_TOL + 5e-7
 
 
-def test_first_stage_widths_agree(blob, orc):
-    """k_layer_mfma's K = 1 form of the v4 first stage (option "layer1" = 1; the default is k_layer1_regs_v4) runs 8 waves / 5 chunks per workgroup (the
-    middle chunk in two pieces that overlap by four steps, so every lane finds its depthwise-conv neighbours in its own wave); option "encoder" = 4 selects 4
-    waves / 2 chunks.  Same arithmetic per column (two template
-    instantiations may contract differently: last-bit differences, a few 1e-6 after the LSTM), on every remainder of chunks per workgroup"""
+def test_first_stage_k1_form_on_every_remainder_of_chunks_per_workgroup(blob, orc):
+    """k_layer_mfma's K = 1 form of the v4 first stage (option "layer1" = 1 -- the fallback of k_layer1_regs_v4: a weight outside fp16's range, a failed
+    self-check) runs 8 waves / 5 chunks per workgroup (the middle chunk in two pieces that overlap by four steps, so every lane finds its depthwise-conv
+    neighbours in its own wave): the oracle's probabilities on every remainder of chunks per workgroup"""
     for S, Cn in ((3, 13), (64, 40), (1, 1), (2, 5), (7, 6)):
         pcm = synth.make_streams(S, Cn, seed0=77 + S)
-        out = {}
-        for enc in (0, 4):
-            e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
-            try:
-                e.set_option("layer1", 1)
-                e.set_option("encoder", enc)
-                out[enc] = e.run(pcm)
-            finally:
-                e.close()
-        assert float(np.abs(out[0] - out[4]).max()) < 2e-5, (S, Cn)        # last-bit differences of the stage, carried through the LSTM
-        assert float(np.abs(out[0][:, :, 1] - orc.forward_streams(pcm)).max()) < PROB_TOL
+        e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+        try:
+            e.set_option("layer1", 1)
+            got = e.run(pcm)
+            assert e.get_option("layer1_kernel") == 1
+        finally:
+            e.close()
+        assert float(np.abs(got[:, :, 1] - orc.forward_streams(pcm)).max()) < PROB_TOL
 
 
 def test_8khz_container_without_dft_symmetries_is_refused():

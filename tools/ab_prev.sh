@@ -2,6 +2,7 @@
 # A/B on one box: the library built from an earlier commit (vadc_amd/csrc/build/prev/libvadc_amd_prev.so: git archive <commit> | tar -x -C /tmp/prev && make -C
 # /tmp/prev/vadc_amd/csrc) against the tree's, alternating, same bench arguments.  gpurun -- 'bash tools/ab_prev.sh [bench.py arguments]'
 P=$GRAFT_REPO_ROOT/vadc_amd/csrc/build/prev/libvadc_amd_prev.so
+[ -f "$P" ] || { echo "ab_prev.sh: $P is missing (build the earlier commit's library there first): nothing to compare with" >&2; exit 1; }
 ARGS="${@:---no-side-config --no-host-fed --no-cpu-baseline}"
 for i in 1 2; do
   for which in prev new; do

@@ -1,5 +1,5 @@
 """Bit comparison of two builds of the library on what k_frontend_gemm2 feeds (s16 input; the stage taps take f32 and run the first form): Silero v4's probabilities
-for 61 streams x 13 chunks at the default window and the two shorter ones, with and without the magnitude array.
+for 61 streams x 13 chunks at the default window and the two shorter ones.
     VADC_AMD_LIB=<other build> python tools/fe_gemm_bits.py dump /tmp/a.npz ;  python tools/fe_gemm_bits.py dump /tmp/b.npz ;  python tools/fe_gemm_bits.py cmp /tmp/a.npz /tmp/b.npz"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +15,6 @@ if sys.argv[1] == "dump":
         if window != 1536: e.set_window(window)
         pcm = synth.make_streams(16, 96, seed0=5).reshape(-1)[: 61 * 13 * window].reshape(61, -1)      # 61 streams x 13 chunks: ragged tiles and groups
         out[f"probs_{window}"] = e.run(pcm)                     # s16 input: k_frontend_gemm2
-        e.set_option("v4_mag", 1)
-        e.reset_streams()
-        out[f"probs_mag_{window}"] = e.run(pcm)                 # ... its magnitude-array form (dword stores)
         e.close()
     np.savez(sys.argv[2], **out)
     print("wrote", sys.argv[2], {k: v.shape for k, v in out.items()})

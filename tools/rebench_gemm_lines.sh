@@ -1,3 +1,8 @@
+#!/bin/bash
+# the bench lines of the GEMM-front-end configurations, side by side.   gpurun -- 'bash tools/rebench_gemm_lines.sh'
+set -e -o pipefail
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out
 O=gpurun_out
 python bench.py --details $O/bench_default_details.json 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --steps 20 --warmup 5 --details $O/bench_driver_form_details.json 2>/dev/null | tail -1 > $O/bench_driver_form.json

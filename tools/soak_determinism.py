@@ -39,7 +39,6 @@ def soak(S, Cn, calls, reps, opts=None, model="v31"):
     e.close()
     return rec
 SHAPES = [(10240, 1, 8, 600), (16384, 1, 4, 200), (4096, 1, 8, 300), (256, 96, 3, 120), (256, 8, 8, 300), (100, 24, 4, 300), (640, 8, 6, 200), (1024, 4, 8, 200), (4096, 16, 2, 60), (256, 96, 3, 60, {"lstm_trail": 0}), (10240, 1, 8, 200, {"lstm": 6}),
-          (10240, 1, 8, 600, {"fe_opt": 11}), (256, 96, 3, 60, {"fe_opt": 11}), (4096, 1, 8, 200, {"fe_opt": 11}),          # k_frontend_ri (an option)
           (256, 96, 3, 60, None, "v4"), (4096, 16, 2, 40, None, "v4"), (10240, 1, 6, 150, None, "v4"), (768, 32, 3, 60, None, "v4"),
           (256, 96, 3, 60, None, "v5"), (4096, 16, 2, 40, None, "v5"), (64, 192, 2, 60, None, "v5")]
 if __name__ == "__main__":

@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvadc_amd.so")
 
 # every symbol include/vadc_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
+ABI_VERSION = 6          # VADC_AMD_ABI_VERSION of the include/vadc_amd.h this module's Caps structure mirrors (tests/test_abi.py compares the two)
 SYMBOLS = [
-    "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps", "vadc_amd_get_caps_sized",
+    "vadc_amd_abi_version", "vadc_amd_create", "vadc_amd_destroy", "vadc_amd_last_error", "vadc_amd_get_caps", "vadc_amd_get_caps_sized",
     "vadc_amd_run_f32", "vadc_amd_run_s16", "vadc_amd_run_device_f32", "vadc_amd_run_device_s16",
     "vadc_amd_run_s16_async", "vadc_amd_run_f32_async", "vadc_amd_wait_async",
     "vadc_amd_synchronize", "vadc_amd_join", "vadc_amd_speech_probabilities", "vadc_amd_reset_streams", "vadc_amd_get_state", "vadc_amd_set_state",
@@ -103,5 +104,8 @@ def load() -> C.CDLL:
     L.vadc_amd_kernel_name.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here == header/library mismatch
+    L.vadc_amd_abi_version.restype = C.c_int
+    if L.vadc_amd_abi_version() != ABI_VERSION:      # before any struct crosses the boundary: get_caps writes the LIBRARY's sizeof(vadc_amd_caps)
+        raise RuntimeError(f"{LIB_PATH} speaks revision {L.vadc_amd_abi_version()} of include/vadc_amd.h, vadc_amd/_lib.py revision {ABI_VERSION}: rebuild (make -C vadc_amd/csrc)")
     _lib = L
     return L

@@ -21,13 +21,12 @@
 namespace vadc {
 void launch_frontend_fl_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
 void launch_frontend_fl_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t);
-void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int, const float *);
-void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int, const float *);
+void launch_frontend_sym_f32(const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
+void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
-void launch_frontend_gemm_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
-void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
+void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
@@ -39,8 +38,8 @@ struct LayerWeightsM {
    const _Float16 *qkv_h, *out_h, *l1_h, *l2_h, *cv_h;
    const _Float16 *pw_h, *pj_h;
 };
-void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, bool);
-void launch_enc_fused(const EncFusedArgs &, int, int, hipStream_t);
+void launch_layer_mfma(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t);
+void launch_enc_fused(const EncFusedArgs &, int, hipStream_t);
 void launch_enc_fused_v4(const EncV4Args &, int, hipStream_t);
 void launch_layer1_tap(int, const float *, const LayerWeightsM &, float *, int, ItemMap, hipStream_t);
 void launch_layer1_regs(const L1RegsArgs &, int, hipStream_t);
@@ -54,7 +53,7 @@ struct V5Weights {
 void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
 void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
 void launch_v5_lstm(const V5Weights &, const float *, float *, float *, float *, int, int, bool, hipStream_t);
-void launch_layer_v4(int, const float *, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, bool, int, int, bool);
+void launch_layer_v4(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, int, int);
 }  // namespace vadc
 
 using namespace vadc;
@@ -155,9 +154,9 @@ struct vadc_amd_engine {
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
    const float *d_afrag2 = nullptr, *d_nyq2 = nullptr; // ... the same for its second form (k_frontend_gemm2: 32x32x16 MFMAs, s16 input)
-   int full_mask_streams = 2;                   // option "full_mask_streams": without a partition, 2 (default) = the front end + encoder stream is a CU-masked stream with EVERY CU
-                                                // (a hardware queue of its own), 1 = all three internal streams are, 0 = plain streams (round 4)
-   int fe_gemm = 2;                             // option "fe_gemm": 2 = k_frontend_gemm2 for s16 input (default), 1 = the first form for everything
+   // (without a CU partition the front end + encoder stream is still a CU-masked stream -- with EVERY CU: a hardware queue of its own, see ensure_pipeline_streams -- unless
+   // the caller asked for plain streams with "cu_partition" = 0.  Rounds 4-5 had an option for it, "full_mask_streams".)
+
    bool gemm_ok = false;                        // the loaded basis has the real-DFT symmetries the folded GEMM needs
    bool use_gemm_frontend() const { return gemm_ok && ((model == VADC_AMD_MODEL_V4 && frontend_variant == 0) || (model != VADC_AMD_MODEL_V4 && precision == VADC_AMD_PRECISION_FAST_STFT)); }
    float *d_MAG = nullptr;                      // v4 only: magnitudes [n][129][24] (the v4 encoder takes magnitude AND log-norm)
@@ -166,7 +165,7 @@ struct vadc_amd_engine {
    hipStream_t stream = nullptr;
    float *d_weights = nullptr;
    const float *d_basis = nullptr;
-   const float *d_basis_ri = nullptr;           // base bins 0..32 with (re, im) interleaved per tap: k_frontend_ri's copy ([33][ii][lp][l % 2][j][re | im]), when sym_ok
+
    bool sym_ok = false;                         // the loaded basis has the bin-mirror / quarter-mirror DFT symmetries bit for bit: k_frontend_sym may run
    bool cu_layout_ok = false;                   // 256 CUs and CU-mask bit i -> XCD i % 8 (cu_mask_layout_ok): what the LSTM partition rules assume
    int cu_mask_check = 1;                       // option "cu_mask_check": 1 = the partition needs cu_layout_ok (default), 0 = trust the rules anyway, 2 = behave as if the check had failed (tests)
@@ -177,10 +176,10 @@ struct vadc_amd_engine {
    bool cu_partition_usable() const { return cu_mask_check == 0 || (cu_mask_check == 1 && cu_layout_ok); }
    bool zero_im0 = false;                       // the basis' im row of bin 0 (-w[n] sin 0) is all +-0: k_frontend_sym skips that tree (its sums are +-0 whatever the input)
    int fe_xcd = 1;                              // option "fe_xcd": the exact-tree front end's workgroups take their blocks of positions in XCD-major order (kernels_frontend.hip, xcd_major_block): the two workgroups that share a chunk write its lines of Y behind one L2
-   int fe_opt = 3;                              // option "fe_opt": k_frontend_sym's OPT mask (0 = round 3's kernel, 3 = rotating splits + bin 0 without its zero tree), or 11 = k_frontend_ri ((re, im)-packed trees and epilogue: 8 % fewer instructions, the same time -- kernels_frontend.hip)
+
    int frontend_variant = 0;                    // v3.1: 0 = auto (k_frontend_sym when the basis has the DFT symmetries, else k_frontend_fl), 1 = k_frontend_fl; v4: 0 = GEMM, 1 = tree
    LayerWeightsM lwm[4];
-   int encoder_variant = 0;                     // 0 = default (layers 2-4 fused in one launch when the weights allow), 2 = first stage as the LDS slab path, 3 = fp32 MFMA for the GEMMs of layers 2-4, 5 = one launch per layer (split-fp16)
+   int encoder_variant = 0;                     // option "encoder": 0 = default (layers 2-4 fused in one launch when the weights allow), 3 = fp32 MFMA, one launch per layer (also what serves a weight outside fp16's range)
    // k_enc_fused (kernels_encoder_fused.hip): the two LDS images (layers 2 + 3; layer 4) and the phase A -> phase B scratch
    void *d_encA = nullptr, *d_encB = nullptr;
    float *d_enc_scratch = nullptr;
@@ -192,9 +191,9 @@ struct vadc_amd_engine {
    std::vector<unsigned char> h_encv4;
    int layer1_selfcheck = -1;                   // -1: not run (no register-resident first layer in this engine), 1: it agrees with the per-layer form on the probe chunks, 0: it does not (the per-layer form serves)
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
-   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && encoder_variant != 2 && layer1_selfcheck != 0; }
-   // Silero v4: k_layer1_regs_v4 serves the default window (24 frames) with the magnitude half of the input recovered from Y ("v4_mag" = 0)
-   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && v4_mag == 0 && layer1_selfcheck != 0; }   // ("encoder" = 2: the first stage as the LDS slab path)
+   bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && layer1_selfcheck != 0; }
+   // Silero v4: k_layer1_regs_v4 serves the default window (24 frames); the magnitude half of the first stage's input is recovered from Y in every form
+   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && layer1_selfcheck != 0; }
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
@@ -211,10 +210,10 @@ struct vadc_amd_engine {
    std::vector<HostRange> pinned;
    unsigned long long pin_clock = 0;
    int pin_host = 1;
-   int enc_batch = 0;                           // option "encoder_batch": form of k_enc_fused (0 / 1: 12 waves x one pair tile per batch, 2: 8 waves x two)
+
    // Silero v4, default window: stages 2-4 in one launch (hot path only: LSTM tiles out, no stage taps); option "encoder" = 5 keeps the per-stage launches
    bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames == 24 && sample_rate == 16000; }
-   bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && (encoder_variant == 0 || encoder_variant == 2); }
+   bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && encoder_variant == 0; }
    LstmWeights lstm;
    // workspace
    float *d_in_f32 = nullptr;
@@ -267,7 +266,7 @@ struct vadc_amd_engine {
    bool lstm_h3_ok = true;                      // every LSTM weight fits fp16's range (|w| < 3e4): the split-fp16 kernel may be used
    bool ev_b_valid[2] = {false, false};         // ev_b[p] has been recorded by a previous forked call that used pair p
    bool ev_c_valid[2] = {false, false};         // ev_c[p]: layer 1 of the last layer-major call that used pair p has read its h0 sequence
-   int v4_mag = 0;                              // option "v4_mag": 0 = the v4 first stage recovers the magnitudes from Y (no MAG array on the hot path), 1 = it reads MAG
+
    int cu_partition = 1;                        // option "cu_partition": 0 = never mask CUs
    // hipGraph replay of the steady-state step (option "graph"): one instantiated graph per distinct call signature
    int use_graph = 0;
@@ -394,17 +393,6 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
                for (int b = 0; b < 2; ++b)
                   tmp2[(size_t)f * 256 + ii * 64 + lp * 16 + j * 2 + b] = tmp[(size_t)f * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + b)];
    const size_t off_basis = pk.add(tmp2.data(), tmp2.size());
-   // the same taps for k_frontend_ri: base bins 0..32, the re and the im tap of a position side by side (an SGPR pair = second operand of one v_pk_mul_f32 whose
-   // first is the sample, broadcast): [f][i = 3,2,1,0][l / 2][l % 2][j][re | im]; one (group, l-pair) block of slack for the pipeline's last prefetch
-   std::vector<float> ri((size_t)(33 + 2) * 512 + 64, 0.0f);
-   for (int f = 0; f < 33; ++f)
-      for (int ii = 0; ii < 4; ++ii)
-         for (int lp = 0; lp < 4; ++lp)
-            for (int h = 0; h < 2; ++h)
-               for (int j = 0; j < 8; ++j)
-                  for (int c = 0; c < 2; ++c)
-                     ri[(size_t)f * 512 + ii * 128 + lp * 32 + h * 16 + j * 2 + c] = tmp[(size_t)(c ? kBins + f : f) * 256 + 64 * (3 - ii) + 8 * j + (2 * lp + h)];
-   const size_t off_basis_ri = pk.add(ri.data(), ri.size());
    size_t off_afrag = 0, off_nyq = 0, off_afrag2 = 0, off_nyq2 = 0;
    e->gemm_ok = build_gemm_frontend(tmp, pk, off_afrag, off_nyq, off_afrag2, off_nyq2);   // FAST_STFT precision mode
    e->sym_ok = basis_has_dft_symmetries(tmp);
@@ -644,7 +632,6 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
-      e->d_basis_ri = base + off_basis_ri;
       if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; e->d_afrag2 = base + off_afrag2; e->d_nyq2 = base + off_nyq2; }
       for (int l = 0; l < 4; ++l) {
          LayerWeights w;
@@ -1005,6 +992,7 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
 // lifetime
 // ---------------------------------------------------------------------------------------------------
 extern "C" const char *vadc_amd_last_error(void) { return g_err.c_str(); }
+extern "C" int vadc_amd_abi_version(void) { return VADC_AMD_ABI_VERSION; }
 
 extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
 {
@@ -1191,7 +1179,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
 extern "C" int vadc_amd_get_caps_sized(const vadc_amd_engine *e, void *caps, size_t caps_size)
 {
    if (!e || !caps || caps_size < sizeof(int32_t)) return fail(VADC_AMD_EINVAL, "get_caps_sized: NULL argument or no room for a field");
-   vadc_amd_caps full;
+   vadc_amd_caps full = {};
    const int rc = vadc_amd_get_caps(e, &full);
    if (rc) return rc;
    memcpy(caps, &full, caps_size < sizeof(full) ? caps_size : sizeof(full));
@@ -1309,7 +1297,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    // Every accepted switch (but "graph" itself) changes the launch sequence a captured graph replays: the captured graphs are dropped (after their last
    // replay has finished) -- only once the key and value have been validated, so that a rejected call leaves them alone.
    {
-      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "v4_mag", "lstm_cus", "cu_partition", "h2d_streams", "encoder_batch", "layer1", "fe_opt", "fe_gemm", "cu_mask_check", "lstm_trail", "full_mask_streams", "fe_xcd"};
+      static const char *const keys[] = {"lstm", "frontend", "encoder", "groups", "window", "defer_join", "lstm_cus", "cu_partition", "h2d_streams", "layer1", "cu_mask_check", "lstm_trail", "fe_xcd"};
       bool known = false;
       for (const char *k : keys) known = known || strcmp(key, k) == 0;
       if (known && !e->graphs.empty()) {
@@ -1332,10 +1320,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    }
    if (strcmp(key, "lstm") == 0 && (value == 0 || value == 3 || value == 6 || value == 7)) { e->lstm_variant = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "frontend") == 0 && (value == 0 || value == 1)) { e->frontend_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "fe_opt") == 0 && (value == 0 || value == 3 || value == 11)) { e->fe_opt = value; return VADC_AMD_OK; }
    if (strcmp(key, "fe_xcd") == 0 && (value == 0 || value == 1)) { e->fe_xcd = value; return VADC_AMD_OK; }
-   if (strcmp(key, "fe_gemm") == 0 && (value == 1 || value == 2)) { e->fe_gemm = value; return VADC_AMD_OK; }
-   if (strcmp(key, "full_mask_streams") == 0 && value >= 0 && value <= 2) { e->full_mask_streams = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "pin_host") == 0 && (value == 0 || value == 1)) { e->pin_host = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "trail_fault") == 0 && value >= 0 && value <= 2) { e->trail_fault = value; return VADC_AMD_OK; }
@@ -1343,7 +1328,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 2 || value == 3 || (value == 4 && e->model == VADC_AMD_MODEL_V4) || (value == 5 && e->model == VADC_AMD_MODEL_V31))) { e->encoder_variant = value; return VADC_AMD_OK; }
+   if (strcmp(key, "encoder") == 0 && (value == 0 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
       // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
@@ -1363,9 +1348,7 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "graph") == 0 && (value == 0 || value == 1)) { e->use_graph = value; return VADC_AMD_OK; }
    if (strcmp(key, "h2d_streams") == 0 && value >= 1 && value <= 4) { e->h2d_parts = value; return VADC_AMD_OK; }
    if (strcmp(key, "layer1") == 0 && (value == 0 || value == 1)) { e->layer1_variant = value; return VADC_AMD_OK; }
-   if (strcmp(key, "encoder_batch") == 0 && value >= 0 && value <= 2) { e->enc_batch = value; return VADC_AMD_OK; }
    if (strcmp(key, "defer_join") == 0 && (value == 0 || value == 1)) { e->defer_join = value; return VADC_AMD_OK; }
-   if (strcmp(key, "v4_mag") == 0 && (value == 0 || value == 1)) { e->v4_mag = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_cus") == 0 && value >= 0 && value <= 128 && value % 8 == 0) { e->lstm_cus_forced = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    if (strcmp(key, "cu_partition") == 0 && value >= 0 && value <= 2) { e->cu_partition = value; e->lstm_cus = -1; return VADC_AMD_OK; }
    return fail(VADC_AMD_EINVAL, "set_option: unknown option %s=%d", key, value);
@@ -1376,10 +1359,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    if (!e || !key || !value) return fail(VADC_AMD_EINVAL, "get_option: NULL argument");
    if (strcmp(key, "lstm") == 0) *value = e->lstm_variant;
    else if (strcmp(key, "frontend") == 0) *value = e->frontend_variant;
-   else if (strcmp(key, "fe_opt") == 0) *value = e->fe_opt;
    else if (strcmp(key, "fe_xcd") == 0) *value = e->fe_xcd;
-   else if (strcmp(key, "fe_gemm") == 0) *value = e->fe_gemm;
-   else if (strcmp(key, "full_mask_streams") == 0) *value = e->full_mask_streams;
    else if (strcmp(key, "layer1_selfcheck") == 0) *value = e->layer1_selfcheck;
    else if (strcmp(key, "layer1_kernel") == 0) *value = (e->use_l1_regs() || e->use_l1_regs_v4()) ? 0 : 1;      // the form that runs (option "layer1" is the request)
    else if (strcmp(key, "pin_host") == 0) *value = e->pin_host;
@@ -1399,12 +1379,10 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "zero_im0") == 0) *value = e->zero_im0 ? 1 : 0;
    else if (strcmp(key, "encoder") == 0) *value = e->encoder_variant;
    else if (strcmp(key, "layer1") == 0) *value = e->layer1_variant;
-   else if (strcmp(key, "encoder_batch") == 0) *value = e->enc_batch;
    else if (strcmp(key, "groups") == 0) *value = e->groups;
    else if (strcmp(key, "graph") == 0) *value = e->use_graph;
    else if (strcmp(key, "window") == 0) *value = e->window;
    else if (strcmp(key, "defer_join") == 0) *value = e->defer_join;
-   else if (strcmp(key, "v4_mag") == 0) *value = e->v4_mag;
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
    else if (strcmp(key, "lstm_kernel") == 0) *value = e->last_lstm_kernel;
@@ -1570,7 +1548,6 @@ static int check_shape(vadc_amd_engine *e, int n_streams, int n_chunks, const ch
 }
 
 // Silero v4: the first stage (K = 1 form) takes the magnitude half of its input from Y = log(1 + 2^20 m) instead of a second array
-static bool v4_mag_from_y(const vadc_amd_engine *e) { return e->model == VADC_AMD_MODEL_V4 && e->encoder_variant != 2 && e->v4_mag == 0; }
 
 // CUs a persistent grid on the front end + encoder stream may count on: the LSTM chain's workgroups keep theirs for a whole call, and an
 // 8-wave workgroup of k_enc_fused (216 registers, 132 KB of LDS) never fits beside one -- a workgroup sent there would wait for the chain
@@ -1605,7 +1582,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          a.tap3 = last == 2 ? e->d_act[2] : nullptr;
          a.tap4 = (last == 3 && lstm_layout == 0) ? e->d_act[3] : nullptr;
          a.n_chunks = n; a.first = l + 1; a.last = last + 1; a.map = map;
-         launch_enc_fused(a, encoder_cus(e, st), e->enc_batch, st);
+         launch_enc_fused(a, encoder_cus(e, st), st);
          return;
       }
       if (l == 1 && last == 3 && lstm_layout == 2 && !in_stage && e->use_enc_fused_v4()) {      // Silero v4: stages 2-4 in one launch
@@ -1628,9 +1605,8 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          launch_layer1_regs(a, encoder_cus(e, st), st);
          continue;
       }
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, v4_mag_from_y(e) ? nullptr : e->d_MAG, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2, e->frames, e->stride3(), e->encoder_variant == 4);
-      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->encoder_variant == 2,
-                                                     e->encoder_variant != 3 && e->enc_h3_ok);
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->frames, e->stride3());
+      else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
    }
 }
 
@@ -1652,18 +1628,17 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       const int fk = pick_frontend(e, d_in);
       if (fk == 2) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0;
-         float *mag = v4_mag_from_y(e) ? nullptr : e->d_MAG;     // the first stage recovers the magnitudes from Y: 0.8 GB per 65,536 chunks not written and not read
-         // s16 input: the second form (32x32x16 MFMAs, one persistent workgroup per CU the stream may count on, pipelined across column tiles); f32 input: the first form
-         if (sizeof(T) == 2 && e->fe_gemm == 2) launch_frontend_gemm2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag2, e->d_nyq2, e->d_Y, mag, e->d_FM, fms, n, map, encoder_cus(e, st), st, geo);
-         else if (sizeof(T) == 2) launch_frontend_gemm_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
-         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, mag, e->d_FM, fms, n, map, e->n_cus, st, geo);
+         // s16 input: the second form (32x32x16 MFMAs, one persistent workgroup per CU the stream may count on, pipelined across column tiles); f32 input: the first form.
+         // No magnitude array on the hot path: the v4 first stage recovers the magnitudes from Y (0.8 GB per 65,536 chunks not written and not read)
+         if (sizeof(T) == 2) launch_frontend_gemm2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag2, e->d_nyq2, e->d_Y, e->d_FM, fms, n, map, encoder_cus(e, st), st, geo);
+         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, nullptr, e->d_FM, fms, n, map, e->n_cus, st, geo);
       } else if (fk == 3) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
       } else if (fk == 0) {
          // bit-exact tree for bins 0..32, the other 96 bins from the basis' symmetries (kernels_frontend.hip)
-         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
-         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
+         if (sizeof(T) == 2) launch_frontend_sym_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_xcd, e->zero_im0);
+         else                launch_frontend_sym_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st, e->fe_xcd, e->zero_im0);
       } else {
          // any basis, any alignment: the full tree for all 129 bins
          if (sizeof(T) == 2) launch_frontend_fl_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_FM, fms, n, map, 0, st);
@@ -1798,7 +1773,7 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
          for (hipStream_t *ps : {&e->sA, &e->sB, &e->sC}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
       }
    }
-   if (!masked && e->full_mask_streams && e->cu_partition_usable()) {
+   if (!masked && e->cu_partition != 0 && e->cu_partition_usable()) {      // ("cu_partition" = 0 is the caller's word for plain streams everywhere)
       // no partition: the front end + encoder stream still gets a CU mask -- a full one.  A masked stream has a hardware queue of its own; plain streams are dealt onto a
       // few shared ones, and behind some predecessors in the same process stream A and the recurrence's stream ended up on one: the recurrence of call k then started when
       // call k + 1's front end had ENDED and ran beside its persistent kernels (10,240 x 1: 2.95 -> 1.77 M, 16,384 x 1: 3.25 -> 2.6 M, every time; tools/queue_probe.py).
@@ -1808,16 +1783,12 @@ static int ensure_pipeline_streams(vadc_amd_engine *e, int n_streams, int lk)
       std::vector<uint32_t> all(words, 0u);
       for (int cu = 0; cu < e->n_cus; ++cu) all[cu / 32] |= 1u << (cu % 32);
       hipError_t ea = hipExtStreamCreateWithCUMask(&e->sA, (uint32_t)words, all.data());
-      hipError_t eb = ea, ec = ea;
-      if (e->full_mask_streams == 2) {                         // only stream A: the recurrence's streams keep their priority
-         int lo = 0, hi = 0;
-         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-         eb = (ea == hipSuccess) ? hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi) : ea;
-         ec = (eb == hipSuccess) ? hipStreamCreateWithPriority(&e->sC, hipStreamNonBlocking, hi) : eb;
-      } else {
-         eb = (ea == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sB, (uint32_t)words, all.data()) : ea;
-         ec = (eb == hipSuccess) ? hipExtStreamCreateWithCUMask(&e->sC, (uint32_t)words, all.data()) : eb;
-      }
+      // only stream A: the recurrence's streams keep their priority (all three masked: 4096 x 16 -3 %).  NOTE: a CU-masked stream is created with
+      // hipStreamDefault flags -- it synchronises with the legacy NULL stream, which callers therefore should not issue from (include/vadc_amd.h)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const hipError_t eb = (ea == hipSuccess) ? hipStreamCreateWithPriority(&e->sB, hipStreamNonBlocking, hi) : ea;
+      const hipError_t ec = (eb == hipSuccess) ? hipStreamCreateWithPriority(&e->sC, hipStreamNonBlocking, hi) : eb;
       masked = (ea == hipSuccess && eb == hipSuccess && ec == hipSuccess);
       if (!masked) {
          (void)hipGetLastError();
@@ -2543,7 +2514,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
                                e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
-   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_opt | (e->fe_xcd ? 16 : 0), e->zero_im0, e->d_basis_ri);
+   else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_xcd, e->zero_im0);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);

@@ -290,11 +290,27 @@ __device__ __forceinline__ void store_chw7(const f4 (&x)[MT], float *out, int it
       for (int r = 0; r < 4; ++r) p[(16 * mt + 4 * q + r) * 7] = x[mt][r];
 }
 
+// A wave-uniform pointer, said so: both halves through readfirstlane, so that it lives in an SGPR pair and the per-lane part of an address stays a 32-bit offset
+// (global_load / global_store saddr form).  Without it hipcc strength-reduces the batch loop's addresses into per-lane 64-bit induction pointers, and at 168
+// registers (12 waves) spilled 17 of them into scratch: 9 scratch loads + 4 stores per batch (round 5's listing).
+template <typename P>
+__device__ __forceinline__ P *uniform_ptr(P *p)
+{
+   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return reinterpret_cast<P *>(((unsigned long long)hi << 32) | lo);
+}
+
 // NP = column tiles per batch in layers 3 / 4 = pairs of chunks; a batch = 2 NP chunks
 // NW = waves per workgroup (one workgroup per CU: the LDS image allows no second one)
-template <int NP, int NW>
-__global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
+// HOT: the product's call -- layers 2, 3 and 4, no stage taps -- with everything else compiled out: the tap stores' and the partial forms' loop-invariant per-lane
+// offsets (and an integer division) were hoisted in front of the batch loops and, at 168 registers, spilled: 17 registers, 9 scratch loads + 4 stores per batch in
+// round 5's listing of the one instantiation that ships.  HOT = false serves the stage taps and the partial ranges (first / last).
+template <int NP, int NW, bool HOT>
+__global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a_)
 {
+   EncFusedArgs a = a_;
+   if (HOT) { a.first = 2; a.last = 4; a.tap2 = nullptr; a.tap3 = nullptr; a.tap4 = nullptr; }
    __shared__ __attribute__((aligned(16))) char lds[kEncLdsBytes];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -344,10 +360,11 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
                   for (int nt = 0; nt < 2; ++nt) {
                      const int item = item0 + 2 * p + nt;
                      const bool ok = lc < 13 && item < a.n_chunks;
-                     const float *xp = a.in + (size_t)a.map(item < a.n_chunks ? item : 0) * (16 * 13) + (8 * (q & 1)) * 13 + lc;
+                     const float *xb = uniform_ptr(a.in + (size_t)a.map(item < a.n_chunks ? item : 0) * (16 * 13));      // (the item is the wave's: uniform)
+                     const int xo = (8 * (q & 1)) * 13 + lc;
                      f4 xv[2], d[2];
 #pragma unroll
-                     for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = ok ? xp[e * 13] : 0.0f;
+                     for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = ok ? xb[xo + e * 13] : 0.0f;
 #pragma unroll
                      for (int e = 0; e < 8; ++e)
                         d[e >> 2][e & 3] = dw5<false>(xv[e >> 2][e & 3], k[0][e >> 2][e & 3], k[1][e >> 2][e & 3], k[2][e >> 2][e & 3], k[3][e >> 2][e & 3],
@@ -397,11 +414,11 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                if (a.tap3) store_chw7<2>(y3[p], a.tap3, item0 + 2 * p, a.n_chunks, a.map, lane);
-               float *sp = a.scratch + ((size_t)b * NP + p) * 512 + lane;
+               float *sp = uniform_ptr(a.scratch + ((size_t)b * NP + p) * 512);
 #pragma unroll
                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) sp[(4 * mt + r) * 64] = y3[p][mt][r];
+                  for (int r = 0; r < 4; ++r) sp[lane + (4 * mt + r) * 64] = y3[p][mt][r];
             }
          }
       }
@@ -419,11 +436,11 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
          if (a.first <= 3) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-               const float *sp = a.scratch + ((size_t)b * NP + p) * 512 + lane;
+               const float *sp = uniform_ptr(a.scratch + ((size_t)b * NP + p) * 512);
 #pragma unroll
                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) x4[p][mt][r] = __builtin_nontemporal_load(sp + (4 * mt + r) * 64);
+                  for (int r = 0; r < 4; ++r) x4[p][mt][r] = __builtin_nontemporal_load(sp + lane + (4 * mt + r) * 64);
             }
          } else {
 #pragma unroll
@@ -455,20 +472,20 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused(EncFusedArgs a)
 }
 
 // grid: one workgroup per CU the stream may use (`max_wgs`), never more than there are batches for its waves.
-// form 0 / 1: 12 waves, one pair tile (two chunks) per batch -- 168 registers, three waves per SIMD; form 2: 8 waves, two pair tiles per batch (half the
-// LDS weight traffic per chunk, two independent MFMA chains per wave, 212 registers).  Measured alone on the chip per 24,576 / 65,536 chunks:
-// 0.110 / 0.329 ms against 0.117 / 0.326 ms (tools/enc_rate.py); 16 waves spill (0.114).  Option "encoder_batch" selects.
-void launch_enc_fused(const EncFusedArgs &a, int max_wgs, int form, hipStream_t st)
+// 12 waves, one pair tile (two chunks) per batch -- 168 registers, three waves per SIMD.  (Round 3 also carried an 8-wave form with two pair tiles per batch -- half
+// the LDS weight traffic per chunk, 212 registers: 0.117 / 0.326 ms per 24,576 / 65,536 chunks against this form's 0.110 / 0.329 -- and a 16-wave form that
+// spilled; both are gone: option "encoder_batch" is no more.)
+void launch_enc_fused(const EncFusedArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
-   const bool two = form == 2;
-   const int nw = two ? 8 : 12;
-   const int nb = two ? (a.n_chunks + 3) / 4 : (a.n_chunks + 1) / 2;
+   const int nw = 12;
+   const int nb = (a.n_chunks + 1) / 2;
    int g = (nb + nw - 1) / nw;
    if (g > max_wgs) g = max_wgs;
    if (g < 1) g = 1;
-   if (two) hipLaunchKernelGGL((k_enc_fused<2, 8>), dim3(g), dim3(512), 0, st, a);
-   else     hipLaunchKernelGGL((k_enc_fused<1, 12>), dim3(g), dim3(768), 0, st, a);
+   const bool hot = a.first == 2 && a.last == 4 && !a.tap2 && !a.tap3 && !a.tap4;
+   if (hot) hipLaunchKernelGGL((k_enc_fused<1, 12, true>), dim3(g), dim3(768), 0, st, a);
+   else     hipLaunchKernelGGL((k_enc_fused<1, 12, false>), dim3(g), dim3(768), 0, st, a);
 }
 
 }  // namespace vadc

@@ -1100,28 +1100,18 @@ extern "C" void vadc_phase_report(void)
 #endif
 
 // chunks per workgroup: L1 T=25 -> 2 (50 of 64 columns), L2 T=13 -> 4 (52), L3/L4 T=7 -> 9 (63)
+// One launch per layer with fp32 MFMA: the FALLBACK of the register-resident kernels (a weight outside fp16's range, a failed self-check), option "encoder" = 3 /
+// "layer1" = 1, and the literal-fp32 configuration of bench.py.  (Until round 5 this launcher also carried the per-layer split-fp16 forms -- option "encoder" = 5, round
+// 2's hot path -- and the first layer's LDS slab path -- "encoder" = 2: experiments, neither a default nor a fallback.)
 void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                       int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, bool h3)
+                       int lstm_layout, size_t fm_stride, hipStream_t st)
 {
-   if (h3 && w.qkv_h) {
-      switch (layer) {
-      case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true, true, false, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); return;
-      case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); return;
-      case 3:
-         if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 2, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-         else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 1, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-         else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 0, 9, true, true, false, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-         return;
-      default: break;
-      }
-   }
    switch (layer) {
    case 0:
-      if (slab) hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
 #ifdef VADC_L1_ABL_NOTF
-      else      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, false, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
 #else
-      else      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      hipLaunchKernelGGL((k_layer_mfma<129, 16, 25, 2, true, true, false, 2, false, true, true>), dim3((n + 1) / 2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
 #endif
       break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
@@ -1149,29 +1139,27 @@ void launch_layer1_tap(int what, const float *y, const LayerWeightsM &w, float *
 // lets the v4 graph take 512 ... 1536 samples): 24 -> 12 -> 6 -> 3 -> 3 (1536), 20 -> 10 -> 5 -> 3 -> 3 (1280), 16 -> 8 -> 4 -> 2 -> 2 (1024), 12 -> 6 -> 3 -> 2 -> 2 (768),
 // 8 -> 4 -> 2 -> 1 -> 1 (512).
 // chunks per workgroup fill the 64 columns: T0 = 24: 2 / 5 / 10 / 21;  16: 4 / 8 / 16 / 32;  8: 8 / 16 / 32 / 64.  S3 = stride of the third strided conv.
-template <int T0, int NCH, bool SLAB, int FIRSTK>
-static void launch_v4_first(const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st, bool narrow)
+// The first stage in its K = 1 form takes the magnitude half of its input from Y (FIRSTK = 3): no magnitude array.  (Until round 5: the LDS slab path -- "encoder" = 2 --,
+// the magnitudes from a second array -- "v4_mag" = 1 -- and a 4-wave form at 24 frames -- "encoder" = 4: experiments.)
+template <int T0, int NCH>
+static void launch_v4_first(const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st)
 {
-   if constexpr (!SLAB && T0 == 24) {                       // 8 waves: 5 chunks per workgroup (120 of 128 lanes own a column instead of 48 of 64)
-      if (!narrow) {
-         hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, 5, false, false, true, false, 8>), dim3((n + 4) / 5), dim3(512), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-         return;
-      }
+   const float *no_in2 = nullptr;
+   if constexpr (T0 == 24) {                                // 8 waves: 5 chunks per workgroup (120 of 128 lanes own a column instead of 48 of 64)
+      hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, 5, false, false, true, false, 8>), dim3((n + 4) / 5), dim3(512), 0, st, in, fm, w, out, n, map, fm_stride, no_in2);
+      return;
    }
-   hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, FIRSTK, false, NCH, false, false, !SLAB>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+   hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, NCH, false, false, true>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, no_in2);
 }
 template <int T0, int S3>
-static void launch_v4_t(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                        int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, bool narrow)
+static void launch_v4_t(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                        int lstm_layout, size_t fm_stride, hipStream_t st)
 {
    constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = S3 == 2 ? (T2 + 1) / 2 : T2;      // a k = 1 conv of stride 2 keeps 1 + (T - 1) / 2 steps (12 -> 6 -> 3 -> 2, 20 -> 10 -> 5 -> 3)
    constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
+   const float *in2 = nullptr;
    switch (layer) {
-   case 0:
-      if (slab)     launch_v4_first<T0, N0, true, 2>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
-      else if (in2) launch_v4_first<T0, N0, false, 2>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
-      else          launch_v4_first<T0, N0, false, 3>(in, in2, fm, w, out, n, map, fm_stride, st, narrow);
-      break;
+   case 0: launch_v4_first<T0, N0>(in, fm, w, out, n, map, fm_stride, st); break;
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
@@ -1184,20 +1172,20 @@ static void launch_v4_t(int layer, const float *in, const float *in2, const floa
 
 // frames = STFT frames per chunk; stride3 = stride of the third strided conv: 2 in the 16 kHz branch (frames 24 / 16 / 8 = 1536- / 1024- / 512-sample
 // windows), 1 in the 8 kHz branch (silero_vad.py:178-181; frames 12 / 8 / 4 = 768- / 512- / 256-sample windows: 12 -> 6 -> 3 -> 3 -> 3, ...)
-void launch_layer_v4(int layer, const float *in, const float *in2, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st, bool slab, int frames, int stride3, bool narrow)
+void launch_layer_v4(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
+                     int lstm_layout, size_t fm_stride, hipStream_t st, int frames, int stride3)
 {
    if (stride3 == 1) {
-      if (frames == 8)      launch_v4_t<8, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
-      else if (frames == 4) launch_v4_t<4, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
-      else                  launch_v4_t<12, 1>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+      if (frames == 8)      launch_v4_t<8, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+      else if (frames == 4) launch_v4_t<4, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+      else                  launch_v4_t<12, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
       return;
    }
-   if (frames == 16)     launch_v4_t<16, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
-   else if (frames == 12) launch_v4_t<12, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);      // 768-sample window (round 5)
-   else if (frames == 20) launch_v4_t<20, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);      // 1280-sample window
-   else if (frames == 8) launch_v4_t<8, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
-   else                  launch_v4_t<24, 2>(layer, in, in2, fm, w, out, n, map, lstm_layout, fm_stride, st, slab, narrow);
+   if (frames == 16)      launch_v4_t<16, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+   else if (frames == 12) launch_v4_t<12, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);      // 768-sample window (round 5)
+   else if (frames == 20) launch_v4_t<20, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);      // 1280-sample window
+   else if (frames == 8)  launch_v4_t<8, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+   else                   launch_v4_t<24, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
 }
 
 }  // namespace vadc

@@ -854,225 +854,6 @@ __global__ __launch_bounds__(256, MINW) void k_frontend_sym(const T *__restrict_
    if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
 }
 
-// =====================================================================================================
-// k_frontend_ri -- k_frontend_sym with the packed pair = (re, im) of ONE tree lane instead of tree lanes (l, l + 1) of one row
-// =====================================================================================================
-// k_frontend_sym packs tree lanes (l, l + 1) of a row into one v_pk_*: its products and lane trees are packed, but everything behind them -- the sign-flipped
-// pair sums of the 8 derived rows (56 additions per base bin), re^2 + im^2, the logarithm -- is one instruction per value: 24 M of its 214 M vector
-// instructions per 24,576 chunks.  Here a packed register holds (re, im) of the SAME tree lane: the product is x[t] * (re[t], im[t]) -- the sample broadcast to
-// both halves by the instruction's op_sel, the two taps an SGPR pair of a basis copy interleaved for it ([f][ii][lp][l % 2][j][re | im]) --, the lane trees are
-// the same v_pk_add_f32 count as before, and at their end the tree lanes 2 LP and 2 LP + 1 arrive as P = (rx, ix), Q = (ry, iy): exactly the operands of
-//     (re b, im b) = P + Q      (re 128-b, im 128-b) = P - Q      (re 64-b, im 64-b) = (-Q.hi, Q.lo) + P      (re 64+b, im 64+b) = (Q.hi, -Q.lo) + P
-// -- four packed additions (op_sel swaps Q's halves, neg_lo / neg_hi negate one: (-b) + a IS a - b) instead of eight, and so for the sums over the l-pairs (28
-// packed instead of 56 per base bin); re^2 and im^2 are one v_pk_mul_f32 of the row's pair with itself; and the epilogue -- magnitude, 2^20, log1p -- runs for two
-// rows at once (v_pk_add / v_pk_mul / v_pk_fma around the four transcendentals).  Every component of every packed instruction is the IEEE operation the
-// reference's expression has at that place, in the same order: the bits of Y, FM and the magnitudes are k_frontend_sym's (tools/fe_bench sym, tests).
-// 198 M instead of 214 M vector instructions per launch, 0.4285 instead of 0.4350 ms alone on 224 CUs: an UNPACKED VGPR-only v_add_f32 issues in 2 cycles against
-// the 4 of a v_pk_add_f32, so packing the tree's epilogue buys instruction count more than time.
-// Bin 0 stays on k_frontend_sym's stages (a batch of one, without the tree of its all-zero im row when `zero_im0`).
-//
-// THE SWAPPED PAIR MUST BE THE FIRST SOURCE (SRC1 = false).  Written the natural way -- v_pk_add_f32 d, P, Q op_sel:[0,1] op_sel_hi:[1,0]: low result = P.lo + Q.HI --
-// the low result came back as P.lo ALONE (Q.hi read as zero) in lanes 48 .. 63, about once in 8 million executions, but only while waves of ANOTHER kernel shared
-// the SIMD (k_lstm_layer beside it at 10,240 x 1: one row 64 -+ b of one workgroup wrong, max |dp| 4e-2; never alone on the chip: DESIGN.md 4.1 (d),
-// tools/study/ri_repro.hip: 164 of 6,000 launches; a sentinel in the destination showed the result WAS written).  The same sum with Q first -- op_sel:[1,0]: low
-// result = Q.HI + P.lo, the selection every product of an odd tree lane uses -- never did: 0 of 12,000 launches.  tools/check_pk_opsel.py keeps the form out of
-// every listing of the build (hipcc writes it by itself for packed horizontal sums).  SRC1 = true exists for the reproducer only.
-constexpr int ri_tap_off(int b, int i, int lp) { return b * 2048 + (3 - i) * 512 + lp * 128; }      // bytes: 32 floats per (bin, group, l-pair) = [l % 2][j][re | im]
-
-// g = ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)),  q_j = x[8j + 2 LP + H] * (re, im)[j]   (stft.c:141-160); xq as fl_tree8, kv = the 8 (re, im) pairs of tree lane 2 LP + H
-template <int H>
-__device__ __forceinline__ f2v ri_tree8(const f4v (&xq)[4], const f16v &kv)
-{
-   f2v q[8];
-#pragma unroll
-   for (int j = 0; j < 8; ++j) {
-      const f2v xp = (j & 1) ? __builtin_shufflevector(xq[j >> 1], xq[j >> 1], 2, 3) : __builtin_shufflevector(xq[j >> 1], xq[j >> 1], 0, 1);
-      const f2v kp = {kv[2 * j], kv[2 * j + 1]};
-      // (as `(f2v){x, x} * kp` hipcc folds only some of the broadcasts into op_sel and copies the others: 113 v_mov per kernel instead of 47;
-      // tools/pk_opsel_probe.hip checks what the selector bits do)
-      if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=&v"(q[j]) : "v"(xp), "s"(kp));
-      else        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=&v"(q[j]) : "v"(xp), "s"(kp));
-   }
-   const f2v a01 = q[0] + q[1], a23 = q[2] + q[3], a45 = q[4] + q[5], a67 = q[6] + q[7];
-   const f2v a0123 = a01 + a23, a4567 = a45 + a67;
-   return a0123 + a4567;
-}
-
-struct RiState {                    // a batch of two base bins
-   f2v ta[4], tb[4];                // g_0 (+ g_1), g_2 of tree lane 2 LP + h of base bin B: [2 B + h], as (re, im)
-   f2v sa[8], sb[8];                // the 4 row pairs of base bin B: [4 B + q] = (re, im) of row {b, 128 - b, 64 - b, 64 + b}[q]: e0 (+- e1), e2; sa ends up as the row's y
-};
-
-template <int LP, bool SRC1>
-__device__ __forceinline__ void ri_rows(RiState &st, int B, f2v P, f2v Q)
-{
-   f2v E[4];
-   E[0] = P + Q;
-   E[1] = P - Q;
-   if constexpr (SRC1) {         // the natural operand order: measured to lose Q.hi in lanes 48 .. 63 beside another kernel's waves (see above); tools/study/ri_repro.hip only
-      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(E[2]) : "v"(P), "v"(Q));      // (rx - iy, ix + ry)
-      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=&v"(E[3]) : "v"(P), "v"(Q));      // (rx + iy, ix - ry)
-   } else {
-      asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=&v"(E[2]) : "v"(P), "v"(Q));      // (-iy + rx, ry + ix)
-      asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=&v"(E[3]) : "v"(P), "v"(Q));      // (iy + rx, -ry + ix)
-   }
-#pragma unroll
-   for (int q = 0; q < 4; ++q) {
-      f2v &sa = st.sa[4 * B + q], &sb = st.sb[4 * B + q];
-      if (LP == 0) sa = E[q];
-      else if (LP == 1) sa = (q < 2) ? sa + E[q] : sa - E[q];
-      else if (LP == 2) sb = E[q];
-      else { const f2v t = (q < 2) ? sb + E[q] : sb - E[q]; sa = sa + t; }
-   }
-}
-
-// Stage K of a batch of two = (step S = K / 2 = 4 LP + I, base bin B = K % 2), pipelined exactly like SymStages; ca / cb = the taps of tree lanes 2 LP / 2 LP + 1
-template <int K, bool SRC1>
-struct RiStages {
-   static __device__ __forceinline__ void run(RiState &st, const float *kf, unsigned xaddr, f16v &ca, f16v &cb, f16v &na, f16v &nb, f4v (&xc)[4], f4v (&xn)[4])
-   {
-      constexpr int S = K / 2, B = K % 2, LP = S / 4, I = S % 4;
-      constexpr int Kn = K + 1;
-      constexpr int Sn = (Kn / 2) % 16, Bn = Kn % 2, LPn = Sn / 4, In = Sn % 4;
-      constexpr int noff = (Kn == 32 ? 2 * 2048 : 0) + ri_tap_off(Bn, In, LPn);
-      if constexpr (B == 0) {
-         constexpr int S1 = (S + 1) % 16;
-         VADC_FL_LDS16(xn, xaddr, ((S1 % 4) * kFlBlockPitch + (S1 / 4) * 16) * 4);
-      }
-      VADC_FL_SLOAD2(na, nb, kf, noff, noff + 64);
-      const f2v g0 = ri_tree8<0>(xc, ca), g1 = ri_tree8<1>(xc, cb);
-      if constexpr (I == 0) { st.ta[2 * B] = g0; st.ta[2 * B + 1] = g1; }
-      else if constexpr (I == 1) { st.ta[2 * B] = st.ta[2 * B] + g0; st.ta[2 * B + 1] = st.ta[2 * B + 1] + g1; }       // g_0 + g_1   (stft.c:165)
-      else if constexpr (I == 2) { st.tb[2 * B] = g0; st.tb[2 * B + 1] = g1; }
-      else {
-         const f2v t0 = st.tb[2 * B] + g0, t1 = st.tb[2 * B + 1] + g1;                                                  // g_2 + g_3   (stft.c:166)
-         ri_rows<LP, SRC1>(st, B, st.ta[2 * B] + t0, st.ta[2 * B + 1] + t1);                                                   // stft.c:167, :176-184
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb));
-      if constexpr (B == 1) {
-         asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
-         __builtin_amdgcn_sched_barrier(0);
-         RiStages<K + 1, SRC1>::run(st, kf, xaddr, na, nb, ca, cb, xn, xc);
-      } else {
-         __builtin_amdgcn_sched_barrier(0);
-         RiStages<K + 1, SRC1>::run(st, kf, xaddr, na, nb, ca, cb, xc, xn);
-      }
-   }
-};
-template <bool SRC1>
-struct RiStages<32, SRC1> {
-   static __device__ __forceinline__ void run(RiState &, const float *, unsigned, f16v &, f16v &, f16v &, f16v &, f4v (&)[4], f4v (&)[4]) {}
-};
-
-// log1p_hw of two values: component for component the same operations
-// log1p_hw of two values: component for component the same operations
-__device__ __forceinline__ f2v log1p_hw2(f2v x)
-{
-   const f2v one = {1.0f, 1.0f};
-   const f2v u = one + x;
-   const f2v c = x - (u - one);
-   f2v y = (f2v){__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)} * 0.6931471805599453f;
-   const f2v t = y * -1.4426950408889634f;
-   const f2v E = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-   y += __builtin_elementwise_fma(u, E, -one);
-   return __builtin_elementwise_fma(c, E, y);
-}
-
-template <typename T, int MODE, int MINW = 4, bool SRC1 = false, bool XCD = false>
-__global__ __launch_bounds__(256, MINW) void k_frontend_ri(const T *__restrict__ pcm,          // [n_chunks][1536], 16-byte aligned
-                                                          const float *__restrict__ basis,    // [258][256] permuted (k_frontend's): bin 0
-                                                          const float *__restrict__ basis_ri, // [33][4][4][2][8][2]: base bins, (re, im) interleaved
-                                                          float *__restrict__ Y,              // [n_chunks][129][25]
-                                                          float *__restrict__ FM,             // [kBinSplit][fm_stride] partial bin sums
-                                                          int n_chunks, ItemMap map, size_t fm_stride, int zero_im0)
-{
-   constexpr int kFlChunks = fl_chunks(1);
-   __shared__ __attribute__((aligned(16))) float xs[kFlChunks * kSymChunkPitch];
-   const int tid = threadIdx.x, lane = tid & 63;
-   const unsigned bid = XCD ? xcd_major_block(blockIdx.x, gridDim.x) : blockIdx.x;
-   const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)bid) & 3;              // base-bin split, rotating with the workgroup (k_frontend_sym's OPT 1)
-   const long total_pos = (long)n_chunks * kFrames;
-   const long p0 = (long)bid * 64;
-   const int item0 = (int)(p0 / kFrames);
-   sym_stage_chunks<T>(xs, pcm, map, item0, n_chunks, tid);
-   __syncthreads();
-
-   const long pe = p0 + lane;
-   const bool writer = pe < total_pos;
-   const long pa_ = writer ? pe : total_pos - 1;
-   const int item = (int)(pa_ / kFrames), n = (int)(pa_ - (long)item * kFrames);
-   const int chunk = map(item);
-   typedef __attribute__((address_space(3))) float lds_f;
-   const unsigned xaddr = (unsigned)(uintptr_t)(lds_f *)(xs + (item - item0) * kSymChunkPitch + kFlBlockPitch * n);
-
-   const int f_start = sym_first_bin(wave, 2), f_end = sym_end_bin(wave, 2);
-   float *yout = Y + (size_t)chunk * (kBins * kFrames) + n;
-   float bin_sum = 0.0f;
-   f16v ca, cb, na, nb;
-   f4v xc[4], xn[4];
-   VADC_FL_LDS16(xc, xaddr, 0);
-   // the samples must have ARRIVED before the compiler may touch their registers (it does not know the asm's reads are in flight, and the branch below makes it
-   // copy them): the wait is tied to them
-   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]));
-   __builtin_amdgcn_sched_barrier(0);
-
-   auto emit_row = [&](int bin, float re, float im) {                             // bin 0's three rows (k_frontend_sym's emit_row)
-      const float re2 = re * re, im2 = im * im;
-      const float p2 = re2 + im2;
-      float val;
-      if (MODE == 0) { val = log1p_hw(__builtin_amdgcn_sqrtf(p2) * 1048576.0f); bin_sum += val; }
-      else val = sqrtf(p2);
-      if (writer) yout[bin * kFrames] = val;
-   };
-   // two rows at once: (re, im) pairs ra, rb of bins ba, bb (in this order into the partial bin sum: misc.c:55-59)
-   auto emit_pair = [&](int ba, int bb, f2v ra, f2v rb) {
-      const f2v sqa = ra * ra, sqb = rb * rb;
-      const f2v p2 = {sqa.x + sqa.y, sqb.x + sqb.y};
-      f2v val;
-      if (MODE == 0) {
-         const f2v m = {__builtin_amdgcn_sqrtf(p2.x), __builtin_amdgcn_sqrtf(p2.y)};
-         val = log1p_hw2(m * 1048576.0f);                                        // misc.c:42-45
-         bin_sum += val.x; bin_sum += val.y;
-      } else val = (f2v){sqrtf(p2.x), sqrtf(p2.y)};                              // stft.c:209
-      if (writer) { yout[ba * kFrames] = val.x; yout[bb * kFrames] = val.y; }
-   };
-   constexpr int kImOffB = kBins * kFilterLen * 4;
-   int f_loop = f_start;
-   if (wave == 0) {                                                               // split 0: bin 0 alone on k_frontend_sym's stages, then bins 1..8 in pairs
-      VADC_FL_SLOAD2(ca, cb, basis, fl_tap_off(0, 0, 0), fl_tap_off(0, 0, 0) + kImOffB);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
-      __builtin_amdgcn_sched_barrier(0);
-      SymState<1> s1;
-      if (zero_im0) SymStages<1, 0, true>::run(s1, basis, xaddr, ca, cb, na, nb, xc, xn);
-      else          SymStages<1, 0, false>::run(s1, basis, xaddr, ca, cb, na, nb, xc, xn);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(s1.sa[k]));
-      emit_row(0, s1.sa[0], s1.sa[1]); emit_row(128, s1.sa[2], s1.sa[3]); emit_row(64, s1.sa[4], s1.sa[5]);     // rows 0, 128, 64 (64 - 0 and 64 + 0 coincide)
-      f_loop = 1;
-   }
-   {
-      const float *k0 = basis_ri + (size_t)f_loop * 512;
-      VADC_FL_SLOAD2(ca, cb, k0, ri_tap_off(0, 0, 0), ri_tap_off(0, 0, 0) + 64);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb));
-      __builtin_amdgcn_sched_barrier(0);
-   }
-#pragma unroll 1
-   for (int f = f_loop; f + 2 <= f_end; f += 2) {
-      const float *kf = basis_ri + (size_t)f * 512;                              // wave-uniform
-      RiState st;
-      RiStages<0, SRC1>::run(st, kf, xaddr, ca, cb, na, nb, xc, xn);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st.sa[k]));            // pin the trees above the epilogue (see k_frontend_fl)
-#pragma unroll
-      for (int B = 0; B < 2; ++B) {
-         const int b = f + B;                                                     // 1 .. 32: rows b, 128 - b and -- below 32 -- 64 - b, 64 + b (at 32 they are rows 32 and 96 again)
-         emit_pair(b, 128 - b, st.sa[4 * B], st.sa[4 * B + 1]);
-         if (b < 32) emit_pair(64 - b, 64 + b, st.sa[4 * B + 2], st.sa[4 * B + 3]);
-      }
-   }
-   if (MODE == 0 && writer) FM[wave * fm_stride + (size_t)chunk * kFrames + n] = bin_sum;   // /129 by the reader (misc.c:60)
-}
-
 // Stage tap only: normalized[n][129][25] = Y - mean_t(smooth7(reflect3(FM)))   (misc.c:65-96).
 // The engine's normal path folds this subtraction into the first encoder layer.
 template <int kFrames>
@@ -1146,33 +927,25 @@ void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, fl
 }
 
 // k_frontend_sym: the default v3.1 front end (basis symmetries verified by the engine, pcm 16-byte aligned)
-// opt: the kernel's OPT mask (0 = round 3's kernel; 3 = rotating splits + bin 0 as a batch of one, its im tree skipped when zero_im0)
+// The kernel's OPT mask is fixed at 3 (rotating splits + bin 0 as a batch of one, its im tree skipped when zero_im0), + 8 = XCD-major block order (xcd_major_block):
+// the engine's option "fe_xcd", default on.  (Round 3's kernel -- OPT 0 -- and the (re, im)-packed form k_frontend_ri -- option "fe_opt" = 11: 8 % fewer vector
+// instructions, the same time, the same bits -- were options until round 5; the latter is kept under tools/study/ beside its reproducer.)
 constexpr int kSymNB = 2;   // tools/fe_bench sym, 16,384 chunks: NB = 2 0.300 ms, NB = 3 0.329 ms (k_frontend_fl: 1.07 ms)
-// opt & 8 (and a basis_ri): k_frontend_ri, the (re, im)-packed form;  opt & 16: XCD-major block order (xcd_major_block), the engine's option "fe_xcd"
 template <typename T>
-static void launch_frontend_sym(const T *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0, const float *basis_ri)
+static void launch_frontend_sym(const T *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int xcd, int zero_im0)
 {
    const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   const bool xcd = (opt & 16) != 0;                    // option "fe_xcd" (default on): XCD-major block order
-   opt &= 15;
-   if ((opt & 8) && basis_ri) {
-      if (mode != 0)  hipLaunchKernelGGL((k_frontend_ri<T, 1, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
-      else if (xcd)   hipLaunchKernelGGL((k_frontend_ri<T, 0, 4, false, true>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
-      else            hipLaunchKernelGGL((k_frontend_ri<T, 0, 4>), grid, dim3(256), 0, st, pcm, basis, basis_ri, Y, FM, n, map, fm_stride, zero_im0);
-      return;
-   }
-   if (mode != 0)            hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else if (opt == 3 && xcd) hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 11>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else if (opt == 3)        hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else                      hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 0>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   if (mode != 0) hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else if (xcd)  hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 11>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   else           hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
 }
-void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0, const float *basis_ri)
+void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int xcd, int zero_im0)
 {
-   launch_frontend_sym<float>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, opt, zero_im0, basis_ri);
+   launch_frontend_sym<float>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, xcd, zero_im0);
 }
-void launch_frontend_sym_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int opt, int zero_im0, const float *basis_ri)
+void launch_frontend_sym_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int xcd, int zero_im0)
 {
-   launch_frontend_sym<int16_t>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, opt, zero_im0, basis_ri);
+   launch_frontend_sym<int16_t>(pcm, basis, Y, FM, fm_stride, n, map, mode, st, xcd, zero_im0);
 }
 
 // Silero v4 geometry (reflect pad 96, 24 frames): Y = log1p(2^20 m), MAG = m, FM = partial bin sums with frame stride 24

@@ -343,10 +343,6 @@ void launch_frontend_gemm_f32(const float *pcm, const float *afrag, const float 
    launch_gemm<float>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo);
 }
 
-void launch_frontend_gemm_s16(const int16_t *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
-                              int n, ItemMap map, int n_cus, hipStream_t st, int geo)
-{
-   launch_gemm<int16_t>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo);
-}
+// (s16 input is k_frontend_gemm2's: kernels_frontend_gemm2.hip.  This form serves f32 input -- the host's backend_run samples, the stage taps.)
 
 }  // namespace vadc

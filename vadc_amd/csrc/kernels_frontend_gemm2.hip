@@ -392,7 +392,8 @@ void launch_frontend_gemm2_abl(const int16_t *pcm, const float *afrag2, const fl
    hipLaunchKernelGGL((k_frontend_gemm2<1, false, ABL>), dim3(groups < n_cus ? groups : n_cus), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride);
 }
 
-void launch_frontend_gemm2_s16(const int16_t *pcm, const float *afrag2, const float *nyq2, float *Y, float *MAG, float *FM, size_t fm_stride,
+// (no magnitude array: the v4 first stage recovers the magnitudes from Y; the WMAG = true instantiations served option "v4_mag" = 1 until round 5)
+void launch_frontend_gemm2_s16(const int16_t *pcm, const float *afrag2, const float *nyq2, float *Y, float *FM, size_t fm_stride,
                                int n, ItemMap map, int n_cus, hipStream_t st, int geo)
 {
    if (n <= 0) return;
@@ -400,8 +401,7 @@ void launch_frontend_gemm2_s16(const int16_t *pcm, const float *afrag2, const fl
    case GEO: { \
       const int groups = (n + G2Geo<GEO>::chunks - 1) / G2Geo<GEO>::chunks; \
       const int grid = groups < n_cus ? groups : n_cus; \
-      if (MAG) hipLaunchKernelGGL((k_frontend_gemm2<GEO, true>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, MAG, FM, n, map, fm_stride); \
-      else     hipLaunchKernelGGL((k_frontend_gemm2<GEO, false>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, MAG, FM, n, map, fm_stride); \
+      hipLaunchKernelGGL((k_frontend_gemm2<GEO, false>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride); \
    } break;
    switch (geo) {
    VADC_G2_CASE(1) VADC_G2_CASE(2) VADC_G2_CASE(3) VADC_G2_CASE(4) VADC_G2_CASE(5) VADC_G2_CASE(6)
