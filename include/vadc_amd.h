@@ -239,6 +239,10 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "h2d_streams" [host-buffer callers on a slow link]  1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call
  *   "pin_host"    [callers whose buffers must not be page-locked]  1 (default): the asynchronous entry points page-lock the caller's buffers and remember them
  *                 (see vadc_amd_run_s16_async); 0: they do not
+ *   "roctx"       [a profiler timeline of a host application]  1: every call and every kernel launch of it is bracketed by a named profiler range (roctxRangePush /
+ *                 Pop: "vadc_amd_run_device [S streams x C chunks]", "k_frontend", "k_layer1", "k_enc234", "k_lstm", "k_lstm_l1") -- the counterpart of the reference's
+ *                 Tracy zones (silero_v3.c:72-215); rocprofv3 --marker-trace shows them beside the kernel rows.  The marker library is looked up when the option is
+ *                 switched on (EINVAL if there is none); 0 (default): no ranges, no lookup
  *  Which kernel form serves (every value other than the default is a FALLBACK the engine also takes by itself, or the literal-fp32 arithmetic):
  *   "lstm"        [weights outside fp16's range; the recurrence's two schedules]  0 = auto (default): split-fp16 operands on the fp16 matrix pipe at fp32 accuracy --
  *                 7 = layer-major (k_lstm_layer: layer 0 and layer 1 as two launches on two CU sets, pipelined over calls / chunk groups) for forked calls up to half

@@ -1313,7 +1313,7 @@ def test_soak_long_run_of_calls_vs_oracle(weights_blob, orc):
     """tests/reports/soak_report.py as a test (shorter): 272 streams (17 tiles: a ragged last one) x 96 chunks x 24 synchronous calls with the state carried on the
     device; the first, a middle and the last stream are recomputed by the oracle over all 2,304 chunks"""
     S, Cn, calls = 272, 96, 24
-    pcm = synth.make_streams(S, Cn * 4, seed0=99)            # 4 distinct windows per stream, cycled
+    pcm = np.ascontiguousarray(np.tile(synth.make_streams(17, Cn * 4, seed0=99), (16, 1)))      # 17 distinct signals (one per tile row), 4 distinct windows per stream, cycled
     pick = [0, 137, 271]
     e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
     try:
@@ -1846,6 +1846,20 @@ def test_runs_repeat_bit_for_bit_beside_their_own_neighbours():
     for shape in ((10240, 1, 8, 40), (256, 96, 3, 8), (100, 24, 4, 20), (640, 8, 6, 16), ):      # (_layer on shared CUs)
         rec = soak.soak(*shape)
         assert rec["runs_differing_from_the_first"] == 0, rec
+
+
+def test_profiler_ranges_change_nothing(eng, gold_py):
+    """option "roctx" = 1 brackets every call and every kernel launch with a named range (the counterpart of the reference's Tracy zones, silero_v3.c:72-215) through a
+    marker library looked up at run time; the results are the bits of a run without, and the library still links the HIP runtime only (tests/test_abi.py)"""
+    pcm = gold_py["pcm_speech0"][: 40 * 1536].reshape(1, -1)
+    eng.reset_streams(); a = eng.run(pcm)
+    eng.set_option("roctx", 1)
+    try:
+        assert eng.get_option("roctx") == 1
+        eng.reset_streams(); b = eng.run(pcm)
+    finally:
+        eng.set_option("roctx", 0)
+    assert np.array_equal(bits(a), bits(b))
 
 
 def test_three_engines_alive_in_one_process(weights_blob, orc):

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -243,6 +244,7 @@ struct vadc_amd_engine {
    int *d_trail_err = nullptr;                  // ... its device address
    int *d_trail_recov = nullptr;                // device counter: tiles the REDO launches have done again (read at host synchronisation points and by "trail_recoveries")
    int trail_recoveries = 0;                    // ... as of the last look
+   int roctx = 0;                               // option "roctx": 1 = a named profiler range around every call and every kernel launch of it (see Roctx)
    bool trail_lost = false;                     // the fatal word was seen: calls are refused until every stream has been reset
    hipEvent_t ev_redo = nullptr;                // trail_fault 1: layer 0 of the faulted pair waits for its layer 1 to have given up
    int *d_lstm_tickets = nullptr;               // [2 layers][8 XCDs]: the counters a TRAIL workgroup draws its tile from (L2-local atomics); ticket_base = what earlier launches drew per XCD
@@ -1232,9 +1234,39 @@ static int drain_events(vadc_amd_engine *e)
    return VADC_AMD_OK;
 }
 
+// Profiler ranges (option "roctx"): the counterpart of the reference's Tracy zones (TracyCZoneN in silero_v3.c:72-215, conv.c, lstm.c, transformer.c: one zone per
+// stage of the forward pass) for a ROCm timeline -- rocprofv3 --marker-trace shows a call and the launch of each of its kernels as named ranges on the host
+// thread, beside the kernel rows.  The marker library is looked up at run time (librocprofiler-sdk-roctx, else libroctx64): libvadc_amd.so keeps linking the HIP
+// runtime only, and a host without the library gets VADC_AMD_EINVAL when it switches the option on, not a load failure.
+struct Roctx {
+   void *lib = nullptr;
+   int (*push)(const char *) = nullptr;
+   int (*pop)() = nullptr;
+   bool load()
+   {
+      if (push && pop) return true;
+      for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+         lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+         if (!lib) continue;
+         push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+         pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+         if (push && pop) return true;
+         dlclose(lib); lib = nullptr; push = nullptr; pop = nullptr;
+      }
+      return false;
+   }
+};
+static Roctx g_roctx;
+struct RoctxRange {
+   bool on;
+   RoctxRange(const vadc_amd_engine *e, const char *name) : on(e->roctx != 0 && g_roctx.push != nullptr) { if (on) (void)g_roctx.push(name); }
+   ~RoctxRange() { if (on) (void)g_roctx.pop(); }
+};
+
 struct KernelTimer {
    vadc_amd_engine *e; int k; hipStream_t st; vadc_amd_engine::EvPair p; bool on;
-   KernelTimer(vadc_amd_engine *e_, int k_, hipStream_t st_) : e(e_), k(k_), st(st_), on(e_->profiling)
+   RoctxRange range;
+   KernelTimer(vadc_amd_engine *e_, int k_, hipStream_t st_) : e(e_), k(k_), st(st_), on(e_->profiling), range(e_, vadc_amd_kernel_name(k_))
    {
       if (!on) return;
       if (e->pool.empty()) { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
@@ -1325,6 +1357,11 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "lstm_trail") == 0 && (value == 0 || value == 1)) { e->lstm_trail = value; return VADC_AMD_OK; }
    if (strcmp(key, "trail_fault") == 0 && value >= 0 && value <= 2) { e->trail_fault = value; return VADC_AMD_OK; }
    if (strcmp(key, "trail_wait") == 0 && value >= 1000) { e->trail_wait_limit = value; return VADC_AMD_OK; }
+   if (strcmp(key, "roctx") == 0 && (value == 0 || value == 1)) {
+      if (value && !g_roctx.load()) return fail(VADC_AMD_EINVAL, "set_option: roctx=1 needs librocprofiler-sdk-roctx.so or libroctx64.so on the library path");
+      e->roctx = value;
+      return VADC_AMD_OK;
+   }
    if (strcmp(key, "overlap_check") == 0 && (value == 1 || value == 2)) { e->overlap_check = value; return VADC_AMD_OK; }
    if (strcmp(key, "lstm_epoch") == 0 && value >= 0 && value <= 2047) { e->lstm_epoch = value; return VADC_AMD_OK; }      // (tests: the epoch's wrap)
    if (strcmp(key, "cu_mask_check") == 0 && value >= 0 && value <= 2) { e->cu_mask_check = value; e->lstm_cus = -1; return VADC_AMD_OK; }
@@ -1366,6 +1403,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "lstm_trail") == 0) *value = e->lstm_trail;
    else if (strcmp(key, "kernels_overlap") == 0) *value = e->kernels_overlap ? 1 : 0;
    else if (strcmp(key, "lstm_trail_used") == 0) *value = e->lstm_trail_used;
+   else if (strcmp(key, "roctx") == 0) *value = e->roctx;
    else if (strcmp(key, "trail_recoveries") == 0) {           // tiles done again by the REDO launches so far (waits for the calls issued before)
       HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
       { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
@@ -1895,6 +1933,9 @@ static int launch_sequence(vadc_amd_engine *e, const SeqKey &k, hipStream_t st, 
 template <typename T>
 static int run_device(vadc_amd_engine *e, const T *d_in, int n_streams, int n_chunks, float *d_probs, hipStream_t st)
 {
+   char rname[64];
+   if (e->roctx) snprintf(rname, sizeof(rname), "vadc_amd_run_device [%d streams x %d chunks]", n_streams, n_chunks);
+   RoctxRange call_range(e, rname);
    if (e->use_gemm_frontend() && (reinterpret_cast<uintptr_t>(d_in) & 15))
       return fail(VADC_AMD_EINVAL, "run: the GEMM front end stages the input with 16-byte loads; the device buffer must be 16-byte aligned");
    if (e->model == VADC_AMD_MODEL_V5) {
