@@ -880,15 +880,28 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
       copy_unaligned(v, ts[2 + 2 * c]);
       o_cb[c] = pk.add(v.data(), v.size());
    }
-   std::vector<float> W;
-   copy_unaligned(W, ts[9]);
+   // GATE ROW ORDER.  The container has PyTorch's [gate i, f, g, o][unit] (utils.py:93-101).  Every kernel here works on rows p(g, u) = 16 (u / 4) + 4 (u % 4) + g instead
+   // -- an MFMA row tile of 16 = four units x four gates, so that the (i, f, g, o) of a unit are the four accumulator registers of ONE lane and a tile's cells can be
+   // updated as soon as ITS twelve MFMAs are done, under the next tile's (k_v5_lstm_h3).  W_ih, the bias and W_hh are permuted here, once; GX[item][512] is in that
+   // order whichever encoder wrote it, and the unit-indexed state h, c [128] is what it always was.
+   std::vector<float> W0, W, lb0;
+   copy_unaligned(W0, ts[9]);
+   copy_unaligned(lb0, ts[10]);
+   W.resize(W0.size());
+   std::vector<float> lbp(512);
+   for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 128; ++u) {
+         const int p = 16 * (u / 4) + 4 * (u % 4) + g;
+         memcpy(&W[(size_t)p * 256], &W0[(size_t)(g * 128 + u) * 256], 256 * sizeof(float));
+         lbp[p] = lb0[g * 128 + u];
+      }
    std::vector<float> wih((size_t)32 * 32 * 64), whh((size_t)512 * 128);
    for (int mt = 0; mt < 32; ++mt)
       for (int kk = 0; kk < 32; ++kk)
          for (int l = 0; l < 64; ++l) wih[((size_t)mt * 32 + kk) * 64 + l] = W[(size_t)(16 * mt + (l & 15)) * 256 + 4 * kk + (l >> 4)];
    for (int r = 0; r < 512; ++r) memcpy(&whh[(size_t)r * 128], &W[(size_t)r * 256 + 128], 128 * sizeof(float));
    const size_t o_wih = pk.add(wih.data(), wih.size()), o_whh = pk.add(whh.data(), whh.size());
-   // split-fp16 A fragments of W_hh for v_mfma_f32_16x16x32_f16: [m-tile][k-block][lane][hi 8 | lo 8], lane l holds W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + e]
+   // split-fp16 A fragments of W_hh for v_mfma_f32_16x16x32_f16: [m-tile][k-block][lane][hi 8 | lo 8], lane l holds W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + e] (permuted rows)
    bool h3_ok = true;
    std::vector<_Float16> wh((size_t)32 * 4 * 64 * 16);
    for (int mt = 0; mt < 32; ++mt)
@@ -970,7 +983,7 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
       o_wny = pk.add(wny.data(), wny.size());
    }
    e->v5_enc_h3_ok = enc_ok;
-   copy_unaligned(v, ts[10]); const size_t o_lb = pk.add(v.data(), v.size());
+   const size_t o_lb = pk.add(lbp.data(), lbp.size());
    copy_unaligned(v, ts[11]); const size_t o_dw = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[12]); const size_t o_db = pk.add(v.data(), v.size());
    HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(256, 2) void k_v5_encoder(const T *__restrict__ pcm
 __device__ __forceinline__ float v5_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float v5_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
+// GATE ROW ORDER of GX, the bias and both W matrices: row 16 (u / 4) + 4 (u % 4) + g for gate g (i, f, g, o) of unit u (permuted once, on the host: engine.hip
+// build_weights_v5) -- an MFMA row tile = four units x four gates, the four gates of a unit = the four accumulator registers of one lane.  Wave w owns row tiles
+// 4 w .. 4 w + 3 = units 16 w .. 16 w + 15; lane (column = stream, quad q) of tile mi holds unit 16 w + 4 mi + q.
 __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx,          // [S * C][512]
                                                     V5Weights w,
                                                     float *__restrict__ hs, float *__restrict__ cs,     // [S][128]
@@ -231,26 +234,26 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx
    const int s0 = blockIdx.x * 16;
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = s0 + col < n_streams;
-   // recurrent weights: gate g, rows g * 128 + 16 wave + (lane & 15), k = 4 kk + quad
+   // recurrent weights: row tile 4 wave + mi, rows + (lane & 15), k = 4 kk + quad
    float a[4][32];
 #pragma unroll
-   for (int g = 0; g < 4; ++g) {
-      const float *row = w.whh + (size_t)(g * kV5Hidden + 16 * wave + (lane & 15)) * kV5Hidden + quad;
+   for (int mi = 0; mi < 4; ++mi) {
+      const float *row = w.whh + (size_t)(16 * (4 * wave + mi) + (lane & 15)) * kV5Hidden + quad;
 #pragma unroll
-      for (int kk = 0; kk < 32; ++kk) a[g][kk] = row[4 * kk];
+      for (int kk = 0; kk < 32; ++kk) a[mi][kk] = row[4 * kk];
    }
    float c[4], dw[4];
 #pragma unroll
-   for (int r = 0; r < 4; ++r) {
-      const int u = 16 * wave + 4 * quad + r;
-      dw[r] = w.dec_w[u];
-      c[r] = cs[(size_t)s_col * kV5Hidden + u];
+   for (int mi = 0; mi < 4; ++mi) {
+      const int u = 16 * wave + 4 * mi + quad;
+      dw[mi] = w.dec_w[u];
+      c[mi] = cs[(size_t)s_col * kV5Hidden + u];
       hb[0][u * 16 + col] = hs[(size_t)s_col * kV5Hidden + u];
    }
-   const float *gx_lane = gx + (size_t)s_col * n_chunks * kV5Gates + 16 * wave + 4 * quad;
+   const float *gx_lane = gx + (size_t)s_col * n_chunks * kV5Gates + 64 * wave + 4 * quad;
    float4 gn[4];
 #pragma unroll
-   for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + g * kV5Hidden);
+   for (int mi = 0; mi < 4; ++mi) gn[mi] = *reinterpret_cast<const float4 *>(gx_lane + 16 * mi);
    __syncthreads();
    int par = 0;
    float hlast[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -258,26 +261,26 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx
    for (int ch = 0; ch < n_chunks; ++ch) {
       f4v5 acc[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = (f4v5){gn[g].x, gn[g].y, gn[g].z, gn[g].w};
+      for (int mi = 0; mi < 4; ++mi) acc[mi] = (f4v5){gn[mi].x, gn[mi].y, gn[mi].z, gn[mi].w};
       if (ch + 1 < n_chunks) {
 #pragma unroll
-         for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + (size_t)(ch + 1) * kV5Gates + g * kV5Hidden);
+         for (int mi = 0; mi < 4; ++mi) gn[mi] = *reinterpret_cast<const float4 *>(gx_lane + (size_t)(ch + 1) * kV5Gates + 16 * mi);
       }
 #pragma unroll
       for (int kk = 0; kk < 32; ++kk) {
          const float bv = hb[par][(4 * kk + quad) * 16 + col];
 #pragma unroll
-         for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][kk], bv, acc[g], 0, 0, 0);
+         for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][kk], bv, acc[mi], 0, 0, 0);
       }
       float d = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const float ig = v5_sigmoid(acc[0][r]), fg = v5_sigmoid(acc[1][r]), gg = v5_tanh(acc[2][r]), og = v5_sigmoid(acc[3][r]);
-         c[r] = fmaf(fg, c[r], ig * gg);
-         const float hn = og * v5_tanh(c[r]);
-         hlast[r] = hn;
-         hb[par ^ 1][(16 * wave + 4 * quad + r) * 16 + col] = hn;
-         d = fmaf(dw[r], fmaxf(hn, 0.0f), d);                         // decoder: ReLU -> conv 128 -> 1 (silero_vad.py:335-338)
+      for (int mi = 0; mi < 4; ++mi) {
+         const float ig = v5_sigmoid(acc[mi][0]), fg = v5_sigmoid(acc[mi][1]), gg = v5_tanh(acc[mi][2]), og = v5_sigmoid(acc[mi][3]);
+         c[mi] = fmaf(fg, c[mi], ig * gg);
+         const float hn = og * v5_tanh(c[mi]);
+         hlast[mi] = hn;
+         hb[par ^ 1][(16 * wave + 4 * mi + quad) * 16 + col] = hn;
+         d = fmaf(dw[mi], fmaxf(hn, 0.0f), d);                        // decoder: ReLU -> conv 128 -> 1 (silero_vad.py:335-338)
       }
       d += __shfl_xor(d, 16);
       d += __shfl_xor(d, 32);
@@ -294,72 +297,78 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx
    }
    if (col_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const int u = 16 * wave + 4 * quad + r;
-         cs[(size_t)s_col * kV5Hidden + u] = c[r];
-         if (n_chunks > 0) hs[(size_t)s_col * kV5Hidden + u] = hlast[r];
+      for (int mi = 0; mi < 4; ++mi) {
+         const int u = 16 * wave + 4 * mi + quad;
+         cs[(size_t)s_col * kV5Hidden + u] = c[mi];
+         if (n_chunks > 0) hs[(size_t)s_col * kV5Hidden + u] = hlast[mi];
       }
    }
 }
 
 // The same recurrence with W_hh h as split-fp16 MFMAs (W h ~ Wl hh + Wh hl + Wh hh, fp32 accumulation: the form the v3.1 / v4 LSTM kernels use,
-// kernels_lstm.hip): 48 v_mfma_f32_16x16x32_f16 per wave and slot instead of 128 fp32 16x16x4 -- 5.0 -> 1.3 us per slot.  h travels through LDS as
-// [stream][unit] halves (hi and lo tiles, pitch 136): a lane's B fragment of a k-block is one 16-byte read per tile, its four new units one
-// 8-byte write per tile.
+// kernels_lstm.hip): 48 v_mfma_f32_16x16x32_f16 per wave and slot instead of 128 fp32 16x16x4.  h travels through LDS as [stream][unit] halves (hi and lo tiles,
+// pitch 144: conflict-free fragment reads): a lane's B fragment of a k-block is one 16-byte read per tile.
+// Round 6: a slot was 2.0 us, of which the 48 MFMAs are 0.35 us of one wave and the gates -- ten transcendentals per cell, four cells per lane -- about as much
+// again, one AFTER the other: with rows ordered [gate][unit] a lane's cells needed all four row tiles.  With the row order above a row tile is COMPLETE cells: the
+// gates of tile mi run under the twelve MFMAs of tile mi + 1 (the MFMAs are issued tile by tile; hipcc schedules the independent vector work between them).
+#ifndef VADC_V5_LSTM_WAVES
+#define VADC_V5_LSTM_WAVES 16
+#endif
 typedef _Float16 v5h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 v5h4 __attribute__((ext_vector_type(4)));
 constexpr int kV5HP = kV5Hidden + 16;                // halves per stream row: 18 slots of 16 bytes -- conflict-free B-fragment reads (136 was 2-way conflicted: tools/lds_frag_probe.hip)
 
-__global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__ gx,       // [S * C][512]
-                                                       V5Weights w,
-                                                       float *__restrict__ hs, float *__restrict__ cs,  // [S][128]
-                                                       float *__restrict__ probs,                       // [S][C][2]
-                                                       int n_streams, int n_chunks)
+// NW waves per workgroup (16: four per SIMD), wave w owns row tiles (32 / NW) w .. : with 8 waves a SIMD's two waves met at every slot's barrier with nothing to
+// cover the dependent MFMA chains (1.9 -> 1.7 us per slot from the row order alone); 16 waves of half the work each hide them.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_v5_lstm_h3(const float *__restrict__ gx,       // [S * C][512]
+                                                           V5Weights w,
+                                                           float *__restrict__ hs, float *__restrict__ cs,  // [S][128]
+                                                           float *__restrict__ probs,                       // [S][C][2]
+                                                           int n_streams, int n_chunks)
 {
+   constexpr int MW = 32 / NW;                          // row tiles (= groups of four units) per wave
    __shared__ __attribute__((aligned(16))) _Float16 hh[2][16 * kV5HP], hl[2][16 * kV5HP];   // [parity][stream][unit]: hi / lo halves of h
-   __shared__ float pd[2][8][16];
+   __shared__ float pd[2][NW][16];
    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int col = lane & 15, quad = lane >> 4;
    const int s0 = blockIdx.x * 16;
    const int s_col = min(s0 + col, n_streams - 1);
    const bool col_ok = s0 + col < n_streams;
-   // recurrent weights of this wave's 16 units: gate g = m-tile 8 g + wave; k-block kb: lane holds k = 32 kb + 8 quad + e
-   v5h8 ah[4][4], al[4][4];
+   // recurrent weights of this wave's 4 MW units: row tile MW wave + mi; k-block kb: lane holds k = 32 kb + 8 quad + e
+   v5h8 ah[MW][4], al[MW][4];
 #pragma unroll
-   for (int g = 0; g < 4; ++g)
+   for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-         const v5h8 *pp = reinterpret_cast<const v5h8 *>(w.whh_h + (((size_t)(8 * g + wave) * 4 + kb) * 64 + lane) * 16);
-         ah[g][kb] = pp[0]; al[g][kb] = pp[1];
+         const v5h8 *pp = reinterpret_cast<const v5h8 *>(w.whh_h + (((size_t)(MW * wave + mi) * 4 + kb) * 64 + lane) * 16);
+         ah[mi][kb] = pp[0]; al[mi][kb] = pp[1];
       }
-   float c[4], dw[4], hlast[4];
-   {
-      v5h4 h4, l4;
+   float c[MW], dw[MW], hlast[MW];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const int u = 16 * wave + 4 * quad + r;
-         dw[r] = w.dec_w[u];
-         c[r] = cs[(size_t)s_col * kV5Hidden + u];
-         hlast[r] = hs[(size_t)s_col * kV5Hidden + u];
-         h4[r] = (_Float16)hlast[r]; l4[r] = (_Float16)(hlast[r] - (float)h4[r]);
-      }
-      *reinterpret_cast<v5h4 *>(&hh[0][col * kV5HP + 16 * wave + 4 * quad]) = h4;
-      *reinterpret_cast<v5h4 *>(&hl[0][col * kV5HP + 16 * wave + 4 * quad]) = l4;
+   for (int mi = 0; mi < MW; ++mi) {
+      const int u = 4 * (MW * wave + mi) + quad;
+      dw[mi] = w.dec_w[u];
+      c[mi] = cs[(size_t)s_col * kV5Hidden + u];
+      hlast[mi] = hs[(size_t)s_col * kV5Hidden + u];
+      const _Float16 hi = (_Float16)hlast[mi];
+      hh[0][col * kV5HP + u] = hi;
+      hl[0][col * kV5HP + u] = (_Float16)(hlast[mi] - (float)hi);
    }
-   const float *gx_lane = gx + (size_t)s_col * n_chunks * kV5Gates + 16 * wave + 4 * quad;
-   float4 gn[4];
+   const float *gx_lane = gx + (size_t)s_col * n_chunks * kV5Gates + 16 * MW * wave + 4 * quad;
+   float4 gn[MW];
 #pragma unroll
-   for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + g * kV5Hidden);
+   for (int mi = 0; mi < MW; ++mi) gn[mi] = *reinterpret_cast<const float4 *>(gx_lane + 16 * mi);
    __syncthreads();
    int par = 0;
 #pragma unroll 1
    for (int ch = 0; ch < n_chunks; ++ch) {
-      f4v5 acc[4];
+      f4v5 acc[MW];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = (f4v5){gn[g].x, gn[g].y, gn[g].z, gn[g].w};
+      for (int mi = 0; mi < MW; ++mi) acc[mi] = (f4v5){gn[mi].x, gn[mi].y, gn[mi].z, gn[mi].w};
       if (ch + 1 < n_chunks) {
 #pragma unroll
-         for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float4 *>(gx_lane + (size_t)(ch + 1) * kV5Gates + g * kV5Hidden);
+         for (int mi = 0; mi < MW; ++mi) gn[mi] = *reinterpret_cast<const float4 *>(gx_lane + (size_t)(ch + 1) * kV5Gates + 16 * mi);
       }
       v5h8 bh[4], bl[4];
 #pragma unroll
@@ -367,28 +376,29 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__
          bh[kb] = *reinterpret_cast<const v5h8 *>(&hh[par][col * kV5HP + 32 * kb + 8 * quad]);
          bl[kb] = *reinterpret_cast<const v5h8 *>(&hl[par][col * kV5HP + 32 * kb + 8 * quad]);
       }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-         for (int g = 0; g < 4; ++g) {
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kb], bh[kb], acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bl[kb], acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kb], bh[kb], acc[g], 0, 0, 0);
-         }
       float d = 0.0f;
-      v5h4 h4, l4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const float ig = v5_sigmoid(acc[0][r]), fg = v5_sigmoid(acc[1][r]), gg = v5_tanh(acc[2][r]), og = v5_sigmoid(acc[3][r]);
-         c[r] = fmaf(fg, c[r], ig * gg);
-         float hn = og * v5_tanh(c[r]);
-         asm volatile("" : "+v"(hn));                                 // the ROUNDED h is what is split (and what a later call re-splits from the state):
-         hlast[r] = hn;                                               // without this the product is contracted into the subtraction below
-         h4[r] = (_Float16)hn; l4[r] = (_Float16)(hn - (float)h4[r]);
-         d = fmaf(dw[r], fmaxf(hn, 0.0f), d);                         // decoder: ReLU -> conv 128 -> 1 (silero_vad.py:335-338)
+      for (int mi = 0; mi < MW; ++mi) {
+#pragma unroll
+         for (int kb = 0; kb < 4; ++kb) {
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi][kb], bh[kb], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi][kb], bl[kb], acc[mi], 0, 0, 0);
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi][kb], bh[kb], acc[mi], 0, 0, 0);
+         }
       }
-      *reinterpret_cast<v5h4 *>(&hh[par ^ 1][col * kV5HP + 16 * wave + 4 * quad]) = h4;
-      *reinterpret_cast<v5h4 *>(&hl[par ^ 1][col * kV5HP + 16 * wave + 4 * quad]) = l4;
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) {
+         const float ig = v5_sigmoid(acc[mi][0]), fg = v5_sigmoid(acc[mi][1]), gg = v5_tanh(acc[mi][2]), og = v5_sigmoid(acc[mi][3]);
+         c[mi] = fmaf(fg, c[mi], ig * gg);
+         float hn = og * v5_tanh(c[mi]);
+         asm volatile("" : "+v"(hn));                                 // the ROUNDED h is what is split (and what a later call re-splits from the state):
+         hlast[mi] = hn;                                              // without this the product is contracted into the subtraction below
+         const _Float16 hi = (_Float16)hn;
+         const int u = 4 * (MW * wave + mi) + quad;
+         hh[par ^ 1][col * kV5HP + u] = hi;
+         hl[par ^ 1][col * kV5HP + u] = (_Float16)(hn - (float)hi);
+         d = fmaf(dw[mi], fmaxf(hn, 0.0f), d);                        // decoder: ReLU -> conv 128 -> 1 (silero_vad.py:335-338)
+      }
       d += __shfl_xor(d, 16);
       d += __shfl_xor(d, 32);
       if (quad == 0) pd[ch & 1][wave][col] = d;
@@ -396,7 +406,11 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__
       par ^= 1;
       if (wave == 0 && lane < 16 && s0 + lane < n_streams) {
          const float *p = &pd[ch & 1][0][lane];
-         const float m = ((p[0] + p[16]) + (p[32] + p[48])) + ((p[64] + p[80]) + (p[96] + p[112])) + w.dec_b[0];
+         float m = 0.0f;
+#pragma unroll
+         for (int g8 = 0; g8 < NW; g8 += 8)                            // (a fixed tree: the probabilities do not depend on timing)
+            m += ((p[16 * g8] + p[16 * g8 + 16]) + (p[16 * g8 + 32] + p[16 * g8 + 48])) + ((p[16 * g8 + 64] + p[16 * g8 + 80]) + (p[16 * g8 + 96] + p[16 * g8 + 112]));
+         m += w.dec_b[0];
          const float pr = 1.0f / (1.0f + expf(-m));                   // sigmoid; the mean over the one step is the value itself (:412)
          probs[((size_t)(s0 + lane) * n_chunks + ch) * 2 + 0] = pr;
          probs[((size_t)(s0 + lane) * n_chunks + ch) * 2 + 1] = pr;
@@ -404,10 +418,10 @@ __global__ __launch_bounds__(512, 1) void k_v5_lstm_h3(const float *__restrict__
    }
    if (col_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-         const int u = 16 * wave + 4 * quad + r;
-         cs[(size_t)s_col * kV5Hidden + u] = c[r];
-         hs[(size_t)s_col * kV5Hidden + u] = hlast[r];                // fp32: the state a later call (or the caller) sees is not rounded to halves
+      for (int mi = 0; mi < MW; ++mi) {
+         const int u = 4 * (MW * wave + mi) + quad;
+         cs[(size_t)s_col * kV5Hidden + u] = c[mi];
+         hs[(size_t)s_col * kV5Hidden + u] = hlast[mi];               // fp32: the state a later call (or the caller) sees is not rounded to halves
       }
    }
 }
@@ -763,7 +777,7 @@ void launch_v5_encoder_s16(const int16_t *pcm, float *ctx, const V5Weights &w, f
 void launch_v5_lstm(const V5Weights &w, const float *gx, float *hs, float *cs, float *probs, int n_streams, int n_chunks, bool fp32, hipStream_t st)
 {
    if (fp32 || !w.whh_h) hipLaunchKernelGGL(k_v5_lstm, dim3((n_streams + 15) / 16), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
-   else                  hipLaunchKernelGGL(k_v5_lstm_h3, dim3((n_streams + 15) / 16), dim3(512), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
+   else                  hipLaunchKernelGGL(k_v5_lstm_h3<VADC_V5_LSTM_WAVES>, dim3((n_streams + 15) / 16), dim3(64 * VADC_V5_LSTM_WAVES), 0, st, gx, w, hs, cs, probs, n_streams, n_chunks);
 }
 
 }  // namespace vadc
