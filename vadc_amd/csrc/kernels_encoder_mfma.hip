@@ -252,8 +252,11 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
                                                     int n_chunks, ItemMap map, size_t fm_stride,
-                                                    const float *__restrict__ in2 = nullptr)
+                                                    const float *__restrict__ in2 = nullptr, int lstm_layout = 0)
 {
+   // LSTM_OUT = 3: the layout of the last stage's output is the kernel ARGUMENT lstm_layout (0 / 1 / 2 as above) -- one instantiation per geometry instead of three
+   // (these per-layer kernels are fallbacks and the non-default windows' path: a uniform branch in their epilogue costs nothing that matters)
+   const int lstm_out = LSTM_OUT == 3 ? lstm_layout : LSTM_OUT;
    static_assert(WAVES == 4 || (WAVES == 8 && K1 && !HAS_TF && NCH == 5 && 64 - 2 * T >= 4 && 5 * T - 60 <= 64),
                  "8 waves: the K = 1 first stage without a transformer block, 5 chunks whose middle one is split with a 4-step overlap");
    constexpr int kPitchG = kPitch;                        // the 4-wave geometry (file scope)
@@ -1031,8 +1034,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
       int ocb, ot; bool oown;
       (void)colmap(ocol, ocb, ot, oown);
       const int oitem = blockIdx.x * NCH + ocb;
-      if constexpr (LSTM_OUT == 2) {
-         static_assert(D == 64 || LSTM_OUT != 2, "split-fp16 LSTM hand-off is the last stage (64 units)");
+      if ((LSTM_OUT == 2 || LSTM_OUT == 3) && lstm_out == 2) {
+         static_assert(D == 64 || (LSTM_OUT != 2 && LSTM_OUT != 3), "the LSTM hand-off is the last stage (64 units)");
          // transpose through LDS (Bb is dead here): Zs[column][unit], then every thread converts 16 consecutive units of one
          // column and stores 32 contiguous bytes of the hi row and of the lo row
          float *Zs = Bb;                                   // 64 columns x pitch 65
@@ -1063,9 +1066,9 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
          }
       } else
       if (oown && oitem < n_chunks && (ot % STRIDE) == 0) {
-         constexpr int ostride = LSTM_OUT ? kLstmTile : TOUT;
+         const int ostride = lstm_out ? kLstmTile : TOUT;
          float *dst;
-         if (LSTM_OUT) {
+         if (lstm_out) {
             int st_, ch_;
             map.split(oitem, st_, ch_);
             dst = out + lstm_x_index(st_, ch_, map.C, ot / STRIDE, 0, TOUT);
@@ -1117,9 +1120,7 @@ void launch_layer_mfma(int layer, const float *in, const float *fm, const LayerW
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, 13, 2, true, false, false, 4, true>), dim3((n + 3) / 4), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, 7, 1, false, false, false, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride); break;
    case 3:
-      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 2, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 1, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
-      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 0, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride);
+      hipLaunchKernelGGL((k_layer_mfma<32, 64, 7, 1, true, 0, 3, 9, true>), dim3((n + 8) / 9), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, (const float *)nullptr, lstm_layout);
       break;
    }
 }
@@ -1163,9 +1164,7 @@ static void launch_v4_t(int layer, const float *in, const float *fm, const Layer
    case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
    case 3:
-      if (lstm_layout == 2)      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 2, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else if (lstm_layout == 1) hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 1, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
-      else                       hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 0, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2);
+      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 3, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2, lstm_layout);
       break;
    }
 }

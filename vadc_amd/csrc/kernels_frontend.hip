@@ -922,8 +922,8 @@ void launch_frontend_fl_f32(const float *pcm, const float *basis, float *Y, floa
 void launch_frontend_fl_s16(const int16_t *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st)
 {
    const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode == 0) hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
-   else           hipLaunchKernelGGL((k_frontend_fl<int16_t, 1, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
+   (void)mode;                                       // (the magnitude tap -- MODE 1 -- takes f32 samples: vadc_amd_debug_stage_from_samples)
+   hipLaunchKernelGGL((k_frontend_fl<int16_t, 0, 3, 4, 0, 1>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, nullptr);
 }
 
 // k_frontend_sym: the default v3.1 front end (basis symmetries verified by the engine, pcm 16-byte aligned)
@@ -935,8 +935,10 @@ template <typename T>
 static void launch_frontend_sym(const T *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int xcd, int zero_im0)
 {
    const dim3 grid((unsigned)(((long)n * kFrames + 63) / 64));
-   if (mode != 0) hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
-   else if (xcd)  hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 11>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
+   if constexpr (sizeof(T) == 4) {                   // (the magnitude tap -- MODE 1 -- takes f32 samples: vadc_amd_debug_stage_from_samples)
+      if (mode != 0) { hipLaunchKernelGGL((k_frontend_sym<T, 1, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0); return; }
+   }
+   if (xcd)  hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 11>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
    else           hipLaunchKernelGGL((k_frontend_sym<T, 0, kSymNB, 4, 3>), grid, dim3(256), 0, st, pcm, basis, Y, FM, n, map, fm_stride, zero_im0);
 }
 void launch_frontend_sym_f32(const float *pcm, const float *basis, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int mode, hipStream_t st, int xcd, int zero_im0)
