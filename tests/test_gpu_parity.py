@@ -1222,6 +1222,27 @@ def test_device_pointer_path_matches_host_path(eng):
     assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
 
 
+def test_speech_probabilities_packs_element_one(eng):
+    """vadc_amd_speech_probabilities: d_speech[stream][chunk] = d_probs[stream][chunk][1] on the caller's stream -- what the multi-GPU hosts gather (4 B per chunk:
+    the element vadc reads, vadc.c:704-713); ragged sizes, and bad arguments are refused"""
+    import torch
+    pcm = synth.make_streams(37, 5, seed0=77)
+    eng.reset_streams()
+    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_out = torch.empty((37, 5, 2), dtype=torch.float32, device="cuda:0")
+    d_sp = torch.full((37, 5), -1.0, dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.Stream()
+    eng.run_device(d_in.data_ptr(), np.int16, 37, 5, d_out.data_ptr(), st.cuda_stream)
+    eng.join(st.cuda_stream)
+    eng.speech_probabilities(d_out.data_ptr(), 37, 5, d_sp.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(bits(d_out.cpu().numpy()[:, :, 1]), bits(d_sp.cpu().numpy()))
+    with pytest.raises(VadcAmdError):
+        eng.speech_probabilities(d_out.data_ptr() + 4, 37, 5, d_sp.data_ptr(), st.cuda_stream)      # not 8-byte aligned: not a [2] pair array
+    with pytest.raises(VadcAmdError):
+        eng.speech_probabilities(0, 37, 5, d_sp.data_ptr(), st.cuda_stream)
+
+
 def test_config2_all_256_streams_vs_oracle(weights_blob, orc):
     """BASELINE config 2 (256 streams, fp32): EVERY stream's probabilities against the oracle, 256 distinct synthetic
     streams x 8 chunks over two calls with carried state, + determinism"""
