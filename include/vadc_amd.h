@@ -106,14 +106,15 @@ typedef struct vadc_amd_caps {
    int32_t device;
    int32_t precision;
    int32_t model_kind;                    /* VADC_AMD_MODEL_*                          */
-   int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3, 3, 2, 2, 1 (v4: windows 1536 ... 512) */
-   int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 also 1280 / 1024 / 768 / 512 (option "window"); v4 8 kHz: 768 / 512 / 256 */
+   int32_t lstm_steps_per_chunk;          /* 7 (v3.1) / 3 ... 1 (v4: three strided stages keep 1 + (T - 1) / 2 of T = window / 64 frames each) */
+   int32_t window_samples;                /* samples per chunk in effect: 1536; Silero v4 every multiple of 64 in 512 .. 1536 (option "window"); v4 8 kHz: 256 .. 768 */
    int32_t sample_rate;                   /* 16000; 8000 for the container of the v4 graph's 8 kHz branch               */
    int32_t context_size;                  /* 0; 64 for Silero v5 (vadc.c:697-701): kept per stream on the device, callers pass windows only */
    int32_t cu_partition_ok;               /* 1: the device has the CU-mask layout the LSTM partition rules were measured on (256 CUs, mask bit i -> XCD i % 8: checked at
                                              create) and the partition may be used; 0: any other layout (CPX / DPX mode, another part): no CU partition, plain streams */
-   int32_t input_size_step;               /* the windows served are input_size_min + k * input_size_step <= input_size_max; 0: one window.  Silero v4: 256 -- the
-                                             reference's onnxruntime path admits every count in 512 .. 1536 (onnx_helpers.c:164-170), this engine the multiples of 256 */
+   int32_t input_size_step;               /* the windows served are input_size_min + k * input_size_step <= input_size_max; 0: one window.  Silero v4: 64 -- the
+                                             reference's onnxruntime path admits every count in 512 .. 1536 (onnx_helpers.c:164-170), this engine every multiple of
+                                             64 samples (= one STFT frame) in that range */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -232,10 +233,12 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 0 (default): strict stream semantics
  *   "groups"      [a single synchronous caller]  number of chunk groups a call is pipelined in: the LSTM of group g overlaps the front end + encoder of group g+1.
  *                 0 = auto (default): up to 4 for calls the caller waits for, 1 with "defer_join" (consecutive calls overlap instead)
- *   "window"      [Silero v4's other input sizes]  samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4 also 1280,
- *                 1024, 768 and 512 -- the v4 graph takes 512 ... 1536 samples (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752): samples / 64 STFT frames,
- *                 3 / 3 / 2 / 2 / 1 LSTM steps (every strided stage keeps 1 + (T - 1) / 2 steps).  Changes the stride of every samples / probability buffer; waits
- *                 for the calls issued before
+ *   "window"      [Silero v4's other input sizes]  samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4: every
+ *                 multiple of 64 in 512 ... 1536 (8 kHz branch: 256 ... 768) -- the v4 graph takes every count in that range (onnx_helpers.c:164-170,
+ *                 --sequence_count vadc.c:743-752): samples / 64 STFT frames, every strided stage keeps 1 + (T - 1) / 2 steps.  The multiples of 256 run kernels
+ *                 built for their geometry (1536: the register-resident ones); a window in between runs the next larger built geometry with its own samples and
+ *                 reflect pad staged and the surplus steps masked (no stage taps there).  Changes the stride of every samples / probability buffer; waits for
+ *                 the calls issued before
  *   "h2d_streams" [host-buffer callers on a slow link]  1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call
  *   "pin_host"    [callers whose buffers must not be page-locked]  1 (default): the asynchronous entry points page-lock the caller's buffers and remember them
  *                 (see vadc_amd_run_s16_async); 0: they do not

@@ -99,7 +99,7 @@ static inline void *backend_init(MemoryArena *arena, String8 model_path_arg, Sil
 
 /* The caller picks the window after backend_init -- `--sequence_count` clamped to [input_size_min, input_size_max] (vadc.c:743-752) -- and sizes
  * buffers.input_samples as input_count x batch floats (vadc.c:773-781).  The engine must run THAT window: the Silero v4 graph takes 512 ... 1536
- * samples (onnx_helpers.c:164-170), of which this engine builds 512 / 768 / 1024 / 1280 / 1536 (8 kHz branch: 256 / 512 / 768).  Any other size aborts with a
+ * samples (onnx_helpers.c:164-170), of which this engine serves every multiple of 64 (8 kHz branch: 256 ... 768).  Any other size aborts with a
  * message, like an onnxruntime error would (onnx_helpers.h:5-14) -- never a silent read past the caller's buffer. */
 static void vadc_hip_sync_window(vadc_amd_engine *engine, int input_count)
 {

@@ -161,6 +161,24 @@ def main():
     path8 = os.path.join(HERE, "python_reference_v4_8k.npz")
     np.savez_compressed(path8, **out8)
     print("wrote", path8, os.path.getsize(path8), "bytes  (pcm: the streams of python_reference_v4.npz)")
+    # every multiple of 64 samples (round 6): windows that are no multiple of 256 -- 9, 11, 13, 15, 17, 19, 21, 22 and 23 STFT frames at 16 kHz, 5, 7 and 11 at 8 kHz -- whose
+    # right reflect pad starts inside the next 64-sample block and whose strided stages meet every parity of lengths (9 -> 5 -> 3 -> 2, 13 -> 7 -> 4 -> 2, 23 -> 12 -> 6 -> 3, ...)
+    out64 = {}
+    for window in (576, 704, 832, 960, 1088, 1216, 1344, 1408, 1472):
+        for name in ("speech0", "speech1", "square"):
+            x = pcm[name][: (pcm[name].size // window) * window]
+            p64, h64, c64 = run_stream(m64, x, torch.float64, window)
+            out64[f"probs64_w{window}_{name}"] = p64; out64[f"h64_w{window}_{name}"] = h64; out64[f"c64_w{window}_{name}"] = c64
+            print(f"window {window} {name}: {p64.size} chunks, p[min,max]=({p64.min():.4f},{p64.max():.4f})")
+    for window in (320, 448, 704):
+        for name in ("speech0", "speech1", "square"):
+            x = pcm[name][: (pcm[name].size // window) * window]
+            p64, h64, c64 = run_stream(m64_8k, x, torch.float64, window)
+            out64[f"probs64_8k_w{window}_{name}"] = p64; out64[f"h64_8k_w{window}_{name}"] = h64; out64[f"c64_8k_w{window}_{name}"] = c64
+            print(f"8 kHz window {window} {name}: {p64.size} chunks, p[min,max]=({p64.min():.4f},{p64.max():.4f})")
+    path64 = os.path.join(HERE, "python_reference_v4_windows_64.npz")
+    np.savez_compressed(path64, **out64)
+    print("wrote", path64, os.path.getsize(path64), "bytes  (pcm: the streams of python_reference_v4.npz)")
 
 
 if __name__ == "__main__":

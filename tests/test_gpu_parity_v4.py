@@ -298,7 +298,7 @@ def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
         assert (c["input_size_min"], c["input_size_max"], c["window_samples"]) == (512, 1536, 1536)
         e.set_window(window)
         c = e.caps()
-        assert c["input_size_step"] == 256
+        assert c["input_size_step"] == 64
         assert c["window_samples"] == window and c["lstm_steps_per_chunk"] == {512: 1, 768: 2, 1024: 2, 1280: 3}[window] and e.get_option("window") == window
         for name in ("speech0", "speech1", "noise", "square"):
             pcm = gold[f"pcm_{name}"]
@@ -319,7 +319,7 @@ def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
         assert e.stage_from_samples(x, "magnitude").shape == (5, 129, window // 64)
         assert e.stage_from_samples(x, "layer4").shape == (5, 64, {512: 1, 768: 2, 1024: 2, 1280: 3}[window])
         with pytest.raises(VadcAmdError):
-            e.set_option("window", 800)                               # not a multiple of 256
+            e.set_option("window", 800)                               # not a multiple of 64
         with pytest.raises(VadcAmdError):
             e.set_option("window", 1792)
         e.set_window(1536)
@@ -344,21 +344,92 @@ def test_window_option_is_v4_only():
 
 
 def test_cli_sequence_count_selects_the_v4_window(gold):
-    """`--sequence_count` (vadc.c:743-752, 1117): clamped to the backend's range; with a Silero v4 container 512 / 768 / 1024 / 1280 / 1536 are run (other
-    values rounded down to one of them), one %f line per FULL chunk of that size"""
+    """`--sequence_count` (vadc.c:743-752, 1117): clamped to the backend's range; with a Silero v4 container every multiple of 64 in 512 .. 1536 is run (other
+    values rounded down to one), one %f line per FULL chunk of that size"""
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "host", "vadc_hip")
     gw = dict(np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz")))
     gw.update(np.load(os.path.join(GOLDEN, "python_reference_v4_windows_768_1280.npz")))
     pcm = gold["pcm_speech0"]
-    for arg, window in (("512", 512), ("1024", 1024), ("1100", 1024), ("100", 512), ("9999", 1536), ("768", 768), ("1000", 768), ("1280", 1280), ("1500", 1280)):
+    gw.update(np.load(os.path.join(GOLDEN, "python_reference_v4_windows_64.npz")))
+    for arg, window in (("512", 512), ("1024", 1024), ("1100", 1088), ("100", 512), ("9999", 1536), ("768", 768), ("1000", 960), ("1280", 1280), ("1500", 1472), ("576", 576)):
         r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities", "--sequence_count", arg], input=pcm.tobytes(), capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr.decode()
         assert f"Running with sequence count {window}" in r.stderr.decode()
         got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
         want = gw[f"probs64_w{window}_speech0"] if window != 1536 else gold["probs64_speech0"]
         assert got.shape == want.shape and float(np.abs(got - want).max()) < PROB_TOL + 5e-7
+
+
+@pytest.mark.parametrize("window", [576, 704, 832, 960, 1088, 1216, 1344, 1408, 1472])
+def test_windows_of_every_multiple_of_64(blob, orc, gold, window):
+    """round 6: the reference's onnxruntime path admits every count in 512 ... 1536 (onnx_helpers.c:164-170); the engine serves every multiple of 64 samples.  A
+    window that is no multiple of 256 runs the next larger built geometry -- the chunk re-laid-out so that its first frames are the window's own frames (samples,
+    then the 96 the right reflect pad reads), the surplus steps masked stage by stage -- with the LSTM steps of its own frame count: probabilities against the float64
+    PyTorch goldens (Silero_V4 at that length) and the oracle on ragged streams, f32 = s16 bit for bit, state carried over calls, forked calls, graph replay"""
+    import torch
+    g = np.load(os.path.join(GOLDEN, "python_reference_v4_windows_64.npz"))
+    f = window // 64
+    t1 = (f + 1) // 2; t2 = (t1 + 1) // 2; t3 = (t2 + 1) // 2
+    e = Engine(blob, max_streams=40, max_chunks_per_call=150, device=0)
+    try:
+        e.set_window(window)
+        c = e.caps()
+        assert c["window_samples"] == window and c["lstm_steps_per_chunk"] == t3 and c["input_size_step"] == 64
+        for name in ("speech0", "speech1", "square"):
+            pcm = gold[f"pcm_{name}"]
+            pcm = pcm[: (pcm.size // window) * window]
+            e.reset_streams()
+            p = e.run(pcm.reshape(1, -1))[0]
+            assert float(np.abs(p[:, 1] - g[f"probs64_w{window}_{name}"]).max()) < PROB_TOL, name
+            e.reset_streams()
+            assert float(np.abs(e.run(f32(pcm).reshape(1, -1))[0] - p).max()) < 5e-5      # f32 samples: k_frontend_gemm instead of k_frontend_gemm2, the same re-laid-out chunk
+        S, n = 37, 120
+        pcm = synth.make_streams(S, (n * window + 1535) // 1536, seed0=6300 + window)[:, : n * window]
+        e.reset_streams()
+        got = np.concatenate([e.run(pcm[:, : 60 * window]), e.run(pcm[:, 60 * window:])], axis=1)[:, :, 1]
+        want = orc.forward_streams(pcm, window=window)
+        assert float(np.abs(got - want).max()) < PROB_TOL
+        # deferred joins + graph replay from device buffers: the same bits as the synchronous calls
+        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * 60 * window:(k + 1) * 60 * window])).cuda() for k in range(2)]
+        d_out = [torch.empty(S, 60, 2, device="cuda") for _ in range(2)]
+        st = torch.cuda.Stream()
+        e.set_option("defer_join", 1); e.set_option("graph", 1)
+        for rep_ in range(2):
+            e.reset_streams()
+            for k in range(2):
+                e.run_device(d_in[k].data_ptr(), np.int16, S, 60, d_out[k].data_ptr(), st.cuda_stream)
+            e.join(st.cuda_stream); st.synchronize()
+            assert np.array_equal(np.concatenate([o.cpu().numpy() for o in d_out], axis=1)[:, :, 1], got), rep_
+        e.set_option("defer_join", 0); e.set_option("graph", 0)
+        with pytest.raises(VadcAmdError):
+            e.stage_from_samples(f32(gold["pcm_speech0"])[: 2 * window], "magnitude")       # stage taps exist at the built windows
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("window", [320, 448, 704])
+def test_8khz_windows_of_every_multiple_of_64(gold, window):
+    g = np.load(os.path.join(GOLDEN, "python_reference_v4_windows_64.npz"))
+    blob8 = open(os.path.join(GOLDEN, "silero_v4_8k.testtensor"), "rb").read()
+    orc8 = O.OracleV4(blob8)
+    e = Engine(blob8, max_streams=40, max_chunks_per_call=300, device=0)
+    try:
+        e.set_window(window)
+        for name in ("speech0", "speech1", "square"):
+            pcm = gold[f"pcm_{name}"]
+            pcm = pcm[: (pcm.size // window) * window]
+            e.reset_streams()
+            p = e.run(pcm.reshape(1, -1))[0]
+            assert float(np.abs(p[:, 1] - g[f"probs64_8k_w{window}_{name}"]).max()) < PROB_TOL, name
+        S, n = 21, 150
+        pcm = synth.make_streams(S, (n * window + 1535) // 1536, seed0=6400 + window)[:, : n * window]
+        e.reset_streams()
+        got = e.run(pcm)[:, :, 1]
+        assert float(np.abs(got - orc8.forward_streams(pcm, window=window)).max()) < PROB_TOL
+    finally:
+        e.close()
 
 
 # ---------------------------------------------------------------------------------------------- the 8 kHz branch of the v4 graph

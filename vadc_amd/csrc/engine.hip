@@ -26,8 +26,8 @@ void launch_frontend_sym_f32(const float *, const float *, float *, float *, siz
 void launch_frontend_sym_s16(const int16_t *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
 void launch_frontend_v4_f32(const float *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
 void launch_frontend_v4_s16(const int16_t *, const float *, float *, float *, float *, size_t, int, ItemMap, hipStream_t);
-void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
-void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int);
+void launch_frontend_gemm_f32(const float *, const float *, const float *, float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
+void launch_frontend_gemm2_s16(const int16_t *, const float *, const float *, float *, float *, size_t, int, ItemMap, int, hipStream_t, int, int);
 void launch_normalize_tap(const float *, const float *, size_t, float *, int, hipStream_t, int);
 void launch_lognorm_from_magnitude(const float *, float *, float *, size_t, int, hipStream_t);
 void launch_lstm(int, const float *, const LstmWeights &, float *, float *, float *, int, int, int, int, hipStream_t, int, int);
@@ -54,7 +54,8 @@ struct V5Weights {
 void launch_v5_encoder_f32(const float *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
 void launch_v5_encoder_s16(const int16_t *, float *, const V5Weights &, float *, float *, int, int, bool, int, hipStream_t);
 void launch_v5_lstm(const V5Weights &, const float *, float *, float *, float *, int, int, bool, hipStream_t);
-void launch_layer_v4(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, int, int);
+void launch_layer_v4(int, const float *, const float *, const LayerWeightsM &, float *, int, ItemMap, int, size_t, hipStream_t, int, int, int);
+
 }  // namespace vadc
 
 using namespace vadc;
@@ -138,7 +139,10 @@ struct Packer {
 struct vadc_amd_engine {
    int device = 0;
    int model = VADC_AMD_MODEL_V31;              // decided by the weights container: 99 tensors = v3.1, 36 = v4
-   int frames = kFrames;                        // STFT frames per chunk: 25 (v3.1) / 24 (v4)
+   int frames = kFrames;                        // STFT frames per chunk of the geometry the kernels run: 25 (v3.1) / 24, 20, 16, 12, 8 (v4; 8 kHz branch 12, 8, 4)
+   int frames_valid = kFrames;                  // ... of which the window in effect fills this many (= frames at the built windows; Silero v4 at a window that is no multiple of
+                                                // 256 samples runs the next larger built geometry: the front end's `nrt`, k_layer_mfma's `tv`)
+   bool padded_window() const { return frames_valid != frames; }
    int lstm_steps = 7;                          // LSTM steps per chunk: 7 (v3.1) / 3, 3, 2, 2, 1 (v4 with 1536-, 1280-, 1024-, 768-, 512-sample windows)
    int window = kChunk;                         // samples per chunk: 1536; Silero v4 also 1280 / 1024 / 768 / 512 (option "window", onnx_helpers.c:164-170); its 8 kHz branch 768 / 512 / 256
    V5Weights v5;                                // Silero v5 shapes (13-tensor container): kernels_v5.hip
@@ -147,10 +151,11 @@ struct vadc_amd_engine {
    float *d_gx5[2] = {nullptr, nullptr}, *d_ctx5 = nullptr;   // v5: LSTM input projection [max_items][512] (one per hand-off parity); per-stream 64-sample context [max_streams][64]
    int sample_rate = 16000;                     // 8000: the 37-tensor container of the v4 graph's 8 kHz branch (third strided conv with stride 1)
    int stride3() const { return sample_rate == 8000 ? 1 : 2; }
-   int v4_geo() const                           // k_frontend_gemm geometry of the window in effect
+   int v4_geo() const                           // k_frontend_gemm geometry of the (built) window the kernels run: 64 frames samples
    {
-      if (sample_rate == 8000) return window == 768 ? 4 : (window == 512 ? 3 : 5);
-      return window == 1024 ? 2 : (window == 512 ? 3 : (window == 768 ? 4 : (window == 1280 ? 6 : 1)));
+      const int tw = 64 * frames;
+      if (sample_rate == 8000) return tw == 768 ? 4 : (tw == 512 ? 3 : 5);
+      return tw == 1024 ? 2 : (tw == 512 ? 3 : (tw == 768 ? 4 : (tw == 1280 ? 6 : 1)));
    }
    int stage_elems[VADC_AMD_STAGE_COUNT] = {0};
    const float *d_afrag = nullptr, *d_nyq = nullptr;   // GEMM front end (v4 default, v3.1 in FAST_STFT precision): folded basis as MFMA A fragments, bin-128 weights
@@ -194,7 +199,7 @@ struct vadc_amd_engine {
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
    bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && layer1_selfcheck != 0; }
    // Silero v4: k_layer1_regs_v4 serves the default window (24 frames); the magnitude half of the first stage's input is recovered from Y in every form
-   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && layer1_selfcheck != 0; }
+   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && !padded_window() && layer1_selfcheck != 0; }
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };
@@ -213,7 +218,7 @@ struct vadc_amd_engine {
    int pin_host = 1;
 
    // Silero v4, default window: stages 2-4 in one launch (hot path only: LSTM tiles out, no stage taps); option "encoder" = 5 keeps the per-stage launches
-   bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames == 24 && sample_rate == 16000; }
+   bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames == 24 && !padded_window() && sample_rate == 16000; }
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && encoder_variant == 0; }
    LstmWeights lstm;
    // workspace
@@ -1089,6 +1094,7 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    e->sample_rate = ts.size() == 37 ? 8000 : 16000;
    e->window = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);   // v5: 512 + 64 of context (vadc.c:105-162); v4 8 kHz: the same 96 ms
    e->frames = e->model == VADC_AMD_MODEL_V4 ? e->window / 64 : kFrames;
+   e->frames_valid = e->frames;
    e->lstm_steps = e->model == VADC_AMD_MODEL_V4 ? 3 : (e->model == VADC_AMD_MODEL_V5 ? 1 : 7);
    if (e->model == VADC_AMD_MODEL_V4) stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
    else memcpy(e->stage_elems, kStageElemsV31, sizeof(kStageElemsV31));
@@ -1210,7 +1216,7 @@ extern "C" int vadc_amd_get_caps(const vadc_amd_engine *e, vadc_amd_caps *caps)
    const int wmax = e->model == VADC_AMD_MODEL_V5 ? 512 : (e->sample_rate == 8000 ? 768 : kChunk);     // v5: onnx_helpers.c:158-160
    caps->input_size_min = (e->model == VADC_AMD_MODEL_V4 && e->gemm_ok) ? wmax / 3 : wmax;
    caps->input_size_max = wmax;
-   caps->input_size_step = caps->input_size_min != wmax ? 256 : 0;      // 16 kHz: 512, 768, 1024, 1280, 1536; 8 kHz: 256, 512, 768
+   caps->input_size_step = caps->input_size_min != wmax ? 64 : 0;       // every multiple of 64 samples (one STFT frame): 16 kHz 512 .. 1536, 8 kHz 256 .. 768
    caps->context_size = e->model == VADC_AMD_MODEL_V5 ? 64 : 0;
    caps->window_samples = e->window;
    caps->sample_rate = e->sample_rate;
@@ -1381,17 +1387,19 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "encoder") == 0 && (value == 0 || value == 3)) { e->encoder_variant = value; return VADC_AMD_OK; }
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
-      // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take 512 ... 1536
-      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752), of which the multiples of 256 (8 / 12 / 16 / 20 / 24 STFT frames) are built here
+      // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take every count in 512 ... 1536
+      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752).  Served here: every multiple of 64 samples (one STFT frame) in that range.  The multiples of 256
+      // (8 / 12 / 16 / 20 / 24 frames) have kernels built for their geometry; a window in between runs the next larger of them -- the front end stages the chunk's
+      // own samples and puts the right reflect pad behind them (`nrt`), so that its first frames ARE the window's frames; the surplus steps are masked stage by stage (`tv`)
       if (value == e->window) return VADC_AMD_OK;
-      const int wmax = e->sample_rate == 8000 ? 768 : kChunk;     // 8 kHz branch: 256 / 512 / 768 samples = the same 32 / 64 / 96 ms
-      const int wstep = 256;                                       // 16 kHz: 512, 768, 1024, 1280, 1536 (round 5: the two between the thirds)
-      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || value < wmax / 3 || value > wmax || value % wstep != 0)
-         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) 512, 768, 1024, 1280 or 1536 "
-                                      "(its 8 kHz branch 256, 512 or 768)", value);
+      const int wmax = e->sample_rate == 8000 ? 768 : kChunk;     // 8 kHz branch: 256 ... 768 samples = the same 32 ... 96 ms
+      if (e->model != VADC_AMD_MODEL_V4 || !e->gemm_ok || e->frontend_variant != 0 || value < wmax / 3 || value > wmax || value % 64 != 0)
+         return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) every multiple of 64 in 512 .. 1536 "
+                                      "(its 8 kHz branch 256 .. 768)", value);
       { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
-      e->window = value; e->frames = value / 64;
-      { const int t1 = (e->frames + 1) / 2, t2 = (t1 + 1) / 2; e->lstm_steps = e->stride3() == 2 ? (t2 + 1) / 2 : t2; }
+      const int fv = value / 64, ft = (fv + 3) / 4 * 4;
+      e->window = value; e->frames = ft; e->frames_valid = fv;
+      { const int t1 = (fv + 1) / 2, t2 = (t1 + 1) / 2; e->lstm_steps = e->stride3() == 2 ? (t2 + 1) / 2 : t2; }      // (the same for ft: every fv in (ft - 4, ft])
       stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
       return VADC_AMD_OK;
    }
@@ -1656,7 +1664,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          launch_layer1_regs(a, encoder_cus(e, st), st);
          continue;
       }
-      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->frames, e->stride3());
+      if (e->model == VADC_AMD_MODEL_V4) launch_layer_v4(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st, e->frames, e->stride3(), e->frames_valid);
       else                         launch_layer_mfma(l, in, e->d_FM, e->lwm[l], e->d_act[l], n, map, (l == 3) ? lstm_layout : 0, e->max_items * kFrames, st);
    }
 }
@@ -1679,10 +1687,11 @@ static void run_front_and_encoder(vadc_amd_engine *e, const T *d_in, int n, Item
       const int fk = pick_frontend(e, d_in);
       if (fk == 2) {
          const int geo = e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0;
+         const int nrt = (e->model == VADC_AMD_MODEL_V4 && e->padded_window()) ? e->window : 0;      // a window between the built ones: the chunk's own sample count (its stride)
          // s16 input: the second form (32x32x16 MFMAs, one persistent workgroup per CU the stream may count on, pipelined across column tiles); f32 input: the first form.
          // No magnitude array on the hot path: the v4 first stage recovers the magnitudes from Y (0.8 GB per 65,536 chunks not written and not read)
-         if (sizeof(T) == 2) launch_frontend_gemm2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag2, e->d_nyq2, e->d_Y, e->d_FM, fms, n, map, encoder_cus(e, st), st, geo);
-         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, nullptr, e->d_FM, fms, n, map, e->n_cus, st, geo);
+         if (sizeof(T) == 2) launch_frontend_gemm2_s16(reinterpret_cast<const int16_t *>(d_in), e->d_afrag2, e->d_nyq2, e->d_Y, e->d_FM, fms, n, map, encoder_cus(e, st), st, geo, nrt);
+         else                launch_frontend_gemm_f32(reinterpret_cast<const float *>(d_in), e->d_afrag, e->d_nyq, e->d_Y, nullptr, e->d_FM, fms, n, map, e->n_cus, st, geo, nrt);
       } else if (fk == 3) {
          if (sizeof(T) == 2) launch_frontend_v4_s16(reinterpret_cast<const int16_t *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
          else                launch_frontend_v4_f32(reinterpret_cast<const float *>(d_in), e->d_basis, e->d_Y, e->d_MAG, e->d_FM, fms, n, map, st);
@@ -2558,6 +2567,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
 {
    if (!e || !samples || !out || stage < 0 || stage >= VADC_AMD_STAGE_COUNT) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: bad argument");
    if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: no stage taps for the Silero v5 path");
+   if (e->padded_window()) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: stage taps exist at the built windows (multiples of 256 samples); window=%d runs in the next larger geometry", e->window);
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: n=%d out of range", n);
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
@@ -2566,7 +2576,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    const ItemMap map{n, 0, n};
    if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
-                               e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0);
+                               e->model == VADC_AMD_MODEL_V4 ? e->v4_geo() : 0, 0);
    else if (e->model == VADC_AMD_MODEL_V4) launch_frontend_v4_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, st);
    else if (e->sym_ok && e->frontend_variant == 0) launch_frontend_sym_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st, e->fe_xcd, e->zero_im0);
    else launch_frontend_fl_f32(e->d_in_f32, e->d_basis, e->d_Y, e->d_FM, e->max_items * kFrames, n, map, stage == VADC_AMD_STAGE_MAGNITUDE ? 1 : 0, st);
@@ -2583,6 +2593,7 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    if (!e || !in || !out || from_stage < 0 || to_stage >= VADC_AMD_STAGE_COUNT || to_stage <= from_stage)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: bad argument");
    if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: no stage taps for the Silero v5 path");
+   if (e->padded_window()) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: stage taps exist at the built windows (multiples of 256 samples); window=%d runs in the next larger geometry", e->window);
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: n=%d out of range", n);
    if (e->model == VADC_AMD_MODEL_V4 && from_stage < VADC_AMD_STAGE_LAYER1)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: the v4 first block takes magnitude AND normalized; feed LAYER1..3 or use from_samples");

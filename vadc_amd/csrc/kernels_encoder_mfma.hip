@@ -25,6 +25,7 @@
 //     from global along the frames (or, option "encoder" = 2, the LDS slab path).
 //   * attention: a lane pair per (head, column), Q / V rows padded per chunk for 16-byte reads, fp32 on the vector ALU.
 #include "common.h"
+#include <algorithm>
 #include <cstdio>
 
 namespace vadc {
@@ -252,8 +253,12 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
                                                     LayerWeightsM w,
                                                     float *__restrict__ out,
                                                     int n_chunks, ItemMap map, size_t fm_stride,
-                                                    const float *__restrict__ in2 = nullptr, int lstm_layout = 0)
+                                                    const float *__restrict__ in2 = nullptr, int lstm_layout = 0, int tv = T)
 {
+   // tv <= T: the VALID input steps of every chunk (Silero v4 at a window that is no multiple of 256 samples runs the next larger built geometry: T is that geometry's
+   // step count, steps tv .. T - 1 of the input hold the front end's surplus frames / the previous stage's surplus outputs).  They enter the stage as ZEROS -- what the
+   // depthwise conv's zero padding behind the last valid step is (conv.c:17-53) --, the normalization offset is taken over the tv valid frames (misc.c:65-82), and the
+   // outputs past the valid ones are the next stage's to ignore.  tv = T (default) changes nothing.
    // LSTM_OUT = 3: the layout of the last stage's output is the kernel ARGUMENT lstm_layout (0 / 1 / 2 as above) -- one instantiation per geometry instead of three
    // (these per-layer kernels are fallbacks and the non-default windows' path: a uniform branch in their epilogue costs nothing that matters)
    const int lstm_out = LSTM_OUT == 3 ? lstm_layout : LSTM_OUT;
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
          for (int i = 0; i < 7; ++i) {
             int qq = q + i - 3;                           // reflect pad 3, no edge repeat
             qq = qq < 0 ? -qq : qq;
-            qq = qq >= T ? 2 * (T - 1) - qq : qq;
-            r += fms[cbp * T + qq] * filt[i];             // same wave: LDS is in order
+            qq = qq >= tv ? 2 * (tv - 1) - qq : qq;
+            r += fms[cbp * T + min(qq, T - 1)] * filt[i]; // same wave: LDS is in order
          }
          rs[tid] = r;
       }
@@ -402,8 +407,8 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
          const int cbp = tid / T, q = tid - cbp * T;
          if (q == 0) {
             float total = 0.0f;
-            for (int tt = 0; tt < T; ++tt) total += rs[cbp * T + tt];
-            mm_s[cbp] = total / (float)T;
+            for (int tt = 0; tt < tv; ++tt) total += rs[cbp * T + tt];
+            mm_s[cbp] = total / (float)tv;
          }
       }
       __syncthreads();
@@ -472,9 +477,9 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
    const int mcol = 16 * wave + lc;                       // this lane's column in every MFMA phase
    const int mcb = mcol / T, mt_ = mcol - mcb * T;
    const int mitem = blockIdx.x * NCH + mcb;
-   const bool mvalid = (mcol < NCOLV) && (mitem < n_chunks);
+   const bool mvalid = (mcol < NCOLV) && (mitem < n_chunks) && mt_ < tv;
    const float mmm = FIRST ? mm_s[mcb < NCH ? mcb : 0] : 0.0f;
-   const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < T, tr2 = mvalid && mt_ + 2 < T;
+   const bool tl2 = mvalid && mt_ >= 2, tl1 = mvalid && mt_ >= 1, tr1 = mvalid && mt_ + 1 < tv, tr2 = mvalid && mt_ + 2 < tv;
    const int ccol = mvalid ? mcol : 0;                    // invalid columns read a valid slot and are zeroed
    const int om2 = tl2 ? -2 : 0, om1 = tl1 ? -1 : 0, op1 = tr1 ? 1 : 0, op2 = tr2 ? 2 : 0;
    if constexpr (H3C) {
@@ -569,9 +574,9 @@ __global__ __launch_bounds__(64 * WAVES, (K1 && CIN < 200) ? VADC_L1_WAVES : 1) 
    int cb, t; bool cown;
    const bool cmv = colmap(64 * (wave >> 2) + lane, cb, t, cown);
    const int item_raw = blockIdx.x * NCH + cb;
-   const bool cvalid = cmv && (item_raw < n_chunks);
+   const bool cvalid = cmv && (item_raw < n_chunks) && t < tv;
    const float mm = FIRST ? mm_s[cb < NCH ? cb : 0] : 0.0f;
-   const bool l2 = t >= 2, l1 = t >= 1, r1 = t + 1 < T, r2 = t + 2 < T;
+   const bool l2 = t >= 2, l1 = t >= 1, r1 = t + 1 < tv, r2 = t + 2 < tv;
    const int ch0 = (wave & 3) * CPW, ch1 = min(ch0 + CPW, CIN);
    f16acc P = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef VADC_PHASE_PROF
@@ -1143,48 +1148,52 @@ void launch_layer1_tap(int what, const float *y, const LayerWeightsM &w, float *
 // The first stage in its K = 1 form takes the magnitude half of its input from Y (FIRSTK = 3): no magnitude array.  (Until round 5: the LDS slab path -- "encoder" = 2 --,
 // the magnitudes from a second array -- "v4_mag" = 1 -- and a 4-wave form at 24 frames -- "encoder" = 4: experiments.)
 template <int T0, int NCH>
-static void launch_v4_first(const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st)
+static void launch_v4_first(const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map, size_t fm_stride, hipStream_t st, int tv)
 {
    const float *no_in2 = nullptr;
    if constexpr (T0 == 24) {                                // 8 waves: 5 chunks per workgroup (120 of 128 lanes own a column instead of 48 of 64)
-      hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, 5, false, false, true, false, 8>), dim3((n + 4) / 5), dim3(512), 0, st, in, fm, w, out, n, map, fm_stride, no_in2);
+      hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, 5, false, false, true, false, 8>), dim3((n + 4) / 5), dim3(512), 0, st, in, fm, w, out, n, map, fm_stride, no_in2, 0, tv);
       return;
    }
-   hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, NCH, false, false, true>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, no_in2);
+   hipLaunchKernelGGL((k_layer_mfma<258, 16, T0, 2, true, 3, false, NCH, false, false, true>), dim3((n + NCH - 1) / NCH), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, no_in2, 0, tv);
 }
+// tv0: the valid STFT frames of a chunk (= T0 at the built windows; fewer at a window in between, which runs the next larger built geometry: see the kernel's `tv`)
 template <int T0, int S3>
 static void launch_v4_t(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                        int lstm_layout, size_t fm_stride, hipStream_t st)
+                        int lstm_layout, size_t fm_stride, hipStream_t st, int tv0)
 {
    constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = S3 == 2 ? (T2 + 1) / 2 : T2;      // a k = 1 conv of stride 2 keeps 1 + (T - 1) / 2 steps (12 -> 6 -> 3 -> 2, 20 -> 10 -> 5 -> 3)
    constexpr int N0 = 64 / T0, N1 = 64 / T1, N2 = 64 / T2, N3 = 64 / T3;
+   const int tv1 = (tv0 + 1) / 2, tv2 = (tv1 + 1) / 2, tv3 = S3 == 2 ? (tv2 + 1) / 2 : tv2;
    const float *in2 = nullptr;
    switch (layer) {
-   case 0: launch_v4_first<T0, N0>(in, fm, w, out, n, map, fm_stride, st); break;
-   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
-   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2); break;
+   case 0: launch_v4_first<T0, N0>(in, fm, w, out, n, map, fm_stride, st, tv0); break;
+   case 1: hipLaunchKernelGGL((k_layer_mfma<16, 32, T1, 2, true, 0, false, N1, true, false>), dim3((n + N1 - 1) / N1), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2, 0, tv1); break;
+   case 2: hipLaunchKernelGGL((k_layer_mfma<32, 32, T2, S3, false, 0, false, N2, true, false>), dim3((n + N2 - 1) / N2), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2, 0, tv2); break;
    case 3:
-      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 3, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2, lstm_layout);
+      hipLaunchKernelGGL((k_layer_mfma<32, 64, T3, 1, true, 0, 3, N3, true, false>), dim3((n + N3 - 1) / N3), dim3(256), 0, st, in, fm, w, out, n, map, fm_stride, in2, lstm_layout, tv3);
       break;
    }
 }
 
-// frames = STFT frames per chunk; stride3 = stride of the third strided conv: 2 in the 16 kHz branch (frames 24 / 16 / 8 = 1536- / 1024- / 512-sample
-// windows), 1 in the 8 kHz branch (silero_vad.py:178-181; frames 12 / 8 / 4 = 768- / 512- / 256-sample windows: 12 -> 6 -> 3 -> 3 -> 3, ...)
+// frames = STFT frames per chunk of the BUILT geometry the window runs in (multiples of 4); frames_valid <= frames: the window's own (a window that is no multiple of
+// 256 samples).  stride3 = stride of the third strided conv: 2 in the 16 kHz branch (frames 24 / 20 / 16 / 12 / 8), 1 in the 8 kHz branch (silero_vad.py:178-181;
+// frames 12 / 8 / 4: 12 -> 6 -> 3 -> 3 -> 3, ...).  The LSTM steps of frames and frames_valid are the same for every frames_valid in (frames - 4, frames].
 void launch_layer_v4(int layer, const float *in, const float *fm, const LayerWeightsM &w, float *out, int n, ItemMap map,
-                     int lstm_layout, size_t fm_stride, hipStream_t st, int frames, int stride3)
+                     int lstm_layout, size_t fm_stride, hipStream_t st, int frames, int stride3, int frames_valid)
 {
+   const int fv = frames_valid > 0 && frames_valid < frames ? frames_valid : frames;
    if (stride3 == 1) {
-      if (frames == 8)      launch_v4_t<8, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
-      else if (frames == 4) launch_v4_t<4, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
-      else                  launch_v4_t<12, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+      if (frames == 8)      launch_v4_t<8, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
+      else if (frames == 4) launch_v4_t<4, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
+      else                  launch_v4_t<12, 1>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
       return;
    }
-   if (frames == 16)      launch_v4_t<16, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
-   else if (frames == 12) launch_v4_t<12, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);      // 768-sample window (round 5)
-   else if (frames == 20) launch_v4_t<20, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);      // 1280-sample window
-   else if (frames == 8)  launch_v4_t<8, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
-   else                   launch_v4_t<24, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st);
+   if (frames == 16)      launch_v4_t<16, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
+   else if (frames == 12) launch_v4_t<12, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);      // 768-sample window (round 5)
+   else if (frames == 20) launch_v4_t<20, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);      // 1280-sample window
+   else if (frames == 8)  launch_v4_t<8, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
+   else                   launch_v4_t<24, 2>(layer, in, fm, w, out, n, map, lstm_layout, fm_stride, st, fv);
 }
 
 }  // namespace vadc

@@ -103,8 +103,11 @@ template <typename T, int GEO>
 __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ pcm, const float *__restrict__ afrag,
                                                           const float *__restrict__ nyq,
                                                           float *__restrict__ Y, float *__restrict__ MAG, float *__restrict__ FM,
-                                                          int n_chunks, ItemMap map, size_t fm_stride)
+                                                          int n_chunks, ItemMap map, size_t fm_stride, int nrt)
 {
+   // nrt <= Geo::samples: the samples a chunk REALLY has (= its stride in pcm).  Silero v4 at a window that is no multiple of 256 samples runs the next larger built
+   // geometry: the chunk's samples are staged where they always are, the right reflect pad goes behind sample nrt - 1 (silero_vad.py:30), and frames 0 .. nrt / 64 - 1
+   // are that window's frames bit for bit; what lies behind in the staging buffer is stale, the surplus frames it feeds are masked by the stages (k_layer_mfma `tv`).
    typedef GemmGeo<GEO> Geo;
    constexpr int kPadG = Geo::pad, kFr = Geo::frames, kBlk = Geo::blocks, kGChunks = Geo::chunks;
    constexpr int kChunk = Geo::samples;                                         // samples per chunk (shadows the v3.1 constant of common.h)
@@ -198,8 +201,9 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       for (int i = tid; i < kGChunks * (kChunk / 8); i += 512) {
          const int c = i / (kChunk / 8), q = i - c * (kChunk / 8);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
+         if (8 * q >= nrt) continue;
          float v[8];
-         g_stage8(pcm + (size_t)map(it) * kChunk + 8 * q, v);
+         g_stage8(pcm + (size_t)map(it) * nrt + 8 * q, v);
          const int p = kPadG + 8 * q;
          float *dst = X0 + c * kChunkPitch + (p >> 6) * kGBlockPitch + (p & 63);
          *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -209,9 +213,9 @@ __global__ __launch_bounds__(512, 4) void k_frontend_gemm(const T *__restrict__ 
       for (int i = tid; i < kGChunks * 2 * kPadG; i += 512) {
          const int c = i / (2 * kPadG), j = i - c * (2 * kPadG);
          const int it = min(grp * kGChunks + c, n_chunks - 1);
-         const T *src = pcm + (size_t)map(it) * kChunk;
-         const int p = j < kPadG ? j : kChunk + j;                             // padded index: left pad | right pad
-         const int sidx = j < kPadG ? kPadG - j : 2 * (kChunk - 1) - (p - kPadG);
+         const T *src = pcm + (size_t)map(it) * nrt;
+         const int p = j < kPadG ? j : nrt + j;                                // padded index: left pad | right pad
+         const int sidx = j < kPadG ? kPadG - j : 2 * (nrt - 1) - (p - kPadG);
          X0[c * kChunkPitch + (p >> 6) * kGBlockPitch + (p & 63)] = g_sample(src[sidx]);
       }
       static_assert(kPaddedG == kBlk * 64, "padded chunk must be whole blocks");
@@ -315,32 +319,34 @@ extern "C" void vadc_gemm_phase_report(void)
 
 template <typename T, int GEO>
 static void launch_gemm_geo(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
-                            int n_cus, hipStream_t st)
+                            int n_cus, hipStream_t st, int nrt)
 {
    const int groups = (n + GemmGeo<GEO>::chunks - 1) / GemmGeo<GEO>::chunks;
    const int grid = groups < 2 * n_cus ? groups : 2 * n_cus;
-   hipLaunchKernelGGL((k_frontend_gemm<T, GEO>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride);
+   hipLaunchKernelGGL((k_frontend_gemm<T, GEO>), dim3(grid), dim3(512), 0, st, pcm, afrag, nyq, Y, MAG, FM, n, map, fm_stride,
+                      (nrt > 0 && nrt < GemmGeo<GEO>::samples) ? nrt : GemmGeo<GEO>::samples);
 }
 template <typename T>
 static void launch_gemm(const T *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride, int n, ItemMap map,
-                        int n_cus, hipStream_t st, int geo)
+                        int n_cus, hipStream_t st, int geo, int nrt)
 {
    switch (geo) {
-   case 1:  launch_gemm_geo<T, 1>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   case 2:  launch_gemm_geo<T, 2>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   case 3:  launch_gemm_geo<T, 3>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   case 4:  launch_gemm_geo<T, 4>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   case 5:  launch_gemm_geo<T, 5>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   case 6:  launch_gemm_geo<T, 6>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
-   default: launch_gemm_geo<T, 0>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st); break;
+   case 1:  launch_gemm_geo<T, 1>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   case 2:  launch_gemm_geo<T, 2>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   case 3:  launch_gemm_geo<T, 3>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   case 4:  launch_gemm_geo<T, 4>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   case 5:  launch_gemm_geo<T, 5>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   case 6:  launch_gemm_geo<T, 6>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, nrt); break;
+   default: launch_gemm_geo<T, 0>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, 0); break;
    }
 }
 
 // geo: 0 = Silero v3.1 geometry (MAG unused), 1 / 2 / 3 / 4 / 5 = Silero v4 with 1536- / 1024- / 512- / 768- / 256-sample windows
+// nrt: samples per chunk in pcm when fewer than the geometry's (0: the geometry's)
 void launch_frontend_gemm_f32(const float *pcm, const float *afrag, const float *nyq, float *Y, float *MAG, float *FM, size_t fm_stride,
-                              int n, ItemMap map, int n_cus, hipStream_t st, int geo)
+                              int n, ItemMap map, int n_cus, hipStream_t st, int geo, int nrt)
 {
-   launch_gemm<float>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo);
+   launch_gemm<float>(pcm, afrag, nyq, Y, MAG, FM, fm_stride, n, map, n_cus, st, geo, nrt);
 }
 
 // (s16 input is k_frontend_gemm2's: kernels_frontend_gemm2.hip.  This form serves f32 input -- the host's backend_run samples, the stage taps.)

@@ -98,8 +98,10 @@ __device__ __forceinline__ void g2_split8_rn(const float (&v)[8], g2_h8v &hi, g2
 template <int GEO, bool WMAG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_frontend_gemm2(const int16_t *__restrict__ pcm, const float *__restrict__ afrag2, const float *__restrict__ nyq2,
                                                            float *__restrict__ Y, float *__restrict__ MAG, float *__restrict__ FM,
-                                                           int n_chunks, ItemMap map, size_t fm_stride)
+                                                           int n_chunks, ItemMap map, size_t fm_stride, int nrt)
 {
+   // nrt <= Geo::samples: the samples a chunk really has (= its stride in pcm) -- a Silero v4 window between the built ones, run in the next larger geometry: see
+   // k_frontend_gemm.  nrt = Geo::samples at the built windows: the address arithmetic below is what it was.
    typedef G2Geo<GEO> Geo;
    constexpr int S = Geo::samples, kPadG = Geo::pad, F = Geo::frames, G = Geo::chunks;
    constexpr int kPadded = S + 2 * kPadG, kBlk = kPadded / 64;
@@ -157,11 +159,12 @@ __global__ __launch_bounds__(512, 2) void k_frontend_gemm2(const int16_t *__rest
    // part p < kTiles - 1 of local group tg: 16-byte pieces [p kPerPart, (p + 1) kPerPart) of its samples, global -> register -> LDS
    auto stage_load = [&](int tg, int part, g2_u4v &r) -> bool {
       const int u = part * kPerPart + tid;
-      const bool on = tg < nlg && tid < kPerPart && u < kMainU;
+      bool on = tg < nlg && tid < kPerPart && u < kMainU;
       if (on) {
          const int c = u / (S / 8), q8 = u - c * (S / 8);
          const int item = min(((int)blockIdx.x + tg * (int)gridDim.x) * G + c, n_chunks - 1);
-         r = *reinterpret_cast<const g2_u4v *>(pcm + (size_t)map(item) * S + 8 * q8);
+         on = 8 * q8 < nrt;
+         if (on) r = *reinterpret_cast<const g2_u4v *>(pcm + (size_t)map(item) * nrt + 8 * q8);
       }
       return on;
    };
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(512, 2) void k_frontend_gemm2(const int16_t *__rest
       int16_t *x = X0[tg & 1];
       for (int i = tid; i < kPads; i += 512) {
          const int c = i / (2 * kPadG), jj = i - c * (2 * kPadG);
-         const int dst = jj < kPadG ? jj : S + jj;
-         const int src = jj < kPadG ? 2 * kPadG - jj : S + 2 * kPadG - 2 - jj;
+         const int dst = jj < kPadG ? jj : nrt + jj;
+         const int src = jj < kPadG ? 2 * kPadG - jj : nrt + 2 * kPadG - 2 - jj;
          x[c * kCP + (dst >> 6) * kG2BlockPitch + (dst & 63)] = x[c * kCP + (src >> 6) * kG2BlockPitch + (src & 63)];
       }
       if (tid < G) {
@@ -389,19 +392,20 @@ template <int ABL>
 void launch_frontend_gemm2_abl(const int16_t *pcm, const float *afrag2, const float *nyq2, float *Y, float *FM, size_t fm_stride, int n, ItemMap map, int n_cus, hipStream_t st)
 {
    const int groups = (n + G2Geo<1>::chunks - 1) / G2Geo<1>::chunks;
-   hipLaunchKernelGGL((k_frontend_gemm2<1, false, ABL>), dim3(groups < n_cus ? groups : n_cus), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride);
+   hipLaunchKernelGGL((k_frontend_gemm2<1, false, ABL>), dim3(groups < n_cus ? groups : n_cus), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride, G2Geo<1>::samples);
 }
 
 // (no magnitude array: the v4 first stage recovers the magnitudes from Y; the WMAG = true instantiations served option "v4_mag" = 1 until round 5)
 void launch_frontend_gemm2_s16(const int16_t *pcm, const float *afrag2, const float *nyq2, float *Y, float *FM, size_t fm_stride,
-                               int n, ItemMap map, int n_cus, hipStream_t st, int geo)
+                               int n, ItemMap map, int n_cus, hipStream_t st, int geo, int nrt)
 {
    if (n <= 0) return;
 #define VADC_G2_CASE(GEO) \
    case GEO: { \
       const int groups = (n + G2Geo<GEO>::chunks - 1) / G2Geo<GEO>::chunks; \
       const int grid = groups < n_cus ? groups : n_cus; \
-      hipLaunchKernelGGL((k_frontend_gemm2<GEO, false>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride); \
+      hipLaunchKernelGGL((k_frontend_gemm2<GEO, false>), dim3(grid), dim3(512), 0, st, pcm, afrag2, nyq2, Y, nullptr, FM, n, map, fm_stride, \
+                         (nrt > 0 && nrt < G2Geo<GEO>::samples) ? nrt : G2Geo<GEO>::samples); \
    } break;
    switch (geo) {
    VADC_G2_CASE(1) VADC_G2_CASE(2) VADC_G2_CASE(3) VADC_G2_CASE(4) VADC_G2_CASE(5) VADC_G2_CASE(6)
