@@ -114,7 +114,7 @@ typedef struct vadc_amd_caps {
                                              create) and the partition may be used; 0: any other layout (CPX / DPX mode, another part): no CU partition, plain streams */
    int32_t input_size_step;               /* the windows served are input_size_min + k * input_size_step <= input_size_max; 0: one window.  Silero v4: 64 -- the
                                              reference's onnxruntime path admits every count in 512 .. 1536 (onnx_helpers.c:164-170), this engine every multiple of
-                                             64 samples (= one STFT frame) in that range */
+                                             64 samples (= one STFT frame) in that range; a host rounds a count in between DOWN (host/vadc_hip.c) */
 } vadc_amd_caps;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

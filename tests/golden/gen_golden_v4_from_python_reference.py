@@ -164,7 +164,7 @@ def main():
     # every multiple of 64 samples (round 6): windows that are no multiple of 256 -- 9, 11, 13, 15, 17, 19, 21, 22 and 23 STFT frames at 16 kHz, 5, 7 and 11 at 8 kHz -- whose
     # right reflect pad starts inside the next 64-sample block and whose strided stages meet every parity of lengths (9 -> 5 -> 3 -> 2, 13 -> 7 -> 4 -> 2, 23 -> 12 -> 6 -> 3, ...)
     out64 = {}
-    for window in (576, 704, 832, 960, 1088, 1216, 1344, 1408, 1472):
+    for window in (576, 704, 832, 960, 1088, 1216, 1344, 1408, 1472, 520, 1000, 1336, 1528):      # (the last four: no multiple of 64 -- trailing samples that fill no frame)
         for name in ("speech0", "speech1", "square"):
             x = pcm[name][: (pcm[name].size // window) * window]
             p64, h64, c64 = run_stream(m64, x, torch.float64, window)

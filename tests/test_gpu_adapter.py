@@ -60,7 +60,7 @@ def test_trio_v5_row_compaction(runner, tmp_path):
         assert float(np.abs(got - want).max()) <= PROB_TOL, batch
 
 
-@pytest.mark.parametrize("seq", [512, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("seq", [512, 768, 1024, 1280, 1536, 960, 1472])      # (960, 1472: windows between the built ones -- every multiple of 64 is served)
 def test_trio_v4_forwards_the_sequence_count(runner, tmp_path, seq):
     """a Silero v4 container accepts --sequence_count 512 ... 1536 (caps.input_size_min / max as ort_init reports them, onnx_helpers.c:164-170); the
     caller sizes its buffers for THAT window (vadc.c:743-781), so the adapter must make the engine run it (it used to keep 1536 and read past the
@@ -68,19 +68,20 @@ def test_trio_v4_forwards_the_sequence_count(runner, tmp_path, seq):
     py = np.load(os.path.join(GOLDEN, "python_reference_v4.npz"))
     w = os.path.join(GOLDEN, "silero_v4_16k.testtensor")
     pcm = py["pcm_speech0"]
-    want = py["probs64_speech0"] if seq == 1536 else np.load(os.path.join(GOLDEN, "python_reference_v4_windows.npz" if seq in (512, 1024) else "python_reference_v4_windows_768_1280.npz"))[f"probs64_w{seq}_speech0"]
+    gfile = "python_reference_v4_windows.npz" if seq in (512, 1024) else ("python_reference_v4_windows_768_1280.npz" if seq in (768, 1280) else "python_reference_v4_windows_64.npz")
+    want = py["probs64_speech0"] if seq == 1536 else np.load(os.path.join(GOLDEN, gfile))[f"probs64_w{seq}_speech0"]
     got, log = run_adapter(runner, tmp_path, w, 1, seq, pcm)
     assert got.shape == want.shape and f"of {seq} samples" in log
     assert float(np.abs(got - want).max()) <= PROB_TOL
 
 
 def test_trio_v4_refuses_a_window_it_cannot_run(runner, tmp_path):
-    """800 lies inside [input_size_min, input_size_max] but is not a built window (they are 256 apart): the adapter aborts with a message (like an onnxruntime error,
-    onnx_helpers.h:5-14) instead of running the wrong window"""
+    """1000 lies inside [input_size_min, input_size_max] but is no multiple of 64 samples (a count in between is not built): the adapter aborts with a message (like
+    an onnxruntime error, onnx_helpers.h:5-14) instead of running the wrong window"""
     py = np.load(os.path.join(GOLDEN, "python_reference_v4.npz"))
     w = os.path.join(GOLDEN, "silero_v4_16k.testtensor")
     x = (py["pcm_noise"].astype(np.float32) / np.float32(32768))
     fin, fout = str(tmp_path / "in.f32"), str(tmp_path / "out.f32")
     x.tofile(fin)
-    r = subprocess.run([runner, w, "1", "800", fin, fout], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "sequence_count 800" in r.stderr
+    r = subprocess.run([runner, w, "1", "1000", fin, fout], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "sequence_count 1000" in r.stderr

@@ -319,7 +319,7 @@ def test_window_sizes_vs_python_reference_and_oracle(blob, orc, gold, window):
         assert e.stage_from_samples(x, "magnitude").shape == (5, 129, window // 64)
         assert e.stage_from_samples(x, "layer4").shape == (5, 64, {512: 1, 768: 2, 1024: 2, 1280: 3}[window])
         with pytest.raises(VadcAmdError):
-            e.set_option("window", 800)                               # not a multiple of 64
+            e.set_option("window", 1000)                              # not a multiple of 64
         with pytest.raises(VadcAmdError):
             e.set_option("window", 1792)
         e.set_window(1536)

@@ -1388,7 +1388,8 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
    if (strcmp(key, "groups") == 0 && value >= 0 && value <= vadc_amd_engine::kMaxGroups) { e->groups = value; return VADC_AMD_OK; }
    if (strcmp(key, "window") == 0) {
       // samples per chunk.  The reference's C backend takes 1536 only (silero.h:41-42); its onnxruntime path lets the v4 graph take every count in 512 ... 1536
-      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752).  Served here: every multiple of 64 samples (one STFT frame) in that range.  The multiples of 256
+      // (onnx_helpers.c:164-170, --sequence_count vadc.c:743-752).  Served here: every multiple of 64 samples (one STFT frame) in that range -- a count in between would add
+      // samples that fill no frame and reach the model through the right reflect pad only: not built.  The multiples of 256
       // (8 / 12 / 16 / 20 / 24 frames) have kernels built for their geometry; a window in between runs the next larger of them -- the front end stages the chunk's
       // own samples and puts the right reflect pad behind them (`nrt`), so that its first frames ARE the window's frames; the surplus steps are masked stage by stage (`tv`)
       if (value == e->window) return VADC_AMD_OK;
