@@ -30,3 +30,13 @@ def weights_blob():
 @pytest.fixture(scope="session")
 def fixture_path():
     return lambda name: os.path.join(FIXTURES, name + ".testtensor")
+
+
+def run_cli(cmd, data, timeout=120):
+    """run a host CLI with `data` on stdin; a run that does not come back fails with what it had written so far (instead of a bare TimeoutExpired)"""
+    import subprocess
+    try:
+        return subprocess.run(cmd, input=data, capture_output=True, timeout=timeout)
+    except subprocess.TimeoutExpired as ex:
+        raise AssertionError(f"{' '.join(map(str, cmd))} did not finish within {timeout} s; stderr so far: {(ex.stderr or b'').decode(errors='replace')[-1500:]!r}; "
+                             f"stdout so far: {len(ex.stdout or b'')} bytes") from None

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth, testtensor as tt
 from vadc_amd.engine import Engine, VadcAmdError
@@ -1395,7 +1395,7 @@ def _run_cli(pcm, *args):
     exe = os.path.join(ROOT, "host", "vadc_hip")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
-    r = subprocess.run([exe, "--model", WEIGHTS, *args], input=pcm.tobytes(), capture_output=True, timeout=300)
+    r = run_cli([exe, "--model", WEIGHTS, *args], pcm.tobytes())
     assert r.returncode == 0, r.stderr.decode()
     return r.stdout.decode().splitlines(), r.stderr.decode()
 
@@ -1455,7 +1455,7 @@ def test_cli_with_embedded_weights(gold_c, gold_py):
     exe = os.path.join(ROOT, "host", "vadc_hip_embedded")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "vadc_hip_embedded"])
-    r = subprocess.run([exe, "--raw_probabilities"], input=gold_py["pcm_speech1"].tobytes(), capture_output=True, timeout=300)
+    r = run_cli([exe, "--raw_probabilities"], gold_py["pcm_speech1"].tobytes())
     assert r.returncode == 0, r.stderr.decode()
     got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
     assert float(np.abs(got - gold_c["probs_speech1"][:, 1]).max()) <= PROB_TOL + 5e-7

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth
 from vadc_amd.engine import Engine, VadcAmdError, MODEL_V4
@@ -275,12 +275,12 @@ def test_cli_with_v4_weights(gold):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
     pcm = gold["pcm_speech0"]
-    r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities"], input=pcm.tobytes(), capture_output=True, timeout=300)
+    r = run_cli([exe, "--model", V4_WEIGHTS, "--raw_probabilities"], pcm.tobytes())
     assert r.returncode == 0, r.stderr.decode()
     got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
     assert got.size == gold["probs64_speech0"].size
     assert float(np.abs(got - gold["probs64_speech0"]).max()) <= PROB_TOL + 5e-7        # %f quantises to 5e-7
-    r = subprocess.run([exe, "--model", V4_WEIGHTS], input=pcm.tobytes(), capture_output=True, timeout=300)
+    r = run_cli([exe, "--model", V4_WEIGHTS], pcm.tobytes())
     sec, _ = O.segments(gold["probs64_speech0"].astype(np.float32))
     assert r.stdout.decode().splitlines() == ["%.2f,%.2f" % (a, b) for a, b in sec]
 
@@ -354,7 +354,7 @@ def test_cli_sequence_count_selects_the_v4_window(gold):
     pcm = gold["pcm_speech0"]
     gw.update(np.load(os.path.join(GOLDEN, "python_reference_v4_windows_64.npz")))
     for arg, window in (("512", 512), ("1024", 1024), ("1100", 1088), ("100", 512), ("9999", 1536), ("768", 768), ("1000", 960), ("1280", 1280), ("1500", 1472), ("576", 576)):
-        r = subprocess.run([exe, "--model", V4_WEIGHTS, "--raw_probabilities", "--sequence_count", arg], input=pcm.tobytes(), capture_output=True, timeout=300)
+        r = run_cli([exe, "--model", V4_WEIGHTS, "--raw_probabilities", "--sequence_count", arg], pcm.tobytes())
         assert r.returncode == 0, r.stderr.decode()
         assert f"Running with sequence count {window}" in r.stderr.decode()
         got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
@@ -362,7 +362,7 @@ def test_cli_sequence_count_selects_the_v4_window(gold):
         assert got.shape == want.shape and float(np.abs(got - want).max()) < PROB_TOL + 5e-7
 
 
-@pytest.mark.parametrize("window", [576, 704, 832, 960, 1088, 1216, 1344, 1408, 1472])
+@pytest.mark.parametrize("window", [576, 832, 960, 1088, 1408, 1472])      # (one to three frames short of each built geometry; all nine in-between windows: tests/test_oracle_v4.py on the CPU)
 def test_windows_of_every_multiple_of_64(blob, orc, gold, window):
     """round 6: the reference's onnxruntime path admits every count in 512 ... 1536 (onnx_helpers.c:164-170); the engine serves every multiple of 64 samples.  A
     window that is no multiple of 256 runs the next larger built geometry -- the chunk re-laid-out so that its first frames are the window's own frames (samples,

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth, testtensor as tt
 from vadc_amd.engine import Engine, VadcAmdError, MODEL_V5
@@ -217,7 +217,7 @@ def test_cli_with_v5_weights(gold):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
     pcm = gold["pcm_speech0"]
-    r = subprocess.run([exe, "--model", V5_WEIGHTS, "--raw_probabilities"], input=pcm.tobytes(), capture_output=True, timeout=300)
+    r = run_cli([exe, "--model", V5_WEIGHTS, "--raw_probabilities"], pcm.tobytes())
     assert r.returncode == 0, r.stderr.decode()
     assert "Running with sequence count 512" in r.stderr.decode()
     got = np.array([float(x) for x in r.stdout.decode().splitlines()], np.float32)
