@@ -939,7 +939,11 @@ def main():
     args.rank_cpus_n = len(pin_rank_to_its_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
     if args.dry_run:
         return dry_run(args, world, rank)
-    return run_rank(args, world, rank, local_rank)
+    rc = run_rank(args, world, rank, local_rank)
+    # A process that has used the GPU leaves WITHOUT the HIP runtime's exit handlers: beside another process's GPU context (the other ranks of this job) they hung one
+    # short-lived process in about two hundred on ROCm 7.2 -- after main() had returned, every engine destroyed (tools/cli_teardown_probe.py).  Everything is flushed first.
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(int(rc or 0))
 
 
 if __name__ == "__main__":

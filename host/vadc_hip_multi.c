@@ -307,5 +307,6 @@ done:
    if (comms_up) for (int r = 0; r < gpus; ++r) if (!ws || !ws[r].aborted) (void)ncclCommDestroy(comms[r]);      /* (an aborted communicator is already gone) */
    if (bar_up) pthread_barrier_destroy(&bar);
    free(blob); free(pcm); free(dump); free(comms); free(devs); free(ws); free(th);
-   return rc;
+   fflush(NULL);
+   _exit(rc);                                                    /* not through the HIP runtime's exit handlers: see the end of vadc_hip.c */
 }

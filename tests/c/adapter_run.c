@@ -8,6 +8,7 @@
  * output[i * output_stride + silero_probability_out_index]).  The types are the layout mirrors of tests/c/vadc_layout_mirror.h (checked against the
  * reference's vadc.h in the build container).  tests/test_gpu_adapter.py compares what it writes with the reference goldens.
  * Build: gcc -std=gnu11 -O1 -Iinclude -Itests/c tests/c/adapter_run.c -Lvadc_amd -lvadc_amd -Wl,-rpath,$PWD/vadc_amd -o tests/c/adapter_run */
+#include <unistd.h>
 #include "vadc_layout_mirror.h"
 #include "vadc_backend_hip.h"
 
@@ -85,5 +86,6 @@ int main(int argc, char **argv)
    if (!f || fwrite(probs, sizeof(float), n_windows, f) != n_windows) { fprintf(stderr, "adapter_run: cannot write %s\n", argv[5]); return 2; }
    fclose(f);
    fprintf(stderr, "adapter_run: %zu windows of %d samples, batch %d, v5 %d\n", n_windows, config.input_count, config.batch_size, config.is_silero_v5);
-   return 0;
+   fflush(NULL);
+   _exit(0);                                                     /* a short-lived GPU process beside the test runner's own context: not through the HIP runtime's exit handlers (host/vadc_hip.c) */
 }

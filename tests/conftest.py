@@ -35,8 +35,9 @@ def fixture_path():
 def run_cli(cmd, data, timeout=120):
     """run a host CLI with `data` on stdin; a run that does not come back fails with what it had written so far (instead of a bare TimeoutExpired)"""
     import subprocess
+    env = dict(os.environ, VADC_AMD_TRACE_TEARDOWN="1")      # (stderr is only looked at when the child does not come back)
     try:
-        return subprocess.run(cmd, input=data, capture_output=True, timeout=timeout)
+        return subprocess.run(cmd, input=data, capture_output=True, timeout=timeout, env=env)
     except subprocess.TimeoutExpired as ex:
         raise AssertionError(f"{' '.join(map(str, cmd))} did not finish within {timeout} s; stderr so far: {(ex.stderr or b'').decode(errors='replace')[-1500:]!r}; "
                              f"stdout so far: {len(ex.stdout or b'')} bytes") from None

@@ -1422,7 +1422,7 @@ def test_cli_short_lived_processes_exit(gold_py):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
     pcm = gold_py["pcm_speech0"].tobytes()
     for _ in range(25):
-        r = subprocess.run([exe, "--model", WEIGHTS], input=pcm, capture_output=True, timeout=30)
+        r = run_cli([exe, "--model", WEIGHTS], pcm, timeout=30)            # (a child that does not come back: its teardown marks say where it stands)
         assert r.returncode == 0 and r.stdout == b"0.07,3.10\n", r.stderr.decode()
 
 

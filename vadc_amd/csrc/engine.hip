@@ -301,7 +301,78 @@ struct vadc_amd_engine {
    std::vector<EvPair> pool;
    int launches[VADC_AMD_KERNEL_COUNT] = {0};
    double total_ms[VADC_AMD_KERNEL_COUNT] = {0};
+   // page-locked staging of the engine's own for the copies between a caller's PAGEABLE memory and the device (host_to_device / device_to_host below)
+   static constexpr size_t kBouncePiece = (size_t)4 << 20, kBounceMax = (size_t)32 << 20;
+   char *bounce[2] = {nullptr, nullptr};
+   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+   bool bounce_busy[2] = {false, false};
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Copies between the caller's pageable memory and the device.  Handed a pageable pointer, the HIP runtime page-locks the range for the transfer (a userptr mapping of
+// heap pages into the GPU's address space, made and torn down per call) -- the engine's synchronous entry points, its debug taps and vadc_amd_create would do that
+// thousands of times in a test run, on whatever heap block the caller's allocator handed out.  Up to kBounceMax bytes go through two page-locked pieces the engine owns
+// instead (memcpy of piece k + 1 beside the DMA of piece k; no system call per copy); a larger transfer is locked in place by the runtime as before (there the
+// extra pass over the data would cost more than the locking: the 75 MB input of a 256 x 96 call).
+// ---------------------------------------------------------------------------------------------------
+static hipError_t bounce_ready(vadc_amd_engine *e)
+{
+   for (int i = 0; i < 2; ++i) {
+      if (!e->bounce[i]) { void *p = nullptr; hipError_t he = hipHostMalloc(&p, vadc_amd_engine::kBouncePiece, hipHostMallocDefault); if (he != hipSuccess) return he; e->bounce[i] = static_cast<char *>(p); }
+      if (!e->bounce_ev[i]) { hipError_t he = hipEventCreateWithFlags(&e->bounce_ev[i], hipEventDisableTiming); if (he != hipSuccess) return he; }
+   }
+   return hipSuccess;
+}
+// enqueued on `st`; `src` may be reused when the call returns
+static hipError_t host_to_device(vadc_amd_engine *e, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+   if (bytes > vadc_amd_engine::kBounceMax) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+   hipError_t he = bounce_ready(e);
+   for (size_t off = 0, k = 0; off < bytes && he == hipSuccess; off += vadc_amd_engine::kBouncePiece, ++k) {
+      const int i = (int)(k & 1);
+      const size_t n = std::min(vadc_amd_engine::kBouncePiece, bytes - off);
+      if (e->bounce_busy[i]) { he = hipEventSynchronize(e->bounce_ev[i]); e->bounce_busy[i] = false; if (he != hipSuccess) break; }
+      memcpy(e->bounce[i], static_cast<const char *>(src) + off, n);
+      he = hipMemcpyAsync(static_cast<char *>(dst) + off, e->bounce[i], n, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipEventRecord(e->bounce_ev[i], st);
+      e->bounce_busy[i] = he == hipSuccess;
+   }
+   return he;
+}
+// returns when the bytes are in `dst` (everything enqueued on `st` before has finished then)
+static hipError_t device_to_host(vadc_amd_engine *e, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+   if (bytes > vadc_amd_engine::kBounceMax) { hipError_t he = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); return he == hipSuccess ? hipStreamSynchronize(st) : he; }
+   hipError_t he = bounce_ready(e);
+   for (int i = 0; i < 2 && he == hipSuccess; ++i) if (e->bounce_busy[i]) { he = hipEventSynchronize(e->bounce_ev[i]); e->bounce_busy[i] = false; }
+   const size_t P = vadc_amd_engine::kBouncePiece, pieces = (bytes + P - 1) / P;
+   for (size_t k = 0; k <= pieces && he == hipSuccess; ++k) {
+      if (k < pieces) {                                         // piece k on its way ...
+         he = hipMemcpyAsync(e->bounce[k & 1], static_cast<const char *>(src) + k * P, std::min(P, bytes - k * P), hipMemcpyDeviceToHost, st);
+         if (he == hipSuccess) he = hipEventRecord(e->bounce_ev[k & 1], st);
+      }
+      if (k > 0 && he == hipSuccess) {                          // ... while piece k - 1 goes to the caller
+         he = hipEventSynchronize(e->bounce_ev[(k - 1) & 1]);
+         if (he == hipSuccess) memcpy(static_cast<char *>(dst) + (k - 1) * P, e->bounce[(k - 1) & 1], std::min(P, bytes - (k - 1) * P));
+      }
+   }
+   return he;
+}
+// vadc_amd_create's uploads (no stream yet): synchronous, through a page-locked buffer of the call's own
+static hipError_t upload(void *dst, const void *src, size_t bytes)
+{
+   if (!bytes) return hipSuccess;
+   const size_t P = std::min(bytes, (size_t)8 << 20);
+   void *h = nullptr;
+   hipError_t he = hipHostMalloc(&h, P, hipHostMallocDefault);
+   for (size_t off = 0; off < bytes && he == hipSuccess; off += P) {
+      const size_t n = std::min(P, bytes - off);
+      memcpy(h, static_cast<const char *>(src) + off, n);
+      he = hipMemcpy(static_cast<char *>(dst) + off, h, n, hipMemcpyHostToDevice);
+   }
+   if (h) (void)hipHostFree(h);
+   return he;
+}
 
 static void copy_unaligned(std::vector<float> &dst, const HostTensor &t)
 {
@@ -636,7 +707,7 @@ static int build_weights(vadc_amd_engine *e, const std::vector<HostTensor> &ts)
       const size_t o_b = pk.add(B.data(), B.size()), o_dw = pk.add(dw.data(), dw.size()), o_db = pk.add(db.data(), db.size());
 
       HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
-      HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      HIP_TRY(upload(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float)), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
       if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; e->d_afrag2 = base + off_afrag2; e->d_nyq2 = base + off_nyq2; }
@@ -830,7 +901,7 @@ static int build_weights_v4(vadc_amd_engine *e, const std::vector<HostTensor> &t
       const size_t o_w = pk.add(W.data(), W.size()), o_wT = pk.add(WT.data(), WT.size());
       const size_t o_b = pk.add(B.data(), B.size()), o_dw = pk.add(dw.data(), dw.size()), o_db = pk.add(db.data(), db.size());
       HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
-      HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+      HIP_TRY(upload(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float)), VADC_AMD_EHIP);
       const float *base = e->d_weights;
       e->d_basis = base + off_basis;
       if (e->gemm_ok) { e->d_afrag = base + off_afrag; e->d_nyq = base + off_nyq; e->d_afrag2 = base + off_afrag2; e->d_nyq2 = base + off_nyq2; }
@@ -992,7 +1063,7 @@ static int build_weights_v5(vadc_amd_engine *e, const std::vector<HostTensor> &t
    copy_unaligned(v, ts[11]); const size_t o_dw = pk.add(v.data(), v.size());
    copy_unaligned(v, ts[12]); const size_t o_db = pk.add(v.data(), v.size());
    HIP_TRY(hipMalloc(&e->d_weights, pk.buf.size() * sizeof(float)), VADC_AMD_ENOMEM);
-   HIP_TRY(hipMemcpy(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+   HIP_TRY(upload(e->d_weights, pk.buf.data(), pk.buf.size() * sizeof(float)), VADC_AMD_EHIP);
    const float *base = e->d_weights;
    e->v5.stft_f = base + o_stft;
    for (int c = 0; c < 4; ++c) { e->v5.conv_f[c] = base + o_cf[c]; e->v5.conv_b[c] = base + o_cb[c]; }
@@ -1017,17 +1088,25 @@ extern "C" int vadc_amd_abi_version(void) { return VADC_AMD_ABI_VERSION; }
 extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
 {
    if (!e) return;
+   // VADC_AMD_TRACE_TEARDOWN=1: a mark on stderr per step (a teardown that does not come back -- seen once in some hundred short-lived processes on ROCm 7.2 -- says where it stands)
+   const bool trace = getenv("VADC_AMD_TRACE_TEARDOWN") != nullptr;
+   auto mark = [&](const char *what) { if (trace) { fprintf(stderr, "vadc_amd_destroy: %s\n", what); fflush(stderr); } };
+   mark("begin");
    (void)hipSetDevice(e->device);
    // The first hipFree below waits for the whole device, the engine's own streams included.  (An explicit hipStreamSynchronize on the idle CU-masked
    // streams here hung one short-lived process in ten -- bisected, ROCm 7.2 -- so there is none.)
    if (e->stream) (void)hipStreamSynchronize(e->stream);
+   mark("engine stream idle");
    for (int k = 0; k < VADC_AMD_KERNEL_COUNT; ++k)
       for (auto &p : e->pending[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    for (auto &p : e->pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
    void *ptrs[] = {e->d_weights, e->d_in_f32, e->d_in_s16, e->d_Y, e->d_MAG, e->d_FM, e->d_tap, e->d_act[0], e->d_act[1],
                    e->d_act[2], e->d_xpair[0], e->d_xpair[1], e->d_probs, e->d_h, e->d_c, e->d_h0pair[0], e->d_h0pair[1], e->d_lstm_progress[0], e->d_lstm_progress[1], e->d_lstm_tickets, e->d_gx5[0], e->d_gx5[1], e->d_x35, e->d_ctx5, e->d_encA, e->d_encB, e->d_enc_scratch, e->d_l1img, e->d_encv4};
-   for (void *p : ptrs) if (p) (void)hipFree(p);
+   mark("events gone");
+   { bool first = true; for (void *p : ptrs) if (p) { (void)hipFree(p); if (first) mark("first hipFree (device-wide wait) back"); first = false; } }
+   mark("device buffers freed");
    if (e->h_trail_err) (void)hipHostFree(const_cast<int *>(e->h_trail_err));
+   for (int i = 0; i < 2; ++i) { if (e->bounce[i]) (void)hipHostFree(e->bounce[i]); if (e->bounce_ev[i]) (void)hipEventDestroy(e->bounce_ev[i]); }
    if (e->d_trail_recov) (void)hipFree(e->d_trail_recov);
    if (e->ev_redo) (void)hipEventDestroy(e->ev_redo);
    for (auto &sl : e->aslot) {
@@ -1037,6 +1116,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
       if (sl.out_done) (void)hipEventDestroy(sl.out_done);
    }
    for (auto &r : e->pinned) if (r.ours) (void)hipHostUnregister(const_cast<char *>(r.p));
+   mark("host memory freed / unregistered");
    for (int i = 0; i < 3; ++i) { if (e->s_h2dx[i]) (void)hipStreamDestroy(e->s_h2dx[i]); if (e->ev_h2dx[i]) (void)hipEventDestroy(e->ev_h2dx[i]); }
    if (e->s_h2d) (void)hipStreamDestroy(e->s_h2d);
    if (e->s_d2h) (void)hipStreamDestroy(e->s_d2h);
@@ -1050,6 +1130,7 @@ extern "C" void vadc_amd_destroy(vadc_amd_engine *e)
    for (hipEvent_t ev : e->ev_wrap) if (ev) (void)hipEventDestroy(ev);
    for (hipEvent_t ev : e->ev_fe) if (ev) (void)hipEventDestroy(ev);
    delete e;
+   mark("end");
 }
 
 static int cu_mask_layout_flags(int device, int n_cus);
@@ -1137,19 +1218,19 @@ extern "C" int vadc_amd_create(const void *blob, size_t len, int device, int max
    if (he == hipSuccess && !e->h_encA.empty()) {
       he = hipMalloc(&e->d_encA, e->h_encA.size());
       if (he == hipSuccess) he = hipMalloc(&e->d_encB, e->h_encB.size());
-      if (he == hipSuccess) he = hipMemcpy(e->d_encA, e->h_encA.data(), e->h_encA.size(), hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = hipMemcpy(e->d_encB, e->h_encB.data(), e->h_encB.size(), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = upload(e->d_encA, e->h_encA.data(), e->h_encA.size());
+      if (he == hipSuccess) he = upload(e->d_encB, e->h_encB.data(), e->h_encB.size());
       if (he == hipSuccess) he = hipMalloc(&e->d_enc_scratch, (N + 4) * kEncScratchPerChunk * sizeof(float));   // batches of up to 4 chunks: the last one may be partial
       e->h_encA.clear(); e->h_encA.shrink_to_fit(); e->h_encB.clear(); e->h_encB.shrink_to_fit();
    }
    if (he == hipSuccess && !e->h_encv4.empty()) {
       he = hipMalloc(&e->d_encv4, e->h_encv4.size());
-      if (he == hipSuccess) he = hipMemcpy(e->d_encv4, e->h_encv4.data(), e->h_encv4.size(), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = upload(e->d_encv4, e->h_encv4.data(), e->h_encv4.size());
       e->h_encv4.clear(); e->h_encv4.shrink_to_fit();
    }
    if (he == hipSuccess && !e->h_l1img.empty()) {
       he = hipMalloc(&e->d_l1img, e->h_l1img.size());
-      if (he == hipSuccess) he = hipMemcpy(e->d_l1img, e->h_l1img.data(), e->h_l1img.size(), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = upload(e->d_l1img, e->h_l1img.data(), e->h_l1img.size());
       e->h_l1img.clear(); e->h_l1img.shrink_to_fit();
    }
    for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipMalloc(&e->d_h0pair[p], padded_streams * max_chunks * 448 * sizeof(float));
@@ -1475,16 +1556,15 @@ static int layer1_selfcheck(vadc_amd_engine *e)
             fm[(size_t)(b / kBinsPerSplit) * fms + (size_t)c * T + t] += v;
          }
    hipStream_t st = e->stream;
-   HIP_TRY(hipMemcpyAsync(e->d_Y, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(e->d_FM, fm.data(), fm.size() * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_Y, y.data(), y.size() * sizeof(float), st), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_FM, fm.data(), fm.size() * sizeof(float), st), VADC_AMD_EHIP);
    const size_t elems = (size_t)n * e->stage_elems[VADC_AMD_STAGE_LAYER1];
    std::vector<float> a(elems), b(elems);
    for (int form = 0; form < 2; ++form) {
       e->layer1_variant = form;
       run_encoder_layers(e, 0, 0, n, ItemMap{n, 0, n}, 0, st, nullptr);
       HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-      HIP_TRY(hipMemcpyAsync((form == 0 ? a : b).data(), e->d_act[0], elems * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
-      HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
+      HIP_TRY(device_to_host(e, (form == 0 ? a : b).data(), e->d_act[0], elems * sizeof(float), st), VADC_AMD_EHIP);
    }
    e->layer1_variant = 0;
    float worst = 0.0f, scale = 1.0f;
@@ -2275,11 +2355,11 @@ extern "C" int vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_
    if (!samples || !probs) return fail(VADC_AMD_EINVAL, "run_f32: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    const size_t n = (size_t)n_streams * n_chunks;
-   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, n * e->window * sizeof(float), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_in_f32, samples, n * e->window * sizeof(float), e->stream), VADC_AMD_EHIP);
    rc = run_device<float>(e, e->d_in_f32, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
-   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, probs, e->d_probs, n * 2 * sizeof(float), e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    look_at_trail_recoveries(e);
    return check_trail_error(e, "run_f32");
@@ -2292,11 +2372,11 @@ extern "C" int vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_st
    if (!pcm || !probs) return fail(VADC_AMD_EINVAL, "run_s16: NULL buffer");
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    const size_t n = (size_t)n_streams * n_chunks;
-   HIP_TRY(hipMemcpyAsync(e->d_in_s16, pcm, n * e->window * sizeof(int16_t), hipMemcpyHostToDevice, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_in_s16, pcm, n * e->window * sizeof(int16_t), e->stream), VADC_AMD_EHIP);
    rc = run_device<int16_t>(e, e->d_in_s16, n_streams, n_chunks, e->d_probs, e->stream);
    if (rc) return rc;
    if (e->defer_join) wait_last_all(e, e->stream);        // the synchronous entry points always join (option "defer_join" is about run_device)
-   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, probs, e->d_probs, n * 2 * sizeof(float), e->stream), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(e->stream), VADC_AMD_EHIP);
    look_at_trail_recoveries(e);
    return check_trail_error(e, "run_s16");
@@ -2573,7 +2653,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
-   HIP_TRY(hipMemcpyAsync(e->d_in_f32, samples, (size_t)n * e->window * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_in_f32, samples, (size_t)n * e->window * sizeof(float), st), VADC_AMD_EHIP);
    const ItemMap map{n, 0, n};
    if (e->use_gemm_frontend() && !(e->model != VADC_AMD_MODEL_V4 && stage == VADC_AMD_STAGE_MAGNITUDE))   // v3.1 keeps no magnitude buffer: that tap comes from the tree kernel
       launch_frontend_gemm_f32(e->d_in_f32, e->d_afrag, e->d_nyq, e->d_Y, e->d_MAG, e->d_FM, e->max_items * kFrames, n, map, e->n_cus, st,
@@ -2584,7 +2664,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
    if (stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    if (stage >= VADC_AMD_STAGE_LAYER1) run_encoder_layers(e, 0, stage - VADC_AMD_STAGE_LAYER1, n, map, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, stage), (size_t)n * e->stage_elems[stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, out, stage_buffer(e, stage), (size_t)n * e->stage_elems[stage] * sizeof(float), st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -2604,20 +2684,20 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    const size_t in_bytes = (size_t)n * e->stage_elems[from_stage] * sizeof(float);
    int first_layer = 0;
    if (from_stage == VADC_AMD_STAGE_MAGNITUDE) {
-      HIP_TRY(hipMemcpyAsync(e->d_tap, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(host_to_device(e, e->d_tap, in, in_bytes, st), VADC_AMD_EHIP);
       launch_lognorm_from_magnitude(e->d_tap, e->d_Y, e->d_FM, e->max_items * kFrames, n, st);
    } else if (from_stage == VADC_AMD_STAGE_NORMALIZED) {
       // already normalized: feed as Y with zero frame means (offset 0)
-      HIP_TRY(hipMemcpyAsync(e->d_Y, in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(host_to_device(e, e->d_Y, in, in_bytes, st), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_FM, 0, kBinSplit * e->max_items * kFrames * sizeof(float), st), VADC_AMD_EHIP);
    } else {
       first_layer = from_stage - VADC_AMD_STAGE_LAYER1 + 1;
-      HIP_TRY(hipMemcpyAsync(e->d_act[first_layer - 1], in, in_bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(host_to_device(e, e->d_act[first_layer - 1], in, in_bytes, st), VADC_AMD_EHIP);
    }
    if (to_stage == VADC_AMD_STAGE_NORMALIZED) launch_normalize_tap(e->d_Y, e->d_FM, e->max_items * kFrames, e->d_tap, n, st, e->frames);
    else run_encoder_layers(e, first_layer, to_stage - VADC_AMD_STAGE_LAYER1, n, ItemMap{n, 0, n}, 0, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(out, stage_buffer(e, to_stage), (size_t)n * e->stage_elems[to_stage] * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, out, stage_buffer(e, to_stage), (size_t)n * e->stage_elems[to_stage] * sizeof(float), st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -2634,17 +2714,17 @@ extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const f
    const size_t bytes = (size_t)n * 16 * 25 * sizeof(float);
    if (what == 4) {
       // the conv block (conv.c:761-814) exactly as the product runs it: the chunk's [129][25] through the LDS-DMA pipeline, partial sums of zero (offset 0)
-      HIP_TRY(hipMemcpyAsync(e->d_Y, y, (size_t)n * kBins * kFrames * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+      HIP_TRY(host_to_device(e, e->d_Y, y, (size_t)n * kBins * kFrames * sizeof(float), st), VADC_AMD_EHIP);
       HIP_TRY(hipMemsetAsync(e->d_FM, 0, kBinSplit * e->max_items * kFrames * sizeof(float), st), VADC_AMD_EHIP);
       L1RegsArgs a;
       a.y = e->d_Y; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_tap; a.n_chunks = n; a.map = ItemMap{n, 0, n};
       launch_layer1_regs_tap(what, a, st);
       HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-      HIP_TRY(hipMemcpyAsync(out, e->d_tap, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+      HIP_TRY(device_to_host(e, out, e->d_tap, bytes, st), VADC_AMD_EHIP);
       HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
       return VADC_AMD_OK;
    }
-   HIP_TRY(hipMemcpyAsync(e->d_tap, y, bytes, hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_tap, y, bytes, st), VADC_AMD_EHIP);
    if (e->use_l1_regs()) {
       L1RegsArgs a;
       a.y = e->d_tap; a.fm = nullptr; a.fm_stride = 0; a.img = e->d_l1img; a.out = e->d_Y; a.n_chunks = n; a.map = ItemMap{n, 0, n};
@@ -2652,7 +2732,7 @@ extern "C" int vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const f
    } else
    launch_layer1_tap(what, e->d_tap, e->lwm[0], e->d_Y, n, ItemMap{n, 0, n}, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(out, e->d_Y, bytes, hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, out, e->d_Y, bytes, st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -2666,10 +2746,10 @@ extern "C" int vadc_amd_debug_decoder(vadc_amd_engine *e, const float *x, int n,
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
    { int rc_ = wait_all_prior(e); if (rc_) return rc_; }
    hipStream_t st = e->stream;
-   HIP_TRY(hipMemcpyAsync(e->d_tap, x, (size_t)n * 64 * e->lstm_steps * sizeof(float), hipMemcpyHostToDevice, st), VADC_AMD_EHIP);
+   HIP_TRY(host_to_device(e, e->d_tap, x, (size_t)n * 64 * e->lstm_steps * sizeof(float), st), VADC_AMD_EHIP);
    launch_lstm_decoder_tap(e->d_tap, e->lstm, e->d_probs, n, st, e->model, e->lstm_steps);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, probs, e->d_probs, (size_t)n * 2 * sizeof(float), st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
@@ -2701,7 +2781,7 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
                      tiles[i] = hi;
                      tiles[i + kLstmTile * 64] = (_Float16)(v - (float)hi);
                   }
-         HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(_Float16), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+         HIP_TRY(upload(e->d_act[3], tiles.data(), tiles.size() * sizeof(_Float16)), VADC_AMD_EHIP);
       } else {
          std::vector<float> tiles(padded * n_chunks * 64 * TS, 0.0f);
          for (int s = 0; s < n_streams; ++s)
@@ -2709,12 +2789,12 @@ extern "C" int vadc_amd_debug_lstm_decoder(vadc_amd_engine *e, const float *x, i
                for (int u = 0; u < 64; ++u)
                   for (int t = 0; t < TS; ++t)
                      tiles[lstm_x_index(s, c, n_chunks, t, u, TS)] = x[(((size_t)s * n_chunks + c) * 64 + u) * TS + t];
-         HIP_TRY(hipMemcpy(e->d_act[3], tiles.data(), tiles.size() * sizeof(float), hipMemcpyHostToDevice), VADC_AMD_EHIP);
+         HIP_TRY(upload(e->d_act[3], tiles.data(), tiles.size() * sizeof(float)), VADC_AMD_EHIP);
       }
    }
    launch_lstm_on(e, lk, e->d_probs, n_streams, n_chunks, 0, n_chunks, st);
    HIP_TRY(hipGetLastError(), VADC_AMD_EHIP);
-   HIP_TRY(hipMemcpyAsync(probs, e->d_probs, n * 2 * sizeof(float), hipMemcpyDeviceToHost, st), VADC_AMD_EHIP);
+   HIP_TRY(device_to_host(e, probs, e->d_probs, n * 2 * sizeof(float), st), VADC_AMD_EHIP);
    HIP_TRY(hipStreamSynchronize(st), VADC_AMD_EHIP);
    return VADC_AMD_OK;
 }
