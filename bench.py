@@ -942,8 +942,12 @@ def main():
     rc = run_rank(args, world, rank, local_rank)
     # A process that has used the GPU leaves WITHOUT the HIP runtime's exit handlers: beside another process's GPU context (the other ranks of this job) they hung one
     # short-lived process in about two hundred on ROCm 7.2 -- after main() had returned, every engine destroyed (tools/cli_teardown_probe.py).  Everything is flushed first.
-    sys.stdout.flush(); sys.stderr.flush()
-    os._exit(int(rc or 0))
+    # (Not under a profiler -- rocprofv3 writes its files from exit handlers -- and not when the process is alone on its GPU.)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if world > 1 and not profiled:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(int(rc or 0))
+    return rc
 
 
 if __name__ == "__main__":

@@ -1788,6 +1788,7 @@ def test_layer1_selfcheck_and_its_fallback(weights_blob, orc, tmp_path):
         "blob = open(%r, 'rb').read(); pcm = synth.make_streams(3, 5, seed0=333)\n"
         "e = Engine(blob, max_streams=3, max_chunks_per_call=5, device=0)\n"
         "print(e.get_option('layer1_selfcheck'), e.get_option('layer1_kernel')); np.save(%r, e.run(pcm)); e.close()\n"
+        "import os; sys.stdout.flush(); sys.stderr.flush(); os._exit(0)\n"      # (a short-lived GPU process beside this one's context: not through the runtime's exit handlers)
     ) % (ROOT, os.path.join(ROOT, "tests", "golden", "reference_fixtures", "silero_v31_16k.testtensor"), str(tmp_path / "p.npy"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VADC_AMD_FORCE_L1_SELFCHECK_FAIL="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
