@@ -89,11 +89,9 @@ def test_round4_fields_of_the_line():
 
 
 def test_round5_fields_of_the_line():
-    """round 5: BASELINE config 4 (Silero v4, 4096 streams x 16 chunks) is timed by the same run -- last, an engine created in front of the 10,240 x 1 configuration
-    cost that one 40 % -- with the front-end kernel that ran named (the engine has two GEMM forms); host_fed is a sustained rate; and every BASELINE
-    configuration has its kernel trace, PMC traffic and PMC compute summaries committed beside the line"""
+    """round 5: BASELINE config 4 (Silero v4, 4096 streams x 16 chunks) is timed by the same run with the front-end kernel that ran named (the engine has two GEMM
+    forms); host_fed is a sustained rate; and every BASELINE configuration has its kernel trace, PMC traffic and PMC compute summaries committed beside the line"""
     d = _latest_default()
-    assert list(d["configs"])[-1] == "v4_4096x16"
     c = d["configs"]["v4_4096x16"]
     want = 4096 * 16 * 0.096 / (c["ms_per_step"] * 1e-3)
     assert abs(c["value"] - want) / want < 1e-3 and c["hipgraph"] is True
@@ -107,13 +105,52 @@ def test_round5_fields_of_the_line():
     assert v4["frontend_kernel"] == "k_frontend_gemm2" and "k_frontend_gemm2" in open(os.path.join(os.path.dirname(latest), "bench_v4_4096x16_kernel_stats.csv")).read()
 
 
+def test_round6_fields_of_the_line():
+    """round 6: the Silero v5 shapes ride in the default line (256 x 288: the shape round 2 measured at 1.23 M; 4096 x 48), with their kernel trace and PMC summary
+    committed; the one-GPU line carries the per-GPU fields of the N-rank schema with N = 1"""
+    d = _latest_default()
+    assert list(d["configs"])[-2:] == ["v5_256x288", "v5_4096x48"]
+    for key, S, Cn in (("v5_256x288", 256, 288), ("v5_4096x48", 4096, 48)):
+        c = d["configs"][key]
+        want = S * Cn * 0.032 / (c["ms_per_step"] * 1e-3)                          # a v5 window is 512 samples = 32 ms
+        assert abs(c["value"] - want) / want < 1e-3, key
+    assert d["configs"]["v5_256x288"]["value"] >= 3.0e6                            # the review's bar for the split-fp16 encoder
+    assert d["n_gpus"] == 1 and d["total_streams"] == d["config"]["streams_per_gpu"] and abs(d["value_per_gpu"] - d["value"]) < 1.0
+    assert d["rccl"]["world_size"] == 1 and "per GPU" in d["metric"]
+    latest = os.path.dirname(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")))[-1])
+    for name in ("v5_256x288_kernel_stats.csv", "v5_256x288_pmc.json"):
+        assert os.path.exists(os.path.join(latest, name)), name
+    txt = open(os.path.join(latest, "v5_256x288_kernel_stats.csv")).read()
+    for k in ("k_v5_encoder_h3", "k_v5_wih", "k_v5_lstm_h3"):
+        assert k in txt, k
+
+
+def test_n_rank_line_as_committed():
+    """what `python bench.py --gpus 8` prints, pinned on committed lines: the dry run at world 8 (CPU, gloo, stand-in engine) and the one-GPU rehearsal at world 6 (the real
+    rank code, six ranks sharing GPU 0, gloo through the host) -- job total under a truthful label, the per-GPU figure, what the process group reports, 4 B per chunk on the
+    wire, and BASELINE config 5's shape timed under the same ranks"""
+    from test_bench_spawn import _assert_n_rank_schema
+    latest = os.path.dirname(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")))[-1])
+    d = json.load(open(os.path.join(latest, "bench_dry_run_world8.json")))
+    assert d["dry_run"] is True
+    _assert_n_rank_schema(d, 8, 256, 96, 4096, 16, "gloo")
+    assert d["configs"]["8x4096x16"]["total_streams"] == 32768                     # BASELINE config 5: 32,768 streams sharded 4096 per GPU
+    r = json.load(open(os.path.join(latest, "bench_rehearsal_world6.json")))
+    S, Cn = r["config"]["streams_per_gpu"], r["config"]["chunks_per_step"]
+    c5 = [k for k in r["configs"] if k.startswith("6x")][0]
+    _, s5, c5n = c5.split("x")
+    _assert_n_rank_schema(r, 6, S, Cn, int(s5), int(c5n), "gloo")
+    assert "rehearsal" in r["configs"][c5]["rccl"]["note"]
+
+
 def test_kernel_stats_list_every_kernel_of_the_step():
-    """the tracked rocprofv3 summary carries all five kernels of the step, the two k_lstm_layer launches (whose names rocprofv3 leaves mangled) included"""
+    """the tracked rocprofv3 summary carries every kernel of the step, the three k_lstm_layer launches (whose names rocprofv3 leaves mangled) included: layer 0, layer 1 and,
+    since round 6, the REDO form behind the pair (a few microseconds: every workgroup leaves at once unless a tile's layer 1 gave up)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_256x96_kernel_stats.csv")))
     txt = open(files[-1]).read()
     for name in ("k_frontend_sym", "k_layer1_regs", "k_enc_fused", "k_lstm_layer"):
         assert name in txt, name
-    assert txt.count("k_lstm_layer") == 2
+    assert txt.count("k_lstm_layer") == 3
 
 
 @pytest.mark.parametrize("name", ["bench_256x96_kernel_stats.csv", "bench_256x96_pmc_traffic.json"])

@@ -4,14 +4,17 @@
 # rocprofv3 rules on this pool: program directly after `--`, PMC passes separate from tracing, one counter group per pass.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
-rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/pmcA $O/pmcB $O/pmcC $O/pmcD
+rm -rf $O/pmcA $O/pmcB $O/pmcC $O/pmcD
 NB="--no-cpu-baseline --no-host-fed --no-side-config"
+B="python3 bench.py --steps 3 --warmup 1 $NB"
+if [ -z "$SKIP_HEADLINE" ]; then       # (SKIP_HEADLINE=1: tools/refresh_headline.sh has taken the headline's trace and traffic passes on the box its line came from)
+rm -rf $O/prof_kt $O/prof_fetch $O/prof_write
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 bench.py $NB > $O/prof_kt.log 2>&1
 echo "kernel trace done"
-B="python3 bench.py --steps 3 --warmup 1 $NB"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- $B > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- $B > $O/prof_write.log 2>&1
 echo "traffic passes done"
+fi
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmcB -- $B > $O/pmcB.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmcC -- $B > $O/pmcC.log 2>&1

@@ -24,7 +24,9 @@ def short_name(full):
         return "k_layer1"
     m = re.search(r"k_lstm_layer<\d+, \d+, (\d)[,>]", full) or re.search(r"k_lstm_layerILi\d+ELi\d+ELi(\d)E", full)     # rocprofv3 leaves some names mangled
     if m:
-        return "k_lstm" if m.group(1) == "0" else "k_lstm_l1"
+        # <TS, DEC, L, TAPDEC, TRAIL, REDO>: the REDO form (round 6: behind every pair, leaves at once unless a tile's layer 1 gave up) is a launch of its own
+        redo = re.search(r"k_lstm_layer<\d+, \d+, \d, (?:true|false), (?:true|false), true>", full) or re.search(r"k_lstm_layerILi\d+ELi\d+ELi\dELb[01]ELb[01]ELb1E", full)
+        return "k_lstm_redo" if redo else ("k_lstm" if m.group(1) == "0" else "k_lstm_l1")
     m = re.search(r"k_layer_mfma<(\d+), (\d+), (\d+)", full) or re.search(r"k_layer<(\d+), (\d+), (\d+)", full)
     if m:
         return {("129", "16"): "k_layer1", ("258", "16"): "k_layer1", ("16", "32"): "k_layer2", ("32", "32"): "k_layer3", ("32", "64"): "k_layer4"}[(m.group(1), m.group(2))]

@@ -1547,17 +1547,17 @@ static int layer1_selfcheck(vadc_amd_engine *e)
    if (!(e->use_l1_regs() || e->use_l1_regs_v4())) return VADC_AMD_OK;
    const int n = (int)std::min<size_t>(3, e->max_items), T = e->frames;
    const size_t fms = e->max_items * (size_t)kFrames;
-   std::vector<float> y((size_t)n * kBins * T), fm(kBinSplit * fms, 0.0f);
+   std::vector<float> y((size_t)n * kBins * T), fm((size_t)kBinSplit * n * T, 0.0f);      // (the partial sums of the probe chunks alone: the device array is [kBinSplit][fms])
    for (int c = 0; c < n; ++c)
       for (int b = 0; b < kBins; ++b)
          for (int t = 0; t < T; ++t) {
             const float v = 5.0f + 4.0f * sinf(0.37f * b + 0.61f * t + 1.3f * c) + (b % 7 == 0 ? 3.0f : 0.0f);      // log-magnitude-like values in 0 .. 13
             y[((size_t)c * kBins + b) * T + t] = v;
-            fm[(size_t)(b / kBinsPerSplit) * fms + (size_t)c * T + t] += v;
+            fm[(size_t)(b / kBinsPerSplit) * n * T + (size_t)c * T + t] += v;
          }
    hipStream_t st = e->stream;
    HIP_TRY(host_to_device(e, e->d_Y, y.data(), y.size() * sizeof(float), st), VADC_AMD_EHIP);
-   HIP_TRY(host_to_device(e, e->d_FM, fm.data(), fm.size() * sizeof(float), st), VADC_AMD_EHIP);
+   for (int sp = 0; sp < kBinSplit; ++sp) HIP_TRY(host_to_device(e, e->d_FM + (size_t)sp * fms, fm.data() + (size_t)sp * n * T, (size_t)n * T * sizeof(float), st), VADC_AMD_EHIP);
    const size_t elems = (size_t)n * e->stage_elems[VADC_AMD_STAGE_LAYER1];
    std::vector<float> a(elems), b(elems);
    for (int form = 0; form < 2; ++form) {
