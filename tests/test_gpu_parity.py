@@ -1413,7 +1413,7 @@ def test_cli_raw_probabilities_contract(gold_c, gold_py):
 
 
 def test_cli_short_lived_processes_exit(gold_py):
-    """create -> one forked call -> destroy, 25 processes in a row, each within seconds: tearing the engine down right behind its CU-masked streams'
+    """create -> one forked call -> destroy, 16 processes in a row, each within seconds: tearing the engine down right behind its CU-masked streams'
     last work once hung one process in ten (an explicit hipStreamSynchronize on those idle streams in vadc_amd_destroy; bisected)"""
     import subprocess
     from conftest import ROOT, WEIGHTS
@@ -1421,7 +1421,7 @@ def test_cli_short_lived_processes_exit(gold_py):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
     pcm = gold_py["pcm_speech0"].tobytes()
-    for _ in range(25):
+    for _ in range(16):
         r = run_cli([exe, "--model", WEIGHTS], pcm, timeout=30)            # (a child that does not come back: its teardown marks say where it stands)
         assert r.returncode == 0 and r.stdout == b"0.07,3.10\n", r.stderr.decode()
 
@@ -1652,6 +1652,40 @@ def test_synchronous_entry_points_join_under_defer_join(weights_blob, orc):
         e.close()
     ref = orc.forward_streams(pcm)
     assert float(np.abs(got - ref).max()) < PROB_TOL
+
+
+def test_host_copies_across_the_staging_pieces(weights_blob):
+    """the synchronous entry points and the stage taps move the caller's pageable buffers through two page-locked 4-MB pieces of the engine's own (engine.hip
+    host_to_device / device_to_host) and hand a copy of more than 32 MB to the runtime: inputs of less than a piece, of a piece and a bit, of several pieces and of
+    more than 32 MB give the bits of the device-resident path on the same samples, and a stage tap's output of three pieces is what the same tap returns piece-sized"""
+    import torch
+    for S, Cn, dtype in ((1, 7, np.int16), (64, 11, np.float32), (128, 11, np.float32), (200, 23, np.int16), (128, 90, np.int16)):      # 21 KB, 4.3 MB, 8.7 MB, 14.1 MB, 35.4 MB
+        pcm = synth.make_streams(min(S, 16), Cn, seed0=4000 + S)
+        pcm = np.ascontiguousarray(np.tile(pcm, (S // pcm.shape[0] + 1, 1))[:S])
+        x = pcm if dtype == np.int16 else (pcm.astype(np.float32) / np.float32(32768))
+        e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+        try:
+            got = e.run(x)
+            e.reset_streams()
+            st = torch.cuda.Stream()
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0")
+            e.run_device(d_in.data_ptr(), dtype, S, Cn, d_out.data_ptr(), st.cuda_stream)
+            e.join(st.cuda_stream); st.synchronize()
+            assert np.array_equal(bits(got), bits(d_out.cpu().numpy())), (S, Cn, dtype)
+            e.reset_streams()
+            assert np.array_equal(bits(e.run(x)), bits(got))                                  # and again: the pieces are reused
+        finally:
+            e.close()
+    n = 700                                                                                  # a magnitude tap of 700 chunks: 9.0 MB out (three pieces), 4.3 MB in (two)
+    x = (synth.make_streams(1, n, seed0=4100)[0].astype(np.float32) / np.float32(32768)).reshape(n, 1536)
+    e = Engine(weights_blob, max_streams=7, max_chunks_per_call=100, device=0)
+    try:
+        whole = e.stage_from_samples(x, "magnitude")
+        parts = np.concatenate([e.stage_from_samples(x[i:i + 100], "magnitude") for i in range(0, n, 100)])
+        assert whole.shape == (n, 129, 25) and np.array_equal(bits(whole), bits(parts))
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("dtype", [np.int16, np.float32])
