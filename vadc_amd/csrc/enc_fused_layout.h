@@ -1,4 +1,4 @@
-// enc_fused_layout.h -- LDS images of k_enc_fused (kernels_encoder_fused.hip): where the host packer (engine.hip) puts every weight
+// enc_fused_layout.h -- LDS images of k_enc_fused (kernels_encoder_fused.hip): where the host packer (engine_weights.hip) puts every weight
 // fragment and vector of encoder layers 2-4, and where the kernel finds them.  Two images, copied verbatim into LDS:
 //   image A = layers 2 and 3 (phase A of the kernel), image B = layer 4 (phase B).
 //

@@ -6,7 +6,7 @@
 namespace vadc {
 
 // basis: the reference's STFT filter bank [258][256] (rows 0..128 re, 129..257 im; silero_vad.py:22-66, stft.c:15-224), already verified to have the real-DFT
-// symmetries (build_gemm_frontend in engine.hip).  Slot j = tap j + 1 (j = 0 .. 127): slots 0 .. 126 pair taps (j + 1, 255 - j), slot 127 pairs the centre tap
+// symmetries (build_gemm_frontend in engine_weights.hip).  Slot j = tap j + 1 (j = 0 .. 127): slots 0 .. 126 pair taps (j + 1, 255 - j), slot 127 pairs the centre tap
 // with itself -- its re weight is halved, its im weight is zero.
 //   af2: [tile 0..7][kb 0..7][lane 0..63][8] = 256 x A[row][slot 16 kb + 8 (lane >> 5) + e];  tile t < 4: row = re of bin 32 t + (lane & 31);
 //        tile t >= 4: row = im of bin 32 (t - 4) + ((lane & 31) + 16) % 32   (im rows rotated by 16: see the kernel's accumulator exchange)

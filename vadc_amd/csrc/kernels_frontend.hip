@@ -430,7 +430,7 @@ __device__ __forceinline__ void fl_accumulate(FlState<NB> &st, int fi, f2v g)
 }
 
 // byte offset of the 16 taps of (bin b of the batch, group i, l-pair lp) from the batch's first filter; basis layout
-// [f][ii = 3 - i][lp][j][l % 2] (engine.hip), re and im rows of a bin are kBins rows apart
+// [f][ii = 3 - i][lp][j][l % 2] (engine_weights.hip), re and im rows of a bin are kBins rows apart
 constexpr int fl_tap_off(int b, int i, int lp) { return b * 1024 + (3 - i) * 256 + lp * 64; }
 
 // Stage K of a batch = (step S = K / NB = 4 LP + I, bin B = K % NB).  On entry ca/cb hold the taps of this stage (waited
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256 * NPS, MINW) void k_frontend_fl(const T *__rest
 // k_frontend_sym -- the bit-exact tree evaluated for 33 of the 129 bins; the other 96 follow from the basis' symmetries
 // =====================================================================================================
 // The reference's basis (row k < 129: w[n] cos(2 pi k n / 256), row 129 + k: -w[n] sin(2 pi k n / 256), w = periodic Hann) satisfies,
-// BIT FOR BIT (the engine verifies it on the loaded tensor at create time, engine.hip basis_has_dft_symmetries; otherwise
+// BIT FOR BIT (the engine verifies it on the loaded tensor at create time, engine_weights.hip basis_has_dft_symmetries; otherwise
 // k_frontend_fl runs):
 //     re[128-b][n] = (-1)^n re[b][n]                      im[128-b][n] = -(-1)^n im[b][n]
 //     re[64-b][n]  = {re, -im, -re, im}[b][n]  by n % 4   im[64-b][n]  = {-im, -re, im, re}[b][n]  by n % 4

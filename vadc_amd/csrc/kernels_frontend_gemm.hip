@@ -15,7 +15,7 @@
 //
 // REAL-INPUT FOLDING.  The basis rows are a windowed DFT: re rows are even about tap 128, im rows odd, tap 0 is zero (periodic
 // Hann), and the im rows of bins 0 and 128 vanish.  vadc_amd_create VERIFIES these identities bit for bit on the loaded basis
-// (engine.hip) and otherwise keeps the tree kernel.  With them
+// (engine_weights.hip) and otherwise keeps the tree kernel.  With them
 //     re_k = sum_{n=0..127} Are[k][n] xs[n],   xs[n] = x[n] + x[256-n] (n >= 1),  xs[0] = x[128],  Are[k][0] = basis[k][128]
 //     im_k = sum_{n=1..127} Aim[k][n] xd[n],   xd[n] = x[n] - x[256-n],           xd[0] = 0
 // i.e. two K = 128 contractions instead of one K = 256: half the MACs of the dense conv.

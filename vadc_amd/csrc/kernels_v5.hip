@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_v5_encoder(const T *__restrict__ pcm
 __device__ __forceinline__ float v5_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float v5_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
-// GATE ROW ORDER of GX, the bias and both W matrices: row 16 (u / 4) + 4 (u % 4) + g for gate g (i, f, g, o) of unit u (permuted once, on the host: engine.hip
+// GATE ROW ORDER of GX, the bias and both W matrices: row 16 (u / 4) + 4 (u % 4) + g for gate g (i, f, g, o) of unit u (permuted once, on the host: engine_weights.hip
 // build_weights_v5) -- an MFMA row tile = four units x four gates, the four gates of a unit = the four accumulator registers of one lane.  Wave w owns row tiles
 // 4 w .. 4 w + 3 = units 16 w .. 16 w + 15; lane (column = stream, quad q) of tile mi holds unit 16 w + 4 mi + q.
 __global__ __launch_bounds__(512, 1) void k_v5_lstm(const float *__restrict__ gx,          // [S * C][512]
