@@ -143,6 +143,50 @@ def test_multi_rank_answers_are_the_oracles(world, total, tmp_path):
             assert float(np.abs(probs[:, s] - want).max()) <= 1e-4, (r, s)
 
 
+_RCCL_ONE_RANK = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+import bench
+from vadc_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+S, Cn = 48, 5
+probs = torch.arange(S * Cn * 2, dtype=torch.float32, device="cuda:0").view(S, Cn, 2)
+side = torch.cuda.Stream()
+buf = [torch.empty((S, Cn), dtype=torch.float32, device="cuda:0")]
+with torch.cuda.stream(side):                                            # the call ProbabilityGather.gather makes for world > 1, on a side stream as bench.py issues it
+    send = probs[:, :, 1].contiguous()
+    dist.gather(send, buf, dst=0)
+side.synchronize()
+ok_gather = bool(torch.equal(buf[0], probs[:, :, 1]))
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")          # the max-over-ranks of the timed region
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+g = shard.ProbabilityGather(S, Cn, "cuda:0")
+facts = bench.collective_facts(torch, dist, 2, False, g)                 # (world = 2: the branch that asks the process group)
+print(json.dumps({"gather": ok_gather, "max": float(t.item()), "facts": facts, "backend": dist.get_backend()}))
+sys.stdout.flush()
+dist.destroy_process_group()
+os._exit(0)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_primitives_with_one_rank():
+    """what the N > 1 path asks of RCCL, on the real library with the one rank a one-GPU box can form: dist.gather into a list on the destination rank from a side
+    stream (ProcessGroupNCCL's gather), all_reduce(MAX) of a float64 device scalar, barrier, and what collective_facts reads off the process group (backend "nccl",
+    world size, ncclGetVersion) -- so that the first 8-GPU run does not start by finding one of them unsupported.  The wire (xGMI, several ranks) stays unexercised."""
+    from test_multi_rank_gloo import _free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK % {"root": ROOT, "port": _free_port()}], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["gather"] is True and d["max"] == 1.25 and d["backend"] == "nccl"
+    assert d["facts"]["backend"] == "nccl" and d["facts"]["world_size"] == 1 and d["facts"]["bytes_per_chunk"] == 4 and "nccl_version" in d["facts"]
+
+
 @pytest.mark.gpu
 def test_rccl_gather_between_two_gpus():
     """the real collective: two ranks on two GPUs, backend nccl (= RCCL), the path's ProbabilityGather.  Needs two visible GPUs -- a one-GPU box skips."""
