@@ -140,7 +140,9 @@ int  vadc_amd_get_caps_sized(const vadc_amd_engine *e, void *caps, size_t caps_s
  * process_chunks hands them over (vadc.c:74-75); probs: [n_streams][n_chunks][2].
  * Limits of a call (else VADC_AMD_EINVAL): n_streams <= max_streams; n_streams * n_chunks <= max_streams * max_chunks_per_call; and, because the encoder ->
  * LSTM hand-off is stored in tiles of 16 streams, ceil(n_streams / 16) * n_chunks <= ceil(max_streams / 16) * max_chunks_per_call (so ONE stream may bring
- * up to ceil(max_streams / 16) * max_chunks_per_call chunks, not max_streams * max_chunks_per_call). */
+ * up to ceil(max_streams / 16) * max_chunks_per_call chunks, not max_streams * max_chunks_per_call).
+ * The buffers may be ordinary pageable memory: up to 32 MB per copy they travel through page-locked pieces the engine owns (no page-locking system call per call),
+ * a larger one is locked in place by the runtime for the transfer.  Both are free for reuse when the call returns. */
 int  vadc_amd_run_f32(vadc_amd_engine *e, const float *samples, int n_streams, int n_chunks, float *probs);
 /* Same from s16le PCM; the /32768.0f of vadc.c:883,898 happens on the device (exact in fp32). */
 int  vadc_amd_run_s16(vadc_amd_engine *e, const int16_t *pcm, int n_streams, int n_chunks, float *probs);
