@@ -14,11 +14,14 @@ scale = 1.0
 def soak(S, Cn, calls, reps, opts=None, model="v31"):
     blob = open(BLOBS[model], "rb").read()
     e = Engine(blob, max_streams=S, max_chunks_per_call=Cn, device=0)
+    if opts and "window" in opts:                                   # (Silero v4 at another window: before the inputs are cut)
+        e.set_window(opts["window"])
     W = e.window                                                   # samples per chunk (1536; Silero v5: 512)
     base = synth.make_streams(min(S, 48), -(-calls * Cn * W // 1536), seed0=4000 + S)
     pcm = np.ascontiguousarray(base[np.arange(S) % base.shape[0]])
     d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * W:(k + 1) * Cn * W])).cuda() for k in range(calls)]
-    for k_, v_ in (opts or {}).items(): e.set_option(k_, v_)
+    for k_, v_ in (opts or {}).items():
+        if k_ != "window": e.set_option(k_, v_)
     e.set_option("defer_join", 1)
     st = torch.cuda.Stream()
     first, bad, worst = None, 0, 0.0
@@ -40,7 +43,9 @@ def soak(S, Cn, calls, reps, opts=None, model="v31"):
     return rec
 SHAPES = [(10240, 1, 8, 600), (16384, 1, 4, 200), (4096, 1, 8, 300), (256, 96, 3, 120), (256, 8, 8, 300), (100, 24, 4, 300), (640, 8, 6, 200), (1024, 4, 8, 200), (4096, 16, 2, 60), (256, 96, 3, 60, {"lstm_trail": 0}), (10240, 1, 8, 200, {"lstm": 6}),
           (256, 96, 3, 60, None, "v4"), (4096, 16, 2, 40, None, "v4"), (10240, 1, 6, 150, None, "v4"), (768, 32, 3, 60, None, "v4"),
-          (256, 96, 3, 60, None, "v5"), (4096, 16, 2, 40, None, "v5"), (64, 192, 2, 60, None, "v5")]
+          (256, 96, 3, 60, None, "v5"), (4096, 16, 2, 40, None, "v5"), (64, 192, 2, 60, None, "v5"),
+          (256, 288, 2, 60, None, "v5"), (4096, 48, 2, 30, None, "v5"),                                                    # round 6: the bench shapes of the split-fp16 v5 kernels
+          (256, 96, 3, 60, {"window": 960}, "v4"), (4096, 16, 2, 40, {"window": 1472}, "v4"), (768, 32, 3, 60, {"window": 576}, "v4")]      # round 6: windows between the built geometries
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     for a in SHAPES:
