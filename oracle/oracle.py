@@ -101,6 +101,17 @@ def _c(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _over_streams(fn, n_streams):
+    """[fn(0), fn(1), ...] -- on the host's cores when there are several streams: they are independent and the C library keeps no state between calls (a model is
+    read-only), the foreign call releases the GIL.  At most 16 threads: a one-GPU box's CPU share."""
+    workers = min(n_streams, 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    if workers <= 1:
+        return [fn(s) for s in range(n_streams)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, range(n_streams)))
+
+
 class Oracle:
     """Whole-path oracle for one weights blob."""
 
@@ -156,8 +167,10 @@ class Oracle:
             h = np.zeros((S, 2, 64), np.float32)
             c = np.zeros((S, 2, 64), np.float32)
         out = np.zeros((S, n), np.float32)
-        for s in range(S):
+
+        def one(s):
             out[s] = self.forward_stream(pcm[s], h[s], c[s])[:, 1]
+        _over_streams(one, S)
         return out
 
 
@@ -208,7 +221,7 @@ class OracleV4:
 
     def forward_streams(self, pcm, window=1536):
         pcm = np.ascontiguousarray(pcm)
-        return np.stack([self.forward_stream(pcm[s], window=window) for s in range(pcm.shape[0])])
+        return np.stack(_over_streams(lambda s: self.forward_stream(pcm[s], window=window), pcm.shape[0]))
 
 
 class OracleV5:
@@ -242,7 +255,7 @@ class OracleV5:
 
     def forward_streams(self, pcm):
         pcm = np.ascontiguousarray(pcm)
-        return np.stack([self.forward_stream(pcm[s]) for s in range(pcm.shape[0])])
+        return np.stack(_over_streams(lambda s: self.forward_stream(pcm[s]), pcm.shape[0]))
 
 
 def segments(probs, threshold=0.5, neg_threshold_relative=0.15, min_silence_ms=200.0, min_speech_ms=250.0,

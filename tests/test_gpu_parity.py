@@ -1341,10 +1341,10 @@ def test_soak_long_run_of_calls_vs_oracle(weights_blob, orc):
         got = np.concatenate([e.run(pcm[:, (k % 4) * Cn * 1536:((k % 4) + 1) * Cn * 1536])[pick] for k in range(calls)], axis=1)
     finally:
         e.close()
+    seqs = np.stack([np.concatenate([pcm[s_, (k % 4) * Cn * 1536:((k % 4) + 1) * Cn * 1536] for k in range(calls)]) for s_ in pick])
+    want = orc.forward_streams(seqs)                                             # (the three streams side by side on the host's cores)
     for j, s_ in enumerate(pick):
-        seq = np.concatenate([pcm[s_, (k % 4) * Cn * 1536:((k % 4) + 1) * Cn * 1536] for k in range(calls)])
-        want = orc.forward_stream(seq)
-        assert float(np.abs(got[j] - want).max()) <= PROB_TOL, (s_, float(np.abs(got[j] - want).max()))
+        assert float(np.abs(got[j][:, 1] - want[j]).max()) <= PROB_TOL, (s_, float(np.abs(got[j][:, 1] - want[j]).max()))
 
 
 @pytest.mark.parametrize("S", [10240, 16384])
