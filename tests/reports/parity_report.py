@@ -52,7 +52,31 @@ def main():
         blob4 = open(v4, "rb").read()
         e4 = Engine(blob4, max_streams=16, max_chunks_per_call=100, device=0)
         rep["silero_v4"] = compare(e4, O.OracleV4(blob4), synth.make_streams(16, 400, seed0=52000), 100)
+        # ... and at a window between two built geometries (round 6: 960 samples run the 1024-sample geometry with its surplus frame masked)
+        e4.set_window(960)
+        pcm4 = synth.make_streams(16, 400, seed0=52000)[:, : 640 * 960]
+        e4.reset_streams()
+        got = np.concatenate([e4.run(pcm4[:, i * 960:(i + 80) * 960]) for i in range(0, 640, 80)], axis=1)[:, :, 1]
+        want = O.OracleV4(blob4).forward_streams(pcm4, window=960)                      # [streams, chunks]: the speech probability
+        d = np.abs(got.astype(np.float64) - want).ravel()
+        rep["silero_v4_window_960"] = {"streams": 16, "chunks_per_stream": 640, "max_abs_dp": float(d.max()), "p999_abs_dp": float(np.quantile(d, 0.999)), "mean_abs_dp": float(d.mean()), "tolerance": 1e-4,
+                                       "note": "against the fp32 ORACLE, whose own distance from the float64 reference reaches 1.5e-4 on stream 2 (tests/test_oracle_v4.py); the yardstick is the line below"}
+        g64 = np.load(os.path.join(ROOT, "tests", "golden", "python_reference_v4_long_windows.npz"))      # the reference's PyTorch class in float64 on streams 2 and 12 of this sweep
+        rep["silero_v4_window_960"]["max_abs_dp_vs_float64_reference"] = {f"stream_{s_}": float(np.abs(got[s_] - g64[f"probs64_w960_s{s_}"]).max()) for s_ in (2, 12)}
+        rep["silero_v4_window_960"]["oracle_vs_float64_reference"] = {f"stream_{s_}": float(np.abs(want[s_] - g64[f"probs64_w960_s{s_}"]).max()) for s_ in (2, 12)}
         e4.close()
+    # Silero v5 shapes (seeded weights: the reference ships none) with the split-fp16 kernels of round 6, against the oracle's restatement of Silero_Vad_5
+    v5 = os.path.join(ROOT, "tests", "golden", "silero_v5_seeded.testtensor")
+    if os.path.exists(v5):
+        blob5 = open(v5, "rb").read()
+        e5 = Engine(blob5, max_streams=16, max_chunks_per_call=300, device=0)
+        pcm5 = synth.make_streams(16, 400, seed0=53000)                                 # 1,200 windows of 512 samples per stream
+        got = np.concatenate([e5.run(pcm5[:, i * 512:(i + 300) * 512]) for i in range(0, 1200, 300)], axis=1)[:, :, 1]
+        want = np.asarray(O.OracleV5(blob5).forward_streams(pcm5)).reshape(16, -1)
+        d = np.abs(got.astype(np.float64) - want).ravel()
+        rep["silero_v5_shapes"] = {"streams": 16, "chunks_per_stream": 1200, "max_abs_dp": float(d.max()), "p999_abs_dp": float(np.quantile(d, 0.999)), "mean_abs_dp": float(d.mean()),
+                                   "prob_range": [float(want.min()), float(want.max())], "tolerance": 1e-4}
+        e5.close()
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(rep, open(out_path, "w"), indent=1)
     print(json.dumps(rep))
