@@ -5,10 +5,11 @@ import numpy as np
 from oracle import oracle as O
 from vadc_amd import synth
 from vadc_amd.engine import Engine
-blob4 = open("tests/golden/silero_v4_16k.testtensor", "rb").read()
+EIGHT = len(sys.argv) > 1 and sys.argv[1] == "8k"                     # python tools/v4_windows_parity.py 8k [windows ...]: the graph's 8 kHz branch (256 ... 768)
+blob4 = open("tests/golden/silero_v4_8k.testtensor" if EIGHT else "tests/golden/silero_v4_16k.testtensor", "rb").read()
 orc = O.OracleV4(blob4)
 base = synth.make_streams(16, 400, seed0=52000)
-WINDOWS = [int(a) for a in sys.argv[1:]] or list(range(512, 1537, 64))
+WINDOWS = [int(a) for a in sys.argv[(2 if EIGHT else 1):]] or (list(range(256, 769, 64)) if EIGHT else list(range(512, 1537, 64)))
 for w, opts in [(w_, {}) for w_ in WINDOWS]:
     e = Engine(blob4, max_streams=16, max_chunks_per_call=80, device=0)
     e.set_window(w)
