@@ -19,7 +19,8 @@ for w, opts in [(w_, {}) for w_ in WINDOWS]:
     n = pcm.shape[1] // w
     n -= n % 80
     pcm = np.ascontiguousarray(pcm[:, : n * w])
-    got = np.concatenate([e.run(pcm[:, i * w:(i + 80) * w]) for i in range(0, n, 80)], axis=1)[:, :, 1]
+    x = (pcm.astype(np.float32) / np.float32(32768)) if os.environ.get("F32") else pcm      # F32=1: the f32 entry point (k_frontend_gemm's first form)
+    got = np.concatenate([e.run(x[:, i * w:(i + 80) * w]) for i in range(0, n, 80)], axis=1)[:, :, 1]
     want = orc.forward_streams(pcm, window=w)
     d = np.abs(got.astype(np.float64) - want)
     i = np.unravel_index(d.argmax(), d.shape)
