@@ -100,11 +100,15 @@ static_assert(EncV4L2::f_end == 4 * kFragBytes && EncV4L3::f_end == 4 * kFragByt
 static_assert(kEncV4Bytes % 16 == 0, "the image is copied in 16-byte pieces");
 
 struct EncV4Args {
-   const float *in;          // first stage's output [n][16][12]
+   const float *in;          // first stage's output [n][16][t1_pitch]
    const void *img;          // device copy of the LDS image
-   void *out;                // split-fp16 LSTM-native tiles, 3 steps per chunk (common.h lstm_xh_index)
+   void *out;                // split-fp16 LSTM-native tiles, ts steps per chunk (common.h lstm_xh_index)
    int n_chunks;
    ItemMap map;
+   // the window's geometry (round 6: every window, both branches): steps per chunk of `in` as the first stage laid it out (<= 12: the built geometry's), of which the first t1 are
+   // VALID (a window between two built ones: the rest enter as the zeros the depthwise conv's padding is), the third strided conv's stride (2; the 8 kHz branch: 1), and the
+   // LSTM steps per chunk = the steps that leave stage 4: t1 -> t2 = (t1 + 1) / 2 -> ts = s3 == 2 ? (t2 + 1) / 2 : t2
+   int t1_pitch, t1, s3, ts;
 };
 
 // ---- layer 1 (k_layer1_regs, kernels_layer1_regs.hip): ONE image ------------------------------------------------------------------------

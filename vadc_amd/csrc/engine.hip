@@ -736,6 +736,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
          KernelTimer t(e, VADC_AMD_KERNEL_ENC234, st);
          EncV4Args a;
          a.in = in; a.img = e->d_encv4; a.out = e->d_act[3]; a.n_chunks = n; a.map = map;
+         a.t1_pitch = (e->frames + 1) / 2; a.t1 = (e->frames_valid + 1) / 2; a.s3 = e->stride3(); a.ts = e->lstm_steps;
          launch_enc_fused_v4(a, encoder_cus(e, st), st);
          return;
       }

@@ -178,8 +178,10 @@ struct vadc_amd_engine {
    unsigned long long pin_clock = 0;
    int pin_host = 1;
 
-   // Silero v4, default window: stages 2-4 in one launch (hot path only: LSTM tiles out, no stage taps); option "encoder" = 5 keeps the per-stage launches
-   bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames == 24 && !padded_window() && sample_rate == 16000; }
+   // Silero v4: stages 2-4 in one launch (hot path only: LSTM tiles out, no stage taps) at every window of both branches; a weight outside fp16's range keeps the per-stage launches
+   // (every window of both branches from 8 frames up: the step counts are kernel arguments.  The 8 kHz branch at 256 samples -- 4 frames, 2 -> 1 -> 1 steps -- keeps the three
+   // small per-stage launches: the fused kernel's cost per chunk pair does not shrink with the steps, 6.31 against 6.54 M there, A/B on one box)
+   bool use_enc_fused_v4() const { return model == VADC_AMD_MODEL_V4 && d_encv4 && encoder_variant == 0 && frames >= 8; }
    bool use_enc_fused() const { return model == VADC_AMD_MODEL_V31 && enc_h3_ok && d_encA && encoder_variant == 0; }
    LstmWeights lstm;
    // workspace

@@ -1,8 +1,10 @@
-// kernels_encoder_fused_v4.hip -- Silero v4 (16 kHz, 1536-sample window): encoder stages 2, 3 and 4 in ONE launch, every activation in registers.
+// kernels_encoder_fused_v4.hip -- Silero v4 (every window, both sample-rate branches): encoder stages 2, 3 and 4 in ONE launch, every activation in registers.
 //
 // Reference arithmetic: silero_vad.py:191-236 (Silero_V4: four ConvBlock -> strided 1x1 conv (BatchNorm folded by the exporter) -> ReLU stages, no transformer
 // blocks; ConvBlock = relu(pw(relu(dw(x))) + (proj(x) | x)), silero_vad.py:69-106; the reference itself reaches the graph through onnxruntime,
-// onnx_helpers.c:532-549).  Stage shapes after the first stage: [16][12] -> [32][6] -> [32][3] -> [64][3] (strides 2, 2, 1), then the LSTM's input tiles.
+// onnx_helpers.c:532-549).  Stage shapes after the first stage at the default window: [16][12] -> [32][6] -> [32][3] -> [64][3] (strides 2, 2, 1), then the LSTM's input tiles;
+// in general [16][t1] -> [32][t2] -> [32][ts] -> [64][ts] with t1 <= 12 valid steps (EncV4Args: the step counts are kernel arguments since round 6 -- the other windows ran three
+// launches of k_layer_mfma: 0.12 - 0.28 ms per 65,536 chunks against 0.03 - 0.07 here), t2 = (t1 + 1) / 2, ts = (t2 + 1) / 2 or, in the 8 kHz branch (third conv of stride 1), t2.
 //
 // Round 4 ran these stages as three launches of k_layer_mfma (fp32 MFMA, activations in LDS, a workgroup barrier between every step): 0.069 + 0.048 + 0.066 ms per
 // 65,536 chunks for 55 K MAC per chunk -- launch and barrier bound (profiles/r05/bench_v4_4096x16_pmc_compute.json: the matrix pipe < 10 % busy, waves waiting 43 %).
@@ -111,11 +113,11 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused_v4(EncV4Args a)
 #pragma unroll
          for (int nt = 0; nt < 2; ++nt) {
             const int item = item0 + nt;
-            const bool ok = lc < 12 && item < a.n_chunks;
-            const float *xp = a.in + (size_t)a.map(item < a.n_chunks ? item : 0) * (16 * 12) + (8 * (q & 1)) * 12 + (lc < 12 ? lc : 0);
+            const bool ok = lc < a.t1 && item < a.n_chunks;                  // (steps past the valid ones are zeros: the depthwise conv's padding)
+            const float *xp = a.in + (size_t)a.map(item < a.n_chunks ? item : 0) * (16 * a.t1_pitch) + (8 * (q & 1)) * a.t1_pitch + (lc < a.t1 ? lc : 0);
             f4 xv[2], d[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = ok ? xp[e * 12] : 0.0f;
+            for (int e = 0; e < 8; ++e) xv[e >> 2][e & 3] = ok ? xp[e * a.t1_pitch] : 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                d[e >> 2][e & 3] = dw5<false>(xv[e >> 2][e & 3], k[0][e >> 2][e & 3], k[1][e >> 2][e & 3], k[2][e >> 2][e & 3], k[3][e >> 2][e & 3],
@@ -136,11 +138,12 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused_v4(EncV4Args a)
       }
       f4 z2[2][2];
       v4_conv1x1<EncV4L2, 32, 2>(y2, z2, f2, v2, lane);
-      // stride 2: step 2 t' of the first / second tile -> column t' / 8 + t' of the pair tile (t' < 6); same quad, same registers
+      // stride 2: step 2 t' of the first / second tile -> column t' / 8 + t' of the pair tile (t' < t2 <= 6); same quad, same registers
+      const int t2 = (a.t1 + 1) >> 1, t3 = a.s3 == 2 ? (t2 + 1) >> 1 : t2;
       f4 x3[2];
       {
          const int t = v4p_step(lc);
-         const bool live = t < 6;
+         const bool live = t < t2;
          const int src = 4 * (16 * q + 2 * (live ? t : 0));
          const bool second = v4p_chunk(lc) == 1;
 #pragma unroll
@@ -153,16 +156,16 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused_v4(EncV4Args a)
                x3[mt][r] = live ? __builtin_bit_cast(float, second ? g1 : g0) : 0.0f;
             }
       }
-      // ---- stage 3 on the pair tile (6 steps per chunk)
+      // ---- stage 3 on the pair tile (t2 steps per chunk)
       f4 y3[1][2], z3[1][2];
       v4_conv_block<EncV4L3, 32, false>(x3, y3[0], f3, v3, lane);
       v4_conv1x1<EncV4L3, 32, 1>(y3, z3, f3, v3, lane);
-      // stride 2: step 2 t' -> column (chunk) 8 + t' (t' < 3)
+      // stride s3: step s3 t' -> column (chunk) 8 + t' (t' < t3 <= 3)
       f4 x4[2];
       {
          const int t = v4p_step(lc);
-         const bool live = t < 3;
-         const int src = 4 * (16 * q + 8 * v4p_chunk(lc) + 2 * (live ? t : 0));
+         const bool live = t < t3;
+         const int src = 4 * (16 * q + 8 * v4p_chunk(lc) + a.s3 * (live ? t : 0));
 #pragma unroll
          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -172,17 +175,17 @@ __global__ __launch_bounds__(64 * NW) void k_enc_fused_v4(EncV4Args a)
                x4[mt][r] = live ? __builtin_bit_cast(float, g0) : 0.0f;
             }
       }
-      // ---- stage 4 on the pair tile (3 steps per chunk), stride 1
+      // ---- stage 4 on the pair tile (t3 steps per chunk), stride 1
       f4 y4[1][4], z4[1][4];
       v4_conv_block<EncV4L4, 64, true>(x4, y4[0], f4_, v4, lane);
       v4_conv1x1<EncV4L4, 64, 1>(y4, z4, f4_, v4, lane);
       // ---- split-fp16 LSTM-native tiles (common.h lstm_xh_index): a (chunk, step) row = 64 units x {hi, lo}; this lane owns units 16 mt + 4 q .. + 3
       {
          const int item = item0 + v4p_chunk(lc), t = v4p_step(lc);
-         if (t < 3 && item < a.n_chunks) {
+         if (t < t3 && item < a.n_chunks) {
             int st_, ch_;
             a.map.split(item, st_, ch_);
-            _Float16 *dst = reinterpret_cast<_Float16 *>(a.out) + lstm_xh_index(st_, ch_, a.map.C, t, 4 * q, 3);
+            _Float16 *dst = reinterpret_cast<_Float16 *>(a.out) + lstm_xh_index(st_, ch_, a.map.C, t, 4 * q, a.ts);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                h2 hi[2], lo[2];
