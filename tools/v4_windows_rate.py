@@ -15,16 +15,18 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rate", type=int, default=16000, choices=[16000, 8000])
+    ap.add_argument("--windows", type=int, nargs="*", default=None, help="windows to time (default: the built ones of the branch)")
     a = ap.parse_args()
     import torch
     from vadc_amd.engine import Engine
     from vadc_amd import synth
     name = "silero_v4_16k.testtensor" if a.rate == 16000 else "silero_v4_8k.testtensor"
     blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
-    windows = (1536, 1280, 1024, 768, 512) if a.rate == 16000 else (768, 512, 256)
+    default_window = 1536 if a.rate == 16000 else 768
+    windows = tuple(a.windows) if a.windows else ((1536, 1280, 1024, 768, 512) if a.rate == 16000 else (768, 512, 256))
     for W in windows:
         eng = Engine(blob, max_streams=a.streams, max_chunks_per_call=a.chunks, device=0)
-        if W != windows[0]:
+        if W != default_window:
             eng.set_window(W)
         eng.set_option("defer_join", 1)
         n = a.chunks * W

@@ -164,6 +164,7 @@ struct L1RegsArgs {
    float *out;               // [n][16][13] (tap: [n][16][25])
    int n_chunks;
    ItemMap map;
+   int tv = 0;               // k_layer1_regs_v4 only: the VALID frames of a chunk when fewer than the geometry's 24 (a window of 1344 / 1408 / 1472 samples); 0 = all
 };
 
 // ---- Silero v4, first stage (k_layer1_regs_v4, kernels_layer1_regs_v4.hip) ---------------------------------------------------------------

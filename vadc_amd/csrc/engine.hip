@@ -744,6 +744,7 @@ static void run_encoder_layers(vadc_amd_engine *e, int first, int last, int n, I
       if (l == 0 && e->use_l1_regs_v4()) {
          L1RegsArgs a;
          a.y = in; a.fm = e->d_FM; a.fm_stride = e->max_items * kFrames; a.img = e->d_l1img; a.out = e->d_act[0]; a.n_chunks = n; a.map = map;
+         a.tv = e->padded_window() ? e->frames_valid : 0;
          launch_layer1_regs_v4(a, encoder_cus(e, st), st);
          continue;
       }

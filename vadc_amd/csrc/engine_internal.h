@@ -160,7 +160,8 @@ struct vadc_amd_engine {
    int layer1_variant = 0;                      // option "layer1": 0 = k_layer1_regs (registers + LDS-DMA) when the weights allow, 1 = the K = 1 fp32-MFMA form of k_layer_mfma
    bool use_l1_regs() const { return model == VADC_AMD_MODEL_V31 && d_l1img && layer1_variant == 0 && layer1_selfcheck != 0; }
    // Silero v4: k_layer1_regs_v4 serves the default window (24 frames); the magnitude half of the first stage's input is recovered from Y in every form
-   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && !padded_window() && layer1_selfcheck != 0; }
+   // (frames = 24: the 1536-sample geometry -- the default window and, since round 6, the three windows of 21 .. 23 valid frames that run in it: the kernel's MASK form)
+   bool use_l1_regs_v4() const { return model == VADC_AMD_MODEL_V4 && d_l1img && layer1_variant == 0 && encoder_variant == 0 && frames == 24 && layer1_selfcheck != 0; }
    // asynchronous host-buffer entry points (vadc_amd_run_*_async): three staging slots in flight -- H2D of call k+1 beside the kernels of call k beside
    // the D2H of call k-1, each on a stream of its own
    struct AsyncSlot { void *d_in = nullptr; float *d_probs = nullptr; hipEvent_t in_done = nullptr, out_done = nullptr; bool busy = false; };

@@ -53,19 +53,23 @@ __device__ __forceinline__ f2 l1v4_input(const f2 &y, float off)
       return f2{fmaf(__builtin_amdgcn_exp2f(y[0] * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f), fmaf(__builtin_amdgcn_exp2f(y[1] * 1.44269504088896340736f), 0x1p-20f, -0x1p-20f)};
    return y - f2{off, off};
 }
-template <int WHICH>
-__device__ __forceinline__ void l1v4_channel_math(const L1V4Chan &s, float off, float &x0, float &x1, float &d0, float &d1)
+// MASK (a window of 21 .. 23 frames in this 24-frame geometry): a frame past the valid ones enters as ZERO in both halves of the concat -- what the depthwise conv's padding
+// behind the last valid frame is (conv.c:17-53); v0 / v1: this lane's step of tile 0 / tile 1 is a valid one
+template <int WHICH, bool MASK>
+__device__ __forceinline__ void l1v4_channel_math(const L1V4Chan &s, float off, bool v0, bool v1, float &x0, float &x1, float &d0, float &d1)
 {
-   const f2 xp = l1v4_input<WHICH>(s.x, off);
+   f2 xp = l1v4_input<WHICH>(s.x, off);
+   if (MASK) { xp[0] = v0 ? xp[0] : 0.0f; xp[1] = v1 ? xp[1] : 0.0f; }
    x0 = xp[0]; x1 = xp[1];
    float a, b;
    dw5x2(xp[0], xp[1], s.ka[0], s.ka[1], s.ka[2], s.ka[3], s.kb[0], s.kb[1], a, b);
    d0 = relu(a); d1 = relu(b);
 }
 
-template <int NW>
+template <int NW, bool MASK>
 __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
 {
+   const int tv = MASK ? a.tv : kT4;                          // valid frames of a chunk (MASK: 21 .. 23 of the geometry's 24; see l1v4_channel_math)
    __shared__ __attribute__((aligned(16))) char lds[kL1V4ImgBytes + NW * kL1V4RingBytes];
    const int tid = threadIdx.x;
    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,35 +130,36 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
       const int nnext = more ? a.map(item + nslots) : n;
       // W0: the chunk's sums and group 0 (younger loads: groups 1 and 2)
       asm volatile("s_waitcnt vmcnt(6)" : "+v"(fmv[0]), "+v"(fmv[1]), "+v"(fmv[2]), "+v"(fmv[3]) :: "memory");
-      // ---- adaptive normalization offset of the chunk (misc.c:65-82) over its 24 frames ----
+      // ---- adaptive normalization offset of the chunk (misc.c:65-82) over its 24 (MASK: tv) frames ----
       float off;
       {
          const float fms = ((fmv[0] + fmv[1]) + (fmv[2] + fmv[3])) / 129.0f;
          const float filt[7] = {0.03663284704089164733887f, 0.11128076165914535522461f, 0.21674531698226928710938f,
                                 0.27068215608596801757812f, 0.21674531698226928710938f, 0.11128076165914535522461f,
                                 0.03663284704089164733887f};
-         const int t = lane < kT4 ? lane : 0;
+         const int t = lane < tv ? lane : 0;
          float nb[7];
 #pragma unroll
          for (int i = 0; i < 7; ++i) {
             int qq = t + i - 3;                                 // reflect pad 3, no edge repeat
             qq = qq < 0 ? -qq : qq;
-            qq = qq >= kT4 ? 2 * (kT4 - 1) - qq : qq;
+            qq = qq >= tv ? 2 * (tv - 1) - qq : qq;
             nb[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * qq, __builtin_bit_cast(int, fms)));
          }
          float r = 0.0f;
 #pragma unroll
          for (int i = 0; i < 7; ++i) r += nb[i] * filt[i];
-         r = lane < kT4 ? r : 0.0f;
+         r = lane < tv ? r : 0.0f;
          r += dpp_row<0x111>(r); r += dpp_row<0x112>(r); r += dpp_row<0x114>(r); r += dpp_row<0x118>(r);     // row_shr:1, 2, 4, 8: lane 15 of a row = its sum
          const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 15)) +
                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 31));
-         off = total / (float)kT4;
+         off = total / (float)tv;
       }
       // ---- conv block: y = relu(pw(relu(dw(x))) + proj(x)), x = concat(magnitude, normalized) ----
       const int lane_part = ((2 * (q & 1) + (q >> 1)) * kT4 + lc) * 4;      // this lane's (quad, column) inside a slab (l1v4_channel)
       auto slab_ptr = [&](int kb) { return reinterpret_cast<const float *>(buf + slab_of(kb) * kL1V4SlabBytes + lane_part); };
       const float *tp = vec + L4::v_taps + q * 8;
+      const bool v0 = lc < tv, v1 = lc + 8 < tv;                 // (MASK) this lane's steps of the two tiles
       f4 acc[2];
       acc[0] = acc[1] = lds_vec4(vec, L4::v_cb_b + 4 * q);
       // channels two ahead of the one in work (a window of three), the 12 MFMAs of virtual k block vb - 1 one at a time between the channels of vb,
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
             __builtin_amdgcn_sched_barrier(0);
             {
                float x0, x1, d0, d1;
-               if (vb & 1) l1v4_channel_math<1>(ch[j % 3], off, x0, x1, d0, d1); else l1v4_channel_math<0>(ch[j % 3], off, x0, x1, d0, d1);
+               if (vb & 1) l1v4_channel_math<1, MASK>(ch[j % 3], off, v0, v1, x0, x1, d0, d1); else l1v4_channel_math<0, MASK>(ch[j % 3], off, v0, v1, x0, x1, d0, d1);
                if (c < 4) { xl0[c] = x0; xl1[c] = x1; dl0[c] = d0; dl1[c] = d1; }
                else       { xh0[c - 4] = x0; xh1[c - 4] = x1; dh0[c - 4] = d0; dh1[c - 4] = d1; }
             }
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(64 * NW) void k_layer1_regs_v4(L1RegsArgs a)
       {
          const AOp wt = lds_aop(img + L4::f_tail, lane);
          float m0, m1, n0_, n1_, dm0, dm1, dn0, dn1;
-         l1v4_channel_math<0>(ch[64 % 3], off, m0, m1, dm0, dm1);      // (use the last LDS reads of the chunk)
-         l1v4_channel_math<1>(ch[65 % 3], off, n0_, n1_, dn0, dn1);
+         l1v4_channel_math<0, MASK>(ch[64 % 3], off, v0, v1, m0, m1, dm0, dm1);      // (use the last LDS reads of the chunk)
+         l1v4_channel_math<1, MASK>(ch[65 % 3], off, v0, v1, n0_, n1_, dn0, dn1);
          if (more) issue_group(nnext, 2, slab_of(3));
 #pragma unroll
          for (int i = 0; i < 6; ++i) pending_mfma(i);
@@ -282,7 +287,8 @@ void launch_layer1_regs_v4(const L1RegsArgs &a, int max_wgs, hipStream_t st)
 {
    if (a.n_chunks <= 0) return;
    const int g = std::min(max_wgs, (a.n_chunks + kL1Waves - 1) / kL1Waves);
-   hipLaunchKernelGGL((k_layer1_regs_v4<kL1Waves>), dim3(g), dim3(64 * kL1Waves), 0, st, a);
+   if (a.tv > 0 && a.tv < kL1V4Frames) hipLaunchKernelGGL((k_layer1_regs_v4<kL1Waves, true>), dim3(g), dim3(64 * kL1Waves), 0, st, a);      // 1344 / 1408 / 1472 samples: 21 .. 23 valid frames
+   else                                hipLaunchKernelGGL((k_layer1_regs_v4<kL1Waves, false>), dim3(g), dim3(64 * kL1Waves), 0, st, a);
 }
 
 }  // namespace vadc
