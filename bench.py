@@ -50,6 +50,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from vadc_amd.staging import pinned, to_device, to_host, to_host_tensor      # noqa: E402  (numpy <-> device through page-locked buffers; imports numpy only: torch stays unimported until a rank needs it)
 
 CHUNK_SECONDS = 1536 / 16000.0
 PEAKS = {"valu_nofma": 78.65,     # fp32 vector ALU with every product and every sum rounded separately (the reference's tree): half of the FMA peak
@@ -358,7 +359,7 @@ class StepLoop:
                 side = self.streams[1 + b % (len(self.streams) - 1)]
                 eng.join(side.cuda_stream)
                 with torch.cuda.stream(side):
-                    gather.gather(self.d_probs[b].cpu() if self.rehearsal else self.d_probs[b])
+                    gather.gather(to_host_tensor(self.d_probs[b]) if self.rehearsal else self.d_probs[b])
                     self.gathered[b] = torch.cuda.Event()
                     self.gathered[b].record(side)
             return
@@ -366,7 +367,7 @@ class StepLoop:
         with torch.cuda.stream(st):
             eng.run_device(self.d_in[b].data_ptr(), np.int16, S, Cn, self.d_probs[b].data_ptr(), st.cuda_stream)
             if self.world > 1:
-                gather.gather(self.d_probs[b].cpu() if self.rehearsal else self.d_probs[b])       # the only collective: final probability gather (RCCL)
+                gather.gather(to_host_tensor(self.d_probs[b]) if self.rehearsal else self.d_probs[b])       # the only collective: final probability gather (RCCL)
 
 
 def collective_facts(torch, dist, world, rehearsal, gather):
@@ -417,7 +418,7 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
         eng.set_option(k_, v_)
     NB = 3
     pcm = _side_input(S, Cn, NB, rank)
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
+    d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]), dev) for i in range(NB)]
     d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
     gather = shard.ProbabilityGather(S * world, Cn, "cpu" if rehearsal else dev)
     loop = StepLoop(torch, eng, S, Cn, d_in, d_out, gather, world, rehearsal, True)
@@ -476,8 +477,8 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
         out["latency_ms"] = round(float(np.median(lat)) * 1e3, 3)
         out["latency_budget_ms"] = 96.0
     if host_fed:
-        host = [np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(NB)]
-        outs = [np.empty((S, Cn, 2), np.float32) for _ in range(NB)]
+        host = [pinned(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]).numpy() for i in range(NB)]      # page-locked by torch's host allocator (see the headline's host_fed leg)
+        outs = [pinned(np.empty((S, Cn, 2), np.float32)).numpy() for _ in range(NB)]
         for i in range(18):
             eng.run_async(host[i % NB], outs[i % NB])
         eng.wait_async()
@@ -504,7 +505,7 @@ def side_config_v5(torch, blob, dev, local_rank, S, Cn, steps=60, warmup=10):
     NB = 3
     base = synth.make_streams(16, -(-NB * Cn * W // 1536), seed0=11)[:, :NB * Cn * W]
     pcm = np.ascontiguousarray(np.tile(base, (-(-S // 16), 1))[:S])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * W:(i + 1) * Cn * W])).to(dev) for i in range(NB)]
+    d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * W:(i + 1) * Cn * W]), dev) for i in range(NB)]
     d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
     st = torch.cuda.Stream()
     eng.set_option("defer_join", 1)
@@ -607,7 +608,7 @@ def run_rank(args, world, rank, local_rank):
     else:
         base = synth.make_streams(min(S, 16), NB * Cn, seed0=1234 + 100 * rank)
         pcm = np.ascontiguousarray(np.tile(base, ((S + base.shape[0] - 1) // base.shape[0], 1))[:S])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to(dev) for i in range(NB)]
+    d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]), dev) for i in range(NB)]
     d_probs = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
     gather = shard.ProbabilityGather(total_streams, Cn, "cpu" if rehearsal else dev)      # weak scaling: S streams per GPU, contiguous blocks; 4 B per chunk
     assert gather.hi - gather.lo == S
@@ -692,7 +693,7 @@ def run_rank(args, world, rank, local_rank):
         if world > 1:
             dist.barrier()
         if rank == 0:
-            res = np.stack([(g.result() if world > 1 else single[i]).detach().cpu().numpy().copy() for i, g in enumerate(gv)])
+            res = np.stack([to_host(g.result() if world > 1 else single[i]) for i, g in enumerate(gv)])
             np.savez(args.verify_dump, probs=res, total_streams=total_streams, world=world, chunks=Cn, buffers=NB, steps=K)
 
     out = None
@@ -784,8 +785,11 @@ def run_rank(args, world, rank, local_rank):
             # PCIe-inclusive rates of the host-buffer entry points (what a drop-in backend_run caller pays); reported, never `value`.
             #   value       -- vadc_amd_run_s16_async: page-locked host buffers, H2D of call k+1 beside the kernels of call k beside the D2H of call k-1
             #   synchronous -- vadc_amd_run_s16: pageable buffers, copy -> run -> copy
-            host = [np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(NB)]
-            outs = [np.empty((S, Cn, 2), np.float32) for _ in range(NB)]
+            # (the asynchronous leg's buffers come page-locked from torch's host allocator: the engine takes such ranges as they are -- hipHostRegister of heap pages is one more
+            # userptr mapping this pool's runtime was seen to fault on, vadc_amd/staging.py; the synchronous leg keeps an ordinary pageable array)
+            host = [pinned(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]).numpy() for i in range(NB)]
+            outs = [pinned(np.empty((S, Cn, 2), np.float32)).numpy() for _ in range(NB)]
+            pageable = np.ascontiguousarray(pcm[:, : Cn * 1536])
             eng.set_option("groups", 1)
             # a SUSTAINED rate: 18 warm-up calls (the runtime's one-off stalls -- first use of each staging slot, page-locking, a 6.7 ms stall inside the
             # eleventh hipMemcpyAsync of a process -- are behind), then 48 calls: the pipeline's fill and drain (one copy in, one step + copy out: 2.3 ms)
@@ -801,11 +805,11 @@ def run_rank(args, world, rank, local_rank):
             dta = time.perf_counter() - t1
             eng.set_option("defer_join", 0)                       # what a plain synchronous caller gets: the call pipelines its own chunk groups
             eng.set_option("groups", 0)
-            eng.run(host[0])
+            eng.run(pageable)
             n_sync = 4
             t1 = time.perf_counter()
             for _ in range(n_sync):
-                eng.run(host[0])
+                eng.run(pageable)
             dts = time.perf_counter() - t1
             out["host_fed"] = {"value": round(S * Cn * n_host * CHUNK_SECONDS / dta, 1), "unit": "audio-seconds/sec", "ms_per_step": round(dta / n_host * 1e3, 3),
                                "pcie_gb_per_s": round(S * Cn * 3072 * n_host / dta / 1e9, 1),

@@ -12,6 +12,7 @@ from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth, testtensor as tt
 from vadc_amd.engine import Engine, VadcAmdError
+from vadc_amd.staging import pinned, to_device, to_host      # numpy <-> device through page-locked buffers (no pageable pointer reaches the runtime)
 
 pytestmark = pytest.mark.gpu
 
@@ -209,12 +210,12 @@ def test_unaligned_device_input_takes_the_full_tree(eng):
     d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream()
     for shift, kernel in ((0, 0), (1, 1), (3, 1)):
-        d_buf[shift:pcm.size + shift].copy_(torch.from_numpy(pcm.reshape(-1)))
+        d_buf[shift:pcm.size + shift].copy_(pinned(pcm.reshape(-1)))
         eng.reset_streams()
         eng.run_device(d_buf.data_ptr() + 2 * shift, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
         st.synchronize()
         assert eng.get_option("frontend_kernel") == kernel
-        assert float(np.abs(want - d_out.cpu().numpy()).max()) < 1e-5      # other order of the partial bin sums, v_sqrt under the log
+        assert float(np.abs(want - to_host(d_out)).max()) < 1e-5      # other order of the partial bin sums, v_sqrt under the log
     eng.reset_streams()
 
 
@@ -598,7 +599,7 @@ def test_lstm_trail_failure_is_recovered(weights_blob, orc):
             pytest.skip("the TRAIL pair is not in use here (kernels do not overlap in this process, or no CU partition)")
         e.reset_streams()
         assert e.get_option("trail_recoveries") == 0
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536])).cuda() for k in range(K)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, k * Cn * 1536:(k + 1) * Cn * 1536])) for k in range(K)]
         d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda") for _ in range(K)]
         st = torch.cuda.Stream()
         e.set_option("defer_join", 1)
@@ -610,7 +611,7 @@ def test_lstm_trail_failure_is_recovered(weights_blob, orc):
         e.join(st.cuda_stream)
         st.synchronize()
         e.synchronize()                                        # no error: the fault was repaired on the device
-        got = np.concatenate([o.cpu().numpy() for o in d_out], axis=1)
+        got = np.concatenate([to_host(o) for o in d_out], axis=1)
         assert e.get_option("trail_recoveries") == S // 16     # every tile of the faulted call was done again, once
         assert e.get_option("lstm_trail") == 0                 # ... and the engine has stopped launching pairs side by side
         hs = [e.get_state(s_) for s_ in (0, 100, 255)]
@@ -655,7 +656,7 @@ def test_lstm_trail_unrecoverable_failure_is_sticky_until_reset(weights_blob, or
             pytest.skip("the TRAIL pair is not in use here (kernels do not overlap in this process, or no CU partition)")
         e.reset_streams()
         before = [e.get_state(s_) for s_ in (0, 255)]
-        d_in = torch.from_numpy(pcm).cuda()
+        d_in = to_device(pcm)
         d_out = torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda")
         st = torch.cuda.Stream()
         e.set_option("defer_join", 1)
@@ -895,10 +896,10 @@ def test_hipgraph_replay_matches_eager(weights_blob):
     outs = []
     with torch.cuda.stream(st):
         for i in range(3):      # same buffers every step => one capture, two replays
-            d_in.copy_(torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])), non_blocking=False)
+            d_in.copy_(pinned(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])), non_blocking=False)
             e.run_device(d_in.data_ptr(), np.int16, S, Cn, d_out.data_ptr(), st.cuda_stream)
             st.synchronize()
-            outs.append(d_out.cpu().numpy().copy())
+            outs.append(to_host(d_out))
     e.close()
     assert np.array_equal(bits(want), bits(np.concatenate(outs, axis=1)))
 
@@ -913,7 +914,7 @@ def test_hipgraph_replay_at_bench_sizes(weights_blob, S, Cn, precision):
     pcm = np.ascontiguousarray(np.tile(base, (S // 16, 1)))
     e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0, precision=precision)
     try:
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(4)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])) for i in range(4)]
         sts = [torch.cuda.Stream(), torch.cuda.Stream()]
 
         def run(graph):
@@ -928,7 +929,7 @@ def test_hipgraph_replay_at_bench_sizes(weights_blob, S, Cn, precision):
                     with torch.cuda.stream(st):
                         e.run_device(d_in[i].data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), st.cuda_stream)
                 torch.cuda.synchronize()
-            return np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+            return np.concatenate([to_host(o) for o in outs], axis=1)
 
         want = run(0)
         got = run(1)
@@ -951,7 +952,7 @@ def test_deferred_join_overlaps_calls_issued_from_one_stream(weights_blob):
         want = np.concatenate([e.run(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536]) for i in range(steps)], axis=1)
         e.reset_streams()
         e.set_option("defer_join", 1)
-        d_in = torch.from_numpy(pcm).to("cuda:0")
+        d_in = to_device(pcm)
         outs = [torch.zeros((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(steps)]
         issue, reader = torch.cuda.Stream(), torch.cuda.Stream()
         blks = [d_in[:, i * Cn * 1536:(i + 1) * Cn * 1536].contiguous() for i in range(steps)]      # every step's block in a buffer of its own, alive until the end
@@ -960,7 +961,7 @@ def test_deferred_join_overlaps_calls_issued_from_one_stream(weights_blob):
             e.run_device(blks[i].data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), issue.cuda_stream)
         e.join(reader.cuda_stream)
         with torch.cuda.stream(reader):
-            got = torch.cat(outs, dim=1).cpu().numpy()
+            got = to_host(torch.cat(outs, dim=1))
         reader.synchronize()
         e.set_option("defer_join", 0)
     finally:
@@ -1002,13 +1003,13 @@ def test_calls_are_ordered_whatever_stream_the_caller_uses(weights_blob, gold_py
     e = Engine(weights_blob, max_streams=1, max_chunks_per_call=8, device=0)
     ref = np.concatenate([e.run(pcm[:, i * 1536:(i + 4) * 1536]) for i in range(0, 40, 4)], axis=1)      # synchronous calls
     e.reset_streams()
-    d_in = torch.from_numpy(pcm.copy()).to("cuda:0")
+    d_in = to_device(pcm.copy())
     d_out = torch.zeros((10, 1, 4, 2), dtype=torch.float32, device="cuda:0")
     sts = [torch.cuda.Stream(device="cuda:0") for _ in range(3)]
     for k in range(10):                                         # ten dependent calls round-robin over three streams, no host sync
         e.run_device(d_in.data_ptr() + k * 4 * 1536 * 2, np.int16, 1, 4, d_out[k].data_ptr(), hip_stream=sts[k % 3].cuda_stream)
     torch.cuda.synchronize()
-    got = d_out.cpu().numpy().reshape(1, 40, 2)
+    got = to_host(d_out).reshape(1, 40, 2)
     e.close()
     assert np.array_equal(got, ref)
 
@@ -1214,12 +1215,12 @@ def test_device_pointer_path_matches_host_path(eng):
     eng.reset_streams()
     want = eng.run(pcm)
     eng.reset_streams()
-    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_in = to_device(pcm)
     d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
     st = torch.cuda.current_stream()
     eng.run_device(d_in.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
     st.synchronize()
-    assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
+    assert np.array_equal(bits(want), bits(to_host(d_out)))
 
 
 def test_speech_probabilities_packs_element_one(eng):
@@ -1228,7 +1229,7 @@ def test_speech_probabilities_packs_element_one(eng):
     import torch
     pcm = synth.make_streams(37, 5, seed0=77)
     eng.reset_streams()
-    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_in = to_device(pcm)
     d_out = torch.empty((37, 5, 2), dtype=torch.float32, device="cuda:0")
     d_sp = torch.full((37, 5), -1.0, dtype=torch.float32, device="cuda:0")
     st = torch.cuda.Stream()
@@ -1236,7 +1237,7 @@ def test_speech_probabilities_packs_element_one(eng):
     eng.join(st.cuda_stream)
     eng.speech_probabilities(d_out.data_ptr(), 37, 5, d_sp.data_ptr(), st.cuda_stream)
     st.synchronize()
-    assert np.array_equal(bits(d_out.cpu().numpy()[:, :, 1]), bits(d_sp.cpu().numpy()))
+    assert np.array_equal(bits(to_host(d_out)[:, :, 1]), bits(to_host(d_sp)))
     with pytest.raises(VadcAmdError):
         eng.speech_probabilities(d_out.data_ptr() + 4, 37, 5, d_sp.data_ptr(), st.cuda_stream)      # not 8-byte aligned: not a [2] pair array
     with pytest.raises(VadcAmdError):
@@ -1303,7 +1304,7 @@ def test_oracle_at_the_bench_shapes_as_bench_drives_them(weights_blob, orc, S, C
     try:
         e.set_option("defer_join", 1)
         e.set_option("groups", 1)
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(NB)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])) for i in range(NB)]
         d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0") for _ in range(NB)]
         st = torch.cuda.Stream()
 
@@ -1321,7 +1322,7 @@ def test_oracle_at_the_bench_shapes_as_bench_drives_them(weights_blob, orc, S, C
             step(i)
         e.join(st.cuda_stream)
         st.synchronize()
-        got = np.concatenate([d_out[i % NB].cpu().numpy() for i in range(steps)], axis=1)      # steps <= NB: every step's buffer is still its own
+        got = np.concatenate([to_host(d_out[i % NB]) for i in range(steps)], axis=1)      # steps <= NB: every step's buffer is still its own
     finally:
         e.close()
     want = orc.forward_streams(sig)
@@ -1362,7 +1363,7 @@ def test_north_star_shape_one_chunk_per_stream_and_call(weights_blob, orc, S):
     try:
         e.set_option("defer_join", 1)
         st = torch.cuda.Stream()
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * 1536:(k + 1) * 1536])).cuda() for k in range(calls)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, k * 1536:(k + 1) * 1536])) for k in range(calls)]
         res = {}
         for graph in (1, 0):
             e.set_option("graph", graph); e.reset_streams()
@@ -1370,7 +1371,7 @@ def test_north_star_shape_one_chunk_per_stream_and_call(weights_blob, orc, S):
             for k in range(calls):
                 e.run_device(d_in[k].data_ptr(), np.int16, S, 1, d_out[k].data_ptr(), st.cuda_stream)
             e.join(st.cuda_stream); st.synchronize()
-            res[graph] = np.concatenate([o.cpu().numpy() for o in d_out], axis=1)
+            res[graph] = np.concatenate([to_host(o) for o in d_out], axis=1)
         e.set_option("defer_join", 0); e.set_option("graph", 1); e.reset_streams()
         parts = [np.ascontiguousarray(pcm[:, k * 1536:(k + 1) * 1536]) for k in range(calls)]
         outs = [np.full((S, 1, 2), np.nan, np.float32) for _ in range(calls)]
@@ -1610,11 +1611,11 @@ def test_fast_stft_device_path_and_alignment_rule(weights_blob):
         d_buf = torch.zeros(pcm.size + 8, dtype=torch.int16, device="cuda:0")
         d_out = torch.empty((8, 4, 2), dtype=torch.float32, device="cuda:0")
         st = torch.cuda.current_stream()
-        d_buf[:pcm.size].copy_(torch.from_numpy(pcm.reshape(-1)))
+        d_buf[:pcm.size].copy_(pinned(pcm.reshape(-1)))
         eng16.run_device(d_buf.data_ptr(), np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
         st.synchronize()
-        assert np.array_equal(bits(want), bits(d_out.cpu().numpy()))
-        d_buf[1:pcm.size + 1].copy_(torch.from_numpy(pcm.reshape(-1)))
+        assert np.array_equal(bits(want), bits(to_host(d_out)))
+        d_buf[1:pcm.size + 1].copy_(pinned(pcm.reshape(-1)))
         with pytest.raises(VadcAmdError) as ei:
             eng16.run_device(d_buf.data_ptr() + 2, np.int16, 8, 4, d_out.data_ptr(), st.cuda_stream)
         assert ei.value.code == _lib_code("EINVAL")
@@ -1668,11 +1669,11 @@ def test_host_copies_across_the_staging_pieces(weights_blob):
             got = e.run(x)
             e.reset_streams()
             st = torch.cuda.Stream()
-            d_in = torch.from_numpy(x).cuda()
+            d_in = to_device(x)
             d_out = torch.empty((S, Cn, 2), dtype=torch.float32, device="cuda:0")
             e.run_device(d_in.data_ptr(), dtype, S, Cn, d_out.data_ptr(), st.cuda_stream)
             e.join(st.cuda_stream); st.synchronize()
-            assert np.array_equal(bits(got), bits(d_out.cpu().numpy())), (S, Cn, dtype)
+            assert np.array_equal(bits(got), bits(to_host(d_out))), (S, Cn, dtype)
             e.reset_streams()
             assert np.array_equal(bits(e.run(x)), bits(got))                                  # and again: the pieces are reused
         finally:
@@ -1927,14 +1928,14 @@ def test_three_engines_alive_in_one_process(weights_blob, orc):
     engines = [Engine(weights_blob, max_streams=s, max_chunks_per_call=c, device=0) for s, c in ((48, 48), (16, 24), (48, 8))]
     try:
         engines[2].set_option("defer_join", 1)
-        d_in = torch.from_numpy(np.ascontiguousarray(pcm[:, : 8 * 1536])).cuda()
+        d_in = to_device(np.ascontiguousarray(pcm[:, : 8 * 1536]))
         d_out = torch.empty((48, 8, 2), dtype=torch.float32, device="cuda")
         st = torch.cuda.Stream()
         a = engines[0].run(pcm)                                                # 2304 chunks: forks
         engines[2].run_device(d_in.data_ptr(), np.int16, 48, 8, d_out.data_ptr(), st.cuda_stream)
         b0 = engines[1].run(pcm[:16, : 24 * 1536])                             # 384 chunks: on the engine's own stream
         engines[2].join(st.cuda_stream); st.synchronize()
-        c = d_out.cpu().numpy()
+        c = to_host(d_out)
         engines[0].close()                                                    # first created, first destroyed, the others keep working
         b1 = engines[1].run(pcm[:16, 24 * 1536:])
         engines[2].close()

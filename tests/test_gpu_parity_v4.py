@@ -11,6 +11,7 @@ from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth
 from vadc_amd.engine import Engine, VadcAmdError, MODEL_V4
+from vadc_amd.staging import to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -121,7 +122,7 @@ def test_config4_full_size_4096_streams(blob, orc):
         want = orc.forward_streams(base)
         assert float(np.abs(a[:64, :, 1] - want).max()) < PROB_TOL
         # graph replay at this size, two caller streams / buffers as bench.py drives it
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])).to("cuda:0") for i in range(2)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * 1536:(i + 1) * Cn * 1536])) for i in range(2)]
         sts = [torch.cuda.Stream(), torch.cuda.Stream()]
         e.set_option("graph", 1)
         for rep in range(2):
@@ -131,7 +132,7 @@ def test_config4_full_size_4096_streams(blob, orc):
                 with torch.cuda.stream(sts[i]):
                     e.run_device(d_in[i].data_ptr(), np.int16, S, Cn, outs[i].data_ptr(), sts[i].cuda_stream)
             torch.cuda.synchronize()
-            g = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+            g = np.concatenate([to_host(o) for o in outs], axis=1)
             assert np.array_equal(g, a), rep
         e.set_option("graph", 0)
     finally:
@@ -255,7 +256,7 @@ def test_device_pointer_and_graph_paths(eng, gold):
     pcm = np.ascontiguousarray(np.tile(gold["pcm_speech0"][:32 * 1536], (8, 1)))
     eng.reset_streams()
     ref = eng.run(pcm)
-    d_in = torch.from_numpy(pcm).to("cuda:0")
+    d_in = to_device(pcm)
     d_out = torch.empty((8, 32, 2), dtype=torch.float32, device="cuda:0")
     for graph in (0, 1):
         eng.set_option("graph", graph)
@@ -263,7 +264,7 @@ def test_device_pointer_and_graph_paths(eng, gold):
         st = torch.cuda.Stream(device="cuda:0")
         eng.run_device(d_in.data_ptr(), np.int16, 8, 32, d_out.data_ptr(), hip_stream=st.cuda_stream)
         st.synchronize()
-        assert float(np.abs(d_out.cpu().numpy() - ref).max()) < 1e-6
+        assert float(np.abs(to_host(d_out) - ref).max()) < 1e-6
     eng.set_option("graph", 0)
 
 
@@ -415,7 +416,7 @@ def test_windows_of_every_multiple_of_64(blob, orc, gold, window):
         want = orc.forward_streams(pcm, window=window)
         assert float(np.abs(got - want).max()) < PROB_TOL
         # deferred joins + graph replay from device buffers: the same bits as the synchronous calls
-        d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * 60 * window:(k + 1) * 60 * window])).cuda() for k in range(2)]
+        d_in = [to_device(np.ascontiguousarray(pcm[:, k * 60 * window:(k + 1) * 60 * window])) for k in range(2)]
         d_out = [torch.empty(S, 60, 2, device="cuda") for _ in range(2)]
         st = torch.cuda.Stream()
         e.set_option("defer_join", 1); e.set_option("graph", 1)
@@ -424,7 +425,7 @@ def test_windows_of_every_multiple_of_64(blob, orc, gold, window):
             for k in range(2):
                 e.run_device(d_in[k].data_ptr(), np.int16, S, 60, d_out[k].data_ptr(), st.cuda_stream)
             e.join(st.cuda_stream); st.synchronize()
-            assert np.array_equal(np.concatenate([o.cpu().numpy() for o in d_out], axis=1)[:, :, 1], got), rep_
+            assert np.array_equal(np.concatenate([to_host(o) for o in d_out], axis=1)[:, :, 1], got), rep_
         e.set_option("defer_join", 0); e.set_option("graph", 0)
         with pytest.raises(VadcAmdError):
             e.stage_from_samples(f32(gold["pcm_speech0"])[: 2 * window], "magnitude")       # stage taps exist at the built windows

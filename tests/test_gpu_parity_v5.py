@@ -10,6 +10,7 @@ from conftest import GOLDEN, run_cli
 from oracle import oracle as O
 from vadc_amd import synth, testtensor as tt
 from vadc_amd.engine import Engine, VadcAmdError, MODEL_V5
+from vadc_amd.staging import to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -114,14 +115,14 @@ def test_forked_calls_and_fp32_recurrence(blob, orc):
             e.reset_streams()
             e.set_option("defer_join", 1)
             torch = pytest.importorskip("torch")
-            d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, a * 512:b * 512])).cuda() for a, b in ((0, 40), (40, 41), (41, 80), (80, 120))]
+            d_in = [to_device(np.ascontiguousarray(pcm[:, a * 512:b * 512])) for a, b in ((0, 40), (40, 41), (41, 80), (80, 120))]
             d_out = [torch.empty(S, x.shape[1] // 512, 2, device="cuda") for x in d_in]
             st = torch.cuda.Stream()
             for x, y in zip(d_in, d_out):                        # forked, small (on the caller's stream), forked, forked
                 e.run_device(x.data_ptr(), np.int16, S, y.shape[1], y.data_ptr(), st.cuda_stream)
             e.join(st.cuda_stream)
             st.synchronize()
-            parts = np.concatenate([y.cpu().numpy() for y in d_out], axis=1)
+            parts = np.concatenate([to_host(y) for y in d_out], axis=1)
             assert np.array_equal(parts, whole)
             assert float(np.abs(whole[:, :, 1] - ref).max()) < PROB_TOL
             out[lstm] = whole
@@ -197,7 +198,7 @@ def test_device_buffers_and_caller_stream(eng, orc):
     torch = pytest.importorskip("torch")
     S, n = 20, 24
     pcm = streams512(S, n, seed0=31)
-    d_in = torch.from_numpy(pcm).cuda()
+    d_in = to_device(pcm)
     d_out = torch.empty(S, n, 2, device="cuda")
     st = torch.cuda.Stream()
     eng.reset_streams(); eng.synchronize()
@@ -205,7 +206,7 @@ def test_device_buffers_and_caller_stream(eng, orc):
         eng.run_device(d_in.data_ptr(), np.int16, S, n, d_out.data_ptr(), st.cuda_stream)
     st.synchronize()
     ref = orc.forward_streams(pcm)
-    assert float(np.abs(d_out.cpu().numpy()[:, :, 1] - ref).max()) < PROB_TOL
+    assert float(np.abs(to_host(d_out)[:, :, 1] - ref).max()) < PROB_TOL
 
 
 def test_cli_with_v5_weights(gold):

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vadc_amd import synth
 from vadc_amd.engine import Engine
+from vadc_amd.staging import to_device, to_host
 BLOBS = {"v31": "tests/golden/reference_fixtures/silero_v31_16k.testtensor", "v4": "tests/golden/silero_v4_16k.testtensor", "v5": "tests/golden/silero_v5_seeded.testtensor"}
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 scale = 1.0
@@ -19,7 +20,7 @@ def soak(S, Cn, calls, reps, opts=None, model="v31"):
     W = e.window                                                   # samples per chunk (1536; Silero v5: 512)
     base = synth.make_streams(min(S, 48), -(-calls * Cn * W // 1536), seed0=4000 + S)
     pcm = np.ascontiguousarray(base[np.arange(S) % base.shape[0]])
-    d_in = [torch.from_numpy(np.ascontiguousarray(pcm[:, k * Cn * W:(k + 1) * Cn * W])).cuda() for k in range(calls)]
+    d_in = [to_device(np.ascontiguousarray(pcm[:, k * Cn * W:(k + 1) * Cn * W])) for k in range(calls)]
     for k_, v_ in (opts or {}).items():
         if k_ != "window": e.set_option(k_, v_)
     e.set_option("defer_join", 1)
@@ -32,7 +33,7 @@ def soak(S, Cn, calls, reps, opts=None, model="v31"):
         for k in range(calls):
             e.run_device(d_in[k].data_ptr(), np.int16, S, Cn, d_out[k].data_ptr(), st.cuda_stream)
         e.join(st.cuda_stream); st.synchronize()
-        r = np.concatenate([o.cpu().numpy() for o in d_out], axis=1)
+        r = np.concatenate([to_host(o) for o in d_out], axis=1)
         if first is None: first = r
         elif not np.array_equal(bits(first), bits(r)):
             bad += 1; worst = max(worst, float(np.abs(first - r).max()))

@@ -19,6 +19,7 @@ def main():
     a = ap.parse_args()
     import torch
     from vadc_amd.engine import Engine
+    from vadc_amd.staging import to_device, to_host
     from vadc_amd import synth
     name = "silero_v4_16k.testtensor" if a.rate == 16000 else "silero_v4_8k.testtensor"
     blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
@@ -32,7 +33,7 @@ def main():
         n = a.chunks * W
         base = synth.make_streams(16, -(-n // 1536), seed0=11)[:, :n]
         pcm = np.ascontiguousarray(np.tile(base, (-(-a.streams // 16), 1))[:a.streams])
-        d_in = torch.from_numpy(pcm).cuda()
+        d_in = to_device(pcm)
         d_out = torch.empty(a.streams, a.chunks, 2, device="cuda")
         st = torch.cuda.Stream()
         for _ in range(3):

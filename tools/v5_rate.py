@@ -17,6 +17,7 @@ def main():
     a = ap.parse_args()
     import torch
     from vadc_amd.engine import Engine
+    from vadc_amd.staging import to_device, to_host
     from vadc_amd import synth
     blob = open(os.path.join(ROOT, "tests", "golden", "silero_v5_seeded.testtensor"), "rb").read()
     eng = Engine(blob, max_streams=a.streams, max_chunks_per_call=a.chunks, device=0)
@@ -25,7 +26,7 @@ def main():
         eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     base = synth.make_streams(16, -(-a.chunks * 512 // 1536), seed0=11)[:, :a.chunks * 512]
     pcm = np.ascontiguousarray(np.tile(base, (-(-a.streams // 16), 1))[:a.streams])
-    d_in = torch.from_numpy(pcm).cuda()
+    d_in = to_device(pcm)
     d_out = torch.empty(a.streams, a.chunks, 2, device="cuda")
     st = torch.cuda.Stream()                        # not the null stream: that one synchronises with the engine's CU-masked (blocking) streams
     for _ in range(a.warmup):
