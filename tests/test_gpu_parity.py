@@ -1714,10 +1714,10 @@ def test_async_host_entry_points_bit_identical_to_the_device_path(weights_blob, 
 
 
 def test_async_calls_through_fresh_host_buffers(weights_blob):
-    """a caller that allocates a NEW pair of host buffers for every asynchronous call and frees them afterwards (telling the engine first: vadc_amd_unpin): 200
+    """a caller that allocates a NEW pair of host buffers for every asynchronous call and frees them afterwards (telling the engine first: vadc_amd_unpin): 64
     calls deliver the bits of the device path, the engine's list of page-locked ranges stays bounded, and with "pin_host" = 0 (no page-locking, nothing to
     forget) the same holds without the unpin"""
-    S, Cn, calls = 64, 4, 200
+    S, Cn, calls = 64, 4, 64                                                            # (64 calls: four times the engine's list of 16 ranges)
     base = synth.make_streams(S, 8 * Cn, seed0=6161)
     e = Engine(weights_blob, max_streams=S, max_chunks_per_call=Cn, device=0)
     try:
