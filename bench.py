@@ -459,7 +459,8 @@ def side_config(torch, blob, dev, local_rank, model, S, Cn, precision, steps=20,
            "precision": {0: "fp32", 1: "split16", 2: "fast_stft"}[precision], "hipgraph": True,
            "roofline_kernel": dom, "roofline_frac": round(exe[pipe] * S * Cn / (kt[dom] * 1e-3) / 1e12 / PEAKS[pipe], 4),
            "frontend_kernel": frontend_name(eng, fe_kernel),
-           "kernels_ms": {k: round(v, 4) for k, v in kt.items()}}
+           "kernels_ms": {k: round(v, 4) for k, v in kt.items()},
+           "resolved": {"lstm": eng.get_option("lstm_kernel"), "lstm_cus": eng.get_option("lstm_cus"), "shared": eng.get_option("lstm_shared")}}      # what the engine's rules (or the forced options) came to
     if world > 1:
         out.update({"n_gpus": world, "total_streams": S * world, "streams_per_gpu": S, "chunks_per_step": Cn, "per_gpu": round(out["value"] / world, 1),
                     "rccl": collective_facts(torch, dist, world, rehearsal, gather)})

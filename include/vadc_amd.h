@@ -290,7 +290,8 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *                 any synchronisation: the word is host memory -- fails with VADC_AMD_EHIP until vadc_amd_reset_streams(e, NULL, 0).
  *                 Tests: "trail_fault" 1 = the next pair's layer 0 comes late (behind its layer 1), 2 = never; "trail_wait" = polls before layer 1 gives up */
 int  vadc_amd_set_option(vadc_amd_engine *e, const char *key, int value);
-/* Reads a switch back, plus read-only facts: "lstm_cus" = CUs reserved for the LSTM by the last call (0 = no partition), "lstm_kernel" = the LSTM variant it ran
+/* Reads a switch back, plus read-only facts: "lstm_cus" = CUs reserved for the LSTM by the last call (0 = no partition), "lstm_shared" = 1 when those CUs
+ * are also in the front end + encoder stream's mask, "lstm_kernel" = the LSTM variant it ran
  * (3 / 6 / 7), "frontend_kernel" = its front end (0 k_frontend_sym, 1 k_frontend_fl, 2 a GEMM front end -- k_frontend_gemm2 for s16, k_frontend_gemm for f32 input --, 3 k_frontend v4 tree; Silero v5: 2 = k_v5_encoder_h3, 1 = k_v5_encoder), "layer1_kernel" = the first
  * layer's form that runs (0 register-resident, 1 per-layer: option "layer1" is the request), "layer1_selfcheck" (1: the register-resident first layer agreed
  * with the per-layer form on the probe chunks at create; 0: it did not and the per-layer form serves; -1: not applicable), "zero_im0" (the basis' im row of

@@ -534,6 +534,7 @@ extern "C" int vadc_amd_get_option(vadc_amd_engine *e, const char *key, int *val
    else if (strcmp(key, "cu_partition") == 0) *value = e->cu_partition;
    else if (strcmp(key, "lstm_cus") == 0) *value = e->lstm_cus < 0 ? 0 : e->lstm_cus;
    else if (strcmp(key, "lstm_kernel") == 0) *value = e->last_lstm_kernel;
+   else if (strcmp(key, "lstm_shared") == 0) *value = e->lstm_shared ? 1 : 0;      // (read only) the recurrence's CUs are also in the front end + encoder stream's mask
    else if (strcmp(key, "frontend_kernel") == 0) *value = e->last_frontend_kernel;
    else return fail(VADC_AMD_EINVAL, "get_option: unknown option %s", key);
    return VADC_AMD_OK;
