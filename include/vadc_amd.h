@@ -238,7 +238,7 @@ int  vadc_amd_debug_layer1_block(vadc_amd_engine *e, int what, const float *y, i
  *   "window"      [Silero v4's other input sizes]  samples per chunk.  1536 (default; the only size of the reference's C backend, silero.h:41-42).  Silero v4: every
  *                 multiple of 64 in 512 ... 1536 (8 kHz branch: 256 ... 768) -- the v4 graph takes every count in that range (onnx_helpers.c:164-170,
  *                 --sequence_count vadc.c:743-752): samples / 64 STFT frames, every strided stage keeps 1 + (T - 1) / 2 steps.  The multiples of 256 run kernels
- *                 built for their geometry (1536 and the windows of 21 .. 23 frames in it: the register-resident first stage; stages 2 - 4 run in one launch at every window); a window in between runs the next larger built geometry with its own samples and
+ *                 built for their geometry (1536 and the windows of 17 .. 23 frames in it: the register-resident first stage; stages 2 - 4 run in one launch at every window); a window in between runs the next larger built geometry with its own samples and
  *                 reflect pad staged and the surplus steps masked (no stage taps there).  Changes the stride of every samples / probability buffer; waits for
  *                 the calls issued before
  *   "h2d_streams" [host-buffer callers on a slow link]  1 (default) .. 4: pieces (= copy streams) of the H2D copy of an asynchronous host-buffer call

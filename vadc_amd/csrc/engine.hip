@@ -486,7 +486,13 @@ extern "C" int vadc_amd_set_option(vadc_amd_engine *e, const char *key, int valu
          return fail(VADC_AMD_EINVAL, "set_option: window=%d: Silero v3.1 takes 1536-sample chunks only; Silero v4 (GEMM front end) every multiple of 64 in 512 .. 1536 "
                                       "(its 8 kHz branch 256 .. 768)", value);
       { int rc_ = wait_all_prior_fwd(e); if (rc_) return rc_; }
-      const int fv = value / 64, ft = (fv + 3) / 4 * 4;
+      const int fv = value / 64;
+      int ft = (fv + 3) / 4 * 4;
+      // 17 .. 20 frames (1088 .. 1280 samples) run the 24-frame geometry as well when its register-resident first stage and the fused stages are there: the front end computes
+      // 24 frames instead of 20 (0.31 -> 0.39 ms per 65,536 chunks) and the first stage takes 0.31 instead of 0.48 ms (its per-stage form at 20 frames) -- 1280: 5.23 -> 5.73 M,
+      // 1216: 4.98 -> 5.43 M, A/B on one box; from 16 frames down the longer front end costs more than the first stage gains (1024: 5.24 -> 4.76 M).  Same probabilities
+      // (tools/v4_windows_parity.py: identical statistics either way)
+      if (e->sample_rate == 16000 && fv >= 17 && e->d_l1img && e->d_encv4 && e->layer1_selfcheck != 0) ft = 24;
       e->window = value; e->frames = ft; e->frames_valid = fv;
       { const int t1 = (fv + 1) / 2, t2 = (t1 + 1) / 2; e->lstm_steps = e->stride3() == 2 ? (t2 + 1) / 2 : t2; }      // (the same for ft: every fv in (ft - 4, ft])
       stage_elems_v4(e->frames, e->stride3(), e->stage_elems);
@@ -1645,6 +1651,17 @@ extern "C" int vadc_amd_set_context(vadc_amd_engine *e, int stream, const float 
 // ---------------------------------------------------------------------------------------------------
 // stage taps
 // ---------------------------------------------------------------------------------------------------
+// A built window (a multiple of 256 samples) that the hot path runs in the 24-frame geometry (17 .. 20 frames: see option "window") has its stage taps in its OWN geometry:
+// for the length of a tap call the engine is put back into it (the per-stage kernels of that geometry serve the taps as before)
+struct OwnGeometryForTaps {
+   vadc_amd_engine *e; int frames;
+   explicit OwnGeometryForTaps(vadc_amd_engine *e_) : e(e_), frames(e_ ? e_->frames : 0)
+   {
+      if (e && e->model == VADC_AMD_MODEL_V4 && e->padded_window() && e->frames_valid % 4 == 0) { e->frames = e->frames_valid; stage_elems_v4(e->frames, e->stride3(), e->stage_elems); }
+   }
+   ~OwnGeometryForTaps() { if (e && e->frames != frames) { e->frames = frames; stage_elems_v4(e->frames, e->stride3(), e->stage_elems); } }
+};
+
 static float *stage_buffer(vadc_amd_engine *e, int stage)
 {
    switch (stage) {
@@ -1658,6 +1675,7 @@ extern "C" int vadc_amd_debug_stage_from_samples(vadc_amd_engine *e, const float
 {
    if (!e || !samples || !out || stage < 0 || stage >= VADC_AMD_STAGE_COUNT) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: bad argument");
    if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: no stage taps for the Silero v5 path");
+   OwnGeometryForTaps own(e);
    if (e->padded_window()) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: stage taps exist at the built windows (multiples of 256 samples); window=%d runs in the next larger geometry", e->window);
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_samples: n=%d out of range", n);
    HIP_TRY(hipSetDevice(e->device), VADC_AMD_EHIP);
@@ -1684,6 +1702,7 @@ extern "C" int vadc_amd_debug_stage_from_stage(vadc_amd_engine *e, const float *
    if (!e || !in || !out || from_stage < 0 || to_stage >= VADC_AMD_STAGE_COUNT || to_stage <= from_stage)
       return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: bad argument");
    if (e->model == VADC_AMD_MODEL_V5) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: no stage taps for the Silero v5 path");
+   OwnGeometryForTaps own(e);
    if (e->padded_window()) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: stage taps exist at the built windows (multiples of 256 samples); window=%d runs in the next larger geometry", e->window);
    if (n <= 0 || (size_t)n > e->max_items) return fail(VADC_AMD_EINVAL, "debug_stage_from_stage: n=%d out of range", n);
    if (e->model == VADC_AMD_MODEL_V4 && from_stage < VADC_AMD_STAGE_LAYER1)
