@@ -17,6 +17,15 @@ def main():
     ap.add_argument("--rate", type=int, default=16000, choices=[16000, 8000])
     ap.add_argument("--windows", type=int, nargs="*", default=None, help="windows to time (default: the built ones of the branch)")
     a = ap.parse_args()
+    wins = tuple(a.windows) if a.windows else ((1536, 1280, 1024, 768, 512) if a.rate == 16000 else (768, 512, 256))
+    if len(wins) > 1:
+        # one process per window: the FOURTH engine a process creates runs 15 - 40 % slower, every kernel of it (its streams land on hardware queues that earlier engines'
+        # streams still hold: DESIGN.md 7a) -- a 768-sample window measured fourth read 3.5 M instead of 4.6 M
+        import subprocess
+        for W in wins:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--streams", str(a.streams), "--chunks", str(a.chunks), "--steps", str(a.steps), "--warmup", str(a.warmup),
+                            "--rate", str(a.rate), "--windows", str(W)], check=False)
+        return
     import torch
     from vadc_amd.engine import Engine
     from vadc_amd.staging import to_device, to_host
