@@ -331,6 +331,18 @@ def dry_run(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------- one rank's step discipline
+_CALLER_STREAMS = []
+
+
+def caller_streams(torch, n):
+    """the streams this process issues its steps from: made once and shared by the headline and every side configuration.  HIP deals a process's plain streams onto four
+    hardware queues in turn, and an engine driven from a NEW stream per configuration ran 7 - 19 % slower whenever that stream's queue was an unlucky one
+    (tools/engine_order_probe.py): a side configuration must not be measured on its position in this file"""
+    while len(_CALLER_STREAMS) < n:
+        _CALLER_STREAMS.append(torch.cuda.Stream())
+    return _CALLER_STREAMS[:n]
+
+
 class StepLoop:
     """How one rank issues its steps -- shared by the headline's timed region and by every configuration timed beside it, at any number of ranks.
     NB input / output buffers used in turn.  Deferred joins (default): every step is issued from streams[0], which a call does not block (engine option
@@ -342,7 +354,7 @@ class StepLoop:
         self.torch, self.eng, self.S, self.Cn, self.d_in, self.d_probs = torch, eng, S, Cn, d_in, d_probs
         self.NB = len(d_in)
         self.gather, self.world, self.rehearsal, self.defer_join = gather, world, rehearsal, defer_join
-        self.streams = [torch.cuda.Stream() for _ in range(max(self.NB, 2 if world > 1 else 1))]
+        self.streams = caller_streams(torch, max(self.NB, 2 if world > 1 else 1))
         self.gathered = [None] * self.NB          # per step buffer: the event behind the gather that last read it (several ranks only)
         if defer_join:
             eng.set_option("defer_join", 1)
@@ -508,7 +520,7 @@ def side_config_v5(torch, blob, dev, local_rank, S, Cn, steps=60, warmup=10):
     pcm = np.ascontiguousarray(np.tile(base, (-(-S // 16), 1))[:S])
     d_in = [to_device(np.ascontiguousarray(pcm[:, i * Cn * W:(i + 1) * Cn * W]), dev) for i in range(NB)]
     d_out = [torch.empty((S, Cn, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
-    st = torch.cuda.Stream()
+    st = caller_streams(torch, 1)[0]
     eng.set_option("defer_join", 1)
 
     def step(i):
